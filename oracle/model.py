@@ -1,0 +1,220 @@
+"""ORACLE (test infrastructure only) — CNN trunk, heads, loss, optimiser, CPU fp32.
+
+Functional restatement of `/root/reference/pytorch/models.py` (ConvBlock :72-115,
+AttBlock :118-149, Cnn_9layers_FrameMax :152, _FrameAvg :237-319, _FrameAtt :322-400,
+_Gru_FrameAvg :403, _Gru_FrameAtt :495-581), `losses.py:5-12`, `pytorch_utils.py:80-93`
+and `optim.Adam(amsgrad=True)` as configured at `main.py:144-145`.  State is a flat dict
+keyed exactly like the reference `state_dict()`.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import frontend
+
+MODEL_TYPES = ("Cnn_9layers_FrameMax", "Cnn_9layers_FrameAvg", "Cnn_9layers_FrameAtt",
+               "Cnn_9layers_Gru_FrameAvg", "Cnn_9layers_Gru_FrameAtt")
+CLASSES = 17
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _bn_keys(prefix, c):
+    return [(prefix + ".weight", (c,)), (prefix + ".bias", (c,)), (prefix + ".running_mean", (c,)),
+            (prefix + ".running_var", (c,)), (prefix + ".num_batches_tracked", ())]
+
+
+def state_layout(model_type):
+    """Ordered (key, shape) list == reference `state_dict()` order."""
+    assert model_type in MODEL_TYPES
+    lay = [("spectrogram_extractor.stft.conv_real.weight", (513, 1, 1024)),
+           ("spectrogram_extractor.stft.conv_imag.weight", (513, 1, 1024)),
+           ("logmel_extractor.melW", (513, 64))]
+    lay += _bn_keys("bn0", 64)
+    cin = 1
+    for i, cout in enumerate((64, 128, 256, 512), start=1):
+        p = "conv_block%d" % i
+        lay += [(p + ".conv1.weight", (cout, cin, 3, 3)), (p + ".conv2.weight", (cout, cout, 3, 3))]
+        lay += _bn_keys(p + ".bn1", cout) + _bn_keys(p + ".bn2", cout)
+        cin = cout
+    if "Gru" in model_type:
+        for sfx in ("", "_reverse"):
+            lay += [("gru.weight_ih_l0" + sfx, (768, 512)), ("gru.weight_hh_l0" + sfx, (768, 256)),
+                    ("gru.bias_ih_l0" + sfx, (768,)), ("gru.bias_hh_l0" + sfx, (768,))]
+    if model_type.endswith("FrameAtt"):
+        lay += [("att_block.att.weight", (CLASSES, 512, 1)), ("att_block.att.bias", (CLASSES,)),
+                ("att_block.cla.weight", (CLASSES, 512, 1)), ("att_block.cla.bias", (CLASSES,))]
+        lay += _bn_keys("att_block.bn_att", CLASSES)
+    else:
+        lay += [("fc.weight", (CLASSES, 512)), ("fc.bias", (CLASSES,))]
+    return lay
+
+
+FROZEN_KEYS = ("spectrogram_extractor.stft.conv_real.weight", "spectrogram_extractor.stft.conv_imag.weight",
+               "logmel_extractor.melW")
+
+
+def is_buffer(key):
+    return key.endswith(("running_mean", "running_var", "num_batches_tracked"))
+
+
+def recipe_state(model_type, seed=0):
+    """Seeded numpy weight recipe iterated over the state_dict keys in order, so that no 19 MB
+    weight file has to be committed: the same values are regenerated wherever they are needed
+    (golden generation with the reference here; parity tests and smoke() on the GPU box)."""
+    wr, wi = frontend.dft_weights()
+    st = OrderedDict()
+    for idx, (key, shape) in enumerate(state_layout(model_type)):
+        rs = np.random.RandomState(seed * 1000 + idx)
+        if key == FROZEN_KEYS[0]:
+            v = wr
+        elif key == FROZEN_KEYS[1]:
+            v = wi
+        elif key == FROZEN_KEYS[2]:
+            v = frontend.mel_matrix()
+        elif key.endswith("num_batches_tracked"):
+            v = np.array(3, dtype=np.int64)
+        elif key.endswith("running_mean"):
+            v = (rs.randn(*shape) * 0.2 + (-20.0 if key.startswith("bn0") else 0.1)).astype(np.float32)
+        elif key.endswith("running_var"):
+            v = ((0.5 + rs.rand(*shape)) * (60.0 if key.startswith("bn0") else 1.0)).astype(np.float32)
+        elif ".bn" in key or key.startswith("bn0"):
+            v = (1.0 + 0.1 * rs.randn(*shape)).astype(np.float32) if key.endswith("weight") \
+                else (0.1 * rs.randn(*shape)).astype(np.float32)
+        elif key.endswith("bias") or "bias_" in key:
+            v = (0.05 * rs.randn(*shape)).astype(np.float32)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            v = (rs.uniform(-1.0, 1.0, size=shape) * math.sqrt(3.0 / fan_in) * 1.4).astype(np.float32)
+        st[key] = torch.from_numpy(np.ascontiguousarray(v)).reshape(shape)
+    return st
+
+
+# --------------------------------------------------------------------------------------------
+# forward pieces
+
+def do_mixup(x, lam):
+    """pytorch_utils.py:80-93: out[i] = lam[2i]*x[2i] + lam[2i+1]*x[2i+1]."""
+    shape = [-1] + [1] * (x.dim() - 1)
+    return x[0::2] * lam[0::2].reshape(shape) + x[1::2] * lam[1::2].reshape(shape)
+
+
+def _bn(x, st, prefix, training, track):
+    """nn.BatchNorm2d forward (eps 1e-5, momentum 0.1; biased var to normalise, unbiased to track)."""
+    rm, rv = st[prefix + ".running_mean"], st[prefix + ".running_var"]
+    if training and not track:
+        rm, rv = rm.clone(), rv.clone()
+    y = F.batch_norm(x, rm, rv, st[prefix + ".weight"], st[prefix + ".bias"], training, BN_MOMENTUM, BN_EPS)
+    if training and track:
+        st[prefix + ".num_batches_tracked"] = st[prefix + ".num_batches_tracked"] + 1
+    return y
+
+
+def conv_block(x, st, prefix, pool, training, track):
+    """models.py:99-115 with pool_type='avg'."""
+    x = F.relu(_bn(F.conv2d(x, st[prefix + ".conv1.weight"], padding=1), st, prefix + ".bn1", training, track))
+    x = F.relu(_bn(F.conv2d(x, st[prefix + ".conv2.weight"], padding=1), st, prefix + ".bn2", training, track))
+    return F.avg_pool2d(x, kernel_size=pool)
+
+
+def gru_bidir(x, st):
+    """nn.GRU(512,256,batch_first,bidirectional) forward, h0=0, gate order (r,z,n), b_hn inside r*(.).
+    models.py:529-530, :565-567.  x (B,T,512) -> (B,T,512)."""
+    B, T, _ = x.shape
+    outs = []
+    for sfx, order in (("", range(T)), ("_reverse", range(T - 1, -1, -1))):
+        w_ih, w_hh = st["gru.weight_ih_l0" + sfx], st["gru.weight_hh_l0" + sfx]
+        b_ih, b_hh = st["gru.bias_ih_l0" + sfx], st["gru.bias_hh_l0" + sfx]
+        gi_all = x @ w_ih.t() + b_ih
+        h = x.new_zeros(B, 256)
+        hs = [None] * T
+        for t in order:
+            gi = gi_all[:, t]
+            gh = h @ w_hh.t() + b_hh
+            r = torch.sigmoid(gi[:, :256] + gh[:, :256])
+            z = torch.sigmoid(gi[:, 256:512] + gh[:, 256:512])
+            n = torch.tanh(gi[:, 512:] + r * gh[:, 512:])
+            h = (1.0 - z) * n + z * h
+            hs[t] = h
+        outs.append(torch.stack(hs, dim=1))
+    return torch.cat(outs, dim=2)
+
+
+def att_block(x, st):
+    """models.py:135-143.  x (B,512,T) -> clip (B,17), norm_att (B,17,T), cla (B,17,T)."""
+    tmp = F.conv1d(x, st["att_block.att.weight"], st["att_block.att.bias"])
+    tmp = torch.clamp(tmp, -10, 10)
+    att = torch.exp(tmp / 1.0) + 1e-6
+    norm_att = att / torch.sum(att, dim=2)[:, :, None]
+    cla = torch.sigmoid(F.conv1d(x, st["att_block.cla.weight"], st["att_block.cla.bias"]))
+    return torch.sum(norm_att * cla, dim=2), norm_att, cla
+
+
+def interpolate(x, ratio):
+    """models.py:58-69: pure repeat along time."""
+    (b, t, c) = x.shape
+    return x[:, :, None, :].repeat(1, 1, ratio, 1).reshape(b, t * ratio, c)
+
+
+def trunk(logmel, st, training, mixup_lambda=None, stripes=None, track=True):
+    """models.py:287-303 (identical in every model): bn0 on the mel axis, SpecAugment, mixup,
+    four ConvBlocks, freq-mean.  logmel (B2,1,T,64) -> (B,512,T/8)."""
+    x = _bn(logmel.transpose(1, 3), st, "bn0", training, track).transpose(1, 3)
+    if training:
+        if stripes is None:
+            stripes = frontend.draw_specaug_stripes(x.shape[0], x.shape[2], x.shape[3])
+        x = frontend.apply_specaug(x, stripes)
+    if training and mixup_lambda is not None:
+        x = do_mixup(x, mixup_lambda)
+    x = conv_block(x, st, "conv_block1", (2, 2), training, track)
+    x = conv_block(x, st, "conv_block2", (2, 2), training, track)
+    x = conv_block(x, st, "conv_block3", (2, 2), training, track)
+    x = conv_block(x, st, "conv_block4", (1, 1), training, track)
+    return torch.mean(x, dim=3)
+
+
+def head(model_type, x, st):
+    """x (B,512,T') -> output dict.  FrameAvg models.py:306-319, FrameMax :221-234,
+    FrameAtt :388-400, Gru_* :565-581."""
+    if "Gru" in model_type:
+        x = gru_bidir(x.transpose(1, 2), st).transpose(1, 2)
+    if model_type.endswith("FrameAtt"):
+        clip, _, cla = att_block(x, st)
+        return {"framewise_output": interpolate(cla.transpose(1, 2), 8), "clipwise_output": clip,
+                "embedding": cla}
+    frame = torch.sigmoid(F.linear(x.transpose(1, 2), st["fc.weight"], st["fc.bias"]))
+    frame = interpolate(frame, 8)
+    if model_type.endswith("FrameMax"):
+        clip = torch.max(frame, dim=1)[0]
+    else:
+        clip = torch.mean(frame, dim=1)
+    return {"framewise_output": frame, "clipwise_output": clip, "embedding": x}
+
+
+def forward(model_type, st, waveform, training=False, mixup_lambda=None, stripes=None, track=True):
+    """Whole-model forward == `Model.forward(input, mixup_lambda)` (models.py:279-319 etc.)."""
+    lm = frontend.logmel(waveform)
+    return head(model_type, trunk(lm, st, training, mixup_lambda, stripes, track), st)
+
+
+def clip_bce(output_dict, target_dict):
+    """losses.py:5-12."""
+    return F.binary_cross_entropy(output_dict["clipwise_output"], target_dict["target"])
+
+
+def trainable_keys(model_type):
+    return [k for k, _ in state_layout(model_type) if k not in FROZEN_KEYS and not is_buffer(k)]
+
+
+def adam_amsgrad_step(p, g, m, v, vmax, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """torch.optim.Adam(amsgrad=True, weight_decay=0) single-tensor update (main.py:144-145)."""
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    torch.maximum(vmax, v, out=vmax)
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = (vmax.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)

@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""Generate the golden vectors in tests/golden/*.npz by running the GENUINE reference code.
+
+Runs ONLY in the build container (needs /root/reference).  Imports the reference's
+`pytorch/models.py`, `pytorch/losses.py`, `pytorch/pytorch_utils.py` unmodified, with the
+test-only `torchlibrosa` stand-in (tests/golden/_torchlibrosa_standin) first on sys.path because
+the real third-party package is absent.  Weights come from the seeded numpy recipe
+`oracle.model.recipe_state` so no weight file has to be committed.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(HERE, "_torchlibrosa_standin"))
+sys.path.insert(1, "/root/reference/pytorch")
+sys.path.insert(2, "/root/reference/utils")
+sys.path.insert(3, REPO)
+
+import numpy as np
+import torch
+import torch.optim as optim
+
+import models as ref_models            # /root/reference/pytorch/models.py
+import losses as ref_losses            # /root/reference/pytorch/losses.py
+import pytorch_utils as ref_utils      # /root/reference/pytorch/pytorch_utils.py
+import config as ref_config            # /root/reference/utils/config.py
+from torchlibrosa.stft import Spectrogram, LogmelFilterBank
+
+from oracle import frontend as ofe
+from oracle import model as om
+
+torch.set_num_threads(8)
+CTOR = (ref_config.sample_rate, ref_config.window_size, ref_config.hop_size, ref_config.mel_bins,
+        ref_config.fmin, ref_config.fmax, ref_config.classes_num)
+
+
+def waves(seed, n, length):
+    return (np.random.RandomState(seed).randn(n, length) * 0.1).astype(np.float32)
+
+
+def targets(seed, n):
+    return (np.random.RandomState(seed).rand(n, 17) < 0.2).astype(np.float32)
+
+
+def summarize(t):
+    f = t.detach().reshape(-1).double()
+    return np.array([f.sum().item(), f.abs().sum().item()] + f[:14].tolist() +
+                    [0.0] * max(0, 14 - f.numel()), dtype=np.float64)[:16]
+
+
+def build(model_type, seed):
+    m = getattr(ref_models, model_type)(*CTOR)
+    st = om.recipe_state(model_type, seed)
+    assert list(m.state_dict().keys()) == list(st.keys()), model_type
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(st[k].shape), (k, v.shape, st[k].shape)
+    m.load_state_dict(st)
+    return m
+
+
+def frontend_fixture():
+    out = {}
+    sp = Spectrogram(n_fft=1024, hop_length=320, win_length=1024, window='hann', center=True,
+                     pad_mode='reflect', freeze_parameters=True)
+    lm = LogmelFilterBank(sr=32000, n_fft=1024, n_mels=64, fmin=50, fmax=14000, ref=1.0, amin=1e-10,
+                          top_db=None, freeze_parameters=True)
+    out["melW"] = lm.melW.detach().numpy()
+    out["conv_real_rows"] = sp.stft.conv_real.weight.detach().numpy()[[0, 1, 7, 256, 512], 0, :]
+    out["conv_imag_rows"] = sp.stft.conv_imag.weight.detach().numpy()[[0, 1, 7, 256, 512], 0, :]
+    x1 = waves(1234, 1, 32000)
+    with torch.no_grad():
+        out["logmel_1s"] = lm(sp(torch.from_numpy(x1))).numpy()[0, 0]
+        x10 = waves(4321, 1, 320000)
+        out["logmel_10s"] = lm(sp(torch.from_numpy(x10))).numpy()[0, 0]
+        n = np.arange(32000)
+        tone = (0.5 * np.cos(2 * np.pi * 1000 * n / 32000)).astype(np.float32)
+        out["tone_power_frame50"] = sp(torch.from_numpy(tone[None])).numpy()[0, 0, 50]
+        out["tone_logmel"] = lm(sp(torch.from_numpy(tone[None]))).numpy()[0, 0]
+        sil = np.zeros((1, 3200), dtype=np.float32)
+        out["silence_logmel"] = lm(sp(torch.from_numpy(sil))).numpy()[0, 0]
+        # short clip of int16-quantised audio as produced by utils/utilities.py:61-67
+        q = np.round(np.clip(waves(77, 1, 6400), -1, 1) * 32767.0).astype(np.int16)
+        out["int16_wave"] = q
+        out["int16_logmel"] = lm(sp(torch.from_numpy((q / 32767.0).astype(np.float32)))).numpy()[0, 0]
+    return out
+
+
+def model_fixture(model_type, seed, long_case=False):
+    out = {}
+    m = build(model_type, seed)
+    # ---- eval mode, B=4, 1 s clips
+    x = torch.from_numpy(waves(100 + seed, 4, 32000))
+    m.eval()
+    with torch.no_grad():
+        o = m(x)
+    out["eval_clip"] = o["clipwise_output"].numpy()
+    out["eval_frame"] = o["framewise_output"].numpy()[:, ::8]          # un-interpolated
+    out["eval_embedding"] = summarize(o["embedding"])
+    if long_case:
+        xl = torch.from_numpy(waves(200 + seed, 2, 320000))
+        with torch.no_grad():
+            o = m(xl)
+        out["eval10_clip"] = o["clipwise_output"].numpy()
+        out["eval10_frame"] = o["framewise_output"].numpy()[:, ::8]
+        assert o["framewise_output"].shape == (2, 1000, 17)
+    # ---- train mode forward (batch-stat BN, SpecAugment with seeded global RNG, mixup), B2=6 -> B=3
+    xt = torch.from_numpy(waves(300 + seed, 6, 32000))
+    lam = ofe.mixup_lambdas(6, np.random.RandomState(1234)).astype(np.float32)
+    torch.manual_seed(500 + seed)
+    out["train_stripes"] = ofe.draw_specaug_stripes(6, 101, 64)         # same draw order as the package
+    m = build(model_type, seed)
+    m.train()
+    torch.manual_seed(500 + seed)
+    with torch.no_grad():
+        o = m(xt, torch.from_numpy(lam))
+    out["train_lambda"] = lam
+    out["train_clip"] = o["clipwise_output"].numpy()
+    out["train_frame"] = o["framewise_output"].numpy()[:, ::8]
+    out["train_bn0_running_mean"] = m.state_dict()["bn0.running_mean"].numpy()
+    out["train_bn0_running_var"] = m.state_dict()["bn0.running_var"].numpy()
+    out["train_b4bn2_running_var"] = m.state_dict()["conv_block4.bn2.running_var"].numpy()
+    # ---- 3 optimisation steps exactly like main.py:233-258 (mixup, clip_bce, Adam amsgrad)
+    m = build(model_type, seed)
+    opt = optim.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-08, weight_decay=0., amsgrad=True)
+    loss_func = ref_losses.get_loss_func('clip_bce')
+    rs = np.random.RandomState(1234)
+    losses, stripes_all = [], []
+    for it in range(3):
+        xw = ref_utils.move_data_to_device(waves(700 + 10 * seed + it, 8, 32000), 'cpu')
+        tg = ref_utils.move_data_to_device(targets(800 + 10 * seed + it, 8), 'cpu')
+        lam_t = ref_utils.move_data_to_device(ofe.mixup_lambdas(8, rs), 'cpu')
+        torch.manual_seed(900 + 10 * seed + it)
+        stripes_all.append(ofe.draw_specaug_stripes(8, 101, 64))
+        torch.manual_seed(900 + 10 * seed + it)
+        m.train()
+        o = m(xw, lam_t)
+        tgt = {'target': ref_utils.do_mixup(tg, lam_t)}
+        loss = loss_func(o, tgt)
+        opt.zero_grad()
+        loss.backward()
+        if it == 0:
+            for k, p in m.named_parameters():
+                if p.grad is not None:
+                    out["grad0/" + k] = summarize(p.grad)
+                    if k in ("fc.weight", "bn0.weight", "bn0.bias", "conv_block1.conv1.weight",
+                             "att_block.att.weight", "att_block.cla.bias", "gru.bias_hh_l0"):
+                        out["gradfull0/" + k] = p.grad.numpy().copy()
+            out["grad0_none_keys"] = np.array([k for k, p in m.named_parameters()
+                                               if p.requires_grad and p.grad is None])
+        opt.step()
+        losses.append(loss.item())
+    out["step_losses"] = np.array(losses)
+    out["step_stripes"] = np.stack(stripes_all)
+    for k, v in m.state_dict().items():
+        if k not in om.FROZEN_KEYS:
+            out["after3/" + k] = summarize(v.float())
+    return out
+
+
+def misc_fixture():
+    out = {"mixup_lambda64": ofe.mixup_lambdas(64, np.random.RandomState(1234))}
+    torch.manual_seed(7)
+    out["specaug_seed7_B4_T1001"] = ofe.draw_specaug_stripes(4, 1001, 64)
+    # do_mixup / clip_bce / move_data_to_device known answers from the reference functions
+    x = torch.from_numpy(np.random.RandomState(5).randn(6, 3, 4).astype(np.float32))
+    lam = torch.from_numpy(out["mixup_lambda64"][:6].astype(np.float32))
+    out["do_mixup_in"], out["do_mixup_out"] = x.numpy(), ref_utils.do_mixup(x, lam).numpy()
+    p = torch.tensor([[0.0, 1.0, 0.5, 1e-45, 1 - 1e-7]], dtype=torch.float32)
+    y = torch.tensor([[1.0, 0.0, 0.3, 1.0, 0.0]], dtype=torch.float32)
+    out["bce_p"], out["bce_y"] = p.numpy(), y.numpy()
+    out["bce_loss"] = ref_losses.clip_bce({'clipwise_output': p}, {'target': y}).numpy()
+    return out
+
+
+if __name__ == "__main__":
+    np.savez_compressed(os.path.join(HERE, "frontend.npz"), **frontend_fixture())
+    np.savez_compressed(os.path.join(HERE, "misc.npz"), **misc_fixture())
+    for i, mt in enumerate(om.MODEL_TYPES):
+        fx = model_fixture(mt, seed=i + 1, long_case=(mt == "Cnn_9layers_FrameAvg"))
+        np.savez_compressed(os.path.join(HERE, mt + ".npz"), **fx)
+        print(mt, "losses", fx["step_losses"])
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
