@@ -113,10 +113,10 @@ def test_three_train_steps_match_reference(mt, golden_dir):
         with torch.no_grad():
             for k, g in zip(used, grads):
                 if it == 0:
-                    check_summary(summarize(g), fx["grad0/" + k], 2e-3, "grad " + k)
+                    check_summary(summarize(g), fx["grad0/" + k], 2e-3, "grad " + k, slack=1e-7)  # att.bias grad is structurally ~0
                     if ("gradfull0/" + k) in fx.files:
                         ref = fx["gradfull0/" + k]
-                        np.testing.assert_allclose(g.numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+                        np.testing.assert_allclose(g.numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max() + 1e-7)
                 m, v, vmax = opt_state[k]
                 om.adam_amsgrad_step(st[k], g, m, v, vmax, it + 1, 1e-3)
     assert unused == ({"att_block.bn_att.weight", "att_block.bn_att.bias"} if mt.endswith("Att") else set())
