@@ -1,0 +1,170 @@
+/* sed_hip.h — C ABI of libsed_hip.so: the MI355X (gfx950) hot path of
+ * qiuqiangkong/sound_event_detection_dcase2017_task4 (log-mel front-end fused into the
+ * Cnn_9layers_* / Cnn_9layers_Gru_FrameAtt train / inference step).
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers + sizes + a HIP stream; no torch / C++ types.
+ *   - every function enqueues on `stream` and never synchronises; returns 0, a hipError_t (>0),
+ *     or -22 (bad argument).
+ *   - activations are NHWC: [B][H=time][W=mel][C] fp32, C contiguous.  Conv weights are exchanged in the
+ *     reference's OIHW layout ((Cout,Cin,3,3), state_dict compatible); packed copies are internal.
+ *   - "partials" buffers are fp32 scratch written by one kernel and merged (in fp64) by the next.
+ *
+ * Each entry cites the reference code it replaces (paths relative to the reference repo).
+ */
+#ifndef SED_HIP_H
+#define SED_HIP_H
+
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
+typedef hipStream_t sed_stream_t;
+#else
+typedef void* sed_stream_t; /* a hipStream_t */
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* sed_version(void);
+
+/* ---- K1 log-mel front-end -------------------------------------------------------------------------------
+ * Replaces torchlibrosa Spectrogram + LogmelFilterBank as constructed at pytorch/models.py:251-258 and called
+ * at :284-285 (reflect pad 512, Hann-windowed 1024-point DFT, hop 320, power, 513x64 Slaney mel matrix,
+ * 10*log10(clamp(., amin))).  wave [B2][L] -> out [B2][T = L/320 + 1][64].
+ * window[1024] = conv_real.weight[0,0,:] (the Hann window); tw1024 [64][16] float2 = exp(-2*pi*i*n2*k1/1024);
+ * tw64 [4][4][4] float2 = exp(-2*pi*i*(4*i'+g)*s/64); mel_* = the non-zero runs of melW per band
+ * (mel_lo first bin, mel_cnt run length, mel_off offset into mel_w).  The i16 variant folds
+ * utils/utilities.py:66-67 (int16 / 32767) into the load. */
+int sed_logmel_f32(const float* wave, int B2, int L, const float* window, const float* tw1024, const float* tw64,
+                   const int* mel_lo, const int* mel_cnt, const int* mel_off, const float* mel_w, int mel_nnz,
+                   float amin, float* out, sed_stream_t stream);
+int sed_logmel_i16(const short* wave, int B2, int L, const float* window, const float* tw1024, const float* tw64,
+                   const int* mel_lo, const int* mel_cnt, const int* mel_off, const float* mel_w, int mel_nnz,
+                   float amin, float* out, sed_stream_t stream);
+
+/* ---- BatchNorm statistics (nn.BatchNorm2d, models.py:87-88, :264; eps 1e-5, momentum 0.1) -------------------
+ * sed_chan_stats: per-channel (sum, M2) partials of x [N][C] in tiles of sed_stats_rows_per_part() rows;
+ * partials [ceil(N/rows)][2][C].  sed_bn_finalize merges partials (from sed_chan_stats, sed_conv1_fwd or
+ * sed_conv3x3_igemm epi 1) into mean / invstd / folded scale = gamma*invstd, shift = beta - mean*scale and
+ * updates the running statistics (unbiased variance).  ws: >= 512*C doubles.
+ * sed_bn_eval_affine: eval mode, fold the running statistics instead. */
+int sed_chan_stats(const float* x, long N, int C, float* partials, sed_stream_t stream);
+int sed_stats_rows_per_part(void);
+int sed_bn_finalize(const float* partials, int nparts, int rows_per_part, long N, int C, const float* gamma,
+                    const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                    float* mean_out, float* invstd_out, float* scale_out, float* shift_out, double* ws,
+                    sed_stream_t stream);
+int sed_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* mean_out, float* invstd_out, float* scale_out,
+                       float* shift_out, sed_stream_t stream);
+/* BN backward, stage 2: partials [nparts][2][C] = (sum dy, sum dy*xhat) -> dgamma, dbeta and (nullable) the
+ * coefficients coef[3][C] of g_y = a*dy + b*y + c. */
+int sed_bn_bwd_finalize(const float* partials, int nparts, long N, int C, const float* mean, const float* invstd,
+                        const float* scale, float* dgamma, float* dbeta, float* coef, double* ws,
+                        sed_stream_t stream);
+/* g_y = a*dy + b*y + c in place on dy [nrows][C]. */
+int sed_bn_bwd_apply(float* dy_inout, const float* y, long nrows, int C, const float* coef, sed_stream_t stream);
+
+/* ---- bn0 + SpecAugmentation + mixup (models.py:287-296; do_mixup pytorch_utils.py:80-93) ----------------------
+ * logmel [B2][T][64] -> out [B2 or B2/2][T][64].  stripes [B2][8] = {t_bgn0,t_len0,t_bgn1,t_len1,f_bgn0,f_len0,
+ * f_bgn1,f_len1} (null: no SpecAugment, eval); lam [B2] (null: no mixup).  The backward only produces the
+ * (sum dy, sum dy*xhat) partials [ceil(B2*T/1024)][2][64] for dgamma0/dbeta0 (the waveform takes no gradient). */
+int sed_bn0_aug_mix_fwd(const float* logmel, int B2, int T, const float* scale, const float* shift,
+                        const int* stripes, const float* lam, float* out, sed_stream_t stream);
+int sed_bn0_aug_mix_bwd(const float* logmel, const float* g_out, int B2, int T, const float* mean,
+                        const float* invstd, const int* stripes, const float* lam, float* partials, int* nparts_out,
+                        sed_stream_t stream);
+
+/* ---- ConvBlock tail: BN (folded) + ReLU + avg_pool2d (models.py:102-107), and torch.mean(dim=3) (:303) as the
+ * (1, W) pool of block 4.  y [B][H][W][C] raw conv output -> out [B][H/ph][W/pw][C] (floor mode).
+ * Backward: pass 1 reduces (sum dy, sum dy*xhat) partials [ceil(B*H*W/1024)][2][C]; pass 2 writes
+ * g_y = a*dy + b*y + c with dy = relu-mask * g_out/(ph*pw). */
+int sed_bn_relu_pool_fwd(const float* y, int B, int H, int W, int C, int ph, int pw, const float* scale,
+                         const float* shift, float* out, sed_stream_t stream);
+int sed_bn_relu_pool_bwd_reduce(const float* y, const float* g_out, int B, int H, int W, int C, int ph, int pw,
+                                const float* scale, const float* shift, const float* mean, const float* invstd,
+                                float* partials, int* nparts_out, sed_stream_t stream);
+int sed_bn_relu_pool_bwd_apply(const float* y, const float* g_out, int B, int H, int W, int C, int ph, int pw,
+                               const float* scale, const float* shift, const float* coef, float* gy,
+                               sed_stream_t stream);
+
+/* ---- 3x3 convolution, stride 1, pad 1, no bias (nn.Conv2d at models.py:77-85) on fp32 MFMA ---------------------
+ * sed_pack_conv_weights: OIHW -> wf [9][Cout][Cin] (forward operand) and wd [9][Cin][Cout], taps flipped (dgrad
+ * operand); either may be null.
+ * sed_conv3x3_igemm: y [B*H*W][Cout] = conv(x [B*H*W][Cin], w_packed [9][Cout][Cin]).  Forward: w_packed = wf.
+ * Dgrad: x = g_y, Cin/Cout swapped, w_packed = wd.
+ *   in_scale/in_shift (nullable): the operand is relu(in_scale*x + in_shift) computed on the fly (the
+ *     preceding BN+ReLU is never materialised).
+ *   epi 0 plain; epi 1 also writes BN statistic partials [sed_conv_num_parts][2][Cout] of y (rows per part =
+ *     sed_conv_rows_per_part(Cout)); epi 2 (dgrad) masks y by relu'(p_scale*yprev + p_shift) and writes
+ *     (sum dy, sum dy*xhat) partials for the BN backward of the previous layer.
+ * sed_conv3x3_wgrad: dw (OIHW) = sum_p gy[p][co] * a[p + tap][ci]; partial: scratch of
+ *   sed_wgrad_partial_floats(B*H*W, Cin, Cout, 9, ...) floats.
+ * sed_conv1_*: conv_block1.conv1 (Cin = 1), HBM-bound direct kernels; partials [ceil(M/256)][2][64];
+ *   scratch dw_partials ceil(M/1024)*576 floats, tbuf 9*M floats (only when gx0 != null). */
+int sed_pack_conv_weights(const float* w_oihw, int Cout, int Cin, float* wf, float* wd, sed_stream_t stream);
+int sed_conv_rows_per_part(int Cout);
+int sed_conv_num_parts(long M, int Cout);
+int sed_conv3x3_igemm(const float* x, const float* w_packed, float* y, int B, int H, int W, int Cin, int Cout,
+                      const float* in_scale, const float* in_shift, int epi, float* partials, const float* yprev,
+                      const float* p_scale, const float* p_shift, const float* p_mean, const float* p_invstd,
+                      sed_stream_t stream);
+long sed_wgrad_partial_floats(long M, int Cin, int Cout, int ntaps, int* nslices_out, int* pix_per_slice_out);
+int sed_conv3x3_wgrad(const float* x, const float* gy, float* dw_oihw, float* partial, int B, int H, int W, int Cin,
+                      int Cout, const float* in_scale, const float* in_shift, sed_stream_t stream);
+int sed_conv1_fwd(const float* x0, const float* w_oihw, float* y, int B, int H, int W, float* partials,
+                  sed_stream_t stream);
+int sed_conv1_rows_per_part(void);
+int sed_conv1_bwd(const float* x0, const float* w_oihw, const float* gy, int B, int H, int W, float* dw, float* gx0,
+                  float* dw_partials, float* tbuf, sed_stream_t stream);
+
+/* ---- dense fp32-MFMA GEMMs for fc (models.py:271,:308), AttBlock 1x1 convs (:124-125), nn.GRU projections (:529)
+ * sed_gemm_nt: y[M][N] = x[M][K] * w[N][K]^T (+ bias[N]);  K % 32 == 0, N % 64 == 0.
+ * sed_gemm_tn: dw[N][K] = sum_m gy[m][n] * x[m][k];  N, K % 64 == 0; partial: scratch of
+ *   sed_wgrad_partial_floats(M, K, N, 1, ...) floats. */
+int sed_gemm_nt(const float* x, const float* w, const float* bias, float* y, long M, int N, int K,
+                sed_stream_t stream);
+int sed_gemm_tn(const float* x, const float* gy, float* dw, float* partial, long M, int N, int K,
+                sed_stream_t stream);
+int sed_reduce_rows(const float* parts, long n, int K, long ld, float* out, int accumulate, float* ws,
+                    sed_stream_t stream);
+int sed_transpose(const float* x, int batch, int rows, int cols, float* out, sed_stream_t stream);
+int sed_axpy(float* out, const float* a, long n, sed_stream_t stream);
+
+/* ---- heads -----------------------------------------------------------------------------------------------
+ * FrameAvg (models.py:306-312) / FrameMax (:221-227): logits [B][T][ldn] = feat x Wfc^T by sed_gemm_nt, then
+ * frame = sigmoid(logits + bias), clip = mean_t (mode 0) or max_t (mode 1).
+ * AttBlock (models.py:135-143): logits columns [0,ncls) = att, [ncls,2ncls) = cla pre-activations; clamp +-10,
+ * exp + 1e-6, normalise over time, sigmoid, weighted sum.  sed_interpolate = models.py:58-69 (x8 repeat). */
+int sed_head_pool_fwd(const float* logits, int B, int T, int ldn, int ncls, const float* bias, int mode, float* frame,
+                      float* clip, int* amax, sed_stream_t stream);
+int sed_head_pool_bwd(const float* g_clip, const float* frame, const int* amax, int B, int T, int ldn, int ncls,
+                      int mode, float* g_logits, sed_stream_t stream);
+int sed_att_pool_fwd(const float* logits, int B, int T, int ldn, int ncls, const float* b_att, const float* b_cla,
+                     float* clip, float* cla, float* norm_att, float* att_sum, sed_stream_t stream);
+int sed_att_pool_bwd(const float* g_clip, const float* logits, const float* b_att, const float* clip,
+                     const float* cla, const float* norm_att, const float* att_sum, int B, int T, int ldn, int ncls,
+                     float* g_logits, sed_stream_t stream);
+int sed_interpolate(const float* x, long BT, int ncls, int ratio, float* out, sed_stream_t stream);
+
+/* ---- nn.GRU gate math (models.py:529-530; PyTorch gate order r,z,n, b_hn inside r*(.)) ------------------------- */
+int sed_gru_gate_fwd(const float* gi, long ld_gi, const float* gh, const float* h_prev, int B, int Hd, float* h_out,
+                     long ld_out, float* h_out2, long ld_out2, float* save, sed_stream_t stream);
+int sed_gru_gate_bwd(const float* g_out, long ld_go, const float* dh_rec, const float* save, const float* h_prev,
+                     int B, int Hd, float* dgi, long ld_dgi, float* dgh, float* dh_prev, sed_stream_t stream);
+
+/* ---- loss / mixup of targets / optimiser ---------------------------------------------------------------------
+ * sed_clip_bce: losses.py:5-12 (F.binary_cross_entropy, mean, log clamped at -100) + d loss / d p.
+ * sed_mixup_rows: pytorch_utils.py:80-93 on a [B2][D] matrix (the targets, main.py:246).
+ * sed_adam_amsgrad: optim.Adam(betas=(0.9,0.999), eps=1e-8, weight_decay=0, amsgrad=True) (main.py:144-145,:258)
+ *   over flat buffers; grad_scale is applied to the gradient first (1/world_size after the RCCL all-reduce). */
+int sed_clip_bce(const float* p, const float* y, long n, float* loss, float* grad, sed_stream_t stream);
+int sed_mixup_rows(const float* x, const float* lam, long B2, long D, float* out, sed_stream_t stream);
+int sed_adam_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, long n, int step, float lr,
+                     float beta1, float beta2, float eps, float grad_scale, sed_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SED_HIP_H */

@@ -1,0 +1,482 @@
+// BatchNorm statistics / finalisation, bn0 + SpecAugment + mixup, and the BN+ReLU+avg-pool stage.
+//
+// Replaces (reference pytorch/models.py): `bn0` applied on the mel axis (:287-289), `spec_augmenter` (:291-292),
+// `do_mixup` (:295-296, pytorch_utils.py:80-93), and inside ConvBlock (:99-115) the `bnX -> relu_ -> avg_pool2d`
+// tail, plus `torch.mean(x, dim=3)` (:303).  All tensors are NHWC ([rows][C], C contiguous); all kernels are
+// HBM-bound streaming kernels (float4 per lane, C/4 lanes per pixel).
+//
+// Statistics are carried as per-tile partials (sum, M2 = sum((x - tile_mean)^2)) in fp32 and merged in fp64
+// (raw moments S1, S2 = M2 + sum^2/n), so var = S2/N - mean^2 is immune to cancellation.
+#include "common.h"
+#include "sed_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// generic per-channel partial statistics of a [N][C] tensor, ROWS rows per workgroup
+template <int ROWS>
+__global__ __launch_bounds__(256) void chan_stats_kernel(const float* __restrict__ x, long N, int C,
+                                                         float* __restrict__ partials /*[nblk][2][C]*/) {
+    __shared__ float4 red_s[256], red_q[256];
+    const int c4n = C >> 2;                 // float4 columns (16..128); 256 % c4n == 0
+    const int rpp = 256 / c4n;              // rows per pass
+    const int c4 = threadIdx.x % c4n, r0 = threadIdx.x / c4n;
+    const long row_base = (long)blockIdx.x * ROWS;
+    const long nrows = min((long)ROWS, N - row_base);
+    const float4* xp = reinterpret_cast<const float4*>(x) + row_base * c4n;
+    const float4 piv = xp[c4];              // pivot = first row of the tile (shifted sums: no cancellation)
+    float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
+    for (long r = r0; r < nrows; r += rpp) {
+        float4 v = xp[r * c4n + c4];
+        float dx = v.x - piv.x, dy = v.y - piv.y, dz = v.z - piv.z, dw = v.w - piv.w;
+        s.x += dx; s.y += dy; s.z += dz; s.w += dw;
+        q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
+    }
+    red_s[threadIdx.x] = s; red_q[threadIdx.x] = q;
+    __syncthreads();
+    if (threadIdx.x < c4n) {
+        for (int j = 1; j < rpp; ++j) {
+            float4 a = red_s[threadIdx.x + j * c4n], b = red_q[threadIdx.x + j * c4n];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            q.x += b.x; q.y += b.y; q.z += b.z; q.w += b.w;
+        }
+        const float n = (float)nrows, inv = 1.0f / n;
+        float4 sum = make_float4(s.x + n * piv.x, s.y + n * piv.y, s.z + n * piv.z, s.w + n * piv.w);
+        float4 m2 = make_float4(fmaxf(q.x - s.x * s.x * inv, 0.f), fmaxf(q.y - s.y * s.y * inv, 0.f),
+                                fmaxf(q.z - s.z * s.z * inv, 0.f), fmaxf(q.w - s.w * s.w * inv, 0.f));
+        float4* po = reinterpret_cast<float4*>(partials + (long)blockIdx.x * 2 * C);
+        po[c4] = sum;
+        po[c4n + c4] = m2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// stage 1 of the deterministic fp64 merge: [nparts][K] fp32 -> ws[nchunks][K] fp64.
+// MODE 0: plain column sums.  MODE 1: K = 2C laid out [sum | M2] per part -> [S1 | S2] raw moments,
+// part i holds n_i = min(rows_per_part, N - i*rows_per_part) rows.
+template <int MODE>
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ parts, int nparts, int K,
+                                                           int parts_per_chunk, long N, int rows_per_part,
+                                                           double* __restrict__ ws) {
+    const int col = blockIdx.y * 256 + threadIdx.x;
+    if (col >= K) return;
+    const int p0 = blockIdx.x * parts_per_chunk, p1 = min(nparts, p0 + parts_per_chunk);
+    double acc = 0.0;
+    if (MODE == 0) {
+        for (int p = p0; p < p1; ++p) acc += (double)parts[(long)p * K + col];
+    } else {
+        const int C = K >> 1;
+        if (col < C) {
+            for (int p = p0; p < p1; ++p) acc += (double)parts[(long)p * K + col];
+        } else {
+            for (int p = p0; p < p1; ++p) {
+                double n = (double)min((long)rows_per_part, N - (long)p * rows_per_part);
+                if (n <= 0.0) continue;              // tile rows past the end of the tensor
+                double s = (double)parts[(long)p * K + col - C];
+                acc += (double)parts[(long)p * K + col] + s * s / n;
+            }
+        }
+    }
+    ws[(long)blockIdx.x * K + col] = acc;
+}
+
+// stage 2 (training): mean / invstd / folded scale,shift / running-stat update.  nn.BatchNorm2d semantics:
+// biased variance normalises, unbiased variance is tracked, momentum 0.1 (reference models.py:87-88, :264).
+__global__ void bn_finalize_kernel(const double* __restrict__ ws, int nchunks, int C, long N,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                   float* __restrict__ scale_out, float* __restrict__ shift_out) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nchunks; ++k) { s1 += ws[(long)k * 2 * C + c]; s2 += ws[(long)k * 2 * C + C + c]; }
+    double mean = s1 / (double)N;
+    double var = s2 / (double)N - mean * mean;
+    if (var < 0.0) var = 0.0;
+    double invstd = 1.0 / sqrt(var + (double)eps);
+    float meanf = (float)mean, invf = (float)invstd;
+    float sc = gamma[c] * invf;
+    mean_out[c] = meanf; invstd_out[c] = invf;
+    scale_out[c] = sc; shift_out[c] = fmaf(-meanf, sc, beta[c]);
+    if (running_mean) {
+        double unbiased = (N > 1) ? var * (double)N / (double)(N - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+}
+
+// eval mode: fold running stats into scale/shift
+__global__ void bn_eval_affine_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                      float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                      float* __restrict__ scale_out, float* __restrict__ shift_out) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float invf = (float)(1.0 / sqrt((double)rv[c] + (double)eps));
+    float sc = gamma[c] * invf;
+    mean_out[c] = rm[c]; invstd_out[c] = invf; scale_out[c] = sc; shift_out[c] = fmaf(-rm[c], sc, beta[c]);
+}
+
+// stage 2 (backward): dbeta = sum dy, dgamma = sum dy*xhat; coefficients of g_y = a*dy + b*y + c.
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int nchunks, int C, long N,
+                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                       const float* __restrict__ scale, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ coef /*[3][C]*/) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nchunks; ++k) { s1 += ws[(long)k * 2 * C + c]; s2 += ws[(long)k * 2 * C + C + c]; }
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+    if (coef) {
+        double a = (double)scale[c];
+        double b = -a * (double)invstd[c] * s2 / (double)N;
+        double cc = -a * s1 / (double)N - b * (double)mean[c];
+        coef[c] = (float)a; coef[C + c] = (float)b; coef[2 * C + c] = (float)cc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// bn0 (folded) + SpecAugment stripes + mixup, forward.  logmel [B2][T][64] -> x0 [Bout][T][64]
+// stripes [B2][8] = {tb0,td0,tb1,td1,fb0,fd0,fb1,fd1} or null; lam [B2] or null (then Bout = B2).
+__device__ __forceinline__ bool specaug_keep(const int* st, int t, int m) {
+    bool drop = ((unsigned)(t - st[0]) < (unsigned)st[1]) | ((unsigned)(t - st[2]) < (unsigned)st[3]) |
+                ((unsigned)(m - st[4]) < (unsigned)st[5]) | ((unsigned)(m - st[6]) < (unsigned)st[7]);
+    return !drop;
+}
+
+__global__ __launch_bounds__(256) void bn0_aug_mix_fwd_kernel(const float* __restrict__ lm, int B2, int T,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift,
+                                                              const int* __restrict__ stripes,
+                                                              const float* __restrict__ lam, float* __restrict__ out) {
+    const long total4 = (long)(lam ? B2 / 2 : B2) * T * 16;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        int m4 = (int)(i & 15);
+        long bt = i >> 4;
+        int t = (int)(bt % T);
+        int bo = (int)(bt / T);
+        float4 sc = reinterpret_cast<const float4*>(scale)[m4], sh = reinterpret_cast<const float4*>(shift)[m4];
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        int nsrc = lam ? 2 : 1;
+        for (int j = 0; j < nsrc; ++j) {
+            int n = lam ? 2 * bo + j : bo;
+            float4 v = reinterpret_cast<const float4*>(lm)[((long)n * T + t) * 16 + m4];
+            float l = lam ? lam[n] : 1.0f;
+            float y[4] = {fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w)};
+            int st[8];
+            if (stripes) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) st[k] = stripes[n * 8 + k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                bool keep = stripes ? specaug_keep(st, t, m4 * 4 + k) : true;
+                float yk = keep ? y[k] : 0.0f;
+                acc[k] = lam ? fmaf(l, yk, acc[k]) : yk;
+            }
+        }
+        reinterpret_cast<float4*>(out)[i] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
+// backward of the same stage: only dgamma0/dbeta0 are needed (the waveform takes no gradient).
+// partials [nblk][2][64]: sum dy, sum dy*xhat with dy = lam*keep*g.
+__global__ __launch_bounds__(256) void bn0_aug_mix_bwd_kernel(const float* __restrict__ lm,
+                                                              const float* __restrict__ g /*[Bout][T][64]*/, int B2,
+                                                              int T, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd,
+                                                              const int* __restrict__ stripes,
+                                                              const float* __restrict__ lam, int rows_per_block,
+                                                              float* __restrict__ partials) {
+    __shared__ float4 red_a[256], red_b[256];
+    const int m4 = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+    const long nrows = (long)B2 * T;
+    const long row_base = (long)blockIdx.x * rows_per_block;
+    const long row_end = min(nrows, row_base + rows_per_block);
+    float4 mu = reinterpret_cast<const float4*>(mean)[m4], is = reinterpret_cast<const float4*>(invstd)[m4];
+    float sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+    for (long r = row_base + r0; r < row_end; r += 16) {
+        int n = (int)(r / T), t = (int)(r % T);
+        int bo = lam ? n >> 1 : n;
+        float l = lam ? lam[n] : 1.0f;
+        float4 v = reinterpret_cast<const float4*>(lm)[r * 16 + m4];
+        float4 gv = reinterpret_cast<const float4*>(g)[((long)bo * T + t) * 16 + m4];
+        int st[8];
+        if (stripes) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) st[k] = stripes[n * 8 + k];
+        }
+        float xv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
+        float muv[4] = {mu.x, mu.y, mu.z, mu.w}, isv[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bool keep = stripes ? specaug_keep(st, t, m4 * 4 + k) : true;
+            float dy = keep ? l * gg[k] : 0.0f;
+            sa[k] += dy;
+            sb[k] = fmaf(dy, (xv[k] - muv[k]) * isv[k], sb[k]);
+        }
+    }
+    red_a[threadIdx.x] = make_float4(sa[0], sa[1], sa[2], sa[3]);
+    red_b[threadIdx.x] = make_float4(sb[0], sb[1], sb[2], sb[3]);
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float4 a = red_a[threadIdx.x], b = red_b[threadIdx.x];
+        for (int j = 1; j < 16; ++j) {
+            float4 a2 = red_a[threadIdx.x + 16 * j], b2 = red_b[threadIdx.x + 16 * j];
+            a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
+            b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+        }
+        float4* po = reinterpret_cast<float4*>(partials + (long)blockIdx.x * 128);
+        po[threadIdx.x] = a;
+        po[16 + threadIdx.x] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BN(folded)+ReLU+avg-pool forward.  y [B][H][W][C] -> out [B][H/ph][W/pw][C]  (floor mode: trailing rows dropped)
+__global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __restrict__ y, int B, int H, int W, int C,
+                                                               int ph, int pw, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift,
+                                                               float* __restrict__ out) {
+    const int Ho = H / ph, Wo = W / pw, c4n = C >> 2;
+    const long total = (long)B * Ho * Wo * c4n;
+    const float inv = 1.0f / (float)(ph * pw);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int c4 = (int)(i % c4n);
+        long p = i / c4n;
+        int wo = (int)(p % Wo);
+        long q = p / Wo;
+        int ho = (int)(q % Ho);
+        int b = (int)(q / Ho);
+        float4 sc = reinterpret_cast<const float4*>(scale)[c4], sh = reinterpret_cast<const float4*>(shift)[c4];
+        float4 acc = make_float4(0, 0, 0, 0);
+        for (int dh = 0; dh < ph; ++dh)
+            for (int dw = 0; dw < pw; ++dw) {
+                long src = (((long)b * H + ho * ph + dh) * W + wo * pw + dw) * c4n + c4;
+                float4 v = reinterpret_cast<const float4*>(y)[src];
+                acc.x += bn_relu(v.x, sc.x, sh.x); acc.y += bn_relu(v.y, sc.y, sh.y);
+                acc.z += bn_relu(v.z, sc.z, sh.z); acc.w += bn_relu(v.w, sc.w, sh.w);
+            }
+        reinterpret_cast<float4*>(out)[i] = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    }
+}
+
+// backward pass 1 / pass 2 of the same stage.  dy = g_out[pooled pos]/(ph*pw) * relu-mask (0 on dropped rows).
+// PASS 1: per-block partial sums (sum dy, sum dy*xhat) -> partials[nblk][2][C]
+// PASS 2: g_y = a*dy + b*y + c  -> gy [B][H][W][C]
+template <int PASS>
+__global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const float* __restrict__ y,
+                                                               const float* __restrict__ gout, int B, int H, int W,
+                                                               int C, int ph, int pw, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd,
+                                                               const float* __restrict__ coef, int rows_per_block,
+                                                               float* __restrict__ partials, float* __restrict__ gy) {
+    __shared__ float4 red_a[256], red_b[256];
+    const int Ho = H / ph, Wo = W / pw, c4n = C >> 2;
+    const int rpp = 256 / c4n;
+    const int c4 = threadIdx.x % c4n, r0 = threadIdx.x / c4n;
+    const long nrows = (long)B * H * W;
+    const long row_base = (long)blockIdx.x * rows_per_block;
+    const long row_end = min(nrows, row_base + rows_per_block);
+    const float inv = 1.0f / (float)(ph * pw);
+    const float4 sc = reinterpret_cast<const float4*>(scale)[c4], sh = reinterpret_cast<const float4*>(shift)[c4];
+    float4 mu, is, ca, cb, cc;
+    if (PASS == 1) {
+        mu = reinterpret_cast<const float4*>(mean)[c4]; is = reinterpret_cast<const float4*>(invstd)[c4];
+    } else {
+        ca = reinterpret_cast<const float4*>(coef)[c4]; cb = reinterpret_cast<const float4*>(coef)[c4n + c4];
+        cc = reinterpret_cast<const float4*>(coef)[2 * c4n + c4];
+    }
+    float4 sa = make_float4(0, 0, 0, 0), sb = make_float4(0, 0, 0, 0);
+    for (long r = row_base + r0; r < row_end; r += rpp) {
+        int w = (int)(r % W);
+        long q = r / W;
+        int h = (int)(q % H);
+        int b = (int)(q / H);
+        int ho = h / ph, wo = w / pw;
+        float4 v = reinterpret_cast<const float4*>(y)[r * c4n + c4];
+        float4 g = make_float4(0, 0, 0, 0);
+        if (ho < Ho && wo < Wo) g = reinterpret_cast<const float4*>(gout)[(((long)b * Ho + ho) * Wo + wo) * c4n + c4];
+        float4 dy;
+        dy.x = bn_relu_active(v.x, sc.x, sh.x) ? g.x * inv : 0.f;
+        dy.y = bn_relu_active(v.y, sc.y, sh.y) ? g.y * inv : 0.f;
+        dy.z = bn_relu_active(v.z, sc.z, sh.z) ? g.z * inv : 0.f;
+        dy.w = bn_relu_active(v.w, sc.w, sh.w) ? g.w * inv : 0.f;
+        if (PASS == 1) {
+            sa.x += dy.x; sa.y += dy.y; sa.z += dy.z; sa.w += dy.w;
+            sb.x = fmaf(dy.x, (v.x - mu.x) * is.x, sb.x); sb.y = fmaf(dy.y, (v.y - mu.y) * is.y, sb.y);
+            sb.z = fmaf(dy.z, (v.z - mu.z) * is.z, sb.z); sb.w = fmaf(dy.w, (v.w - mu.w) * is.w, sb.w);
+        } else {
+            float4 o;
+            o.x = fmaf(ca.x, dy.x, fmaf(cb.x, v.x, cc.x)); o.y = fmaf(ca.y, dy.y, fmaf(cb.y, v.y, cc.y));
+            o.z = fmaf(ca.z, dy.z, fmaf(cb.z, v.z, cc.z)); o.w = fmaf(ca.w, dy.w, fmaf(cb.w, v.w, cc.w));
+            reinterpret_cast<float4*>(gy)[r * c4n + c4] = o;
+        }
+    }
+    if (PASS == 1) {
+        red_a[threadIdx.x] = sa; red_b[threadIdx.x] = sb;
+        __syncthreads();
+        if (threadIdx.x < c4n) {
+            for (int j = 1; j < rpp; ++j) {
+                float4 a2 = red_a[threadIdx.x + j * c4n], b2 = red_b[threadIdx.x + j * c4n];
+                sa.x += a2.x; sa.y += a2.y; sa.z += a2.z; sa.w += a2.w;
+                sb.x += b2.x; sb.y += b2.y; sb.z += b2.z; sb.w += b2.w;
+            }
+            float4* po = reinterpret_cast<float4*>(partials + (long)blockIdx.x * 2 * C);
+            po[c4] = sa;
+            po[c4n + c4] = sb;
+        }
+    }
+}
+
+// g_y = a*dy + b*y + c, in place on dy (the conv1-side BN backward, dy produced by the dgrad epilogue)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ dy, const float* __restrict__ y,
+                                                           long nrows, int C, const float* __restrict__ coef) {
+    const int c4n = C >> 2;
+    const long total = nrows * c4n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int c4 = (int)(i % c4n);
+        float4 ca = reinterpret_cast<const float4*>(coef)[c4], cb = reinterpret_cast<const float4*>(coef)[c4n + c4],
+               cc = reinterpret_cast<const float4*>(coef)[2 * c4n + c4];
+        float4 d = reinterpret_cast<float4*>(dy)[i], v = reinterpret_cast<const float4*>(y)[i];
+        float4 o;
+        o.x = fmaf(ca.x, d.x, fmaf(cb.x, v.x, cc.x)); o.y = fmaf(ca.y, d.y, fmaf(cb.y, v.y, cc.y));
+        o.z = fmaf(ca.z, d.z, fmaf(cb.z, v.z, cc.z)); o.w = fmaf(ca.w, d.w, fmaf(cb.w, v.w, cc.w));
+        reinterpret_cast<float4*>(dy)[i] = o;
+    }
+}
+
+int stream_grid(long work_items) {
+    long blocks = (work_items + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+int reduce_chunks(int nparts) {
+    int ppc = sed_cdiv(nparts, 256);
+    if (ppc < 8) ppc = 8;
+    return ppc;
+}
+
+}  // namespace
+
+// ---- C ABI --------------------------------------------------------------------------------------------
+
+// Partial statistics of x [N][C] in tiles of 1024 rows.  partials must hold ceil(N/1024)*2*C floats.
+SED_API int sed_chan_stats(const float* x, long N, int C, float* partials, hipStream_t stream) {
+    if (N <= 0 || C < 64 || C > 512 || (256 % (C / 4)) != 0) return SED_EINVAL;
+    hipLaunchKernelGGL(chan_stats_kernel<1024>, dim3(sed_cdiv(N, 1024)), dim3(256), 0, stream, x, N, C, partials);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+SED_API int sed_stats_rows_per_part(void) { return 1024; }
+
+// ws: at least 256*2*C doubles.
+SED_API int sed_bn_finalize(const float* partials, int nparts, int rows_per_part, long N, int C, const float* gamma,
+                            const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                            float* mean_out, float* invstd_out, float* scale_out, float* shift_out, double* ws,
+                            hipStream_t stream) {
+    if (nparts <= 0 || C <= 0 || N <= 0) return SED_EINVAL;
+    int ppc = reduce_chunks(nparts), nchunks = sed_cdiv(nparts, ppc), K = 2 * C;
+    hipLaunchKernelGGL(reduce_parts_kernel<1>, dim3(nchunks, sed_cdiv(K, 256)), dim3(256), 0, stream, partials, nparts, K,
+                       ppc, N, rows_per_part, ws);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(sed_cdiv(C, 64)), dim3(64), 0, stream, ws, nchunks, C, N, gamma, beta, eps,
+                       momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+SED_API int sed_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
+                               const float* running_var, float eps, float* mean_out, float* invstd_out,
+                               float* scale_out, float* shift_out, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(sed_cdiv(C, 64)), dim3(64), 0, stream, C, gamma, beta, running_mean,
+                       running_var, eps, mean_out, invstd_out, scale_out, shift_out);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// partials [nparts][2][C] = (sum dy, sum dy*xhat).  coef may be null (bn0: only dgamma/dbeta wanted).
+SED_API int sed_bn_bwd_finalize(const float* partials, int nparts, long N, int C, const float* mean,
+                                const float* invstd, const float* scale, float* dgamma, float* dbeta, float* coef,
+                                double* ws, hipStream_t stream) {
+    if (nparts <= 0 || C <= 0 || N <= 0) return SED_EINVAL;
+    int ppc = reduce_chunks(nparts), nchunks = sed_cdiv(nparts, ppc), K = 2 * C;
+    hipLaunchKernelGGL(reduce_parts_kernel<0>, dim3(nchunks, sed_cdiv(K, 256)), dim3(256), 0, stream, partials, nparts, K,
+                       ppc, N, 0, ws);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sed_cdiv(C, 64)), dim3(64), 0, stream, ws, nchunks, C, N, mean, invstd,
+                       scale, dgamma, dbeta, coef);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+SED_API int sed_bn0_aug_mix_fwd(const float* logmel, int B2, int T, const float* scale, const float* shift,
+                                const int* stripes, const float* lam, float* out, hipStream_t stream) {
+    if (B2 <= 0 || T <= 0 || (lam && (B2 & 1))) return SED_EINVAL;
+    long total4 = (long)(lam ? B2 / 2 : B2) * T * 16;
+    hipLaunchKernelGGL(bn0_aug_mix_fwd_kernel, dim3(stream_grid(total4)), dim3(256), 0, stream, logmel, B2, T, scale, shift,
+                       stripes, lam, out);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// partials must hold ceil(B2*T/1024)*128 floats; returns the number of parts through *nparts_out (host int).
+SED_API int sed_bn0_aug_mix_bwd(const float* logmel, const float* g_out, int B2, int T, const float* mean,
+                                const float* invstd, const int* stripes, const float* lam, float* partials,
+                                int* nparts_out, hipStream_t stream) {
+    if (B2 <= 0 || T <= 0 || (lam && (B2 & 1))) return SED_EINVAL;
+    int nblk = sed_cdiv((long)B2 * T, 1024);
+    hipLaunchKernelGGL(bn0_aug_mix_bwd_kernel, dim3(nblk), dim3(256), 0, stream, logmel, g_out, B2, T, mean, invstd, stripes,
+                       lam, 1024, partials);
+    if (nparts_out) *nparts_out = nblk;
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+SED_API int sed_bn_relu_pool_fwd(const float* y, int B, int H, int W, int C, int ph, int pw, const float* scale,
+                                 const float* shift, float* out, hipStream_t stream) {
+    if (B <= 0 || (C & 3) || ph <= 0 || pw <= 0 || H / ph <= 0 || W / pw <= 0) return SED_EINVAL;
+    long total = (long)B * (H / ph) * (W / pw) * (C / 4);
+    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(stream_grid(total)), dim3(256), 0, stream, y, B, H, W, C, ph, pw, scale,
+                       shift, out);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// pass 1: partials must hold ceil(B*H*W/1024)*2*C floats
+SED_API int sed_bn_relu_pool_bwd_reduce(const float* y, const float* g_out, int B, int H, int W, int C, int ph, int pw,
+                                        const float* scale, const float* shift, const float* mean,
+                                        const float* invstd, float* partials, int* nparts_out, hipStream_t stream) {
+    if (B <= 0 || C < 64 || C > 512 || (256 % (C / 4)) != 0) return SED_EINVAL;
+    int nblk = sed_cdiv((long)B * H * W, 1024);
+    hipLaunchKernelGGL(bn_relu_pool_bwd_kernel<1>, dim3(nblk), dim3(256), 0, stream, y, g_out, B, H, W, C, ph, pw, scale, shift,
+                       mean, invstd, (const float*)nullptr, 1024, partials, (float*)nullptr);
+    if (nparts_out) *nparts_out = nblk;
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// pass 2: gy [B][H][W][C]
+SED_API int sed_bn_relu_pool_bwd_apply(const float* y, const float* g_out, int B, int H, int W, int C, int ph, int pw,
+                                       const float* scale, const float* shift, const float* coef, float* gy,
+                                       hipStream_t stream) {
+    if (B <= 0 || C < 64 || C > 512 || (256 % (C / 4)) != 0) return SED_EINVAL;
+    int nblk = sed_cdiv((long)B * H * W, 1024);
+    hipLaunchKernelGGL(bn_relu_pool_bwd_kernel<2>, dim3(nblk), dim3(256), 0, stream, y, g_out, B, H, W, C, ph, pw, scale, shift,
+                       (const float*)nullptr, (const float*)nullptr, coef, 1024, (float*)nullptr, gy);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+SED_API int sed_bn_bwd_apply(float* dy_inout, const float* y, long nrows, int C, const float* coef, hipStream_t stream) {
+    if (nrows <= 0 || (C & 3)) return SED_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(nrows * (C / 4))), dim3(256), 0, stream, dy_inout, y, nrows, C,
+                       coef);
+    SED_LAUNCH_CHECK();
+    return 0;
+}

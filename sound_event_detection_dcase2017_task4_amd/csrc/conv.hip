@@ -1,0 +1,666 @@
+// 3x3 convolution (stride 1, pad 1, no bias) for the ConvBlocks of reference pytorch/models.py:72-115, NHWC.
+//
+//  * conv_igemm_kernel  : implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32; exact fp32, needed for the 1e-4
+//    parity budget).  M = B*H*W pixels, N = Cout, K = 9*Cin.  Used for forward AND dgrad (dgrad = the same
+//    kernel over the tap-flipped, transposed weight pack).  Optional fusions:
+//      - input operand transform  a = relu(scale*y + shift)  (the previous BN+ReLU, never materialised);
+//      - epilogue 1: per-channel BatchNorm partial statistics (sum, M2) of the raw conv output;
+//      - epilogue 2: ReLU mask of the previous BN + BN-backward partial sums (sum dy, sum dy*xhat);
+//      - epilogue 3: bias add (NTAPS=1: plain NT GEMM for the GRU / dense heads).
+//  * wgrad_kernel       : dW[tap][co][ci] = sum_p gy[p][co] * a[p+tap][ci], fp32 MFMA, split over pixel slices.
+//  * conv1 (Cin = 1)    : K = 9 is HBM-bound (AI 4.4 flop/B): direct kernels, no MFMA.
+#include "common.h"
+#include "sed_hip.h"
+
+namespace {
+
+constexpr int LDS_STRIDE = 36;   // 32 floats + 4 pad: ds_read_b128 of 16 distinct rows hits 16 distinct 16-B slots
+
+struct ConvP {
+    const float* x;          // [M][K] NHWC input (raw previous conv output if in_scale != null)
+    const float* w;          // [NTAPS][N][K] packed weights
+    float* y;                // [M][N]
+    const float* in_scale;   // [K] or null
+    const float* in_shift;
+    float* partials;         // EPI 1/2: [ceil(M/BM)*WM][2][N]
+    const float* yprev;      // EPI 2: raw output of the conv whose BN+ReLU produced this layer's input grad mask
+    const float* p_scale;    // EPI 2: [N] ; EPI 3: unused
+    const float* p_shift;    // EPI 2: [N] ; EPI 3: bias [N]
+    const float* p_mean;     // EPI 2
+    const float* p_invstd;   // EPI 2
+    int H, W, K, N;
+    long M;
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+template <int WM, int WN, int TM, int TN, int NTAPS, bool INT, int EPI>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int A_LD = BM * 8 / 256, B_LD = BN * 8 / 256;
+    static_assert(WM * WN == 4, "4 waves");
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_STRIDE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv / WN, wn = wv % WN;
+    const int nt_n = p.N / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const long m0 = (long)(tile / nt_n) * BM;
+    const int n0 = (tile % nt_n) * BN;
+    const int c4 = tid & 7, lrow = tid >> 3;
+
+    // per-row metadata of the A rows this thread stages
+    int rpix[A_LD], rh[A_LD], rw[A_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+        long pm = m0 + lrow + 32 * i;
+        if (pm < p.M) {
+            rpix[i] = (int)pm;
+            if (NTAPS == 9) { rw[i] = (int)(pm % p.W); rh[i] = (int)((pm / p.W) % p.H); } else { rw[i] = 0; rh[i] = 0; }
+        } else { rpix[i] = 0; rh[i] = -(1 << 20); rw[i] = -(1 << 20); }
+    }
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int kchunks = p.K >> 5;
+    const int KT = kchunks * NTAPS;
+    float4 areg[A_LD], breg[B_LD];
+
+    auto gload = [&](int it) {
+        const int tap = (NTAPS == 9) ? it % 9 : 0;
+        const int c0 = ((NTAPS == 9) ? it / 9 : it) << 5;
+        const int dy = (NTAPS == 9) ? tap / 3 - 1 : 0, dx = (NTAPS == 9) ? tap % 3 - 1 : 0;
+        float4 sc, sh;
+        if (INT) {
+            sc = *reinterpret_cast<const float4*>(p.in_scale + c0 + c4 * 4);
+            sh = *reinterpret_cast<const float4*>(p.in_shift + c0 + c4 * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            bool valid = (NTAPS == 9) ? ((unsigned)(rh[i] + dy) < (unsigned)p.H && (unsigned)(rw[i] + dx) < (unsigned)p.W)
+                                      : (rh[i] >= 0);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) {
+                const float* src = p.x + (long)(rpix[i] + dy * p.W + dx) * p.K + c0 + c4 * 4;
+                v = *reinterpret_cast<const float4*>(src);
+                if (INT) {
+                    v.x = bn_relu(v.x, sc.x, sh.x); v.y = bn_relu(v.y, sc.y, sh.y);
+                    v.z = bn_relu(v.z, sc.z, sh.z); v.w = bn_relu(v.w, sc.w, sh.w);
+                }
+            }
+            areg[i] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            const float* src = p.w + ((long)tap * p.N + n0 + lrow + 32 * j) * p.K + c0 + c4 * 4;
+            breg[j] = *reinterpret_cast<const float4*>(src);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i)
+            *reinterpret_cast<float4*>(&As[buf][(lrow + 32 * i) * LDS_STRIDE + c4 * 4]) = areg[i];
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j)
+            *reinterpret_cast<float4*>(&Bs[buf][(lrow + 32 * j) * LDS_STRIDE + c4 * 4]) = breg[j];
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int arow = (wm * TM * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
+    const int brow = (wn * TN * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
+    for (int it = 0; it < KT; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < KT) gload(it + 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const float4*>(&As[buf][arow + a * 32 * LDS_STRIDE + q * 8]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const float4*>(&Bs[buf][brow + b * 32 * LDS_STRIDE + q * 8]);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].x, bf[b].x, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].y, bf[b].y, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].z, bf[b].z, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
+                }
+        }
+        if (it + 1 < KT) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const long wrow0 = m0 + wm * TM * 32;
+    const int half = lane >> 5;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int col = n0 + wn * TN * 32 + b * 32 + (lane & 31);
+        float s1 = 0.f, s2 = 0.f;
+        float e_sc = 0.f, e_sh = 0.f, e_mu = 0.f, e_is = 0.f, bias = 0.f;
+        if (EPI == 2) { e_sc = p.p_scale[col]; e_sh = p.p_shift[col]; e_mu = p.p_mean[col]; e_is = p.p_invstd[col]; }
+        if (EPI == 3) bias = p.p_shift[col];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                long row = wrow0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float v = acc[a][b][r];
+                if (row < p.M) {
+                    if (EPI == 2) {
+                        float yv = p.yprev[row * p.N + col];
+                        v = bn_relu_active(yv, e_sc, e_sh) ? v : 0.f;
+                        s1 += v;
+                        s2 = fmaf(v, (yv - e_mu) * e_is, s2);
+                        acc[a][b][r] = v;
+                    }
+                    if (EPI == 3) v += bias;
+                    if (EPI == 1) s1 += v;
+                    p.y[row * p.N + col] = v;
+                }
+            }
+        if (EPI == 1) {
+            long cnt_l = p.M - wrow0;
+            float cnt = (float)(cnt_l < 0 ? 0 : (cnt_l > TM * 32 ? TM * 32 : cnt_l));
+            s1 += __shfl_xor(s1, 32, 64);
+            float mean = cnt > 0.f ? s1 / cnt : 0.f;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    long row = wrow0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float d = acc[a][b][r] - mean;
+                    if (row < p.M) s2 = fmaf(d, d, s2);
+                }
+            s2 += __shfl_xor(s2, 32, 64);
+        }
+        if (EPI == 2) { s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64); }
+        if ((EPI == 1 || EPI == 2) && half == 0) {
+            long part = (m0 / BM) * WM + wm;
+            p.partials[(part * 2 + 0) * p.N + col] = s1;
+            p.partials[(part * 2 + 1) * p.N + col] = s2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct WgradP {
+    const float* x;          // [M][K] layer input (raw previous conv output if in_scale != null)
+    const float* gy;         // [M][N] gradient wrt this conv's output
+    float* partial;          // [nslices][NTAPS][N][K]
+    const float* in_scale;
+    const float* in_shift;
+    int H, W, K, N;
+    long M;
+    int pix_per_slice;
+};
+
+template <int TM, int TN, int NTAPS, bool INT>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
+    constexpr int CO_T = 64 * TM, CI_T = 64 * TN, BKP = 32;
+    constexpr int G_C4 = 16 * TM, X_C4 = 16 * TN;
+    constexpr int G_RPP = 256 / G_C4, X_RPP = 256 / X_C4;
+    constexpr int G_LD = BKP / G_RPP, X_LD = BKP / X_RPP;
+    __shared__ __attribute__((aligned(16))) float Gs[2][BKP * CO_T];
+    __shared__ __attribute__((aligned(16))) float Xs[2][BKP * CI_T];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int ci_tiles = p.K / CI_T;
+    int id = blockIdx.x;
+    const int tap = (NTAPS == 9) ? id % 9 : 0;
+    id = (NTAPS == 9) ? id / 9 : id;
+    const int ci0 = (id % ci_tiles) * CI_T, co0 = (id / ci_tiles) * CO_T;
+    const int dy = (NTAPS == 9) ? tap / 3 - 1 : 0, dx = (NTAPS == 9) ? tap % 3 - 1 : 0;
+    const long pbeg = (long)blockIdx.y * p.pix_per_slice;
+    long pend = pbeg + p.pix_per_slice;
+    if (pend > p.M) pend = p.M;
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int g_c4 = tid % G_C4, g_r = tid / G_C4;
+    const int x_c4 = tid % X_C4, x_r = tid / X_C4;
+    float4 xsc, xsh;
+    if (INT) {
+        xsc = *reinterpret_cast<const float4*>(p.in_scale + ci0 + x_c4 * 4);
+        xsh = *reinterpret_cast<const float4*>(p.in_shift + ci0 + x_c4 * 4);
+    }
+    float4 greg[G_LD], xreg[X_LD];
+    auto gload = [&](long pb) {
+#pragma unroll
+        for (int i = 0; i < G_LD; ++i) {
+            long pm = pb + g_r + G_RPP * i;
+            greg[i] = (pm < pend) ? *reinterpret_cast<const float4*>(p.gy + pm * p.N + co0 + g_c4 * 4)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < X_LD; ++i) {
+            long pm = pb + x_r + X_RPP * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool valid = pm < pend;
+            if (NTAPS == 9 && valid) {
+                unsigned pu = (unsigned)pm;            // M < 2^31: 32-bit divides
+                int w = (int)(pu % (unsigned)p.W), h = (int)((pu / (unsigned)p.W) % (unsigned)p.H);
+                valid = (unsigned)(h + dy) < (unsigned)p.H && (unsigned)(w + dx) < (unsigned)p.W;
+            }
+            if (valid) {
+                v = *reinterpret_cast<const float4*>(p.x + (pm + dy * p.W + dx) * p.K + ci0 + x_c4 * 4);
+                if (INT) {
+                    v.x = bn_relu(v.x, xsc.x, xsh.x); v.y = bn_relu(v.y, xsc.y, xsh.y);
+                    v.z = bn_relu(v.z, xsc.z, xsh.z); v.w = bn_relu(v.w, xsc.w, xsh.w);
+                }
+            }
+            xreg[i] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < G_LD; ++i)
+            *reinterpret_cast<float4*>(&Gs[buf][(g_r + G_RPP * i) * CO_T + g_c4 * 4]) = greg[i];
+#pragma unroll
+        for (int i = 0; i < X_LD; ++i)
+            *reinterpret_cast<float4*>(&Xs[buf][(x_r + X_RPP * i) * CI_T + x_c4 * 4]) = xreg[i];
+    };
+
+    const int nsteps = (int)((pend - pbeg + BKP - 1) / BKP);
+    if (nsteps > 0) {
+        gload(pbeg);
+        lstore(0);
+    }
+    __syncthreads();
+    const int half = lane >> 5;
+    const int gcol = wm * 32 * TM + (lane & 31), xcol = wn * 32 * TN + (lane & 31);
+    for (int it = 0; it < nsteps; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nsteps) gload(pbeg + (long)(it + 1) * BKP);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[a] = Gs[buf][(2 * j + half) * CO_T + gcol + a * 32];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bf[b] = Xs[buf][(2 * j + half) * CI_T + xcol + b * 32];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        if (it + 1 < nsteps) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    float* out = p.partial + ((long)blockIdx.y * NTAPS + tap) * p.N * p.K;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int co = co0 + wm * 32 * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                int ci = ci0 + wn * 32 * TN + b * 32 + (lane & 31);
+                out[(long)co * p.K + ci] = acc[a][b][r];
+            }
+}
+
+// sum the pixel-slice partials in fp64 and scatter into the reference's OIHW gradient layout
+// (NTAPS == 9: out[co][ci][tap]; NTAPS == 1: out[n][k]).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nslices, int ntaps,
+                                                           int N, int K, float* __restrict__ out) {
+    const long per = (long)ntaps * N * K;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
+        double s = 0.0;
+        for (int sl = 0; sl < nslices; ++sl) s += (double)partial[(long)sl * per + i];
+        int ci = (int)(i % K);
+        long q = i / K;
+        int co = (int)(q % N);
+        int tap = (int)(q / N);
+        out[((long)co * K + ci) * ntaps + tap] = (float)s;
+    }
+}
+
+// OIHW master weights -> forward pack wf[tap][co][ci] and dgrad pack wd[tap'][ci][co] = W[co][ci][8-tap']
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, int Cout, int Cin,
+                                                           float* __restrict__ wf, float* __restrict__ wd) {
+    const long total = (long)Cout * Cin * 9;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int tap = (int)(i % 9);
+        long q = i / 9;
+        int ci = (int)(q % Cin), co = (int)(q / Cin);
+        float v = w[i];
+        if (wf) wf[((long)tap * Cout + co) * Cin + ci] = v;
+        if (wd) wd[((long)(8 - tap) * Cin + ci) * Cout + co] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// conv_block1.conv1: Cin = 1 -> Cout = 64, direct.  x0 [M] (M = B*H*W), w [64][1][3][3] (OIHW), y [M][64].
+// Also emits BN partial statistics (sum, M2) per 256-pixel tile via pivot-shifted sums.
+constexpr int C1_ROWS = 256;
+
+__device__ __forceinline__ void c1_taps(const float* __restrict__ x0, long pm, int H, int W, float (&xs)[9]) {
+    int w = (int)(pm % W), h = (int)((pm / W) % H);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        int dy = t / 3 - 1, dx = t % 3 - 1;
+        bool valid = (unsigned)(h + dy) < (unsigned)H && (unsigned)(w + dx) < (unsigned)W;
+        xs[t] = valid ? x0[pm + dy * W + dx] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x0, const float* __restrict__ w,
+                                                        long M, int H, int W, float* __restrict__ y,
+                                                        float* __restrict__ partials) {
+    __shared__ float4 red_s[256], red_q[256];
+    const int c4 = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    float wr[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wr[t][k] = w[(c4 * 4 + k) * 9 + t];
+    const long base = (long)blockIdx.x * C1_ROWS;
+    const long nrows = min((long)C1_ROWS, M - base);
+    float piv[4] = {0, 0, 0, 0};
+    {
+        float xs[9];
+        c1_taps(x0, base, H, W, xs);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) piv[k] = fmaf(xs[t], wr[t][k], piv[k]);
+    }
+    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    for (int r = pl; r < nrows; r += 16) {
+        long pm = base + r;
+        float xs[9], o[4] = {0, 0, 0, 0};
+        c1_taps(x0, pm, H, W, xs);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = fmaf(xs[t], wr[t][k], o[k]);
+        reinterpret_cast<float4*>(y)[pm * 16 + c4] = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { float d = o[k] - piv[k]; s[k] += d; q[k] = fmaf(d, d, q[k]); }
+    }
+    if (partials) {
+        red_s[threadIdx.x] = make_float4(s[0], s[1], s[2], s[3]);
+        red_q[threadIdx.x] = make_float4(q[0], q[1], q[2], q[3]);
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            float4 a = red_s[threadIdx.x], b = red_q[threadIdx.x];
+            for (int j = 1; j < 16; ++j) {
+                float4 a2 = red_s[threadIdx.x + 16 * j], b2 = red_q[threadIdx.x + 16 * j];
+                a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
+                b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+            }
+            float n = (float)nrows, inv = 1.0f / n;
+            float4* po = reinterpret_cast<float4*>(partials + (long)blockIdx.x * 128);
+            po[threadIdx.x] = make_float4(a.x + n * piv[0], a.y + n * piv[1], a.z + n * piv[2], a.w + n * piv[3]);
+            po[16 + threadIdx.x] = make_float4(fmaxf(b.x - a.x * a.x * inv, 0.f), fmaxf(b.y - a.y * a.y * inv, 0.f),
+                                               fmaxf(b.z - a.z * a.z * inv, 0.f), fmaxf(b.w - a.w * a.w * inv, 0.f));
+        }
+    }
+}
+
+// backward of the Cin=1 conv: one pass over gy produces (i) per-block dW partials [nblk][9][64] and
+// (ii) t[p][tap] = <gy[p][:], w[:, tap]> (the scatter form of dgrad); conv1_dgrad_gather then sums 9 neighbours.
+constexpr int C1B_ROWS = 1024;
+__global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict__ x0, const float* __restrict__ w,
+                                                        const float* __restrict__ gy, long M, int H, int W,
+                                                        float* __restrict__ dw_partials, float* __restrict__ tbuf) {
+    __shared__ float red[16][9 * 64 + 4];
+    const int c4 = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    float wr[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wr[t][k] = w[(c4 * 4 + k) * 9 + t];
+    float dw[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dw[t][k] = 0.f;
+    const long base = (long)blockIdx.x * C1B_ROWS;
+    const long nrows = min((long)C1B_ROWS, M - base);
+    for (int r = pl; r < nrows; r += 16) {
+        long pm = base + r;
+        float4 g = reinterpret_cast<const float4*>(gy)[pm * 16 + c4];
+        float xs[9];
+        c1_taps(x0, pm, H, W, xs);
+        float tp[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            dw[t][0] = fmaf(g.x, xs[t], dw[t][0]); dw[t][1] = fmaf(g.y, xs[t], dw[t][1]);
+            dw[t][2] = fmaf(g.z, xs[t], dw[t][2]); dw[t][3] = fmaf(g.w, xs[t], dw[t][3]);
+            tp[t] = g.x * wr[t][0] + g.y * wr[t][1] + g.z * wr[t][2] + g.w * wr[t][3];
+        }
+        if (tbuf) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                float v = tp[t];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                tp[t] = v;
+            }
+            if (c4 < 9) {
+                float v = tp[0];
+#pragma unroll
+                for (int t = 1; t < 9; ++t) v = (c4 == t) ? tp[t] : v;
+                tbuf[pm * 9 + c4] = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[pl][t * 64 + c4 * 4 + k] = dw[t][k];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * 64; i += 256) {
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v += red[j][i];
+        dw_partials[(long)blockIdx.x * 576 + i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void conv1_dgrad_gather_kernel(const float* __restrict__ tbuf, long M, int H, int W,
+                                                                 float* __restrict__ gx0) {
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < M; q += (long)gridDim.x * 256) {
+        int w = (int)(q % W), h = (int)((q / W) % H);
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            int dy = t / 3 - 1, dx = t % 3 - 1;        // forward: y[p] += x[p + (dy,dx)] * w[t]  =>  p = q - (dy,dx)
+            bool valid = (unsigned)(h - dy) < (unsigned)H && (unsigned)(w - dx) < (unsigned)W;
+            if (valid) s += tbuf[(q - dy * W - dx) * 9 + t];
+        }
+        gx0[q] = s;
+    }
+}
+
+// dW[co][0][tap] = sum over blocks of dw_partials[blk][tap][co]
+__global__ void conv1_wgrad_reduce_kernel(const float* __restrict__ parts, int nblk, float* __restrict__ dw) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 576) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)parts[(long)b * 576 + i];
+    int tap = i / 64, co = i % 64;
+    dw[co * 9 + tap] = (float)s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN, int NTAPS>
+int launch_igemm(const ConvP& p, bool in_transform, int epi, hipStream_t stream) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    if (p.N % BN != 0 || p.K % 32 != 0) return SED_EINVAL;
+    dim3 grid((unsigned)(sed_cdiv(p.M, BM) * (p.N / BN))), block(256);
+#define SED_LAUNCH(INT_, EPI_) \
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, TM, TN, NTAPS, INT_, EPI_>), grid, block, 0, stream, p)
+    if (in_transform) {
+        if (epi == 0) SED_LAUNCH(true, 0); else if (epi == 1) SED_LAUNCH(true, 1); else return SED_EINVAL;
+    } else {
+        if (epi == 0) SED_LAUNCH(false, 0); else if (epi == 1) SED_LAUNCH(false, 1);
+        else if (epi == 2) SED_LAUNCH(false, 2); else if (epi == 3) SED_LAUNCH(false, 3); else return SED_EINVAL;
+    }
+#undef SED_LAUNCH
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int TM, int TN, int NTAPS>
+int launch_wgrad(const WgradP& p, int nslices, bool in_transform, hipStream_t stream) {
+    if (p.N % (64 * TM) != 0 || p.K % (64 * TN) != 0) return SED_EINVAL;
+    dim3 grid((unsigned)(NTAPS * (p.N / (64 * TM)) * (p.K / (64 * TN))), (unsigned)nslices), block(256);
+    if (in_transform) hipLaunchKernelGGL((wgrad_kernel<TM, TN, NTAPS, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((wgrad_kernel<TM, TN, NTAPS, false>), grid, block, 0, stream, p);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+// ---- C ABI --------------------------------------------------------------------------------------------
+
+// rows covered by one statistics partial of sed_conv3x3_igemm for a given Cout (depends on the tile config)
+SED_API int sed_conv_rows_per_part(int Cout) { return Cout >= 128 ? 64 : 32; }
+SED_API int sed_conv_num_parts(long M, int Cout) { return sed_cdiv(M, 128) * (Cout >= 128 ? 2 : 4); }
+
+// Forward or dgrad 3x3 conv on fp32 MFMA.  x [B*H*W][Cin], w_packed [9][Cout][Cin], y [B*H*W][Cout].
+//   epi 0: plain store.   epi 1: + BN statistics partials (sum, M2) of y.
+//   epi 2: y <- y * [relu mask of (p_scale*yprev + p_shift)], + partials (sum dy, sum dy*xhat)   (dgrad side)
+//   in_scale/in_shift != null: the input operand is relu(in_scale*x + in_shift) computed on the fly.
+SED_API int sed_conv3x3_igemm(const float* x, const float* w_packed, float* y, int B, int H, int W, int Cin, int Cout,
+                              const float* in_scale, const float* in_shift, int epi, float* partials,
+                              const float* yprev, const float* p_scale, const float* p_shift, const float* p_mean,
+                              const float* p_invstd, hipStream_t stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin % 32 != 0 || Cout % 64 != 0) return SED_EINVAL;
+    if ((long)B * H * W * (long)(Cin > Cout ? Cin : Cout) >= (1L << 31) * 16L) return SED_EINVAL;
+    if ((long)B * H * W >= (1L << 31)) return SED_EINVAL;
+    ConvP p{x, w_packed, y, in_scale, in_shift, partials, yprev, p_scale, p_shift, p_mean, p_invstd, H, W, Cin, Cout,
+            (long)B * H * W};
+    bool in_t = in_scale != nullptr;
+    if (Cout >= 128) return launch_igemm<2, 2, 2, 2, 9>(p, in_t, epi, stream);
+    return launch_igemm<4, 1, 1, 2, 9>(p, in_t, epi, stream);
+}
+
+// Plain fp32-MFMA GEMM, "NT": y[M][N] = x[M][K] * w[N][K]^T (+ bias[N]).  K % 32 == 0, N % 64 == 0.
+SED_API int sed_gemm_nt(const float* x, const float* w, const float* bias, float* y, long M, int N, int K,
+                        hipStream_t stream) {
+    if (M <= 0 || K % 32 != 0 || N % 64 != 0 || M >= (1L << 31)) return SED_EINVAL;
+    ConvP p{x, w, y, nullptr, nullptr, nullptr, nullptr, nullptr, bias, nullptr, nullptr, 1, 1, K, N, M};
+    int epi = bias ? 3 : 0;
+    if (N % 128 == 0 && M >= 4096) return launch_igemm<2, 2, 2, 2, 1>(p, false, epi, stream);
+    return launch_igemm<2, 2, 1, 1, 1>(p, false, epi, stream);
+}
+
+SED_API long sed_wgrad_partial_floats(long M, int Cin, int Cout, int ntaps, int* nslices_out, int* pix_per_slice_out) {
+    // slices: bound the fp32 accumulation chain (<= 16384 pixels) and fill the chip (>= ~1024 workgroups)
+    long tiles = (long)ntaps * sed_cdiv(Cout, Cout >= 128 ? 128 : 64) * sed_cdiv(Cin, Cin >= 128 ? 128 : 64);
+    long want = (1024 + tiles - 1) / tiles;
+    long by_chain = (M + 16383) / 16384;
+    long ns = want > by_chain ? want : by_chain;
+    long pps = ((M + ns - 1) / ns + 31) / 32 * 32;
+    if (pps < 32) pps = 32;
+    ns = (M + pps - 1) / pps;
+    if (nslices_out) *nslices_out = (int)ns;
+    if (pix_per_slice_out) *pix_per_slice_out = (int)pps;
+    return ns * ntaps * (long)Cin * Cout;
+}
+
+// dW (OIHW, [Cout][Cin][3][3]) = sum_p gy[p][co] * a[p+tap][ci];  a = relu(in_scale*x+in_shift) if in_scale.
+// partial: scratch of sed_wgrad_partial_floats(...) floats.
+SED_API int sed_conv3x3_wgrad(const float* x, const float* gy, float* dw_oihw, float* partial, int B, int H, int W,
+                              int Cin, int Cout, const float* in_scale, const float* in_shift, hipStream_t stream) {
+    if (B <= 0 || Cin % 64 != 0 || Cout % 64 != 0 || (long)B * H * W >= (1L << 31)) return SED_EINVAL;
+    long M = (long)B * H * W;
+    int ns, pps;
+    sed_wgrad_partial_floats(M, Cin, Cout, 9, &ns, &pps);
+    WgradP p{x, gy, partial, in_scale, in_shift, H, W, Cin, Cout, M, pps};
+    bool in_t = in_scale != nullptr;
+    int rc;
+    if (Cout >= 128 && Cin >= 128) rc = launch_wgrad<2, 2, 9>(p, ns, in_t, stream);
+    else if (Cout >= 128) rc = launch_wgrad<2, 1, 9>(p, ns, in_t, stream);
+    else rc = launch_wgrad<1, 1, 9>(p, ns, in_t, stream);
+    if (rc) return rc;
+    long per = 9L * Cin * Cout;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(sed_cdiv(per, 256) > 4096 ? 4096 : sed_cdiv(per, 256)), dim3(256), 0, stream,
+                       partial, ns, 9, Cout, Cin, dw_oihw);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// "TN" GEMM: dw[N][K] = sum_m gy[m][n] * x[m][k]   (weight gradients of the dense layers).  N,K % 64 == 0.
+SED_API int sed_gemm_tn(const float* x, const float* gy, float* dw, float* partial, long M, int N, int K,
+                        hipStream_t stream) {
+    if (M <= 0 || N % 64 != 0 || K % 64 != 0 || M >= (1L << 31)) return SED_EINVAL;
+    int ns, pps;
+    sed_wgrad_partial_floats(M, K, N, 1, &ns, &pps);
+    WgradP p{x, gy, partial, nullptr, nullptr, 1, 1, K, N, M, pps};
+    int rc;
+    if (N >= 128 && K >= 128) rc = launch_wgrad<2, 2, 1>(p, ns, false, stream);
+    else if (N >= 128) rc = launch_wgrad<2, 1, 1>(p, ns, false, stream);
+    else rc = launch_wgrad<1, 1, 1>(p, ns, false, stream);
+    if (rc) return rc;
+    long per = (long)N * K;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(sed_cdiv(per, 256) > 4096 ? 4096 : sed_cdiv(per, 256)), dim3(256), 0, stream,
+                       partial, ns, 1, N, K, dw);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// OIHW -> wf [9][Cout][Cin] (forward) and wd [9][Cin][Cout] tap-flipped (dgrad).  Either output may be null.
+SED_API int sed_pack_conv_weights(const float* w_oihw, int Cout, int Cin, float* wf, float* wd, hipStream_t stream) {
+    long total = (long)Cout * Cin * 9;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(sed_cdiv(total, 256) > 2048 ? 2048 : sed_cdiv(total, 256)), dim3(256), 0, stream,
+                       w_oihw, Cout, Cin, wf, wd);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// conv_block1.conv1 (Cin=1, Cout=64).  partials (nullable): ceil(M/256)*128 floats, rows per part = 256.
+SED_API int sed_conv1_fwd(const float* x0, const float* w_oihw, float* y, int B, int H, int W, float* partials,
+                          hipStream_t stream) {
+    long M = (long)B * H * W;
+    if (M <= 0 || M >= (1L << 31)) return SED_EINVAL;
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(sed_cdiv(M, C1_ROWS)), dim3(256), 0, stream, x0, w_oihw, M, H, W, y, partials);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+SED_API int sed_conv1_rows_per_part(void) { return C1_ROWS; }
+
+// backward of conv_block1.conv1: dw [64][1][3][3]; gx0 [M] (nullable: skip the input gradient).
+// scratch: dw_partials ceil(M/1024)*576 floats; tbuf M*9 floats (only if gx0).
+SED_API int sed_conv1_bwd(const float* x0, const float* w_oihw, const float* gy, int B, int H, int W, float* dw,
+                          float* gx0, float* dw_partials, float* tbuf, hipStream_t stream) {
+    long M = (long)B * H * W;
+    if (M <= 0 || M >= (1L << 31) / 9) return SED_EINVAL;
+    int nblk = sed_cdiv(M, C1B_ROWS);
+    hipLaunchKernelGGL(conv1_bwd_kernel, dim3(nblk), dim3(256), 0, stream, x0, w_oihw, gy, M, H, W, dw_partials,
+                       gx0 ? tbuf : (float*)nullptr);
+    hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(9), dim3(64), 0, stream, dw_partials, nblk, dw);
+    if (gx0) {
+        int g = sed_cdiv(M, 256);
+        hipLaunchKernelGGL(conv1_dgrad_gather_kernel, dim3(g > 8192 ? 8192 : g), dim3(256), 0, stream, tbuf, M, H, W, gx0);
+    }
+    SED_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,419 @@
+// Heads, loss, mixup-of-targets, optimiser and GRU gate kernels.  The dense contractions of the heads
+// (fc / AttBlock 1x1 convs / GRU projections) run on the fp32-MFMA GEMMs in conv.hip (sed_gemm_nt / sed_gemm_tn);
+// the kernels here are the small per-clip / per-element stages around them.
+//
+// Reference: FrameAvg head models.py:306-312, FrameMax :221-227, AttBlock :135-143, interpolate :58-69,
+// nn.GRU gates :529-530, clip_bce losses.py:5-12, do_mixup pytorch_utils.py:80-93, Adam(amsgrad) main.py:144-145.
+#include "common.h"
+#include "sed_hip.h"
+
+namespace {
+
+constexpr int NCLS_MAX = 32;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// column sums of a [n][K] fp32 matrix accumulated in fp64 (bias gradients, per-clip partials)
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ parts, long n, int K, long ld,
+                                                          float* __restrict__ out, int accumulate) {
+    int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= K) return;
+    double s = 0.0;
+    for (long i = 0; i < n; ++i) s += (double)parts[i * ld + col];
+    out[col] = accumulate ? out[col] + (float)s : (float)s;
+}
+
+// two-level variant for long columns: grid.y chunks -> ws, then the kernel above over ws
+__global__ __launch_bounds__(256) void reduce_rows_chunk_kernel(const float* __restrict__ parts, long n, int K, long ld,
+                                                                long rows_per_chunk, float* __restrict__ ws) {
+    int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= K) return;
+    long r0 = (long)blockIdx.y * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
+    double s = 0.0;
+    for (long i = r0; i < r1; ++i) s += (double)parts[i * ld + col];
+    ws[(long)blockIdx.y * K + col] = (float)s;
+}
+
+// ---- FrameAvg / FrameMax head around logits = feat x Wfc^T (GEMM), one workgroup per clip --------------------
+// logits [B][T][ldn] (first ncls columns used), bias [ncls] -> frame [B][T][ncls] = sigmoid, clip [B][ncls]
+// mode 0: mean over frames; mode 1: max over frames (argmax index stored in amax [B][ncls]).
+__global__ __launch_bounds__(128) void head_pool_fwd_kernel(const float* __restrict__ logits, int T, int ldn, int ncls,
+                                                            const float* __restrict__ bias, int mode,
+                                                            float* __restrict__ frame, float* __restrict__ clip,
+                                                            int* __restrict__ amax) {
+    extern __shared__ float fs[];   // [T][ncls]
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < T * ncls; i += 128) {
+        int t = i / ncls, k = i % ncls;
+        float s = sigmoidf_(logits[((long)b * T + t) * ldn + k] + bias[k]);
+        fs[i] = s;
+        frame[(long)b * T * ncls + i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < ncls) {
+        int k = threadIdx.x;
+        if (mode == 0) {
+            float s = 0.f;
+            for (int t = 0; t < T; ++t) s += fs[t * ncls + k];
+            clip[b * ncls + k] = s / (float)T;
+        } else {
+            float m = fs[k]; int am = 0;
+            for (int t = 1; t < T; ++t) { float v = fs[t * ncls + k]; if (v > m) { m = v; am = t; } }
+            clip[b * ncls + k] = m;
+            amax[b * ncls + k] = am;
+        }
+    }
+}
+
+// g_logits [B][T][ldn] (pad columns zeroed) from g_clip [B][ncls]
+__global__ __launch_bounds__(128) void head_pool_bwd_kernel(const float* __restrict__ g_clip,
+                                                            const float* __restrict__ frame, const int* __restrict__ amax,
+                                                            int T, int ldn, int ncls, int mode,
+                                                            float* __restrict__ g_logits) {
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < T * ldn; i += 128) {
+        int t = i / ldn, k = i % ldn;
+        float g = 0.f;
+        if (k < ncls) {
+            float s = frame[((long)b * T + t) * ncls + k];
+            float gc = g_clip[b * ncls + k];
+            float up = (mode == 0) ? gc / (float)T : ((amax[b * ncls + k] == t) ? gc : 0.f);
+            g = up * s * (1.0f - s);
+        }
+        g_logits[((long)b * T) * ldn + i] = g;
+    }
+}
+
+// ---- AttBlock pooling around logits = feat x [Watt;Wcla]^T.  logits columns [0,ncls) att, [ncls,2ncls) cla --------
+__global__ __launch_bounds__(128) void att_pool_fwd_kernel(const float* __restrict__ logits, int T, int ldn, int ncls,
+                                                           const float* __restrict__ b_att,
+                                                           const float* __restrict__ b_cla, float* __restrict__ clip,
+                                                           float* __restrict__ cla, float* __restrict__ norm_att,
+                                                           float* __restrict__ att_sum) {
+    extern __shared__ float sh[];          // e [T][ncls], c [T][ncls]
+    float* es = sh;
+    float* cs = sh + T * ncls;
+    __shared__ float ssum[NCLS_MAX];
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < T * ncls; i += 128) {
+        int t = i / ncls, k = i % ncls;
+        const float* row = logits + ((long)b * T + t) * ldn;
+        float a = row[k] + b_att[k];
+        a = fminf(fmaxf(a, -10.0f), 10.0f);
+        es[i] = expf(a) + 1e-6f;
+        cs[i] = sigmoidf_(row[ncls + k] + b_cla[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x < ncls) {
+        int k = threadIdx.x;
+        float s = 0.f;
+        for (int t = 0; t < T; ++t) s += es[t * ncls + k];
+        ssum[k] = s;
+        float acc = 0.f;
+        for (int t = 0; t < T; ++t) acc += (es[t * ncls + k] / s) * cs[t * ncls + k];
+        clip[b * ncls + k] = acc;
+        att_sum[b * ncls + k] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < T * ncls; i += 128) {
+        int k = i % ncls;
+        cla[(long)b * T * ncls + i] = cs[i];
+        norm_att[(long)b * T * ncls + i] = es[i] / ssum[k];
+    }
+}
+
+__global__ __launch_bounds__(128) void att_pool_bwd_kernel(const float* __restrict__ g_clip,
+                                                           const float* __restrict__ logits,
+                                                           const float* __restrict__ b_att, const float* __restrict__ clip,
+                                                           const float* __restrict__ cla, const float* __restrict__ norm_att,
+                                                           const float* __restrict__ att_sum, int T, int ldn, int ncls,
+                                                           float* __restrict__ g_logits) {
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < T * ldn; i += 128) {
+        int t = i / ldn, k = i % ldn;
+        float g = 0.f;
+        if (k < ncls) {
+            long o = ((long)b * T + t) * ncls + k;
+            float a = logits[((long)b * T + t) * ldn + k] + b_att[k];
+            bool pass = (a >= -10.0f) && (a <= 10.0f);
+            float n = norm_att[o], S = att_sum[b * ncls + k];
+            float c = cla[o];
+            g = pass ? g_clip[b * ncls + k] * (c - clip[b * ncls + k]) * (n - 1e-6f / S) : 0.f;
+        } else if (k < 2 * ncls) {
+            int kk = k - ncls;
+            long o = ((long)b * T + t) * ncls + kk;
+            float c = cla[o];
+            g = g_clip[b * ncls + kk] * norm_att[o] * c * (1.0f - c);
+        }
+        g_logits[((long)b * T) * ldn + i] = g;
+    }
+}
+
+// interpolate (models.py:58-69): out[b][t*ratio + r][k] = x[b][t][k]
+__global__ __launch_bounds__(256) void interpolate_kernel(const float* __restrict__ x, long BT, int ncls, int ratio,
+                                                          float* __restrict__ out) {
+    long total = BT * ratio * ncls;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int k = (int)(i % ncls);
+        long q = i / ncls;
+        long bt = q / ratio;
+        out[i] = x[bt * ncls + k];
+    }
+}
+
+// freq-mean'd features are [B][T][C]; the reference exposes `embedding` as (B, C, T): generic 2-D transpose per batch
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, int rows, int cols,
+                                                        float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const long boff = (long)blockIdx.z * rows * cols;
+    int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < rows && c0 + tx < cols) tile[j][tx] = x[boff + (long)(r0 + j) * cols + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < cols && r0 + tx < rows) out[boff + (long)(c0 + j) * rows + r0 + tx] = tile[tx][j];
+}
+
+// ---- clip_bce (F.binary_cross_entropy, mean; log terms clamped at -100) + its gradient -------------------------
+__global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ p, const float* __restrict__ y, long n,
+                                                  float* __restrict__ loss, float* __restrict__ grad) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    const float inv_n = 1.0f / (float)n;
+    for (long i = threadIdx.x; i < n; i += 256) {
+        float pi = p[i], yi = y[i];
+        float lp = fmaxf(logf(pi), -100.0f), lq = fmaxf(log1pf(-pi), -100.0f);
+        acc += (double)(-(yi * lp + (1.0f - yi) * lq));
+        if (grad) grad[i] = (pi - yi) / fmaxf((1.0f - pi) * pi, 1e-12f) * inv_n;
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (float)((red[0] + red[1] + red[2] + red[3]) / (double)n);
+}
+
+// do_mixup on a [2B][D] matrix
+__global__ __launch_bounds__(256) void mixup_rows_kernel(const float* __restrict__ x, const float* __restrict__ lam,
+                                                         long Bout, long D, float* __restrict__ out) {
+    long total = Bout * D;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        long b = i / D, d = i % D;
+        out[i] = x[(2 * b) * D + d] * lam[2 * b] + x[(2 * b + 1) * D + d] * lam[2 * b + 1];
+    }
+}
+
+// ---- Adam(amsgrad=True, weight_decay=0) over one flat buffer ----------------------------------------------------
+__global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                           float* __restrict__ m, float* __restrict__ v,
+                                                           float* __restrict__ vmax, long n, float lr, float beta1,
+                                                           float beta2, float eps, float bc1, float bc2_sqrt,
+                                                           float grad_scale) {
+    const float step_size = lr / bc1;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float gi = g[i] * grad_scale;
+        float mi = fmaf(1.0f - beta1, gi - m[i], m[i]);                 // exp_avg.lerp_(grad, 1-beta1)
+        float vi = fmaf(1.0f - beta2, gi * gi, v[i] * beta2);           // mul_(beta2).addcmul_(g, g, 1-beta2)
+        float vm = fmaxf(vmax[i], vi);
+        float denom = sqrtf(vm) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+        m[i] = mi; v[i] = vi; vmax[i] = vm;
+    }
+}
+
+// ---- GRU gates (PyTorch order r,z,n; b_hn inside r*(.)), one direction, one time step ---------------------------
+// gi [B][3H] (row stride ld_gi) input projection incl. b_ih; gh [B][3H] hidden projection incl. b_hh.
+// h_out = (1-z)*n + z*h_prev.  Saves r,z,n and gh_n for the backward pass.
+__global__ __launch_bounds__(256) void gru_gate_fwd_kernel(const float* __restrict__ gi, long ld_gi,
+                                                           const float* __restrict__ gh, const float* __restrict__ h_prev,
+                                                           int B, int Hd, float* __restrict__ h_out, long ld_out,
+                                                           float* __restrict__ h_out2, long ld_out2,
+                                                           float* __restrict__ save /*[B][4H]: r,z,n,ghn*/) {
+    long total = (long)B * Hd;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int b = (int)(i / Hd), j = (int)(i % Hd);
+        const float* gir = gi + (long)b * ld_gi;
+        const float* ghr = gh + (long)b * 3 * Hd;
+        float r = sigmoidf_(gir[j] + ghr[j]);
+        float z = sigmoidf_(gir[Hd + j] + ghr[Hd + j]);
+        float ghn = ghr[2 * Hd + j];
+        float n = tanhf(gir[2 * Hd + j] + r * ghn);
+        float hp = h_prev ? h_prev[(long)b * Hd + j] : 0.f;
+        float h = (1.0f - z) * n + z * hp;
+        h_out[(long)b * ld_out + j] = h;
+        if (h_out2) h_out2[(long)b * ld_out2 + j] = h;
+        if (save) {
+            float* s = save + (long)b * 4 * Hd;
+            s[j] = r; s[Hd + j] = z; s[2 * Hd + j] = n; s[3 * Hd + j] = ghn;
+        }
+    }
+}
+
+// dh = (gradient arriving at h_t from the output [row stride ld_go]) + dh_rec (from step t+1, nullable).
+// Produces dgi [B][3H] (row stride ld_dgi), dgh [B][3H], and dh_prev_direct [B][H] = dh*z  (the W_hh path is added
+// by the caller's GEMM).
+__global__ __launch_bounds__(256) void gru_gate_bwd_kernel(const float* __restrict__ g_out, long ld_go,
+                                                           const float* __restrict__ dh_rec,
+                                                           const float* __restrict__ save,
+                                                           const float* __restrict__ h_prev, int B, int Hd,
+                                                           float* __restrict__ dgi, long ld_dgi, float* __restrict__ dgh,
+                                                           float* __restrict__ dh_prev) {
+    long total = (long)B * Hd;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int b = (int)(i / Hd), j = (int)(i % Hd);
+        const float* s = save + (long)b * 4 * Hd;
+        float r = s[j], z = s[Hd + j], n = s[2 * Hd + j], ghn = s[3 * Hd + j];
+        float hp = h_prev ? h_prev[(long)b * Hd + j] : 0.f;
+        float dh = g_out[(long)b * ld_go + j] + (dh_rec ? dh_rec[(long)b * Hd + j] : 0.f);
+        float dn = dh * (1.0f - z);
+        float dz = dh * (hp - n);
+        float dn_pre = dn * (1.0f - n * n);
+        float dr = dn_pre * ghn;
+        float dr_pre = dr * r * (1.0f - r);
+        float dz_pre = dz * z * (1.0f - z);
+        float* gi_o = dgi + (long)b * ld_dgi;
+        float* gh_o = dgh + (long)b * 3 * Hd;
+        gi_o[j] = dr_pre; gi_o[Hd + j] = dz_pre; gi_o[2 * Hd + j] = dn_pre;
+        gh_o[j] = dr_pre; gh_o[Hd + j] = dz_pre; gh_o[2 * Hd + j] = dn_pre * r;
+        dh_prev[(long)b * Hd + j] = dh * z;
+    }
+}
+
+// out += a   (accumulate the recurrent path into dh_prev)
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ out, const float* __restrict__ a, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] += a[i];
+}
+
+int grid_for(long n) {
+    long b = (n + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+// ---- C ABI --------------------------------------------------------------------------------------------------
+
+// out[K] (=|+=) column sums of parts [n][K] with row stride ld.  ws: scratch of 256*K floats when n > 4096 (else unused).
+SED_API int sed_reduce_rows(const float* parts, long n, int K, long ld, float* out, int accumulate, float* ws,
+                            hipStream_t stream) {
+    if (n <= 0 || K <= 0) return SED_EINVAL;
+    if (n > 4096 && ws) {
+        long rpc = (n + 255) / 256;
+        int chunks = (int)((n + rpc - 1) / rpc);
+        hipLaunchKernelGGL(reduce_rows_chunk_kernel, dim3(sed_cdiv(K, 256), chunks), dim3(256), 0, stream, parts, n, K, ld, rpc, ws);
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(sed_cdiv(K, 256)), dim3(256), 0, stream, ws, (long)chunks, K, (long)K, out,
+                           accumulate);
+    } else {
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(sed_cdiv(K, 256)), dim3(256), 0, stream, parts, n, K, ld, out, accumulate);
+    }
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+SED_API int sed_head_pool_fwd(const float* logits, int B, int T, int ldn, int ncls, const float* bias, int mode,
+                              float* frame, float* clip, int* amax, hipStream_t stream) {
+    if (B <= 0 || ncls > NCLS_MAX || ncls > ldn || (size_t)T * ncls * 4 > 60000) return SED_EINVAL;
+    hipLaunchKernelGGL(head_pool_fwd_kernel, dim3(B), dim3(128), (size_t)T * ncls * 4, stream, logits, T, ldn, ncls, bias, mode,
+                       frame, clip, amax);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+SED_API int sed_head_pool_bwd(const float* g_clip, const float* frame, const int* amax, int B, int T, int ldn, int ncls,
+                              int mode, float* g_logits, hipStream_t stream) {
+    if (B <= 0 || ncls > ldn) return SED_EINVAL;
+    hipLaunchKernelGGL(head_pool_bwd_kernel, dim3(B), dim3(128), 0, stream, g_clip, frame, amax, T, ldn, ncls, mode, g_logits);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+SED_API int sed_att_pool_fwd(const float* logits, int B, int T, int ldn, int ncls, const float* b_att, const float* b_cla,
+                             float* clip, float* cla, float* norm_att, float* att_sum, hipStream_t stream) {
+    if (B <= 0 || ncls > NCLS_MAX || 2 * ncls > ldn || (size_t)T * ncls * 8 > 60000) return SED_EINVAL;
+    hipLaunchKernelGGL(att_pool_fwd_kernel, dim3(B), dim3(128), (size_t)T * ncls * 8, stream, logits, T, ldn, ncls, b_att, b_cla,
+                       clip, cla, norm_att, att_sum);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+SED_API int sed_att_pool_bwd(const float* g_clip, const float* logits, const float* b_att, const float* clip,
+                             const float* cla, const float* norm_att, const float* att_sum, int B, int T, int ldn,
+                             int ncls, float* g_logits, hipStream_t stream) {
+    if (B <= 0 || 2 * ncls > ldn) return SED_EINVAL;
+    hipLaunchKernelGGL(att_pool_bwd_kernel, dim3(B), dim3(128), 0, stream, g_clip, logits, b_att, clip, cla, norm_att, att_sum,
+                       T, ldn, ncls, g_logits);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+SED_API int sed_interpolate(const float* x, long BT, int ncls, int ratio, float* out, hipStream_t stream) {
+    if (BT <= 0 || ncls <= 0 || ratio <= 0) return SED_EINVAL;
+    hipLaunchKernelGGL(interpolate_kernel, dim3(grid_for(BT * ratio * ncls)), dim3(256), 0, stream, x, BT, ncls, ratio, out);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// out[b][c][r] = x[b][r][c]
+SED_API int sed_transpose(const float* x, int batch, int rows, int cols, float* out, hipStream_t stream) {
+    if (batch <= 0 || rows <= 0 || cols <= 0 || batch > 65535) return SED_EINVAL;
+    hipLaunchKernelGGL(transpose_kernel, dim3(sed_cdiv(cols, 32), sed_cdiv(rows, 32), batch), dim3(256), 0, stream, x, rows, cols,
+                       out);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// loss[0] = mean BCE; grad (nullable) = d loss / d p
+SED_API int sed_clip_bce(const float* p, const float* y, long n, float* loss, float* grad, hipStream_t stream) {
+    if (n <= 0) return SED_EINVAL;
+    hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(256), 0, stream, p, y, n, loss, grad);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+SED_API int sed_mixup_rows(const float* x, const float* lam, long B2, long D, float* out, hipStream_t stream) {
+    if (B2 <= 0 || (B2 & 1) || D <= 0) return SED_EINVAL;
+    hipLaunchKernelGGL(mixup_rows_kernel, dim3(grid_for(B2 / 2 * D)), dim3(256), 0, stream, x, lam, B2 / 2, D, out);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// One Adam-amsgrad step (step >= 1) over flat buffers; grad_scale multiplies the gradient first (1/world_size).
+SED_API int sed_adam_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, long n, int step, float lr,
+                             float beta1, float beta2, float eps, float grad_scale, hipStream_t stream) {
+    if (n <= 0 || step < 1) return SED_EINVAL;
+    double bc1 = 1.0 - pow((double)beta1, (double)step);
+    double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_amsgrad_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, m, v, vmax, n, lr, beta1, beta2, eps,
+                       (float)bc1, (float)sqrt(bc2), grad_scale);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+SED_API int sed_gru_gate_fwd(const float* gi, long ld_gi, const float* gh, const float* h_prev, int B, int Hd,
+                             float* h_out, long ld_out, float* h_out2, long ld_out2, float* save, hipStream_t stream) {
+    if (B <= 0 || Hd <= 0) return SED_EINVAL;
+    hipLaunchKernelGGL(gru_gate_fwd_kernel, dim3(grid_for((long)B * Hd)), dim3(256), 0, stream, gi, ld_gi, gh, h_prev, B, Hd,
+                       h_out, ld_out, h_out2, ld_out2, save);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+SED_API int sed_gru_gate_bwd(const float* g_out, long ld_go, const float* dh_rec, const float* save, const float* h_prev,
+                             int B, int Hd, float* dgi, long ld_dgi, float* dgh, float* dh_prev, hipStream_t stream) {
+    if (B <= 0 || Hd <= 0) return SED_EINVAL;
+    hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3(grid_for((long)B * Hd)), dim3(256), 0, stream, g_out, ld_go, dh_rec, save,
+                       h_prev, B, Hd, dgi, ld_dgi, dgh, dh_prev);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+SED_API int sed_axpy(float* out, const float* a, long n, hipStream_t stream) {
+    if (n <= 0) return SED_EINVAL;
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, stream, out, a, n);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+SED_API const char* sed_version(void) { return "sed-hip 0.1 (gfx950)"; }

@@ -1,0 +1,572 @@
+"""Tensor-level wrappers over the C ABI (include/sed_hip.h) + the autograd Functions of the hot path.
+
+PyTorch is used here only for device memory (caching allocator), the current HIP stream and autograd
+bookkeeping; every computation is a hand-written HIP kernel in libsed_hip.so.  There is no CPU path: passing
+CPU tensors raises.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("sound_event_detection_dcase2017_task4_amd: the hot path runs on the GPU only "
+                               "(HIP kernels, gfx950); got a CPU tensor.  Move model and inputs to 'cuda'.")
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _call(name, *args):
+    fn = getattr(_lib.lib(), name)
+    _lib.check(fn(*args), name)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# front-end constants (host side, built once per model; numpy float64 -> float32)
+
+def frontend_tables(window, melW, device):
+    """window: (1024,) tensor = conv_real.weight[0,0,:]; melW (513,64) tensor.  Returns the device tables the
+    log-mel kernel needs (FFT twiddles + compact mel filter runs)."""
+    n2 = np.arange(64)[:, None]
+    k1 = np.arange(16)[None, :]
+    tw = np.exp(-2j * np.pi * (n2 * k1) / 1024.0)
+    tw1024 = np.stack([tw.real, tw.imag], axis=-1).astype(np.float32)            # [64][16][2]
+    g = np.arange(4)[:, None, None]
+    ip = np.arange(4)[None, :, None]
+    s = np.arange(4)[None, None, :]
+    t64 = np.exp(-2j * np.pi * ((4 * ip + g) * s) / 64.0)
+    tw64 = np.stack([t64.real, t64.imag], axis=-1).astype(np.float32)            # [4][4][4][2]
+    W = melW.detach().cpu().numpy().astype(np.float32)                           # (513, 64)
+    lo, cnt, off, vals = [], [], [], []
+    for m in range(W.shape[1]):
+        nz = np.nonzero(W[:, m])[0]
+        if len(nz) == 0:
+            lo.append(0); cnt.append(0); off.append(len(vals))
+            continue
+        a, b = int(nz[0]), int(nz[-1]) + 1
+        lo.append(a); cnt.append(b - a); off.append(len(vals))
+        vals.extend(W[a:b, m].tolist())
+    if len(vals) > 1024:
+        raise RuntimeError("mel filter bank has %d non-zeros; the kernel table holds 1024" % len(vals))
+    dev = torch.device(device)
+    return {
+        "window": window.detach().to(dev, torch.float32).contiguous(),
+        "tw1024": torch.from_numpy(tw1024).to(dev).contiguous(),
+        "tw64": torch.from_numpy(tw64).to(dev).contiguous(),
+        "mel_lo": torch.tensor(lo, dtype=torch.int32, device=dev),
+        "mel_cnt": torch.tensor(cnt, dtype=torch.int32, device=dev),
+        "mel_off": torch.tensor(off, dtype=torch.int32, device=dev),
+        "mel_w": torch.tensor(vals, dtype=torch.float32, device=dev),
+        "mel_nnz": len(vals),
+    }
+
+
+def logmel(wave, tables, amin=1e-10):
+    """wave (B2, L) float32 or int16 on the GPU -> (B2, T, 64) float32.  models.py:284-285."""
+    _chk_dev(wave)
+    if wave.dim() != 2:
+        raise RuntimeError("waveform must be (batch, samples)")
+    wave = wave.contiguous()
+    B2, L = wave.shape
+    T = L // 320 + 1
+    out = torch.empty((B2, T, 64), dtype=torch.float32, device=wave.device)
+    name = "sed_logmel_i16" if wave.dtype == torch.int16 else "sed_logmel_f32"
+    if wave.dtype not in (torch.int16, torch.float32):
+        wave = wave.float()
+    _call(name, _ptr(wave), B2, L, _ptr(tables["window"]), _ptr(tables["tw1024"]), _ptr(tables["tw64"]),
+          _ptr(tables["mel_lo"]), _ptr(tables["mel_cnt"]), _ptr(tables["mel_off"]), _ptr(tables["mel_w"]),
+          tables["mel_nnz"], amin, _ptr(out), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# BatchNorm helpers
+
+class BnStats(object):
+    __slots__ = ("mean", "invstd", "scale", "shift")
+
+    def __init__(self, C, device):
+        buf = torch.empty((4, C), dtype=torch.float32, device=device)
+        self.mean, self.invstd, self.scale, self.shift = buf[0], buf[1], buf[2], buf[3]
+
+
+def _ws(C, device):
+    return torch.empty((512 * C,), dtype=torch.float64, device=device)
+
+
+def bn_finalize(partials, nparts, rows_per_part, N, bn_w, bn_b, running_mean, running_var):
+    C = bn_w.numel()
+    st = BnStats(C, bn_w.device)
+    _call("sed_bn_finalize", _ptr(partials), nparts, rows_per_part, N, C, _ptr(bn_w), _ptr(bn_b), BN_EPS, BN_MOMENTUM,
+          _ptr(running_mean), _ptr(running_var), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale), _ptr(st.shift),
+          _ptr(_ws(C, bn_w.device)), _stream())
+    return st
+
+
+def bn_eval_affine(bn_w, bn_b, running_mean, running_var):
+    C = bn_w.numel()
+    st = BnStats(C, bn_w.device)
+    _call("sed_bn_eval_affine", C, _ptr(bn_w), _ptr(bn_b), _ptr(running_mean), _ptr(running_var), BN_EPS, _ptr(st.mean),
+          _ptr(st.invstd), _ptr(st.scale), _ptr(st.shift), _stream())
+    return st
+
+
+def bn_bwd_finalize(partials, nparts, N, st, want_coef=True):
+    C = st.mean.numel()
+    dev = st.mean.device
+    dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
+    dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
+    coef = torch.empty((3, C), dtype=torch.float32, device=dev) if want_coef else None
+    _call("sed_bn_bwd_finalize", _ptr(partials), nparts, N, C, _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale), _ptr(dgamma),
+          _ptr(dbeta), _ptr(coef), _ptr(_ws(C, dev)), _stream())
+    return dgamma, dbeta, coef
+
+
+# ------------------------------------------------------------------------------------------------------------
+# bn0 + SpecAugment + mixup
+
+class Bn0AugMix(torch.autograd.Function):
+    """models.py:287-296.  logmel (B2,T,64) -> x0 (B,T,64) [NHWC with C=1].  Gradients: bn0.weight/bias only."""
+
+    @staticmethod
+    def forward(ctx, lm, bn_w, bn_b, running_mean, running_var, training, stripes, lam):
+        _chk_dev(lm, bn_w)
+        lm = _f32c(lm)
+        B2, T, M = lm.shape
+        assert M == 64
+        dev = lm.device
+        if training:
+            N = B2 * T
+            rpp = _lib.lib().sed_stats_rows_per_part()
+            nparts = (N + rpp - 1) // rpp
+            partials = torch.empty((nparts, 2, 64), dtype=torch.float32, device=dev)
+            _call("sed_chan_stats", _ptr(lm), N, 64, _ptr(partials), _stream())
+            st = bn_finalize(partials, nparts, rpp, N, bn_w, bn_b, running_mean, running_var)
+        else:
+            st = bn_eval_affine(bn_w, bn_b, running_mean, running_var)
+            stripes, lam = None, None
+        Bout = B2 // 2 if lam is not None else B2
+        out = torch.empty((Bout, T, 64), dtype=torch.float32, device=dev)
+        _call("sed_bn0_aug_mix_fwd", _ptr(lm), B2, T, _ptr(st.scale), _ptr(st.shift), _ptr(stripes), _ptr(lam), _ptr(out),
+              _stream())
+        ctx.st, ctx.training = st, training
+        ctx.save_for_backward(lm, stripes, lam)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lm, stripes, lam = ctx.saved_tensors
+        st = ctx.st
+        g = _f32c(g)
+        B2, T, _ = lm.shape
+        nparts_max = (B2 * T + 1023) // 1024
+        partials = torch.empty((nparts_max, 2, 64), dtype=torch.float32, device=lm.device)
+        n = ctypes.c_int(0)
+        _call("sed_bn0_aug_mix_bwd", _ptr(lm), _ptr(g), B2, T, _ptr(st.mean), _ptr(st.invstd), _ptr(stripes), _ptr(lam),
+              _ptr(partials), ctypes.byref(n), _stream())
+        dgamma, dbeta, _ = bn_bwd_finalize(partials, n.value, B2 * T, st, want_coef=False)
+        if not ctx.training:
+            # eval-mode BN: y = scale*x + shift with fixed stats -> dgamma = sum dy * (x-mean)*invstd, same formula
+            pass
+        return None, dgamma, dbeta, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------------------
+# ConvBlock
+
+def _conv_igemm(x, w_packed, B, H, W, Cin, Cout, in_st=None, epi=0, partials=None, yprev=None, p_st=None):
+    y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+    _call("sed_conv3x3_igemm", _ptr(x), _ptr(w_packed), _ptr(y), B, H, W, Cin, Cout,
+          _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, epi,
+          _ptr(partials), _ptr(yprev), _ptr(p_st.scale) if p_st is not None else None,
+          _ptr(p_st.shift) if p_st is not None else None, _ptr(p_st.mean) if p_st is not None else None,
+          _ptr(p_st.invstd) if p_st is not None else None, _stream())
+    return y
+
+
+def _pack(w, want_f=True, want_d=False):
+    Cout, Cin = w.shape[0], w.shape[1]
+    wf = torch.empty((9, Cout, Cin), dtype=torch.float32, device=w.device) if want_f else None
+    wd = torch.empty((9, Cin, Cout), dtype=torch.float32, device=w.device) if want_d else None
+    _call("sed_pack_conv_weights", _ptr(w), Cout, Cin, _ptr(wf), _ptr(wd), _stream())
+    return wf, wd
+
+
+def _wgrad(x, gy, B, H, W, Cin, Cout, in_st=None):
+    ns, pps = ctypes.c_int(0), ctypes.c_int(0)
+    nfl = _lib.lib().sed_wgrad_partial_floats(B * H * W, Cin, Cout, 9, ctypes.byref(ns), ctypes.byref(pps))
+    partial = torch.empty((nfl,), dtype=torch.float32, device=x.device)
+    dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
+    _call("sed_conv3x3_wgrad", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
+          _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, _stream())
+    return dw
+
+
+class ConvBlockFn(torch.autograd.Function):
+    """One reference ConvBlock (models.py:99-115, pool_type='avg'), NHWC, training or eval.
+    x (B,H,W,Cin) -> (B,H//ph,W//pw,Cout).  Only the two raw conv outputs are saved; BN+ReLU is recomputed
+    on the fly by the consumers."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, training, ph, pw):
+        _chk_dev(x, w1, w2)
+        x = _f32c(x)
+        B, H, W, Cin = x.shape
+        Cout = w1.shape[0]
+        dev = x.device
+        L = _lib.lib()
+        M = B * H * W
+        w1c, w2c = _f32c(w1), _f32c(w2)
+        # conv1 (+ statistics)
+        if Cin == 1:
+            rpp1 = L.sed_conv1_rows_per_part()
+            np1 = (M + rpp1 - 1) // rpp1
+            part1 = torch.empty((np1, 2, Cout), dtype=torch.float32, device=dev) if training else None
+            y1 = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
+            _call("sed_conv1_fwd", _ptr(x), _ptr(w1c), _ptr(y1), B, H, W, _ptr(part1), _stream())
+        else:
+            wf1, _ = _pack(w1c)
+            rpp1 = L.sed_conv_rows_per_part(Cout)
+            np1 = L.sed_conv_num_parts(M, Cout)
+            part1 = torch.empty((np1, 2, Cout), dtype=torch.float32, device=dev) if training else None
+            y1 = _conv_igemm(x, wf1, B, H, W, Cin, Cout, epi=1 if training else 0, partials=part1)
+        st1 = bn_finalize(part1, np1, rpp1, M, g1, b1, rm1, rv1) if training else bn_eval_affine(g1, b1, rm1, rv1)
+        # conv2 over relu(bn1(y1)) computed on the fly (+ statistics)
+        wf2, _ = _pack(w2c)
+        rpp2 = L.sed_conv_rows_per_part(Cout)
+        np2 = L.sed_conv_num_parts(M, Cout)
+        part2 = torch.empty((np2, 2, Cout), dtype=torch.float32, device=dev) if training else None
+        y2 = _conv_igemm(y1, wf2, B, H, W, Cout, Cout, in_st=st1, epi=1 if training else 0, partials=part2)
+        st2 = bn_finalize(part2, np2, rpp2, M, g2, b2, rm2, rv2) if training else bn_eval_affine(g2, b2, rm2, rv2)
+        out = torch.empty((B, H // ph, W // pw, Cout), dtype=torch.float32, device=dev)
+        _call("sed_bn_relu_pool_fwd", _ptr(y2), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift), _ptr(out), _stream())
+        ctx.save_for_backward(x, y1, y2, w1c, w2c)
+        ctx.st1, ctx.st2, ctx.pool, ctx.need_gx = st1, st2, (ph, pw), True
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, y1, y2, w1, w2 = ctx.saved_tensors
+        st1, st2 = ctx.st1, ctx.st2
+        ph, pw = ctx.pool
+        g_out = _f32c(g_out)
+        B, H, W, Cin = x.shape
+        Cout = w1.shape[0]
+        dev = x.device
+        M = B * H * W
+        # BN2 + ReLU + pool backward
+        npmax = (M + 1023) // 1024
+        part = torch.empty((npmax, 2, Cout), dtype=torch.float32, device=dev)
+        n = ctypes.c_int(0)
+        _call("sed_bn_relu_pool_bwd_reduce", _ptr(y2), _ptr(g_out), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift),
+              _ptr(st2.mean), _ptr(st2.invstd), _ptr(part), ctypes.byref(n), _stream())
+        dg2, db2, coef2 = bn_bwd_finalize(part, n.value, M, st2)
+        gy2 = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
+        _call("sed_bn_relu_pool_bwd_apply", _ptr(y2), _ptr(g_out), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift),
+              _ptr(coef2), _ptr(gy2), _stream())
+        # conv2: wgrad (operand relu(bn1(y1)) on the fly) and dgrad fused with relu-mask + BN1 backward sums
+        dw2 = _wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=st1)
+        _, wd2 = _pack(w2, want_f=False, want_d=True)
+        L = _lib.lib()
+        npb = L.sed_conv_num_parts(M, Cout)
+        partb = torch.empty((npb, 2, Cout), dtype=torch.float32, device=dev)
+        gy1 = _conv_igemm(gy2, wd2, B, H, W, Cout, Cout, epi=2, partials=partb, yprev=y1, p_st=st1)
+        del gy2
+        dg1, db1, coef1 = bn_bwd_finalize(partb, npb, M, st1)
+        _call("sed_bn_bwd_apply", _ptr(gy1), _ptr(y1), M, Cout, _ptr(coef1), _stream())
+        # conv1
+        gx = None
+        if Cin == 1:
+            nblk = (M + 1023) // 1024
+            dwp = torch.empty((nblk, 576), dtype=torch.float32, device=dev)
+            dw1 = torch.empty((Cout, 1, 3, 3), dtype=torch.float32, device=dev)
+            want_gx = ctx.needs_input_grad[0]
+            tbuf = torch.empty((M, 9), dtype=torch.float32, device=dev) if want_gx else None
+            gx = torch.empty((B, H, W, 1), dtype=torch.float32, device=dev) if want_gx else None
+            _call("sed_conv1_bwd", _ptr(x), _ptr(w1), _ptr(gy1), B, H, W, _ptr(dw1), _ptr(gx), _ptr(dwp), _ptr(tbuf), _stream())
+        else:
+            dw1 = _wgrad(x, gy1, B, H, W, Cin, Cout)
+            if ctx.needs_input_grad[0]:
+                _, wd1 = _pack(w1, want_f=False, want_d=True)
+                gx = _conv_igemm(gy1, wd1, B, H, W, Cout, Cin, epi=0)
+        return gx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------------------
+# dense helpers
+
+def gemm_nt(x, w, bias=None):
+    """y[M][N] = x[M][K] w[N][K]^T (+bias)."""
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    _call("sed_gemm_nt", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), M, N, K, _stream())
+    return y
+
+
+def gemm_tn(x, gy):
+    """dw[N][K] = sum_m gy[m][n] x[m][k]."""
+    M, K = x.shape
+    N = gy.shape[1]
+    ns, pps = ctypes.c_int(0), ctypes.c_int(0)
+    nfl = _lib.lib().sed_wgrad_partial_floats(M, K, N, 1, ctypes.byref(ns), ctypes.byref(pps))
+    partial = torch.empty((nfl,), dtype=torch.float32, device=x.device)
+    dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
+    _call("sed_gemm_tn", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), M, N, K, _stream())
+    return dw
+
+
+def col_sums(x2d, ncols=None):
+    n, ld = x2d.shape
+    K = ld if ncols is None else ncols
+    out = torch.empty((K,), dtype=torch.float32, device=x2d.device)
+    ws = torch.empty((256 * K,), dtype=torch.float32, device=x2d.device) if n > 4096 else None
+    _call("sed_reduce_rows", _ptr(x2d), n, K, ld, _ptr(out), 0, _ptr(ws), _stream())
+    return out
+
+
+def transpose_b(x):
+    """(B, R, C) -> (B, C, R) contiguous."""
+    B, R, C = x.shape
+    out = torch.empty((B, C, R), dtype=torch.float32, device=x.device)
+    _call("sed_transpose", _ptr(x), B, R, C, _ptr(out), _stream())
+    return out
+
+
+def interpolate(frame, ratio):
+    """models.py:58-69.  (B,T,K) -> (B,T*ratio,K)."""
+    B, T, K = frame.shape
+    out = torch.empty((B, T * ratio, K), dtype=torch.float32, device=frame.device)
+    _call("sed_interpolate", _ptr(frame), B * T, K, ratio, _ptr(out), _stream())
+    return out
+
+
+LDN = 64   # padded logit width of the 17-class heads (MFMA GEMM N granularity)
+
+
+def _pad_rows(ws, device):
+    """Stack weight matrices (each (17, K)) into a zero-padded (64, K) operand (device copy only)."""
+    K = ws[0].shape[-1]
+    out = torch.zeros((LDN, K), dtype=torch.float32, device=device)
+    r = 0
+    for w in ws:
+        w2 = w.reshape(w.shape[0], K)
+        out[r:r + w2.shape[0]].copy_(w2)
+        r += w2.shape[0]
+    return out
+
+
+class FcHeadFn(torch.autograd.Function):
+    """FrameAvg (mode 0, models.py:306-312) / FrameMax (mode 1, :221-227) head.
+    feat (B,T,512) -> frame (B,T,17), clip (B,17).  Gradient flows from `clip` only."""
+
+    @staticmethod
+    def forward(ctx, feat, w, b, mode):
+        _chk_dev(feat, w)
+        feat = _f32c(feat)
+        B, T, C = feat.shape
+        ncls = w.shape[0]
+        wp = _pad_rows([w], feat.device)
+        logits = gemm_nt(feat.view(B * T, C), wp)
+        frame = torch.empty((B, T, ncls), dtype=torch.float32, device=feat.device)
+        clip = torch.empty((B, ncls), dtype=torch.float32, device=feat.device)
+        amax = torch.empty((B, ncls), dtype=torch.int32, device=feat.device) if mode == 1 else None
+        _call("sed_head_pool_fwd", _ptr(logits), B, T, LDN, ncls, _ptr(_f32c(b)), mode, _ptr(frame), _ptr(clip), _ptr(amax),
+              _stream())
+        ctx.save_for_backward(feat, wp, frame, amax)
+        ctx.mode, ctx.ncls = mode, ncls
+        ctx.mark_non_differentiable(frame)
+        return frame, clip
+
+    @staticmethod
+    def backward(ctx, g_frame, g_clip):
+        feat, wp, frame, amax = ctx.saved_tensors
+        B, T, C = feat.shape
+        ncls = ctx.ncls
+        g_clip = _f32c(g_clip)
+        gl = torch.empty((B * T, LDN), dtype=torch.float32, device=feat.device)
+        _call("sed_head_pool_bwd", _ptr(g_clip), _ptr(frame), _ptr(amax), B, T, LDN, ncls, ctx.mode, _ptr(gl), _stream())
+        wpt = transpose_b(wp.view(1, LDN, C)).view(C, LDN)
+        g_feat = gemm_nt(gl, wpt).view(B, T, C)
+        dwp = gemm_tn(feat.view(B * T, C), gl)
+        db = col_sums(gl, ncls)
+        return g_feat, dwp[:ncls].contiguous(), db, None
+
+
+class AttHeadFn(torch.autograd.Function):
+    """AttBlock(512, 17, 'sigmoid') (models.py:118-149).  feat (B,T,512) -> clip (B,17), cla (B,T,17),
+    norm_att (B,T,17).  Gradient flows from `clip` only (clip_bce)."""
+
+    @staticmethod
+    def forward(ctx, feat, w_att, b_att, w_cla, b_cla):
+        _chk_dev(feat, w_att)
+        feat = _f32c(feat)
+        B, T, C = feat.shape
+        ncls = w_att.shape[0]
+        dev = feat.device
+        wp = _pad_rows([w_att, w_cla], dev)
+        logits = gemm_nt(feat.view(B * T, C), wp)
+        clip = torch.empty((B, ncls), dtype=torch.float32, device=dev)
+        cla = torch.empty((B, T, ncls), dtype=torch.float32, device=dev)
+        natt = torch.empty((B, T, ncls), dtype=torch.float32, device=dev)
+        asum = torch.empty((B, ncls), dtype=torch.float32, device=dev)
+        b_att, b_cla = _f32c(b_att), _f32c(b_cla)
+        _call("sed_att_pool_fwd", _ptr(logits), B, T, LDN, ncls, _ptr(b_att), _ptr(b_cla), _ptr(clip), _ptr(cla), _ptr(natt),
+              _ptr(asum), _stream())
+        ctx.save_for_backward(feat, wp, logits, b_att, clip, cla, natt, asum)
+        ctx.ncls, ctx.wshape = ncls, w_att.shape
+        ctx.mark_non_differentiable(cla, natt)
+        return clip, cla, natt
+
+    @staticmethod
+    def backward(ctx, g_clip, g_cla, g_natt):
+        feat, wp, logits, b_att, clip, cla, natt, asum = ctx.saved_tensors
+        B, T, C = feat.shape
+        ncls = ctx.ncls
+        g_clip = _f32c(g_clip)
+        gl = torch.empty((B * T, LDN), dtype=torch.float32, device=feat.device)
+        _call("sed_att_pool_bwd", _ptr(g_clip), _ptr(logits), _ptr(b_att), _ptr(clip), _ptr(cla), _ptr(natt), _ptr(asum), B, T,
+              LDN, ncls, _ptr(gl), _stream())
+        wpt = transpose_b(wp.view(1, LDN, C)).view(C, LDN)
+        g_feat = gemm_nt(gl, wpt).view(B, T, C)
+        dwp = gemm_tn(feat.view(B * T, C), gl)
+        dbias = col_sums(gl, 2 * ncls)
+        return (g_feat, dwp[:ncls].reshape(ctx.wshape).contiguous(), dbias[:ncls].contiguous(),
+                dwp[ncls:2 * ncls].reshape(ctx.wshape).contiguous(), dbias[ncls:2 * ncls].contiguous())
+
+
+class GruFn(torch.autograd.Function):
+    """nn.GRU(512, 256, num_layers=1, bias=True, batch_first=True, bidirectional=True), h0 = 0
+    (models.py:529-530, :565-567).  x (B,T,512) -> (B,T,512) = concat(forward, backward)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_b, w_hh_b, b_ih_b, b_hh_b):
+        _chk_dev(x, w_ih_f)
+        x = _f32c(x)
+        B, T, I = x.shape
+        Hd = w_hh_f.shape[1]
+        dev = x.device
+        out = torch.empty((B, T, 2 * Hd), dtype=torch.float32, device=dev)
+        w_ih = torch.cat([_f32c(w_ih_f), _f32c(w_ih_b)], dim=0).contiguous()          # (6H, I)   device copy
+        b_ih = torch.cat([_f32c(b_ih_f), _f32c(b_ih_b)], dim=0).contiguous()
+        gi = gemm_nt(x.view(B * T, I), w_ih, b_ih)                                     # (B*T, 6H)
+        hs = torch.empty((2, T, B, Hd), dtype=torch.float32, device=dev)
+        saves = torch.empty((2, T, B, 4 * Hd), dtype=torch.float32, device=dev)
+        s = _stream()
+        for d, (w_hh, b_hh) in enumerate(((w_hh_f, b_hh_f), (w_hh_b, b_hh_b))):
+            w_hh, b_hh = _f32c(w_hh), _f32c(b_hh)
+            order = range(T) if d == 0 else range(T - 1, -1, -1)
+            prev = None
+            for t in order:
+                if prev is None:
+                    gh = b_hh.view(1, -1).expand(B, -1).contiguous()
+                else:
+                    gh = gemm_nt(prev, w_hh, b_hh)
+                h_t = hs[d, t]
+                gi_t = gi.view(B, T, 6 * Hd)[:, t, d * 3 * Hd:(d + 1) * 3 * Hd]
+                out_t = out[:, t, d * Hd:(d + 1) * Hd]
+                _call("sed_gru_gate_fwd", _ptr(gi_t), T * 6 * Hd, _ptr(gh), _ptr(prev), B, Hd, _ptr(h_t), Hd, _ptr(out_t),
+                      T * 2 * Hd, _ptr(saves[d, t]), s)
+                prev = h_t
+        ctx.save_for_backward(x, w_ih, _f32c(w_hh_f), _f32c(w_hh_b), hs, saves)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, w_ih, w_hh_f, w_hh_b, hs, saves = ctx.saved_tensors
+        g_out = _f32c(g_out)
+        B, T, I = x.shape
+        Hd = w_hh_f.shape[1]
+        dev = x.device
+        s = _stream()
+        dgi = torch.empty((B, T, 6 * Hd), dtype=torch.float32, device=dev)
+        dgh_all = torch.empty((2, T, B, 3 * Hd), dtype=torch.float32, device=dev)
+        hprev_all = torch.zeros((2, T, B, Hd), dtype=torch.float32, device=dev)
+        grads_hh, grads_bhh = [], []
+        for d, w_hh in enumerate((w_hh_f, w_hh_b)):
+            w_hh_t = transpose_b(w_hh.view(1, 3 * Hd, Hd)).view(Hd, 3 * Hd)          # (H, 3H)
+            order = list(range(T)) if d == 0 else list(range(T - 1, -1, -1))
+            dh_rec = None
+            for idx in range(T - 1, -1, -1):
+                t = order[idx]
+                prev = hs[d, order[idx - 1]] if idx > 0 else None
+                if prev is not None:
+                    hprev_all[d, t].copy_(prev)
+                g_t = g_out[:, t, d * Hd:(d + 1) * Hd]
+                dgi_t = dgi[:, t, d * 3 * Hd:(d + 1) * 3 * Hd]
+                dh_prev = torch.empty((B, Hd), dtype=torch.float32, device=dev)
+                _call("sed_gru_gate_bwd", _ptr(g_t), T * 2 * Hd, _ptr(dh_rec), _ptr(saves[d, t]), _ptr(prev), B, Hd,
+                      _ptr(dgi_t), T * 6 * Hd, _ptr(dgh_all[d, t]), _ptr(dh_prev), s)
+                if idx > 0:
+                    rec = gemm_nt(dgh_all[d, t], w_hh_t)                                 # (B, H)
+                    _call("sed_axpy", _ptr(dh_prev), _ptr(rec), B * Hd, s)
+                dh_rec = dh_prev
+            grads_hh.append(gemm_tn(hprev_all[d].view(T * B, Hd), dgh_all[d].view(T * B, 3 * Hd)))
+            grads_bhh.append(col_sums(dgh_all[d].view(T * B, 3 * Hd)))
+        dgi2 = dgi.view(B * T, 6 * Hd)
+        w_ih_t = transpose_b(w_ih.view(1, 6 * Hd, I)).view(I, 6 * Hd)
+        gx = gemm_nt(dgi2, w_ih_t).view(B, T, I)
+        dw_ih = gemm_tn(x.view(B * T, I), dgi2)                                          # (6H, I)
+        db_ih = col_sums(dgi2)
+        return (gx, dw_ih[:3 * Hd].contiguous(), grads_hh[0], db_ih[:3 * Hd].contiguous(), grads_bhh[0],
+                dw_ih[3 * Hd:].contiguous(), grads_hh[1], db_ih[3 * Hd:].contiguous(), grads_bhh[1])
+
+
+class ClipBceFn(torch.autograd.Function):
+    """losses.py:5-12."""
+
+    @staticmethod
+    def forward(ctx, p, y):
+        _chk_dev(p, y)
+        p, y = _f32c(p), _f32c(y)
+        loss = torch.empty((1,), dtype=torch.float32, device=p.device)
+        grad = torch.empty_like(p)
+        _call("sed_clip_bce", _ptr(p), _ptr(y), p.numel(), _ptr(loss), _ptr(grad), _stream())
+        ctx.save_for_backward(grad)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None
+
+
+def mixup_rows(x, lam):
+    """pytorch_utils.py:80-93 for a (2B, ...) tensor (the targets)."""
+    _chk_dev(x, lam)
+    x = _f32c(x)
+    lam = _f32c(lam)
+    B2 = x.shape[0]
+    D = x.numel() // B2
+    out = torch.empty((B2 // 2,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+    _call("sed_mixup_rows", _ptr(x), _ptr(lam), B2, D, _ptr(out), _stream())
+    return out
+
+
+def adam_amsgrad_(p, g, m, v, vmax, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    _chk_dev(p, g)
+    _call("sed_adam_amsgrad", _ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vmax), p.numel(), step, lr, beta1, beta2, eps,
+          grad_scale, _stream())
