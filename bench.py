@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""Headline benchmark: training clips/s (10 s @ 32 kHz) of Cnn_9layers_FrameAvg on MI355X, synthetic data.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one pass of the hot path over one batch: log-mel -> bn0+SpecAugment+mixup -> 4 ConvBlocks -> head ->
+clip_bce -> backward -> (RCCL all-reduce) -> Adam-amsgrad, with the waveforms already resident in HBM.  Workload at
+N=1 = BASELINE.json configs[1] (B=256 post-mixup clips = 512 waveforms per step, mixup on); weak scaling (B per GPU
+fixed).  Prints ONE JSON line on rank 0 carrying `roofline` (dominant kernel, HIP-event timed inside the timed
+region) and `cpu_baseline` (the CPU oracle timed on this host's cores, config 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from sound_event_detection_dcase2017_task4_amd import ops, parallel
+from sound_event_detection_dcase2017_task4_amd.optim import FusedAdamAmsgrad
+from sound_event_detection_dcase2017_task4_amd.pytorch import models
+from sound_event_detection_dcase2017_task4_amd.pytorch.losses import get_loss_func
+from sound_event_detection_dcase2017_task4_amd.pytorch.pytorch_utils import do_mixup
+from sound_event_detection_dcase2017_task4_amd.utils.utilities import Mixup
+
+FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+HBM_PEAK_GBPS = 8000.0
+
+
+def synth_batch(B2, L, seed, device):
+    """SURVEY.md §8d synthetic inputs: N(0, 0.1^2) clipped to [-1, 1]; Bernoulli(0.2) targets."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    wave = (torch.randn((B2, L), generator=g, device=device, dtype=torch.float32) * 0.1).clamp_(-1.0, 1.0)
+    target = (torch.rand((B2, 17), generator=g, device=device) < 0.2).float()
+    return wave, target
+
+
+def cpu_baseline(batch=32, clips=64, seconds=10):
+    """Config 0 on the host cores with the CPU oracle (a "port": the reference's Python cannot travel):
+    Cnn_9layers_FrameAvg, B=32, clip_bce, no mixup (SpecAugment on), Adam-amsgrad, `clips`/32 steps; first step =
+    warm-up, the rest timed."""
+    from oracle import frontend as ofe
+    from oracle import model as om
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    mt = "Cnn_9layers_FrameAvg"
+    st = om.recipe_state(mt, 2)
+    keys = om.trainable_keys(mt)
+    for k in keys:
+        st[k].requires_grad_(True)
+    opt_state = {k: [torch.zeros_like(st[k]) for _ in range(3)] for k in keys}
+    L = 32000 * seconds
+    rs = np.random.RandomState(1234)
+    times = []
+    for it in range(clips // batch):
+        x = torch.from_numpy((rs.randn(batch, L) * 0.1).astype(np.float32))
+        y = torch.from_numpy((rs.rand(batch, 17) < 0.2).astype(np.float32))
+        t0 = time.time()
+        o = om.forward(mt, st, x, training=True)
+        loss = om.clip_bce(o, {"target": y})
+        grads = torch.autograd.grad(loss, [st[k] for k in keys])
+        with torch.no_grad():
+            for k, g in zip(keys, grads):
+                m, v, vm = opt_state[k]
+                om.adam_amsgrad_step(st[k], g, m, v, vm, it + 1, 1e-3)
+        times.append(time.time() - t0)
+    timed = times[1:] if len(times) > 1 else times
+    return {"value": round(batch * len(timed) / sum(timed), 3), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": "config 0: %d x %d-clip train steps (10 s clips, no mixup, SpecAugment on, Adam-amsgrad) of the "
+                      "CPU oracle (torch fp32, %d threads); first step warm-up, %d timed" % (len(times), batch, threads, len(timed))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model_type", type=str, default="Cnn_9layers_FrameAvg")
+    ap.add_argument("--batch_size", type=int, default=256, help="post-mixup clips per GPU per step")
+    ap.add_argument("--no_mixup", action="store_true")
+    ap.add_argument("--seconds", type=int, default=10)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--int16", action="store_true", help="feed int16 waveforms (the HDF5 storage dtype)")
+    args = ap.parse_args()
+
+    rank, world, local_rank = parallel.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (HIP kernels only; no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    B = args.batch_size
+    mix = not args.no_mixup
+    B2 = 2 * B if mix else B
+    L = 32000 * args.seconds
+    torch.manual_seed(1234 + rank)
+    model = getattr(models, args.model_type)(32000, 1024, 320, 64, 50, 14000, 17).to(dev)
+    model.train()
+    opt = FusedAdamAmsgrad(model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, world_size=world)
+    parallel.broadcast_flat(opt.flat)
+    parallel.broadcast_buffers(model)
+    loss_func = get_loss_func("clip_bce")
+    mixup = Mixup(mixup_alpha=1., random_seed=1234 + rank)
+    pool = [synth_batch(B2, L, 1000 * rank + i, dev) for i in range(2)]
+    if args.int16:
+        pool = [((w * 32767.0).round().to(torch.int16), t) for (w, t) in pool]
+
+    def step(i):
+        wave, target = pool[i % len(pool)]
+        if mix:
+            lam = torch.from_numpy(mixup.get_lambda(B2).astype(np.float32)).to(dev, non_blocking=True)
+            out = model(wave, lam)
+            tgt = do_mixup(target, lam)
+        else:
+            out = model(wave, None)
+            tgt = target
+        loss = loss_func(out, {"target": tgt})
+        opt.zero_grad()
+        loss.backward()
+        parallel.allreduce_flat_grad(opt.flat_grad)
+        opt.step()
+        return loss
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    ops.TIMING = {}
+    t0 = time.time()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    sync()
+    dt = time.time() - t0
+    timing, ops.TIMING = ops.TIMING, None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return
+
+    kern = {}
+    for tag, evs in timing.items():
+        ms = sum(a.elapsed_time(b) for a, b, _ in evs)
+        fl = sum(f for _, _, f in evs)
+        kern[tag] = {"launches": len(evs), "ms_total": round(ms, 3), "avg_ms": round(ms / max(len(evs), 1), 4),
+                     "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else None}
+    dom = max(kern, key=lambda k: kern[k]["ms_total"]) if kern else None
+    roofline = None
+    if dom is not None:
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": kern[dom]["launches"] // args.steps, "avg_launch_ms": kern[dom]["avg_ms"]}
+    conv_ms = sum(v["ms_total"] for v in kern.values())
+    clips_per_s = B * world * args.steps / dt
+    line = {
+        "metric": "training clips/sec (10s@32kHz) Cnn_9layers_FrameAvg" if args.model_type == "Cnn_9layers_FrameAvg"
+                  else "training clips/sec (10s@32kHz) " + args.model_type,
+        "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s, batch_size=%d per GPU (post-mixup clips)%s, %d s @ 32 kHz %s waveforms resident in HBM, "
+                               "SpecAugment on, clip_bce, Adam-amsgrad; BASELINE.json configs[1]%s"
+                               % (args.model_type, B, ", mixup (%d waveforms/step/GPU)" % B2 if mix else ", no mixup",
+                                  args.seconds, "int16" if args.int16 else "fp32",
+                                  "" if (B == 256 and mix and args.model_type == "Cnn_9layers_FrameAvg") else " (modified by flags)"),
+                   "global_batch": B * world, "waveforms_per_step": B2 * world, "parallelism": "dp%d" % world},
+        "waveforms_per_s": round(B2 * world * args.steps / dt, 2),
+        "loss": round(float(loss.item()), 5),
+        "roofline": roofline,
+        "kernels": kern,
+        "mfma_kernels_share_of_step": round(conv_ms / (dt * 1e3), 4),
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline()
+    else:
+        line["cpu_baseline"] = None
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

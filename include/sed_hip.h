@@ -59,9 +59,10 @@ int sed_bn_eval_affine(int C, const float* gamma, const float* beta, const float
                        const float* running_var, float eps, float* mean_out, float* invstd_out, float* scale_out,
                        float* shift_out, sed_stream_t stream);
 /* BN backward, stage 2: partials [nparts][2][C] = (sum dy, sum dy*xhat) -> dgamma, dbeta and (nullable) the
- * coefficients coef[3][C] of g_y = a*dy + b*y + c. */
+ * coefficients coef[3][C] of g_y = a*dy + b*y + c.  batch_stats = 1: training-mode BN (gradient also flows
+ * through the batch mean/variance); 0: eval-mode BN (fixed affine: b = c = 0). */
 int sed_bn_bwd_finalize(const float* partials, int nparts, long N, int C, const float* mean, const float* invstd,
-                        const float* scale, float* dgamma, float* dbeta, float* coef, double* ws,
+                        const float* scale, int batch_stats, float* dgamma, float* dbeta, float* coef, double* ws,
                         sed_stream_t stream);
 /* g_y = a*dy + b*y + c in place on dy [nrows][C]. */
 int sed_bn_bwd_apply(float* dy_inout, const float* y, long nrows, int C, const float* coef, sed_stream_t stream);

