@@ -41,13 +41,13 @@ def synth_batch(B2, L, seed, device):
     return wave, target
 
 
-def cpu_baseline(batch=32, clips=64, seconds=10):
+def cpu_baseline(batch=32, clips=64, seconds=10, threads=0):
     """Config 0 on the host cores with the CPU oracle (a "port": the reference's Python cannot travel):
     Cnn_9layers_FrameAvg, B=32, clip_bce, no mixup (SpecAugment on), Adam-amsgrad, `clips`/32 steps; first step =
     warm-up, the rest timed."""
     from oracle import frontend as ofe
     from oracle import model as om
-    threads = os.cpu_count() or 1
+    threads = threads or min(os.cpu_count() or 1, 32)      # torch CPU conv scaling flattens/regresses beyond ~32 threads
     torch.set_num_threads(threads)
     mt = "Cnn_9layers_FrameAvg"
     st = om.recipe_state(mt, 2)
@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--seconds", type=int, default=10)
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--int16", action="store_true", help="feed int16 waveforms (the HDF5 storage dtype)")
+    ap.add_argument("--by_shape", action="store_true", help="print a per-layer MFMA kernel table to stderr")
+    ap.add_argument("--cpu_threads", type=int, default=0)
     args = ap.parse_args()
 
     rank, world, local_rank = parallel.init_from_env()
@@ -151,12 +153,23 @@ def main():
     if rank != 0:
         return
 
-    kern = {}
+    def summarise(groups):
+        out = {}
+        for tag, evs in groups.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in evs)
+            fl = sum(f for _, _, f in evs)
+            out[tag] = {"launches": len(evs), "ms_total": round(ms, 3), "avg_ms": round(ms / max(len(evs), 1), 4),
+                        "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else None}
+        return out
+
+    fam = {}
     for tag, evs in timing.items():
-        ms = sum(a.elapsed_time(b) for a, b, _ in evs)
-        fl = sum(f for _, _, f in evs)
-        kern[tag] = {"launches": len(evs), "ms_total": round(ms, 3), "avg_ms": round(ms / max(len(evs), 1), 4),
-                     "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else None}
+        fam.setdefault(tag.split("|")[0], []).extend(evs)
+    kern = summarise(fam)
+    if args.by_shape:
+        for tag, v in sorted(summarise(timing).items()):
+            print("# %-62s %3d launches  %8.3f ms/launch  %6.1f TFLOP/s" % (tag, v["launches"], v["avg_ms"], v["tflops"]),
+                  file=sys.stderr)
     dom = max(kern, key=lambda k: kern[k]["ms_total"]) if kern else None
     roofline = None
     if dom is not None:
@@ -184,7 +197,7 @@ def main():
         "mfma_kernels_share_of_step": round(conv_ms / (dt * 1e3), 4),
     }
     if world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline()
+        line["cpu_baseline"] = cpu_baseline(threads=args.cpu_threads)
     else:
         line["cpu_baseline"] = None
     print(json.dumps(line))

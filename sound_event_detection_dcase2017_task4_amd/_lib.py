@@ -45,6 +45,20 @@ def parse_header(path=HEADER):
 _LIB = None
 
 
+def _load_hip_runtime():
+    """libsed_hip.so carries no DT_NEEDED for the HIP runtime (see build.py): make the process-wide runtime --
+    PyTorch-ROCm's bundled libamdhip64.so -- globally visible before dlopen()ing it."""
+    import torch  # noqa: F401  (loads its HIP runtime)
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    for path in (cand, "libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"):
+        try:
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            return
+        except OSError:
+            continue
+    raise RuntimeError("no HIP runtime (libamdhip64.so) could be loaded")
+
+
 def lib():
     """Load (once) and return the ctypes handle with prototypes installed.  Raises if unavailable."""
     global _LIB
@@ -53,6 +67,7 @@ def lib():
             raise RuntimeError(
                 "libsed_hip.so not found at %s — build it with `python -m sound_event_detection_dcase2017_task4_amd.build` "
                 "(hipcc, gfx950).  There is no CPU/PyTorch fallback for the hot path." % LIB_PATH)
+        _load_hip_runtime()
         h = ctypes.CDLL(LIB_PATH)
         for name, (ret, argtypes) in parse_header().items():
             fn = getattr(h, name)            # AttributeError if the library lacks a declared symbol

@@ -47,7 +47,11 @@ def build(force=False, verbose=False):
         list(ex.map(run, jobs))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        # Link with the host C++ driver and NO DT_NEEDED on libamdhip64: the hip* symbols (and the fat-binary
+        # registration) must bind to the ONE HIP runtime already loaded in the process -- PyTorch-ROCm bundles its own
+        # libamdhip64.so (soname without version), and a second runtime from /opt/rocm would not know torch's streams
+        # and allocations.  _lib.py loads torch's runtime RTLD_GLOBAL first; a plain-C consumer links libamdhip64 itself.
+        run([os.environ.get("CXX", "g++"), "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB
 
 

@@ -217,7 +217,8 @@ class Bn0AugMix(torch.autograd.Function):
 
 def _conv_igemm(x, w_packed, B, H, W, Cin, Cout, in_st=None, epi=0, partials=None, yprev=None, p_st=None):
     y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
-    with _timed("conv3x3_igemm_mfma(fwd+dgrad)", 2.0 * 9 * B * H * W * Cin * Cout):
+    with _timed("conv3x3_igemm_mfma(fwd+dgrad)|%d->%d@%dx%d epi%d%s" % (Cin, Cout, H, W, epi, "+inT" if in_st is not None else ""),
+                2.0 * 9 * B * H * W * Cin * Cout):
         _call("sed_conv3x3_igemm", _ptr(x), _ptr(w_packed), _ptr(y), B, H, W, Cin, Cout,
               _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, epi,
               _ptr(partials), _ptr(yprev), _ptr(p_st.scale) if p_st is not None else None,
@@ -239,7 +240,8 @@ def _wgrad(x, gy, B, H, W, Cin, Cout, in_st=None):
     nfl = _lib.lib().sed_wgrad_partial_floats(B * H * W, Cin, Cout, 9, ctypes.byref(ns), ctypes.byref(pps))
     partial = torch.empty((nfl,), dtype=torch.float32, device=x.device)
     dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
-    with _timed("conv3x3_wgrad_mfma(+slice reduce)", 2.0 * 9 * B * H * W * Cin * Cout):
+    with _timed("conv3x3_wgrad_mfma(+slice reduce)|%d->%d@%dx%d%s" % (Cin, Cout, H, W, "+inT" if in_st is not None else ""),
+                2.0 * 9 * B * H * W * Cin * Cout):
         _call("sed_conv3x3_wgrad", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
               _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, _stream())
     return dw
