@@ -1,0 +1,196 @@
+"""Train / inference CLI of the hot path — same sub-commands and flags as reference pytorch/main.py (:379-421), same
+workspace layout (:72-110, :297-324) and checkpoint format (`{'iteration', 'model', 'optimizer'}`, :221-231).
+
+    python -m sound_event_detection_dcase2017_task4_amd.pytorch.main train --dataset_dir D --workspace W \
+        --holdout_fold 1 --model_type Cnn_9layers_FrameAvg --loss_type clip_bce --augmentation mixup \
+        --learning_rate 1e-3 --batch_size 32 --resume_iteration 0 --stop_iteration 50000 --cuda
+
+Differences, all additive: one process per GPU under torchrun (RCCL all-reduce of one flat gradient buffer) instead
+of nn.DataParallel; `--synthetic N` trains on N synthetic clips when no packed data exists; `--print_every` (the
+reference prints, i.e. synchronises, every iteration).  The every-1000-iterations evaluation branch needs the
+reference's sed_eval-based Evaluator, which is out of scope: it is skipped with a log line.
+"""
+import argparse
+import logging
+import os
+import pickle
+import time
+
+import numpy as np
+import torch
+import torch.utils.data
+
+from .. import parallel
+from ..optim import FusedAdamAmsgrad
+from ..utils.config import (sample_rate, classes_num, mel_bins, fmin, fmax, window_size, hop_size)
+from ..utils.data_generator import DCASE2017Task4Dataset, TrainSampler, TestSampler, collate_fn
+from ..utils.utilities import create_folder, get_filename, create_logging, Mixup
+from . import models as _models
+from .losses import get_loss_func
+from .models import *  # noqa: F401,F403  (model lookup by name, like the reference's `eval(model_type)`)
+from .pytorch_utils import move_data_to_device, do_mixup, forward
+
+
+def _paths(args, prefix):
+    sub = os.path.join('{}{}'.format(prefix, args.filename), 'holdout_fold={}'.format(args.holdout_fold),
+                       'model_type={}'.format(args.model_type), 'loss_type={}'.format(args.loss_type),
+                       'augmentation={}'.format(args.augmentation), 'batch_size={}'.format(args.batch_size))
+    return (os.path.join(args.workspace, 'checkpoints', sub), os.path.join(args.workspace, 'logs', sub),
+            os.path.join(args.workspace, 'predictions', sub))
+
+
+def _build_model(model_type):
+    assert model_type, 'Please specify model_type!'
+    if model_type not in _models.__all__:
+        raise Exception('Incorrect argument!')
+    Model = getattr(_models, model_type)
+    return Model(sample_rate, window_size, hop_size, mel_bins, fmin, fmax, classes_num)
+
+
+def train(args):
+    rank, world, local_rank = parallel.init_from_env()
+    device = 'cuda' if (args.cuda and torch.cuda.is_available()) else 'cpu'
+    if device != 'cuda':
+        raise SystemExit('This build runs the hot path on MI355X only: pass --cuda on a GPU box (no CPU fallback).')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    prefix = 'minidata_' if args.mini_data else ''
+    checkpoints_dir, logs_dir, _ = _paths(args, prefix)
+    if rank == 0:
+        create_folder(checkpoints_dir)
+        create_logging(logs_dir, 'w')
+        logging.info(args)
+        logging.info('Using GPU. ranks: {}'.format(world))
+    loss_func = get_loss_func(args.loss_type)
+    if args.synthetic:
+        train_path = 'synthetic:{}'.format(args.synthetic)
+    else:
+        train_path = os.path.join(args.workspace, 'hdf5s', '{}training.h5'.format(prefix))
+        if not os.path.exists(train_path) and os.path.isdir(train_path[:-3]):
+            train_path = train_path[:-3]
+
+    model = _build_model(args.model_type)
+    iteration = 0
+    if args.resume_iteration:
+        ck = torch.load(os.path.join(checkpoints_dir, '{}_iterations.pth'.format(args.resume_iteration)), map_location='cpu')
+        model.load_state_dict(ck['model'])
+        iteration = ck['iteration']
+    model.to(device)
+    optimizer = FusedAdamAmsgrad(model, lr=args.learning_rate, betas=(0.9, 0.999), eps=1e-08, world_size=world)
+    if args.resume_iteration and 'exp_avg' in ck.get('optimizer', {}):
+        optimizer.load_state_dict(ck['optimizer'])
+    parallel.broadcast_flat(optimizer.flat)
+    parallel.broadcast_buffers(model)
+
+    mix = 'mixup' in args.augmentation
+    per_rank = args.batch_size * 2 if mix else args.batch_size
+    dataset = DCASE2017Task4Dataset(keep_int16=True)
+    train_sampler = TrainSampler(hdf5_path=train_path, batch_size=per_rank, random_seed=1234 + rank)
+    train_loader = torch.utils.data.DataLoader(dataset=dataset, batch_sampler=train_sampler, collate_fn=collate_fn,
+                                               num_workers=0 if args.synthetic else 8, pin_memory=True)
+    mixup_augmenter = Mixup(mixup_alpha=1., random_seed=1234 + rank) if mix else None
+    train_bgn_time = time.time()
+
+    for batch_data_dict in train_loader:
+        if iteration % 1000 == 0 and iteration > (args.resume_iteration or 0) and rank == 0:
+            logging.info('Iteration: {}  train time: {:.3f} s  (evaluation branch out of scope, skipped)'.format(
+                iteration, time.time() - train_bgn_time))
+            train_bgn_time = time.time()
+        if iteration % 10000 == 0 and rank == 0:
+            checkpoint = {'iteration': iteration, 'model': model.state_dict(), 'optimizer': optimizer.state_dict()}
+            checkpoint_path = os.path.join(checkpoints_dir, '{}_iterations.pth'.format(iteration))
+            torch.save(checkpoint, checkpoint_path)
+            logging.info('Model saved to {}'.format(checkpoint_path))
+        if mix:
+            batch_data_dict['mixup_lambda'] = mixup_augmenter.get_lambda(batch_size=len(batch_data_dict['waveform']))
+        wave = torch.from_numpy(batch_data_dict['waveform']).to(device, non_blocking=True)     # int16 over PCIe
+        target = move_data_to_device(batch_data_dict['target'], device)
+        model.train()
+        if mix:
+            lam = move_data_to_device(batch_data_dict['mixup_lambda'], device)
+            batch_output_dict = model(wave, lam)
+            batch_target_dict = {'target': do_mixup(target, lam)}
+        else:
+            batch_output_dict = model(wave, None)
+            batch_target_dict = {'target': target}
+        loss = loss_func(batch_output_dict, batch_target_dict)
+        optimizer.zero_grad()
+        loss.backward()
+        parallel.allreduce_flat_grad(optimizer.flat_grad)
+        optimizer.step()
+        if rank == 0 and args.print_every and iteration % args.print_every == 0:
+            print(iteration, loss.item())
+        if iteration == args.stop_iteration:
+            break
+        iteration += 1
+
+
+def inference_prob(args):
+    """Dump eval-mode probabilities of the test / evaluation packs to pickles (main.py:267-376, minus sed_eval)."""
+    device = torch.device('cuda', 0) if (args.cuda and torch.cuda.is_available()) else None
+    if device is None:
+        raise SystemExit('This build runs the hot path on MI355X only: pass --cuda on a GPU box (no CPU fallback).')
+    checkpoints_dir, _, predictions_dir = _paths(args, '')
+    create_folder(predictions_dir)
+    model = _build_model(args.model_type)
+    checkpoint = torch.load(os.path.join(checkpoints_dir, '{}_iterations.pth'.format(args.iteration)), map_location='cpu')
+    model.load_state_dict(checkpoint['model'])
+    model.to(device)
+    dataset = DCASE2017Task4Dataset()
+    for data_type, name in (('test', 'testing.h5'), ('evaluate', 'evaluation.h5')):
+        path = 'synthetic:{}'.format(args.synthetic) if args.synthetic else os.path.join(args.workspace, 'hdf5s', name)
+        sampler = TestSampler(hdf5_path=path, batch_size=args.batch_size)
+        loader = torch.utils.data.DataLoader(dataset=dataset, batch_sampler=sampler, collate_fn=collate_fn,
+                                             num_workers=0 if args.synthetic else 8, pin_memory=True)
+        print('Inferencing {} data ...'.format(data_type))
+        output_dict = forward(model, loader, return_target=True)
+        prediction_path = os.path.join(predictions_dir, '{}_iterations.prediction.{}.pkl'.format(args.iteration, data_type))
+        pickle.dump(output_dict, open(prediction_path, 'wb'))
+        print('Write out to {}'.format(prediction_path))
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description='Example of parser. ')
+    subparsers = parser.add_subparsers(dest='mode')
+    p = subparsers.add_parser('train')
+    p.add_argument('--dataset_dir', type=str, required=True, help='Directory of dataset.')
+    p.add_argument('--workspace', type=str, required=True, help='Directory of your workspace.')
+    p.add_argument('--holdout_fold', type=str, choices=['1'], required=True)
+    p.add_argument('--model_type', type=str, required=True)
+    p.add_argument('--loss_type', type=str, required=True)
+    p.add_argument('--augmentation', type=str, choices=['none', 'mixup'], required=True)
+    p.add_argument('--learning_rate', type=float, required=True)
+    p.add_argument('--batch_size', type=int, required=True)
+    p.add_argument('--resume_iteration', type=int)
+    p.add_argument('--stop_iteration', type=int, required=True)
+    p.add_argument('--cuda', action='store_true', default=False)
+    p.add_argument('--mini_data', action='store_true', default=False)
+    p.add_argument('--synthetic', type=int, default=0, help='(extension) train on N synthetic clips')
+    p.add_argument('--print_every', type=int, default=100, help='(extension) loss print cadence; 1 = reference')
+    q = subparsers.add_parser('inference_prob')
+    q.add_argument('--dataset_dir', type=str, required=True, help='Directory of dataset.')
+    q.add_argument('--workspace', type=str, required=True, help='Directory of your workspace.')
+    q.add_argument('--holdout_fold', type=str, choices=['1'], required=True)
+    q.add_argument('--model_type', type=str, required=True)
+    q.add_argument('--loss_type', type=str, required=True)
+    q.add_argument('--augmentation', type=str, choices=['none', 'mixup'], required=True)
+    q.add_argument('--batch_size', type=int, required=True)
+    q.add_argument('--iteration', type=int, required=True)
+    q.add_argument('--cuda', action='store_true', default=False)
+    q.add_argument('--synthetic', type=int, default=0)
+    return parser
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    args.filename = get_filename(__file__)
+    if args.mode == 'train':
+        train(args)
+    elif args.mode == 'inference_prob':
+        inference_prob(args)
+    else:
+        raise Exception('Error argument!')
+
+
+if __name__ == '__main__':
+    main()

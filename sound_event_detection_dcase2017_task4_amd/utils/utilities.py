@@ -36,7 +36,8 @@ def create_logging(log_dir, filemode):
 
 
 def float32_to_int16(x):
-    assert np.max(np.abs(x)) <= 1.
+    if np.max(np.abs(x)) > 1.:
+        x = x / np.max(np.abs(x))
     return (x * 32767.).astype(np.int16)
 
 

@@ -1,0 +1,173 @@
+"""CPU: the C-ABI library loads and exports every symbol include/sed_hip.h declares (no compute calls without a
+GPU), plus the host-side logic of the product (SpecAugment draws, Mixup lambdas, state_dict layout, utilities)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import frontend as ofe
+from oracle import model as om
+
+
+def test_header_symbols_all_exported():
+    from sound_event_detection_dcase2017_task4_amd import _lib
+    protos = _lib.parse_header()
+    assert len(protos) >= 38 and "sed_conv3x3_igemm" in protos and "sed_logmel_f32" in protos
+    h = _lib.lib()
+    for name in protos:
+        assert hasattr(h, name), name
+    # and nothing is exported that the header does not declare
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (sed_\w+)", out))
+    assert exported == set(protos), exported ^ set(protos)
+
+
+def test_host_only_entry_points():
+    from sound_event_detection_dcase2017_task4_amd import _lib
+    h = _lib.lib()
+    assert h.sed_version().startswith(b"sed-hip")
+    assert h.sed_stats_rows_per_part() == 1024 and h.sed_conv1_rows_per_part() == 256
+    assert h.sed_conv_rows_per_part(64) == 32 and h.sed_conv_rows_per_part(512) == 64
+    assert h.sed_conv_num_parts(1000, 128) == 16 and h.sed_conv_num_parts(1000, 64) == 32
+    ns, pps = ctypes.c_int(), ctypes.c_int()
+    M = 256 * 1001 * 64
+    n = h.sed_wgrad_partial_floats(M, 64, 64, 9, ctypes.byref(ns), ctypes.byref(pps))
+    assert ns.value * pps.value >= M and pps.value % 32 == 0 and pps.value <= 16384
+    assert n == ns.value * 9 * 64 * 64
+
+
+def test_argument_errors_are_reported_not_crashes():
+    """Bad sizes are rejected on the host before any launch (error behaviour of the boundary)."""
+    from sound_event_detection_dcase2017_task4_amd import _lib
+    h = _lib.lib()
+    assert h.sed_conv3x3_igemm(None, None, None, 1, 8, 8, 48, 64, None, None, 0, None, None, None, None, None, None, None) == -22
+    assert h.sed_logmel_f32(None, 1, 100, None, None, None, None, None, None, None, 866, 1e-10, None, None) == -22
+    assert h.sed_mixup_rows(None, None, 3, 17, None, None) == -22
+    assert h.sed_adam_amsgrad(None, None, None, None, None, 10, 0, 1e-3, 0.9, 0.999, 1e-8, 1.0, None) == -22
+
+
+def test_product_refuses_cpu_tensors():
+    from sound_event_detection_dcase2017_task4_amd.pytorch import models
+    from sound_event_detection_dcase2017_task4_amd.pytorch.pytorch_utils import do_mixup
+    m = models.Cnn_9layers_FrameAvg(32000, 1024, 320, 64, 50, 14000, 17)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, 32000))
+    with pytest.raises(RuntimeError):
+        do_mixup(torch.zeros(4, 17), torch.ones(4))
+    with pytest.raises(Exception):
+        models.Cnn_9layers_FrameAvg(32000, 2048, 320, 64, 50, 14000, 17)      # kernels are specialised: loud failure
+
+
+def test_product_never_imports_oracle():
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sound_event_detection_dcase2017_task4_amd")
+    for dp, _, fs in os.walk(root):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), os.path.join(dp, f)
+
+
+@pytest.mark.parametrize("mt", om.MODEL_TYPES)
+def test_state_dict_layout_is_reference_compatible(mt):
+    from sound_event_detection_dcase2017_task4_amd.pytorch import models
+    m = getattr(models, mt)(32000, 1024, 320, 64, 50, 14000, 17)
+    sd = m.state_dict()
+    lay = om.state_layout(mt)
+    assert list(sd.keys()) == [k for k, _ in lay]
+    for k, shape in lay:
+        assert tuple(sd[k].shape) == tuple(shape), k
+    m.load_state_dict(om.recipe_state(mt, 1))                       # a reference-shaped checkpoint loads
+    frozen = [k for k, p in m.named_parameters() if not p.requires_grad]
+    assert sorted(frozen) == sorted(om.FROZEN_KEYS)
+    np.testing.assert_allclose(sd["logmel_extractor.melW"].numpy(), ofe.mel_matrix(), atol=2e-9)
+    wr, wi = ofe.dft_weights()
+    np.testing.assert_allclose(sd["spectrogram_extractor.stft.conv_real.weight"].numpy(), wr, atol=1e-6)
+    np.testing.assert_allclose(sd["spectrogram_extractor.stft.conv_imag.weight"].numpy(), wi, atol=1e-6)
+
+
+def test_specaug_fast_draw_equals_package_order():
+    from sound_event_detection_dcase2017_task4_amd.utils.augmentation import draw_specaug_stripes
+    for seed, (B, T) in enumerate([(1, 101), (6, 101), (64, 1001), (512, 1001)]):
+        torch.manual_seed(seed)
+        want = ofe.draw_specaug_stripes(B, T, 64)
+        after_want = torch.randint(0, 1000, (4,))
+        torch.manual_seed(seed)
+        got = draw_specaug_stripes(B, T, 64)
+        after_got = torch.randint(0, 1000, (4,))
+        np.testing.assert_array_equal(got, want)
+        assert torch.equal(after_want, after_got)                  # the generator is left in the same state
+
+
+def test_mixup_generator_and_utilities(golden_dir, tmp_path):
+    from sound_event_detection_dcase2017_task4_amd.utils.utilities import (Mixup, float32_to_int16, int16_to_float32,
+                                                                          create_folder, get_filename)
+    misc = np.load(os.path.join(golden_dir, "misc.npz"))
+    np.testing.assert_array_equal(Mixup(1.).get_lambda(64), misc["mixup_lambda64"])
+    g = Mixup(1.)
+    a, b = g.get_lambda(4), g.get_lambda(4)                        # the stream continues across calls (main.py:233-235)
+    np.testing.assert_array_equal(np.concatenate([a, b]), misc["mixup_lambda64"][:8])
+    x = np.array([0.5, -1.0, 0.25], dtype=np.float32)
+    np.testing.assert_allclose(int16_to_float32(float32_to_int16(x)), x, atol=1 / 32767.)
+    create_folder(str(tmp_path / "a" / "b"))
+    assert os.path.isdir(str(tmp_path / "a" / "b")) and get_filename("/x/y/main.py") == "main"
+
+
+def test_move_data_to_device_semantics():
+    from sound_event_detection_dcase2017_task4_amd.pytorch.pytorch_utils import move_data_to_device, append_to_dict
+    assert move_data_to_device(np.zeros(3, dtype=np.float64), "cpu").dtype == torch.float32
+    assert move_data_to_device(np.zeros(3, dtype=np.int16), "cpu").dtype == torch.int64
+    names = np.array(["a.wav", "b.wav"])
+    assert move_data_to_device(names, "cpu") is names
+    d = {}
+    append_to_dict(d, "k", 1); append_to_dict(d, "k", 2)
+    assert d == {"k": [1, 2]}
+
+
+def test_config_constants():
+    from sound_event_detection_dcase2017_task4_amd.utils import config
+    assert (config.sample_rate, config.window_size, config.hop_size, config.mel_bins, config.fmin, config.fmax) == \
+        (32000, 1024, 320, 64, 50, 14000)
+    assert config.classes_num == 17 and config.frames_per_second == 100 and len(config.ids) == 17
+    assert config.lb_to_idx["Train"] == 16 and sum(config.samples_num) == 58662
+
+
+def test_samplers_and_collate_match_reference_order():
+    """TrainSampler reproduces the reference stream incl. its double indexing (data_generator.py:88,:98)."""
+    from sound_event_detection_dcase2017_task4_amd.utils.data_generator import (TrainSampler, TestSampler, collate_fn,
+                                                                               DCASE2017Task4Dataset)
+    path = "synthetic:10:3200"
+    ts = TrainSampler(path, batch_size=4)
+    it = iter(ts)
+    got = [m["index_in_hdf5"] for _ in range(4) for m in next(it)]
+    rs = np.random.RandomState(1234)
+    idx = np.arange(10); rs.shuffle(idx)
+    want, pointer = [], 0
+    for _ in range(16):
+        index = idx[pointer]; pointer += 1
+        if pointer >= 10:
+            pointer = 0; rs.shuffle(idx)
+        want.append(idx[index])
+    assert got == want
+    batches = list(iter(TestSampler(path, batch_size=4)))
+    assert [len(b) for b in batches] == [4, 4, 2] and batches[2][1]["index_in_hdf5"] == 9
+    ds = DCASE2017Task4Dataset()
+    b = collate_fn([ds[m] for m in batches[0]])
+    assert b["waveform"].shape == (4, 3200) and b["waveform"].dtype == np.float32 and b["target"].shape == (4, 17)
+    assert b["audio_name"][1] == "syn_00001.wav"
+    raw = DCASE2017Task4Dataset(keep_int16=True)[batches[0][0]]["waveform"]
+    assert raw.dtype == np.int16 and np.allclose(raw / 32767., b["waveform"][0], atol=1e-7)
+
+
+def test_cli_flags_match_reference():
+    from sound_event_detection_dcase2017_task4_amd.pytorch.main import build_parser
+    a = build_parser().parse_args("train --dataset_dir d --workspace w --holdout_fold 1 --model_type Cnn_9layers_FrameAvg "
+                                  "--loss_type clip_bce --augmentation mixup --learning_rate 1e-3 --batch_size 32 "
+                                  "--resume_iteration 0 --stop_iteration 50000 --cuda".split())
+    assert a.mode == "train" and a.batch_size == 32 and a.cuda and a.augmentation == "mixup"
+    b = build_parser().parse_args("inference_prob --dataset_dir d --workspace w --holdout_fold 1 --model_type X "
+                                  "--loss_type clip_bce --augmentation mixup --batch_size 32 --iteration 50000 --cuda".split())
+    assert b.mode == "inference_prob" and b.iteration == 50000
