@@ -38,8 +38,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return base + (bid >> 3);
 }
 
+// Staging of one K-step of the implicit GEMM is written with NAMED registers (macros over literal row indices), not
+// arrays: hipcc left a `float4 breg[4]` array in scratch memory (private segment) with an `s_waitcnt vmcnt(0)` right
+// after the loads, which exposed the full global-load latency every K-step (measured: 93 -> see DESIGN.md).
 template <int WM, int WN, int TM, int TN, int NTAPS, bool INT, int EPI>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int A_LD = BM * 8 / 256, B_LD = BN * 8 / 256;
     static_assert(WM * WN == 4, "4 waves");
@@ -54,16 +57,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     const int n0 = (tile % nt_n) * BN;
     const int c4 = tid & 7, lrow = tid >> 3;
 
-    // per-row metadata of the A rows this thread stages
-    int rpix[A_LD], rh[A_LD], rw[A_LD];
-#pragma unroll
-    for (int i = 0; i < A_LD; ++i) {
-        long pm = m0 + lrow + 32 * i;
-        if (pm < p.M) {
-            rpix[i] = (int)pm;
-            if (NTAPS == 9) { rw[i] = (int)(pm % p.W); rh[i] = (int)((pm / p.W) % p.H); } else { rw[i] = 0; rh[i] = 0; }
-        } else { rpix[i] = 0; rh[i] = -(1 << 20); rw[i] = -(1 << 20); }
-    }
+    // per-row metadata of the rows this thread stages: A rows lrow + 32*i (i < A_LD), B rows lrow + 32*j (j < B_LD).
+    // Rows past M alias row 0 and are always masked.
+#define SED_ROW_META(i)                                                                                         \
+    const float* aptr##i = p.x + c4 * 4; int rh##i = -(1 << 20), rw##i = -(1 << 20);                            \
+    if (i < A_LD) {                                                                                             \
+        long pm = m0 + lrow + 32 * i;                                                                           \
+        if (pm < p.M) {                                                                                         \
+            aptr##i = p.x + pm * p.K + c4 * 4;                                                                  \
+            if (NTAPS == 9) {                                                                                   \
+                unsigned pu = (unsigned)pm;                                                                     \
+                rw##i = (int)(pu % (unsigned)p.W); rh##i = (int)((pu / (unsigned)p.W) % (unsigned)p.H);         \
+            } else { rw##i = 0; rh##i = 0; }                                                                    \
+        }                                                                                                       \
+    }                                                                                                           \
+    const float* bptr##i = p.w + (long)(n0 + lrow + 32 * (i < B_LD ? i : 0)) * p.K + c4 * 4;                    \
+    float4 areg##i = make_float4(0.f, 0.f, 0.f, 0.f), breg##i = areg##i;                                        \
+    bool vld##i = false;
+    SED_ROW_META(0) SED_ROW_META(1) SED_ROW_META(2) SED_ROW_META(3)
+#undef SED_ROW_META
 
     floatx16 acc[TM][TN];
 #pragma unroll
@@ -75,46 +87,49 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 
     const int kchunks = p.K >> 5;
     const int KT = kchunks * NTAPS;
-    float4 areg[A_LD], breg[B_LD];
-
-    auto gload = [&](int it) {
-        const int tap = (NTAPS == 9) ? it % 9 : 0;
-        const int c0 = ((NTAPS == 9) ? it / 9 : it) << 5;
-        const int dy = (NTAPS == 9) ? tap / 3 - 1 : 0, dx = (NTAPS == 9) ? tap % 3 - 1 : 0;
-        float4 sc, sh;
-        if (INT) {
-            sc = *reinterpret_cast<const float4*>(p.in_scale + c0 + c4 * 4);
-            sh = *reinterpret_cast<const float4*>(p.in_shift + c0 + c4 * 4);
-        }
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            bool valid = (NTAPS == 9) ? ((unsigned)(rh[i] + dy) < (unsigned)p.H && (unsigned)(rw[i] + dx) < (unsigned)p.W)
-                                      : (rh[i] >= 0);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid) {
-                const float* src = p.x + (long)(rpix[i] + dy * p.W + dx) * p.K + c0 + c4 * 4;
-                v = *reinterpret_cast<const float4*>(src);
-                if (INT) {
-                    v.x = bn_relu(v.x, sc.x, sh.x); v.y = bn_relu(v.y, sc.y, sh.y);
-                    v.z = bn_relu(v.z, sc.z, sh.z); v.w = bn_relu(v.w, sc.w, sh.w);
-                }
-            }
-            areg[i] = v;
-        }
-#pragma unroll
-        for (int j = 0; j < B_LD; ++j) {
-            const float* src = p.w + ((long)tap * p.N + n0 + lrow + 32 * j) * p.K + c0 + c4 * 4;
-            breg[j] = *reinterpret_cast<const float4*>(src);
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i)
-            *reinterpret_cast<float4*>(&As[buf][(lrow + 32 * i) * LDS_STRIDE + c4 * 4]) = areg[i];
-#pragma unroll
-        for (int j = 0; j < B_LD; ++j)
-            *reinterpret_cast<float4*>(&Bs[buf][(lrow + 32 * j) * LDS_STRIDE + c4 * 4]) = breg[j];
-    };
+    float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
+    // A: zero outside the image (branch-free: an invalid row reads its own, always-safe pixel and is zeroed by a
+    // select), optional BN+ReLU on the fly.  All per-step address arithmetic is wave-uniform (scalar).
+#define SED_A_LOAD(i)                                                                                           \
+    if (i < A_LD) {                                                                                             \
+        vld##i = (NTAPS == 9) ? ((unsigned)(rh##i + dy) < (unsigned)p.H && (unsigned)(rw##i + dx) < (unsigned)p.W) \
+                              : (rh##i >= 0);                                                                   \
+        areg##i = *reinterpret_cast<const float4*>(aptr##i + (vld##i ? a_off : (long)c0));                      \
+    }
+// applied at LDS-store time (after the MFMA block), so nothing waits on the loads before the MFMAs start
+#define SED_A_FIX(i)                                                                                            \
+    if (i < A_LD) {                                                                                             \
+        if (INT) {                                                                                              \
+            areg##i.x = bn_relu(areg##i.x, sc.x, sh.x); areg##i.y = bn_relu(areg##i.y, sc.y, sh.y);             \
+            areg##i.z = bn_relu(areg##i.z, sc.z, sh.z); areg##i.w = bn_relu(areg##i.w, sc.w, sh.w);             \
+        }                                                                                                       \
+        areg##i.x = vld##i ? areg##i.x : 0.f; areg##i.y = vld##i ? areg##i.y : 0.f;                             \
+        areg##i.z = vld##i ? areg##i.z : 0.f; areg##i.w = vld##i ? areg##i.w : 0.f;                             \
+    }
+#define SED_B_LOAD(j) if (j < B_LD) breg##j = *reinterpret_cast<const float4*>(bptr##j + b_off);
+#define gload(IT)                                                                                               \
+    {                                                                                                           \
+        const int it_ = (IT);                                                                                   \
+        const int tap = (NTAPS == 9) ? it_ % 9 : 0;                                                             \
+        const int c0 = ((NTAPS == 9) ? it_ / 9 : it_) << 5;                                                     \
+        const int dy = (NTAPS == 9) ? tap / 3 - 1 : 0, dx = (NTAPS == 9) ? tap % 3 - 1 : 0;                     \
+        const long a_off = (long)(dy * p.W + dx) * p.K + c0;                                                    \
+        const long b_off = (long)tap * p.N * p.K + c0;                                                          \
+        if (INT) {                                                                                              \
+            sc = *reinterpret_cast<const float4*>(p.in_scale + c0 + c4 * 4);                                    \
+            sh = *reinterpret_cast<const float4*>(p.in_shift + c0 + c4 * 4);                                    \
+        }                                                                                                       \
+        SED_B_LOAD(0) SED_B_LOAD(1) SED_B_LOAD(2) SED_B_LOAD(3)                                                 \
+        SED_A_LOAD(0) SED_A_LOAD(1) SED_A_LOAD(2) SED_A_LOAD(3)                                                 \
+    }
+#define SED_A_STORE(BUF, i) if (i < A_LD) *reinterpret_cast<float4*>(&As[(BUF)][(lrow + 32 * i) * LDS_STRIDE + c4 * 4]) = areg##i;
+#define SED_B_STORE(BUF, j) if (j < B_LD) *reinterpret_cast<float4*>(&Bs[(BUF)][(lrow + 32 * j) * LDS_STRIDE + c4 * 4]) = breg##j;
+#define lstore(BUF)                                                                                             \
+    {                                                                                                           \
+        SED_A_FIX(0) SED_A_FIX(1) SED_A_FIX(2) SED_A_FIX(3)                                                     \
+        SED_A_STORE(BUF, 0) SED_A_STORE(BUF, 1) SED_A_STORE(BUF, 2) SED_A_STORE(BUF, 3)                         \
+        SED_B_STORE(BUF, 0) SED_B_STORE(BUF, 1) SED_B_STORE(BUF, 2) SED_B_STORE(BUF, 3)                         \
+    }
 
     gload(0);
     lstore(0);
@@ -123,7 +138,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     const int brow = (wn * TN * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
     for (int it = 0; it < KT; ++it) {
         const int buf = it & 1;
-        if (it + 1 < KT) gload(it + 1);
+        // unconditional prefetch (the last iteration re-fetches its own tile into the idle buffer): no branches and
+        // no "maybe-uninitialised" staging registers in the loop, which is what keeps them out of scratch memory
+        gload(it + 1 < KT ? it + 1 : it);
+        __builtin_amdgcn_sched_barrier(0);       // keep all eight global loads ABOVE the MFMA block (latency hidden by it)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 af[TM], bf[TN];
@@ -141,9 +159,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
                 }
         }
-        if (it + 1 < KT) lstore(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);       // ... and the LDS stores (which wait for them) BELOW it
+        lstore(buf ^ 1);
         __syncthreads();
     }
+#undef gload
+#undef lstore
+#undef SED_A_LOAD
+#undef SED_A_FIX
+#undef SED_B_LOAD
+#undef SED_A_STORE
+#undef SED_B_STORE
 
     // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const long wrow0 = m0 + wm * TM * 32;
@@ -211,11 +237,11 @@ struct WgradP {
 };
 
 template <int TM, int TN, int NTAPS, bool INT>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
     constexpr int CO_T = 64 * TM, CI_T = 64 * TN, BKP = 32;
     constexpr int G_C4 = 16 * TM, X_C4 = 16 * TN;
     constexpr int G_RPP = 256 / G_C4, X_RPP = 256 / X_C4;
-    constexpr int G_LD = BKP / G_RPP, X_LD = BKP / X_RPP;
+    constexpr int G_LD = BKP / G_RPP, X_LD = BKP / X_RPP;       // 2*TM, 2*TN float4 per thread per K-step (<= 4)
     __shared__ __attribute__((aligned(16))) float Gs[2][BKP * CO_T];
     __shared__ __attribute__((aligned(16))) float Xs[2][BKP * CI_T];
 
@@ -241,59 +267,79 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
 
     const int g_c4 = tid % G_C4, g_r = tid / G_C4;
     const int x_c4 = tid % X_C4, x_r = tid / X_C4;
-    float4 xsc, xsh;
+    float4 xsc = make_float4(0.f, 0.f, 0.f, 0.f), xsh = xsc;
     if (INT) {
         xsc = *reinterpret_cast<const float4*>(p.in_scale + ci0 + x_c4 * 4);
         xsh = *reinterpret_cast<const float4*>(p.in_shift + ci0 + x_c4 * 4);
     }
-    float4 greg[G_LD], xreg[X_LD];
-    auto gload = [&](long pb) {
-#pragma unroll
-        for (int i = 0; i < G_LD; ++i) {
-            long pm = pb + g_r + G_RPP * i;
-            greg[i] = (pm < pend) ? *reinterpret_cast<const float4*>(p.gy + pm * p.N + co0 + g_c4 * 4)
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < X_LD; ++i) {
-            long pm = pb + x_r + X_RPP * i;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            bool valid = pm < pend;
-            if (NTAPS == 9 && valid) {
-                unsigned pu = (unsigned)pm;            // M < 2^31: 32-bit divides
-                int w = (int)(pu % (unsigned)p.W), h = (int)((pu / (unsigned)p.W) % (unsigned)p.H);
-                valid = (unsigned)(h + dy) < (unsigned)p.H && (unsigned)(w + dx) < (unsigned)p.W;
-            }
-            if (valid) {
-                v = *reinterpret_cast<const float4*>(p.x + (pm + dy * p.W + dx) * p.K + ci0 + x_c4 * 4);
-                if (INT) {
-                    v.x = bn_relu(v.x, xsc.x, xsh.x); v.y = bn_relu(v.y, xsc.y, xsh.y);
-                    v.z = bn_relu(v.z, xsc.z, xsh.z); v.w = bn_relu(v.w, xsc.w, xsh.w);
-                }
-            }
-            xreg[i] = v;
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < G_LD; ++i)
-            *reinterpret_cast<float4*>(&Gs[buf][(g_r + G_RPP * i) * CO_T + g_c4 * 4]) = greg[i];
-#pragma unroll
-        for (int i = 0; i < X_LD; ++i)
-            *reinterpret_cast<float4*>(&Xs[buf][(x_r + X_RPP * i) * CI_T + x_c4 * 4]) = xreg[i];
-    };
+    // Named staging registers (see conv_igemm_kernel).  Each staged row advances by BKP = 32 pixels per K-step; its
+    // (h, w) is tracked incrementally (one 32-bit divide per row per workgroup instead of per step).
+    const int dq = BKP / p.W, dr = BKP % p.W;
+    const long x_tap_off = (long)(dy * p.W + dx) * p.K;
+#define SED_W_META(i)                                                                                           \
+    const float* gptr##i = p.gy + (pbeg + g_r + G_RPP * (i < G_LD ? i : 0)) * p.N + co0 + g_c4 * 4;             \
+    const float* xptr##i = p.x + (pbeg + x_r + X_RPP * (i < X_LD ? i : 0)) * p.K + ci0 + x_c4 * 4;              \
+    long gpm##i = pbeg + g_r + G_RPP * i, xpm##i = pbeg + x_r + X_RPP * i;                                      \
+    int xh##i = 0, xw##i = 0;                                                                                   \
+    if (NTAPS == 9 && i < X_LD) {                                                                               \
+        unsigned pu = (unsigned)xpm##i;                                                                         \
+        xw##i = (int)(pu % (unsigned)p.W); xh##i = (int)((pu / (unsigned)p.W) % (unsigned)p.H);                 \
+    }                                                                                                           \
+    float4 greg##i = make_float4(0.f, 0.f, 0.f, 0.f), xreg##i = greg##i;                                        \
+    bool gv##i = false, xv##i = false;
+    SED_W_META(0) SED_W_META(1) SED_W_META(2) SED_W_META(3)
+#undef SED_W_META
+    // loads are branch-free: an out-of-range row re-reads the slice's first (always valid) row and is zeroed at store
+#define SED_G_LOAD(i)                                                                                           \
+    if (i < G_LD) {                                                                                             \
+        gv##i = gpm##i < pend;                                                                                  \
+        greg##i = *reinterpret_cast<const float4*>(gv##i ? gptr##i : p.gy + pbeg * p.N + co0 + g_c4 * 4);       \
+        gptr##i += (long)BKP * p.N; gpm##i += BKP;                                                              \
+    }
+#define SED_X_LOAD(i)                                                                                           \
+    if (i < X_LD) {                                                                                             \
+        xv##i = xpm##i < pend;                                                                                  \
+        if (NTAPS == 9) xv##i = xv##i && (unsigned)(xh##i + dy) < (unsigned)p.H && (unsigned)(xw##i + dx) < (unsigned)p.W; \
+        xreg##i = *reinterpret_cast<const float4*>(xv##i ? xptr##i + x_tap_off : p.x + pbeg * p.K + ci0 + x_c4 * 4); \
+        xptr##i += (long)BKP * p.K; xpm##i += BKP;                                                              \
+        if (NTAPS == 9) {                                                                                       \
+            xw##i += dr; xh##i += dq;                                                                           \
+            if (xw##i >= p.W) { xw##i -= p.W; xh##i += 1; }                                                     \
+            while (xh##i >= p.H) xh##i -= p.H;                                                                  \
+        }                                                                                                       \
+    }
+#define SED_G_STORE(BUF, i)                                                                                     \
+    if (i < G_LD) {                                                                                             \
+        float4 v = greg##i;                                                                                     \
+        v.x = gv##i ? v.x : 0.f; v.y = gv##i ? v.y : 0.f; v.z = gv##i ? v.z : 0.f; v.w = gv##i ? v.w : 0.f;     \
+        *reinterpret_cast<float4*>(&Gs[(BUF)][(g_r + G_RPP * i) * CO_T + g_c4 * 4]) = v;                        \
+    }
+#define SED_X_STORE(BUF, i)                                                                                     \
+    if (i < X_LD) {                                                                                             \
+        float4 v = xreg##i;                                                                                     \
+        if (INT) {                                                                                              \
+            v.x = bn_relu(v.x, xsc.x, xsh.x); v.y = bn_relu(v.y, xsc.y, xsh.y);                                 \
+            v.z = bn_relu(v.z, xsc.z, xsh.z); v.w = bn_relu(v.w, xsc.w, xsh.w);                                 \
+        }                                                                                                       \
+        v.x = xv##i ? v.x : 0.f; v.y = xv##i ? v.y : 0.f; v.z = xv##i ? v.z : 0.f; v.w = xv##i ? v.w : 0.f;     \
+        *reinterpret_cast<float4*>(&Xs[(BUF)][(x_r + X_RPP * i) * CI_T + x_c4 * 4]) = v;                        \
+    }
+#define wg_load() { SED_G_LOAD(0) SED_G_LOAD(1) SED_G_LOAD(2) SED_G_LOAD(3) SED_X_LOAD(0) SED_X_LOAD(1) SED_X_LOAD(2) SED_X_LOAD(3) }
+#define wg_store(BUF) { SED_G_STORE(BUF, 0) SED_G_STORE(BUF, 1) SED_G_STORE(BUF, 2) SED_G_STORE(BUF, 3) \
+                        SED_X_STORE(BUF, 0) SED_X_STORE(BUF, 1) SED_X_STORE(BUF, 2) SED_X_STORE(BUF, 3) }
 
     const int nsteps = (int)((pend - pbeg + BKP - 1) / BKP);
     if (nsteps > 0) {
-        gload(pbeg);
-        lstore(0);
+        wg_load();
+        wg_store(0);
     }
     __syncthreads();
     const int half = lane >> 5;
     const int gcol = wm * 32 * TM + (lane & 31), xcol = wn * 32 * TN + (lane & 31);
     for (int it = 0; it < nsteps; ++it) {
         const int buf = it & 1;
-        if (it + 1 < nsteps) gload(pbeg + (long)(it + 1) * BKP);
+        wg_load();                               // unconditional prefetch (rows past `pend` are masked to zero)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             float af[TM], bf[TN];
@@ -307,9 +353,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
                 for (int b = 0; b < TN; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
-        if (it + 1 < nsteps) lstore(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        wg_store(buf ^ 1);
         __syncthreads();
     }
+#undef SED_G_LOAD
+#undef SED_X_LOAD
+#undef SED_G_STORE
+#undef SED_X_STORE
+#undef wg_load
+#undef wg_store
     float* out = p.partial + ((long)blockIdx.y * NTAPS + tap) * p.N * p.K;
 #pragma unroll
     for (int a = 0; a < TM; ++a)
