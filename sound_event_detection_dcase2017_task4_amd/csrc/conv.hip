@@ -14,7 +14,17 @@
 
 namespace {
 
-constexpr int LDS_STRIDE = 36;   // 32 floats + 4 pad: ds_read_b128 of 16 distinct rows hits 16 distinct 16-B slots
+constexpr int LDS_STRIDE = 36;   // padded layout: 32 floats + 4 pad: ds_read_b128 of 16 distinct rows -> 16 distinct 16-B slots
+
+// LDS tile addressing.  SWZ = false: rows padded to 36 floats (conflict-free b128 reads).  SWZ = true: unpadded 128-B
+// rows with the 16-B chunk index XORed by (row & 7): at most 2-way conflicts (irrelevant next to 64-cycle fp32 MFMAs)
+// but 11 % less LDS, which is what lets THREE 128x64 workgroups share a CU.
+template <bool SWZ> __device__ __forceinline__ int lds_off(int row, int chunk) {
+    return SWZ ? row * 32 + ((chunk ^ (row & 7)) << 2) : row * LDS_STRIDE + (chunk << 2);
+}
+template <bool SWZ> __device__ __forceinline__ float4 lds_frag(const float* base, int row, int chunk) {
+    return *reinterpret_cast<const float4*>(base + lds_off<SWZ>(row, chunk));
+}
 
 struct ConvP {
     const float* x;          // [M][K] NHWC input (raw previous conv output if in_scale != null)
@@ -46,8 +56,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int A_LD = BM * 8 / 256, B_LD = BN * 8 / 256;
     static_assert(WM * WN == 4, "4 waves");
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_STRIDE];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_STRIDE];
+    constexpr bool SWZ = (BN == 64 && BM == 128);            // 48 KB -> 3 workgroups per CU for the Cout = 64 layers
+    constexpr int ROWF = SWZ ? 32 : LDS_STRIDE;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * ROWF];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * ROWF];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv / WN, wn = wv % WN;
@@ -122,8 +134,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
         SED_B_LOAD(0) SED_B_LOAD(1) SED_B_LOAD(2) SED_B_LOAD(3)                                                 \
         SED_A_LOAD(0) SED_A_LOAD(1) SED_A_LOAD(2) SED_A_LOAD(3)                                                 \
     }
-#define SED_A_STORE(BUF, i) if (i < A_LD) *reinterpret_cast<float4*>(&As[(BUF)][(lrow + 32 * i) * LDS_STRIDE + c4 * 4]) = areg##i;
-#define SED_B_STORE(BUF, j) if (j < B_LD) *reinterpret_cast<float4*>(&Bs[(BUF)][(lrow + 32 * j) * LDS_STRIDE + c4 * 4]) = breg##j;
+#define SED_A_STORE(BUF, i) if (i < A_LD) *reinterpret_cast<float4*>(&As[(BUF)][lds_off<SWZ>(lrow + 32 * i, c4)]) = areg##i;
+#define SED_B_STORE(BUF, j) if (j < B_LD) *reinterpret_cast<float4*>(&Bs[(BUF)][lds_off<SWZ>(lrow + 32 * j, c4)]) = breg##j;
 #define lstore(BUF)                                                                                             \
     {                                                                                                           \
         SED_A_FIX(0) SED_A_FIX(1) SED_A_FIX(2) SED_A_FIX(3)                                                     \
@@ -134,21 +146,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     gload(0);
     lstore(0);
     __syncthreads();
-    const int arow = (wm * TM * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
-    const int brow = (wn * TN * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
+    const int arow_base = wm * TM * 32 + (lane & 31);
+    const int brow_base = wn * TN * 32 + (lane & 31);
     for (int it = 0; it < KT; ++it) {
         const int buf = it & 1;
         // unconditional prefetch (the last iteration re-fetches its own tile into the idle buffer): no branches and
         // no "maybe-uninitialised" staging registers in the loop, which is what keeps them out of scratch memory
         gload(it + 1 < KT ? it + 1 : it);
-        __builtin_amdgcn_sched_barrier(0);       // keep all eight global loads ABOVE the MFMA block (latency hidden by it)
+        __builtin_amdgcn_sched_barrier(0);       // keep all global loads ABOVE the MFMA block (latency hidden by it)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 af[TM], bf[TN];
 #pragma unroll
-            for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const float4*>(&As[buf][arow + a * 32 * LDS_STRIDE + q * 8]);
+            for (int a = 0; a < TM; ++a) af[a] = lds_frag<SWZ>(&As[buf][0], arow_base + a * 32, q * 2 + (lane >> 5));
 #pragma unroll
-            for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const float4*>(&Bs[buf][brow + b * 32 * LDS_STRIDE + q * 8]);
+            for (int b = 0; b < TN; ++b) bf[b] = lds_frag<SWZ>(&Bs[buf][0], brow_base + b * 32, q * 2 + (lane >> 5));
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -158,9 +170,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].z, bf[b].z, acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
                 }
+            if (q == 2) {
+                // stage the next tile into the idle LDS buffer while the MFMA pipe drains the q=2 block: by now the
+                // loads issued at the top have had 3/4 of the K-step to land; only the barrier is left at the end
+                __builtin_amdgcn_sched_barrier(0);
+                lstore(buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);       // ... and the LDS stores (which wait for them) BELOW it
-        lstore(buf ^ 1);
         __syncthreads();
     }
 #undef gload
@@ -340,21 +357,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
         const int buf = it & 1;
         wg_load();                               // unconditional prefetch (rows past `pend` are masked to zero)
         __builtin_amdgcn_sched_barrier(0);
+        float af[TM], bf[TN], afn[TM], bfn[TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) af[a] = Gs[buf][half * CO_T + gcol + a * 32];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bf[b] = Xs[buf][half * CI_T + xcol + b * 32];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            float af[TM], bf[TN];
+            if (j < 15) {                        // fragments of the next pixel pair are in flight during these MFMAs
 #pragma unroll
-            for (int a = 0; a < TM; ++a) af[a] = Gs[buf][(2 * j + half) * CO_T + gcol + a * 32];
+                for (int a = 0; a < TM; ++a) afn[a] = Gs[buf][(2 * j + 2 + half) * CO_T + gcol + a * 32];
 #pragma unroll
-            for (int b = 0; b < TN; ++b) bf[b] = Xs[buf][(2 * j + half) * CI_T + xcol + b * 32];
+                for (int b = 0; b < TN; ++b) bfn[b] = Xs[buf][(2 * j + 2 + half) * CI_T + xcol + b * 32];
+            }
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+            if (j == 11) {                       // stage the next tile while the MFMA pipe is busy (cf. conv_igemm_kernel)
+                __builtin_amdgcn_sched_barrier(0);
+                wg_store(buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[a] = afn[a];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bf[b] = bfn[b];
         }
-        __builtin_amdgcn_sched_barrier(0);
-        wg_store(buf ^ 1);
         __syncthreads();
     }
 #undef SED_G_LOAD
@@ -550,14 +580,20 @@ __global__ __launch_bounds__(256) void conv1_dgrad_gather_kernel(const float* __
     }
 }
 
-// dW[co][0][tap] = sum over blocks of dw_partials[blk][tap][co]
-__global__ void conv1_wgrad_reduce_kernel(const float* __restrict__ parts, int nblk, float* __restrict__ dw) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 576) return;
+// dW[co][0][tap] = sum over blocks of dw_partials[blk][tap][co]; one workgroup per 64 outputs, 4 row-slices each
+__global__ __launch_bounds__(256) void conv1_wgrad_reduce_kernel(const float* __restrict__ parts, int nblk,
+                                                                 float* __restrict__ dw) {
+    __shared__ double red[256];
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)parts[(long)b * 576 + i];
-    int tap = i / 64, co = i % 64;
-    dw[co * 9 + tap] = (float)s;
+    for (int b = sl + 4 * blockIdx.y; b < nblk; b += 4 * gridDim.y) s += (double)parts[(long)b * 576 + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (sl == 0) {
+        s = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+        int tap = i / 64, co = i % 64;
+        atomicAdd(&dw[co * 9 + tap], (float)s);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -709,7 +745,8 @@ SED_API int sed_conv1_bwd(const float* x0, const float* w_oihw, const float* gy,
     int nblk = sed_cdiv(M, C1B_ROWS);
     hipLaunchKernelGGL(conv1_bwd_kernel, dim3(nblk), dim3(256), 0, stream, x0, w_oihw, gy, M, H, W, dw_partials,
                        gx0 ? tbuf : (float*)nullptr);
-    hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(9), dim3(64), 0, stream, dw_partials, nblk, dw);
+    (void)hipMemsetAsync(dw, 0, 576 * sizeof(float), stream);
+    hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(9, 32), dim3(256), 0, stream, dw_partials, nblk, dw);
     if (gx0) {
         int g = sed_cdiv(M, 256);
         hipLaunchKernelGGL(conv1_dgrad_gather_kernel, dim3(g > 8192 ? 8192 : g), dim3(256), 0, stream, tbuf, M, H, W, gx0);
