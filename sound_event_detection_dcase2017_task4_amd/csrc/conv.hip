@@ -662,13 +662,20 @@ SED_API int sed_gemm_nt(const float* x, const float* w, const float* bias, float
 }
 
 SED_API long sed_wgrad_partial_floats(long M, int Cin, int Cout, int ntaps, int* nslices_out, int* pix_per_slice_out) {
-    // slices: bound the fp32 accumulation chain (<= 16384 pixels) and fill the chip (>= ~1024 workgroups)
-    long tiles = (long)ntaps * sed_cdiv(Cout, Cout >= 128 ? 128 : 64) * sed_cdiv(Cin, Cin >= 128 ? 128 : 64);
-    long want = (1024 + tiles - 1) / tiles;
-    long by_chain = (M + 16383) / 16384;
-    long ns = want > by_chain ? want : by_chain;
+    // Pixel slices: (i) bound the fp32 accumulation chain (<= 16384 pixels per slice), (ii) fill the chip, and
+    // (iii) make the workgroup count land just under a whole number of "rounds" of the chip's concurrent capacity
+    // (256 CUs x workgroups/CU for the tile config) -- a 4.4-round grid wastes the tail of its 5th round.
+    const int tm = Cout >= 128 ? 2 : 1, tn = Cin >= 128 ? 2 : 1;
+    const long tiles = (long)ntaps * (Cout / (64 * tm)) * (Cin / (64 * tn));
+    const long capacity = 256L * (tm * tn == 4 ? 2 : (tm * tn == 2 ? 3 : 4));
+    long ns_min = (M + 16383) / 16384;
+    long fill = (2 * capacity + tiles - 1) / tiles;
+    if (fill > ns_min) ns_min = fill;
+    long rounds = (tiles * ns_min + capacity - 1) / capacity;
+    long ns = rounds * capacity / tiles;
+    if (ns < ns_min) ns = ns_min;
     long pps = ((M + ns - 1) / ns + 31) / 32 * 32;
-    if (pps < 32) pps = 32;
+    if (pps < 256) pps = 256;                    // tiny problems: do not explode the partial buffer
     ns = (M + pps - 1) / pps;
     if (nslices_out) *nslices_out = (int)ns;
     if (pix_per_slice_out) *pix_per_slice_out = (int)pps;
