@@ -163,9 +163,18 @@ def main():
         return out
 
     fam = {}
+    fe = timing.pop("logmel_frontend", None)
     for tag, evs in timing.items():
         fam.setdefault(tag.split("|")[0], []).extend(evs)
     kern = summarise(fam)
+    frontend = None
+    if fe:
+        ms = sum(a.elapsed_time(b) for a, b, _ in fe)
+        gbps = sum(nb for _, _, nb in fe) / (ms * 1e-3) / 1e9
+        frontend = {"kernel": "logmel_kernel (STFT+mel+log, K1)", "bound": "hbm", "achieved": round(gbps, 1),
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "avg_launch_ms": round(ms / len(fe), 4),
+                    "bytes_per_waveform": int(fe[0][2] / B2)}
     if args.by_shape:
         for tag, v in sorted(summarise(timing).items()):
             print("# %-62s %3d launches  %8.3f ms/launch  %6.1f TFLOP/s" % (tag, v["launches"], v["avg_ms"], v["tflops"]),
@@ -193,6 +202,7 @@ def main():
         "waveforms_per_s": round(B2 * world * args.steps / dt, 2),
         "loss": round(float(loss.item()), 5),
         "roofline": roofline,
+        "roofline_frontend": frontend,
         "kernels": kern,
         "mfma_kernels_share_of_step": round(conv_ms / (dt * 1e3), 4),
     }

@@ -251,6 +251,7 @@ struct WgradP {
     int H, W, K, N;
     long M;
     int pix_per_slice;
+    int ids_per_slice;       // NTAPS * (N / CO_T) * (K / CI_T)
 };
 
 template <int TM, int TN, int NTAPS, bool INT>
@@ -265,12 +266,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv >> 1, wn = wv & 1;
     const int ci_tiles = p.K / CI_T;
-    int id = blockIdx.x;
+    // 1-D grid, XCD-aware: workgroup b runs on XCD b % 8, so hand each XCD a CONTIGUOUS range of (slice, tile, tap)
+    // items -- the 9 taps (and the channel tiles) of one pixel slice then share that XCD's L2 instead of each pulling
+    // the same G/X tiles from HBM through a different L2 (PMC: 35 GB fetched for 8.4 GB of operands before this).
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int slice = logical / p.ids_per_slice;
+    int id = logical % p.ids_per_slice;
     const int tap = (NTAPS == 9) ? id % 9 : 0;
     id = (NTAPS == 9) ? id / 9 : id;
     const int ci0 = (id % ci_tiles) * CI_T, co0 = (id / ci_tiles) * CO_T;
     const int dy = (NTAPS == 9) ? tap / 3 - 1 : 0, dx = (NTAPS == 9) ? tap % 3 - 1 : 0;
-    const long pbeg = (long)blockIdx.y * p.pix_per_slice;
+    const long pbeg = (long)slice * p.pix_per_slice;
     long pend = pbeg + p.pix_per_slice;
     if (pend > p.M) pend = p.M;
 
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
 #undef SED_X_STORE
 #undef wg_load
 #undef wg_store
-    float* out = p.partial + ((long)blockIdx.y * NTAPS + tap) * p.N * p.K;
+    float* out = p.partial + ((long)slice * NTAPS + tap) * p.N * p.K;
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -618,9 +624,11 @@ int launch_igemm(const ConvP& p, bool in_transform, int epi, hipStream_t stream)
 template <int TM, int TN, int NTAPS>
 int launch_wgrad(const WgradP& p, int nslices, bool in_transform, hipStream_t stream) {
     if (p.N % (64 * TM) != 0 || p.K % (64 * TN) != 0) return SED_EINVAL;
-    dim3 grid((unsigned)(NTAPS * (p.N / (64 * TM)) * (p.K / (64 * TN))), (unsigned)nslices), block(256);
-    if (in_transform) hipLaunchKernelGGL((wgrad_kernel<TM, TN, NTAPS, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((wgrad_kernel<TM, TN, NTAPS, false>), grid, block, 0, stream, p);
+    WgradP q = p;
+    q.ids_per_slice = NTAPS * (p.N / (64 * TM)) * (p.K / (64 * TN));
+    dim3 grid((unsigned)((long)q.ids_per_slice * nslices)), block(256);
+    if (in_transform) hipLaunchKernelGGL((wgrad_kernel<TM, TN, NTAPS, true>), grid, block, 0, stream, q);
+    else hipLaunchKernelGGL((wgrad_kernel<TM, TN, NTAPS, false>), grid, block, 0, stream, q);
     SED_LAUNCH_CHECK();
     return 0;
 }
@@ -690,7 +698,7 @@ SED_API int sed_conv3x3_wgrad(const float* x, const float* gy, float* dw_oihw, f
     long M = (long)B * H * W;
     int ns, pps;
     sed_wgrad_partial_floats(M, Cin, Cout, 9, &ns, &pps);
-    WgradP p{x, gy, partial, in_scale, in_shift, H, W, Cin, Cout, M, pps};
+    WgradP p{x, gy, partial, in_scale, in_shift, H, W, Cin, Cout, M, pps, 0};
     bool in_t = in_scale != nullptr;
     int rc;
     if (Cout >= 128 && Cin >= 128) rc = launch_wgrad<2, 2, 9>(p, ns, in_t, stream);
@@ -710,7 +718,7 @@ SED_API int sed_gemm_tn(const float* x, const float* gy, float* dw, float* parti
     if (M <= 0 || N % 64 != 0 || K % 64 != 0 || M >= (1L << 31)) return SED_EINVAL;
     int ns, pps;
     sed_wgrad_partial_floats(M, K, N, 1, &ns, &pps);
-    WgradP p{x, gy, partial, nullptr, nullptr, 1, 1, K, N, M, pps};
+    WgradP p{x, gy, partial, nullptr, nullptr, 1, 1, K, N, M, pps, 0};
     int rc;
     if (N >= 128 && K >= 128) rc = launch_wgrad<2, 2, 1>(p, ns, false, stream);
     else if (N >= 128) rc = launch_wgrad<2, 1, 1>(p, ns, false, stream);

@@ -117,9 +117,11 @@ def logmel(wave, tables, amin=1e-10):
     name = "sed_logmel_i16" if wave.dtype == torch.int16 else "sed_logmel_f32"
     if wave.dtype not in (torch.int16, torch.float32):
         wave = wave.float()
-    _call(name, _ptr(wave), B2, L, _ptr(tables["window"]), _ptr(tables["tw1024"]), _ptr(tables["tw64"]),
-          _ptr(tables["mel_lo"]), _ptr(tables["mel_cnt"]), _ptr(tables["mel_off"]), _ptr(tables["mel_w"]),
-          tables["mel_nnz"], amin, _ptr(out), _stream())
+    in_bytes = 2 if wave.dtype == torch.int16 else 4
+    with _timed("logmel_frontend", float(B2) * (L * in_bytes + T * 64 * 4)):      # "flops" slot carries ALGORITHMIC BYTES
+        _call(name, _ptr(wave), B2, L, _ptr(tables["window"]), _ptr(tables["tw1024"]), _ptr(tables["tw64"]),
+              _ptr(tables["mel_lo"]), _ptr(tables["mel_cnt"]), _ptr(tables["mel_off"]), _ptr(tables["mel_w"]),
+              tables["mel_nnz"], amin, _ptr(out), _stream())
     return out
 
 
