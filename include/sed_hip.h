@@ -32,15 +32,17 @@ const char* sed_version(void);
  * Replaces torchlibrosa Spectrogram + LogmelFilterBank as constructed at pytorch/models.py:251-258 and called
  * at :284-285 (reflect pad 512, Hann-windowed 1024-point DFT, hop 320, power, 513x64 Slaney mel matrix,
  * 10*log10(clamp(., amin))).  wave [B2][L] -> out [B2][T = L/320 + 1][64].
- * window[1024] = conv_real.weight[0,0,:] (the Hann window); tw1024 [64][16] float2 = exp(-2*pi*i*n2*k1/1024);
- * tw64 [4][4][4] float2 = exp(-2*pi*i*(4*i'+g)*s/64); mel_* = the non-zero runs of melW per band
- * (mel_lo first bin, mel_cnt run length, mel_off offset into mel_w).  The i16 variant folds
- * utils/utilities.py:66-67 (int16 / 32767) into the load. */
-int sed_logmel_f32(const float* wave, int B2, int L, const float* window, const float* tw1024, const float* tw64,
-                   const int* mel_lo, const int* mel_cnt, const int* mel_off, const float* mel_w, int mel_nnz,
+ * window[1024] = conv_real.weight[0,0,:] (the Hann window); tw1024t [16][64] float2 = exp(-2*pi*i*lane*k1/1024)
+ * laid out [k1][lane]; tw64t [16][4] float2 = exp(-2*pi*i*(4*i'+g)*s/64) laid out [i'*4+s][g];
+ * mel_tasks [n_tasks][4] int32 = {first bin, taps (<= 12), offset into mel_w, band}: the non-zero run of each melW
+ * column cut into <= 12-tap tasks, sorted by band; mel_bands [64][2] int32 = {first task, #tasks} per band; mel_w =
+ * the concatenated non-zero runs (mel_nnz <= 1024 floats).  The i16 variant folds utils/utilities.py:66-67
+ * (int16 / 32767) into the load. */
+int sed_logmel_f32(const float* wave, int B2, int L, const float* window, const float* tw1024t, const float* tw64t,
+                   const int* mel_tasks, int n_tasks, const int* mel_bands, const float* mel_w, int mel_nnz,
                    float amin, float* out, sed_stream_t stream);
-int sed_logmel_i16(const short* wave, int B2, int L, const float* window, const float* tw1024, const float* tw64,
-                   const int* mel_lo, const int* mel_cnt, const int* mel_off, const float* mel_w, int mel_nnz,
+int sed_logmel_i16(const short* wave, int B2, int L, const float* window, const float* tw1024t, const float* tw64t,
+                   const int* mel_tasks, int n_tasks, const int* mel_bands, const float* mel_w, int mel_nnz,
                    float amin, float* out, sed_stream_t stream);
 
 /* ---- BatchNorm statistics (nn.BatchNorm2d, models.py:87-88, :264; eps 1e-5, momentum 0.1) -------------------

@@ -2,8 +2,7 @@
 //
 // Replaces the reference's `Spectrogram` + `LogmelFilterBank` calls (reference pytorch/models.py:284-285;
 // torchlibrosa 0.0.4 semantics) WITHOUT materialising the (B2,1,T,513) power
-// spectrogram: one workgroup stages 16 frames' worth of waveform (5824 samples, 3.2x overlap reuse) in LDS,
-// each wave packs two real frames into one 1024-point complex FFT (16 x 4 x 16 factorisation: two in-register
+// spectrogram: each wave packs two real frames into one 1024-point complex FFT (16 x 4 x 16 factorisation: two in-register
 // radix-16 passes, one LDS transpose, one 4-lane shuffle transpose), unpacks the two spectra, and lane m
 // accumulates mel band m from the compact (non-zero only) filter table.  HBM traffic = waveform once +
 // (T,64) out: 1,536,256 B per 10 s clip (fp32 in) -- the roofline denominator of SURVEY.md §8d.
@@ -14,8 +13,6 @@ namespace {
 
 constexpr int NFFT = 1024;
 constexpr int HOP = 320;
-constexpr int FPB = 16;                          // frames per workgroup (4 waves x 2 FFTs x 2 frames)
-constexpr int SPAN = (FPB - 1) * HOP + NFFT;     // 5824 samples
 constexpr int TROW = 68;                         // transpose row stride in float2 (64 + 4 pad: conflict-free)
 constexpr int NBINS = 513;
 constexpr int PSTR = 516;
@@ -63,92 +60,97 @@ template <> __device__ __forceinline__ float load_sample<float>(const float* p, 
 // utils/utilities.py:66-67  int16_to_float32: x / 32767.
 template <> __device__ __forceinline__ float load_sample<short>(const short* p, long i) { return (float)p[i] / 32767.0f; }
 
+// v2 structure (occupancy first): no LDS sample staging (frames are read straight from global memory: 256-B
+// coalesced segments, the 3.2x overlap is served by L2), twiddles streamed from L1-resident tables instead of living in
+// 64 VGPRs, spectra / powers / mel partials aliased onto ONE 8.7 KB per-wave LDS buffer  =>  <= 128 VGPRs and 38.9 KB
+// per workgroup  =>  4 workgroups (16 waves) per CU instead of 2 (8 waves).  The mel stage is balanced: the 866
+// non-zero filter taps are cut into <= 12-tap tasks (105 of them) spread over the lanes in two rounds (24 iterations
+// instead of 47 x 2), partial sums combined per band through LDS.
+constexpr int FPW = 8;                            // frames per wave (4 FFT pairs), 32 frames per workgroup
+constexpr int TASK_TAPS = 12;
+constexpr int MAX_TASKS = 128;
+
 template <typename T>
-__global__ __launch_bounds__(256) void logmel_kernel(const T* __restrict__ wave, int L, int T_frames,
-                                                     const float* __restrict__ window,     // [1024]
-                                                     const float2* __restrict__ tw1024,    // [64][16]  W1024^(n2*k1)
-                                                     const float2* __restrict__ tw64,      // [4 g][4 i'][4 s] W64^((4i'+g)*s)
-                                                     const int* __restrict__ mel_lo, const int* __restrict__ mel_cnt,
-                                                     const int* __restrict__ mel_off, const float* __restrict__ mel_w,
-                                                     int mel_nnz, float amin, float* __restrict__ out) {
+__global__ __launch_bounds__(256, 3) void logmel_kernel(const T* __restrict__ wave, int L, int T_frames,
+                                                        const float* __restrict__ window,      // [16][64] = natural order
+                                                        const float2* __restrict__ tw1024t,    // [16 k1][64 lane] W1024^(lane*k1)
+                                                        const float2* __restrict__ tw64t,      // [16 e = i'*4+s][4 g] W64^((4i'+g)*s)
+                                                        const int4* __restrict__ tasks,        // [ntasks] {lo, cnt, off, band}
+                                                        int ntasks, const int2* __restrict__ bands,   // [64] {first task, #tasks}
+                                                        const float* __restrict__ mel_w, int mel_nnz, float amin,
+                                                        float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* smp = reinterpret_cast<float*>(smem_raw);                          // [SPAN]
-    float* melw_s = smp + SPAN;                                               // [MELW_MAX]
+    float* melw_s = reinterpret_cast<float*>(smem_raw);                       // [MELW_MAX]
     float2* tbuf_all = reinterpret_cast<float2*>(melw_s + MELW_MAX);          // 4 x [16*TROW]
-    float* pbuf_all = reinterpret_cast<float*>(tbuf_all + 4 * 16 * TROW);     // 4 x [2*PSTR]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int b = blockIdx.y, t0 = blockIdx.x * FPB;
+    const int b = blockIdx.y;
+    const int frame0 = blockIdx.x * (4 * FPW) + wv * FPW;
     const T* x = wave + (long)b * L;
-
-    // stage the padded-signal span [t0*HOP, t0*HOP+SPAN) with reflect indexing (F.pad(mode='reflect'))
-    for (int j = tid; j < SPAN; j += 256) {
-        long idx = (long)t0 * HOP + j - NFFT / 2;
-        if (idx < 0) idx = -idx;
-        if (idx >= L) idx = 2L * (L - 1) - idx;
-        float v = 0.f;
-        if (idx >= 0 && idx < L) v = load_sample<T>(x, idx);
-        smp[j] = v;
-    }
     for (int j = tid; j < mel_nnz; j += 256) melw_s[j] = mel_w[j];
-
     float win[16];
-    float twr[16], twi[16];
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) {
-        win[n1] = window[64 * n1 + lane];
-        float2 w = tw1024[lane * 16 + n1];
-        twr[n1] = w.x; twi[n1] = w.y;
-    }
+    for (int n1 = 0; n1 < 16; ++n1) win[n1] = window[64 * n1 + lane];
     const int k1 = lane >> 2, g = lane & 3;
-    float t64r[16], t64i[16];                    // [i'*4 + s]
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { float2 w = tw64[g * 16 + e]; t64r[e] = w.x; t64i[e] = w.y; }
-    const int mlo = mel_lo[lane], mcnt = mel_cnt[lane], moff = mel_off[lane];
     __syncthreads();
 
     float2* tb = tbuf_all + wv * 16 * TROW;
-    float* pa = pbuf_all + wv * 2 * PSTR;
+    float* pa = reinterpret_cast<float*>(tb);          // powers alias the (dead) spectrum buffer
     float* pb = pa + PSTR;
+    float2* mp = reinterpret_cast<float2*>(pb + PSTR); // mel partials [MAX_TASKS]
 
-    for (int f = 0; f < 2; ++f) {
-        const int la = 4 * wv + 2 * f;           // local frame index of frame "a"; frame "b" = la + 1
-        const int ta = t0 + la;
-        if (ta >= T_frames) break;               // wave-uniform
+    for (int pr = 0; pr < FPW / 2; ++pr) {
+        const int ta = frame0 + 2 * pr;
+        if (ta >= T_frames) break;                     // wave-uniform
+        const long base_a = (long)ta * HOP - NFFT / 2; // signal index of n = 0 of frame a (frame b: + HOP)
+        const bool fast = base_a >= 0 && base_a + HOP + NFFT <= (long)L && ta + 1 < T_frames;
         float re[16], im[16];
+        if (fast) {
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) {
-            int n = 64 * n1 + lane;
-            re[n1] = smp[la * HOP + n] * win[n1];
-            im[n1] = smp[(la + 1) * HOP + n] * win[n1];
+            for (int n1 = 0; n1 < 16; ++n1) {
+                re[n1] = load_sample<T>(x, base_a + 64 * n1 + lane) * win[n1];
+                im[n1] = load_sample<T>(x, base_a + HOP + 64 * n1 + lane) * win[n1];
+            }
+        } else {                                       // clip edges: F.pad(mode='reflect') indexing, frames past the end = 0
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                long ia = base_a + 64 * n1 + lane, ib = ia + HOP;
+                if (ia < 0) ia = -ia;
+                if (ia >= L) ia = 2L * (L - 1) - ia;
+                if (ib < 0) ib = -ib;
+                if (ib >= L) ib = 2L * (L - 1) - ib;
+                float va = (ia >= 0 && ia < L) ? load_sample<T>(x, ia) : 0.f;
+                float vb = (ib >= 0 && ib < L && ta + 1 < T_frames) ? load_sample<T>(x, ib) : 0.f;
+                re[n1] = va * win[n1];
+                im[n1] = vb * win[n1];
+            }
         }
         // pass A: 16-point DFT over n1, twiddle W1024^(lane*k1)
         fft16(re, im);
 #pragma unroll
-        for (int k = 1; k < 16; ++k) cmul(re[k], im[k], twr[k], twi[k]);
+        for (int k = 1; k < 16; ++k) { float2 w = tw1024t[k * 64 + lane]; cmul(re[k], im[k], w.x, w.y); }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int k = 0; k < 16; ++k) tb[k * TROW + lane] = make_float2(re[k], im[k]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // lane (k1,g) takes n2 = 4i+g, i = 4p+i'
 #pragma unroll
         for (int i = 0; i < 16; ++i) { float2 v = tb[k1 * TROW + 4 * i + g]; re[i] = v.x; im[i] = v.y; }
-        // pass B1: 4-point DFT over p for each i' (elements i', 4+i', 8+i', 12+i'), twiddle W64^(q*s)
+        // pass B1: 4-point DFT over p for each i', twiddle W64^(q*s), q = 4i'+g
 #pragma unroll
         for (int ip = 0; ip < 4; ++ip) {
             fft4(re[ip], im[ip], re[4 + ip], im[4 + ip], re[8 + ip], im[8 + ip], re[12 + ip], im[12 + ip]);
 #pragma unroll
-            for (int s = 1; s < 4; ++s) cmul(re[4 * s + ip], im[4 * s + ip], t64r[ip * 4 + s], t64i[ip * 4 + s]);
+            for (int s = 1; s < 4; ++s) { float2 w = tw64t[(ip * 4 + s) * 4 + g]; cmul(re[4 * s + ip], im[4 * s + ip], w.x, w.y); }
         }
-        // element (s, i') is at index 4s+i'.  4x4 transpose across the quad's lanes: lane s must own all q = 4i'+g.
+        // 4x4 transpose across the quad's lanes: lane s must own all q = 4i'+g
         float vr[16], vi[16];
 #pragma unroll
         for (int ip = 0; ip < 4; ++ip) {
             float ar[4], ai[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) { ar[s] = re[4 * s + ip]; ai[s] = im[4 * s + ip]; }
-            {   // xor 1
+            {
                 bool odd = g & 1;
                 float s0r = odd ? ar[0] : ar[1], s0i = odd ? ai[0] : ai[1];
                 float s1r = odd ? ar[2] : ar[3], s1i = odd ? ai[2] : ai[3];
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const T* __restrict__ wave,
                 if (odd) { ar[0] = r0r; ai[0] = r0i; ar[2] = r1r; ai[2] = r1i; }
                 else     { ar[1] = r0r; ai[1] = r0i; ar[3] = r1r; ai[3] = r1i; }
             }
-            {   // xor 2
+            {
                 bool hi = g & 2;
                 float s0r = hi ? ar[0] : ar[2], s0i = hi ? ai[0] : ai[2];
                 float s1r = hi ? ar[1] : ar[3], s1i = hi ? ai[1] : ai[3];
@@ -166,7 +168,6 @@ __global__ __launch_bounds__(256) void logmel_kernel(const T* __restrict__ wave,
                 if (hi) { ar[0] = r0r; ai[0] = r0i; ar[1] = r1r; ai[1] = r1i; }
                 else    { ar[2] = r0r; ai[2] = r0i; ar[3] = r1r; ai[3] = r1i; }
             }
-            // ar[j] = value from quad-lane j, element s = g(this lane)  ->  q = 4i' + j
 #pragma unroll
             for (int j = 0; j < 4; ++j) { vr[4 * ip + j] = ar[j]; vi[4 * ip + j] = ai[j]; }
         }
@@ -177,59 +178,88 @@ __global__ __launch_bounds__(256) void logmel_kernel(const T* __restrict__ wave,
         for (int u = 0; u < 16; ++u) tb[k1 + 16 * g + 64 * u] = make_float2(vr[u], vi[u]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // unpack the two real spectra: A = (Z[k]+conj Z[N-k])/2, B = (Z[k]-conj Z[N-k])/(2i); power
+        // unpack the two real spectra and take |.|^2 into registers, then overwrite the spectrum buffer with them
+        float ppa[9], ppb[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             int k = lane + 64 * i;
+            ppa[i] = 0.f; ppb[i] = 0.f;
             if (k < NBINS) {
                 float2 zk = tb[k], zn = tb[(NFFT - k) & (NFFT - 1)];
                 float ar_ = zk.x + zn.x, ai_ = zk.y - zn.y;
                 float br_ = zk.x - zn.x, bi_ = zk.y + zn.y;
-                pa[k] = 0.25f * (ar_ * ar_ + ai_ * ai_);
-                pb[k] = 0.25f * (br_ * br_ + bi_ * bi_);
+                ppa[i] = 0.25f * (ar_ * ar_ + ai_ * ai_);
+                ppb[i] = 0.25f * (br_ * br_ + bi_ * bi_);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            int k = lane + 64 * i;
+            if (k < NBINS) { pa[k] = ppa[i]; pb[k] = ppb[i]; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // mel: <= 12-tap tasks over the lanes (two rounds), then one lane per band combines its tasks
+#pragma unroll
+        for (int r = 0; r < MAX_TASKS / 64; ++r) {
+            int t = lane + 64 * r;
+            if (t < ntasks) {
+                int4 tk = tasks[t];
+                float sa = 0.f, sb = 0.f;
+#pragma unroll
+                for (int i = 0; i < TASK_TAPS; ++i)
+                    if (i < tk.y) {
+                        float w = melw_s[tk.z + i];
+                        sa = fmaf(w, pa[tk.x + i], sa);
+                        sb = fmaf(w, pb[tk.x + i], sb);
+                    }
+                mp[t] = make_float2(sa, sb);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        float ma = 0.f, mb = 0.f;
-        for (int i = 0; i < mcnt; ++i) {
-            float w = melw_s[moff + i];
-            ma = fmaf(w, pa[mlo + i], ma);
-            mb = fmaf(w, pb[mlo + i], mb);
+        {
+            int2 bd = bands[lane];
+            float ma = 0.f, mb = 0.f;
+            for (int j = 0; j < bd.y; ++j) { float2 v = mp[bd.x + j]; ma += v.x; mb += v.y; }
+            float* o = out + ((long)b * T_frames + ta) * 64 + lane;
+            o[0] = (float)(10.0 * log10((double)fmaxf(ma, amin)));       // fp64 log: exact -100 dB at the clamp
+            if (ta + 1 < T_frames) o[64] = (float)(10.0 * log10((double)fmaxf(mb, amin)));
         }
-        float* o = out + ((long)b * T_frames + ta) * 64 + lane;
-        o[0] = (float)(10.0 * log10((double)fmaxf(ma, amin)));       // fp64 log: exact -100 dB at the clamp
-        if (ta + 1 < T_frames) o[64] = (float)(10.0 * log10((double)fmaxf(mb, amin)));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-constexpr size_t LOGMEL_SMEM = (size_t)SPAN * 4 + MELW_MAX * 4 + 4 * 16 * TROW * 8 + 4 * 2 * PSTR * 4;
+constexpr size_t LOGMEL_SMEM = (size_t)MELW_MAX * 4 + 4 * 16 * TROW * 8;
 
 template <typename T>
-int launch_logmel(const T* wave, int B2, int L, const float* window, const float* tw1024, const float* tw64,
-                  const int* mel_lo, const int* mel_cnt, const int* mel_off, const float* mel_w, int mel_nnz,
-                  float amin, float* out, hipStream_t stream) {
-    if (B2 <= 0 || L <= NFFT / 2 || mel_nnz <= 0 || mel_nnz > MELW_MAX) return SED_EINVAL;
+int launch_logmel(const T* wave, int B2, int L, const float* window, const float* tw1024t, const float* tw64t,
+                  const int* tasks, int ntasks, const int* bands, const float* mel_w, int mel_nnz, float amin, float* out,
+                  hipStream_t stream) {
+    if (B2 <= 0 || L <= NFFT / 2 || mel_nnz <= 0 || mel_nnz > MELW_MAX || ntasks <= 0 || ntasks > MAX_TASKS) return SED_EINVAL;
     int T_frames = L / HOP + 1;
-    dim3 grid(sed_cdiv(T_frames, FPB), B2);
+    dim3 grid(sed_cdiv(T_frames, 4 * FPW), B2);
     hipLaunchKernelGGL(logmel_kernel<T>, grid, dim3(256), LOGMEL_SMEM, stream, wave, L, T_frames, window,
-                       reinterpret_cast<const float2*>(tw1024), reinterpret_cast<const float2*>(tw64), mel_lo, mel_cnt,
-                       mel_off, mel_w, mel_nnz, amin, out);
+                       reinterpret_cast<const float2*>(tw1024t), reinterpret_cast<const float2*>(tw64t),
+                       reinterpret_cast<const int4*>(tasks), ntasks, reinterpret_cast<const int2*>(bands), mel_w, mel_nnz,
+                       amin, out);
     SED_LAUNCH_CHECK();
     return 0;
 }
 
 }  // namespace
 
-SED_API int sed_logmel_f32(const float* wave, int B2, int L, const float* window, const float* tw1024,
-                           const float* tw64, const int* mel_lo, const int* mel_cnt, const int* mel_off,
+SED_API int sed_logmel_f32(const float* wave, int B2, int L, const float* window, const float* tw1024t,
+                           const float* tw64t, const int* mel_tasks, int n_tasks, const int* mel_bands,
                            const float* mel_w, int mel_nnz, float amin, float* out, hipStream_t stream) {
-    return launch_logmel<float>(wave, B2, L, window, tw1024, tw64, mel_lo, mel_cnt, mel_off, mel_w, mel_nnz, amin, out, stream);
+    return launch_logmel<float>(wave, B2, L, window, tw1024t, tw64t, mel_tasks, n_tasks, mel_bands, mel_w, mel_nnz, amin, out, stream);
 }
 
-SED_API int sed_logmel_i16(const short* wave, int B2, int L, const float* window, const float* tw1024,
-                           const float* tw64, const int* mel_lo, const int* mel_cnt, const int* mel_off,
+SED_API int sed_logmel_i16(const short* wave, int B2, int L, const float* window, const float* tw1024t,
+                           const float* tw64t, const int* mel_tasks, int n_tasks, const int* mel_bands,
                            const float* mel_w, int mel_nnz, float amin, float* out, hipStream_t stream) {
-    return launch_logmel<short>(wave, B2, L, window, tw1024, tw64, mel_lo, mel_cnt, mel_off, mel_w, mel_nnz, amin, out, stream);
+    return launch_logmel<short>(wave, B2, L, window, tw1024t, tw64t, mel_tasks, n_tasks, mel_bands, mel_w, mel_nnz, amin, out, stream);
 }

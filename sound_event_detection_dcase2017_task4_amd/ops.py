@@ -68,38 +68,43 @@ def _call(name, *args):
 # ------------------------------------------------------------------------------------------------------------
 # front-end constants (host side, built once per model; numpy float64 -> float32)
 
+MEL_TASK_TAPS = 12
+
+
 def frontend_tables(window, melW, device):
     """window: (1024,) tensor = conv_real.weight[0,0,:]; melW (513,64) tensor.  Returns the device tables the
-    log-mel kernel needs (FFT twiddles + compact mel filter runs)."""
-    n2 = np.arange(64)[:, None]
-    k1 = np.arange(16)[None, :]
-    tw = np.exp(-2j * np.pi * (n2 * k1) / 1024.0)
-    tw1024 = np.stack([tw.real, tw.imag], axis=-1).astype(np.float32)            # [64][16][2]
-    g = np.arange(4)[:, None, None]
-    ip = np.arange(4)[None, :, None]
-    s = np.arange(4)[None, None, :]
-    t64 = np.exp(-2j * np.pi * ((4 * ip + g) * s) / 64.0)
-    tw64 = np.stack([t64.real, t64.imag], axis=-1).astype(np.float32)            # [4][4][4][2]
+    log-mel kernel needs (FFT twiddles + the mel filter bank cut into <= 12-tap tasks)."""
+    lane = np.arange(64)[None, :]
+    k1 = np.arange(16)[:, None]
+    tw = np.exp(-2j * np.pi * (lane * k1) / 1024.0)                              # [16 k1][64 lane]
+    tw1024t = np.stack([tw.real, tw.imag], axis=-1).astype(np.float32)
+    e = np.arange(16)[:, None]
+    g = np.arange(4)[None, :]
+    ip, s = e // 4, e % 4
+    t64 = np.exp(-2j * np.pi * ((4 * ip + g) * s) / 64.0)                        # [16 e=i'*4+s][4 g]
+    tw64t = np.stack([t64.real, t64.imag], axis=-1).astype(np.float32)
     W = melW.detach().cpu().numpy().astype(np.float32)                           # (513, 64)
-    lo, cnt, off, vals = [], [], [], []
+    tasks, bands, vals = [], [], []
     for m in range(W.shape[1]):
         nz = np.nonzero(W[:, m])[0]
-        if len(nz) == 0:
-            lo.append(0); cnt.append(0); off.append(len(vals))
-            continue
-        a, b = int(nz[0]), int(nz[-1]) + 1
-        lo.append(a); cnt.append(b - a); off.append(len(vals))
-        vals.extend(W[a:b, m].tolist())
-    if len(vals) > 1024:
-        raise RuntimeError("mel filter bank has %d non-zeros; the kernel table holds 1024" % len(vals))
+        first = len(tasks)
+        if len(nz):
+            a, b = int(nz[0]), int(nz[-1]) + 1
+            off = len(vals)
+            vals.extend(W[a:b, m].tolist())
+            for c in range(0, b - a, MEL_TASK_TAPS):
+                tasks.append([a + c, min(MEL_TASK_TAPS, b - a - c), off + c, m])
+        bands.append([first, len(tasks) - first])
+    if len(vals) > 1024 or len(tasks) > 128 or W.shape[1] != 64:
+        raise RuntimeError("mel filter bank does not fit the kernel tables (%d non-zeros, %d tasks)" % (len(vals), len(tasks)))
     dev = torch.device(device)
     return {
         "window": window.detach().to(dev, torch.float32).contiguous(),
-        "tw1024": torch.from_numpy(tw1024).to(dev).contiguous(),
-        "tw64": torch.from_numpy(tw64).to(dev).contiguous(),
-        "mel_lo": torch.tensor(lo, dtype=torch.int32, device=dev),
-        "mel_cnt": torch.tensor(cnt, dtype=torch.int32, device=dev),
-        "mel_off": torch.tensor(off, dtype=torch.int32, device=dev),
+        "tw1024t": torch.from_numpy(tw1024t).to(dev).contiguous(),
+        "tw64t": torch.from_numpy(tw64t).to(dev).contiguous(),
+        "mel_tasks": torch.tensor(tasks, dtype=torch.int32, device=dev).contiguous(),
+        "n_tasks": len(tasks),
+        "mel_bands": torch.tensor(bands, dtype=torch.int32, device=dev).contiguous(),
         "mel_w": torch.tensor(vals, dtype=torch.float32, device=dev),
         "mel_nnz": len(vals),
     }
@@ -119,8 +124,8 @@ def logmel(wave, tables, amin=1e-10):
         wave = wave.float()
     in_bytes = 2 if wave.dtype == torch.int16 else 4
     with _timed("logmel_frontend", float(B2) * (L * in_bytes + T * 64 * 4)):      # "flops" slot carries ALGORITHMIC BYTES
-        _call(name, _ptr(wave), B2, L, _ptr(tables["window"]), _ptr(tables["tw1024"]), _ptr(tables["tw64"]),
-              _ptr(tables["mel_lo"]), _ptr(tables["mel_cnt"]), _ptr(tables["mel_off"]), _ptr(tables["mel_w"]),
+        _call(name, _ptr(wave), B2, L, _ptr(tables["window"]), _ptr(tables["tw1024t"]), _ptr(tables["tw64t"]),
+              _ptr(tables["mel_tasks"]), tables["n_tasks"], _ptr(tables["mel_bands"]), _ptr(tables["mel_w"]),
               tables["mel_nnz"], amin, _ptr(out), _stream())
     return out
 
