@@ -49,7 +49,7 @@ int sed_logmel_i16(const short* wave, int B2, int L, const float* window, const 
  * sed_chan_stats: per-channel (sum, M2) partials of x [N][C] in tiles of sed_stats_rows_per_part() rows;
  * partials [ceil(N/rows)][2][C].  sed_bn_finalize merges partials (from sed_chan_stats, sed_conv1_fwd or
  * sed_conv3x3_igemm epi 1) into mean / invstd / folded scale = gamma*invstd, shift = beta - mean*scale and
- * updates the running statistics (unbiased variance).  ws: >= 512*C doubles.
+ * updates the running statistics (unbiased variance).  ws: >= 2048*C doubles.
  * sed_bn_eval_affine: eval mode, fold the running statistics instead. */
 int sed_chan_stats(const float* x, long N, int C, float* partials, sed_stream_t stream);
 int sed_stats_rows_per_part(void);

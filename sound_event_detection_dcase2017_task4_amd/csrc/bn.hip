@@ -361,8 +361,8 @@ int stream_grid(long work_items) {
     return (int)blocks;
 }
 
-int reduce_chunks(int nparts) {
-    int ppc = sed_cdiv(nparts, 256);
+int reduce_chunks(int nparts) {          // parts per chunk: <= 1024 chunks (ws holds 1024 * 2C doubles)
+    int ppc = sed_cdiv(nparts, 1024);
     if (ppc < 8) ppc = 8;
     return ppc;
 }
@@ -381,7 +381,7 @@ SED_API int sed_chan_stats(const float* x, long N, int C, float* partials, hipSt
 
 SED_API int sed_stats_rows_per_part(void) { return 1024; }
 
-// ws: at least 256*2*C doubles.
+// ws: at least 1024*2*C doubles.
 SED_API int sed_bn_finalize(const float* partials, int nparts, int rows_per_part, long N, int C, const float* gamma,
                             const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                             float* mean_out, float* invstd_out, float* scale_out, float* shift_out, double* ws,

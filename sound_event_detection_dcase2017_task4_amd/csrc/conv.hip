@@ -586,19 +586,20 @@ __global__ __launch_bounds__(256) void conv1_dgrad_gather_kernel(const float* __
     }
 }
 
-// dW[co][0][tap] = sum over blocks of dw_partials[blk][tap][co]; one workgroup per 64 outputs, 4 row-slices each
-__global__ __launch_bounds__(256) void conv1_wgrad_reduce_kernel(const float* __restrict__ parts, int nblk,
-                                                                 float* __restrict__ dw) {
-    __shared__ double red[256];
+// dW[co][0][tap] = sum over blocks of dw_partials[blk][tap][co]; one workgroup per tap (64 outputs) x 16 row slices,
+// fixed-order tree in LDS (deterministic: no atomics on the value path)
+__global__ __launch_bounds__(1024) void conv1_wgrad_reduce_kernel(const float* __restrict__ parts, int nblk,
+                                                                  float* __restrict__ dw) {
+    __shared__ double red[1024];
     const int i = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
     double s = 0.0;
-    for (int b = sl + 4 * blockIdx.y; b < nblk; b += 4 * gridDim.y) s += (double)parts[(long)b * 576 + i];
+    for (int b = sl; b < nblk; b += 16) s += (double)parts[(long)b * 576 + i];
     red[threadIdx.x] = s;
     __syncthreads();
     if (sl == 0) {
-        s = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+        for (int j = 1; j < 16; ++j) s += red[threadIdx.x + 64 * j];
         int tap = i / 64, co = i % 64;
-        atomicAdd(&dw[co * 9 + tap], (float)s);
+        dw[co * 9 + tap] = (float)s;
     }
 }
 
@@ -760,8 +761,7 @@ SED_API int sed_conv1_bwd(const float* x0, const float* w_oihw, const float* gy,
     int nblk = sed_cdiv(M, C1B_ROWS);
     hipLaunchKernelGGL(conv1_bwd_kernel, dim3(nblk), dim3(256), 0, stream, x0, w_oihw, gy, M, H, W, dw_partials,
                        gx0 ? tbuf : (float*)nullptr);
-    (void)hipMemsetAsync(dw, 0, 576 * sizeof(float), stream);
-    hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(9, 32), dim3(256), 0, stream, dw_partials, nblk, dw);
+    hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(9), dim3(1024), 0, stream, dw_partials, nblk, dw);
     if (gx0) {
         int g = sed_cdiv(M, 256);
         hipLaunchKernelGGL(conv1_dgrad_gather_kernel, dim3(g > 8192 ? 8192 : g), dim3(256), 0, stream, tbuf, M, H, W, gx0);

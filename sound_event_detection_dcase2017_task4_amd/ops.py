@@ -142,7 +142,7 @@ class BnStats(object):
 
 
 def _ws(C, device):
-    return torch.empty((512 * C,), dtype=torch.float64, device=device)
+    return torch.empty((2048 * C,), dtype=torch.float64, device=device)
 
 
 def bn_finalize(partials, nparts, rows_per_part, N, bn_w, bn_b, running_mean, running_var):

@@ -193,3 +193,73 @@ def test_full_size_batch_properties():
     with torch.no_grad():
         mixed = m(x, lam, specaug_stripes=stripes)["clipwise_output"]
     assert mixed.shape == (8, 17) and torch.isfinite(mixed).all()
+
+
+def test_full_size_train_step_properties():
+    """BASELINE.json configs[1] at FULL size (B=256 post-mixup clips = 512 x 10 s waveforms, mixup + SpecAugment):
+    size-independent properties instead of an oracle run (the CPU oracle needs minutes for this batch)."""
+    from sound_event_detection_dcase2017_task4_amd import ops
+    from sound_event_detection_dcase2017_task4_amd.optim import FusedAdamAmsgrad
+    from sound_event_detection_dcase2017_task4_amd.pytorch.losses import clip_bce
+    from sound_event_detection_dcase2017_task4_amd.pytorch.pytorch_utils import do_mixup
+    mt = "Cnn_9layers_FrameAvg"
+    B2, L = 512, 320000
+    g = torch.Generator(device="cuda").manual_seed(3)
+    wave = (torch.randn((B2, L), generator=g, device="cuda") * 0.1).clamp_(-1, 1)
+    target = (torch.rand((B2, 17), generator=g, device="cuda") < 0.2).float()
+    lam = torch.from_numpy(ofe.mixup_lambdas(B2, np.random.RandomState(1234)).astype(np.float32)).cuda()
+
+    def one_step():
+        m = build(mt).train()
+        opt = FusedAdamAmsgrad(m, lr=1e-3)
+        torch.manual_seed(77)
+        out = m(wave, lam)
+        loss = clip_bce(out, {"target": do_mixup(target, lam)})
+        opt.zero_grad()
+        loss.backward()
+        gsum = opt.flat_grad.double().abs().sum().item()
+        opt.step()
+        return out, loss.item(), gsum, opt.flat.double().sum().item(), m
+
+    out, loss, gsum, psum, m = one_step()
+    assert out["clipwise_output"].shape == (256, 17) and out["framewise_output"].shape == (256, 1000, 17)
+    assert out["embedding"].shape == (256, 512, 125)
+    p = out["clipwise_output"]
+    assert torch.isfinite(p).all() and (p >= 0).all() and (p <= 1).all() and np.isfinite(loss) and gsum > 0
+    fw = out["framewise_output"]
+    assert torch.equal(fw[:, 0::8], fw[:, 7::8])                                   # interpolate = x8 repeat
+    assert torch.allclose(fw.mean(dim=1), p, atol=1e-5)                            # FrameAvg: clip = mean over frames
+    # BN bookkeeping: batch mean of log-mel noise is far from the recipe's running mean -> moved by momentum 0.1
+    assert int(m.bn0.num_batches_tracked) == 4
+    # determinism: the same step twice is bit-identical (no atomics on the value path)
+    out2, loss2, gsum2, psum2, _ = one_step()
+    assert loss2 == loss and gsum2 == gsum and psum2 == psum and torch.equal(out2["clipwise_output"], p)
+    # mixup linearity of the targets and of the log-mel stage at full size
+    t2 = do_mixup(target, lam)
+    assert torch.allclose(t2, target[0::2] * lam[0::2, None] + target[1::2] * lam[1::2, None], atol=1e-6)
+    lm = m.extract_logmel(wave[:64])
+    lm2 = m.extract_logmel(wave[:64] * 0.5)
+    assert (lm - lm2 - 20.0 * np.log10(2.0)).abs().max().item() < 1e-3
+    # conv linearity on the largest layer (block-1 conv2, 16.4 M pixels x 64 -> 64): conv(2x) == 2 conv(x)
+    x = torch.randn((256, 1001, 64, 64), generator=g, device="cuda")
+    wf, _ = ops._pack(m.conv_block1.conv2.weight.detach())
+    y1 = ops._conv_igemm(x, wf, 256, 1001, 64, 64, 64)
+    x.mul_(2.0)
+    y2 = ops._conv_igemm(x, wf, 256, 1001, 64, 64, 64)
+    assert (y2 - 2.0 * y1).abs().max().item() <= 1e-5 * y1.abs().max().item()
+    del x, y1, y2
+
+
+def test_int16_waveforms_end_to_end():
+    """The HDF5 storage dtype (int16, utils/features.py) fed straight to the model equals the reference's
+    int16_to_float32 path (utilities.py:66-67) to within fp32 rounding of the division."""
+    mt = "Cnn_9layers_FrameAtt"
+    m = build(mt).eval()
+    q = np.round(np.clip(waves(11, 3, 32000), -1, 1) * 32767.0).astype(np.int16)
+    with torch.no_grad():
+        a = m(torch.from_numpy(q).cuda())["clipwise_output"].cpu()
+        b = m(torch.from_numpy((q / 32767.0).astype(np.float32)).cuda())["clipwise_output"].cpu()
+    st = om.recipe_state(mt, SEEDS[mt])
+    with torch.no_grad():
+        ref = om.forward(mt, st, torch.from_numpy((q / 32767.0).astype(np.float32)))["clipwise_output"]
+    assert (a - b).abs().max().item() < 1e-6 and (a - ref).abs().max().item() < 1e-4
