@@ -11,6 +11,7 @@
 //  * conv1 (Cin = 1)    : K = 9 is HBM-bound (AI 4.4 flop/B): direct kernels, no MFMA.
 #include "common.h"
 #include "sed_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -40,7 +41,14 @@ struct ConvP {
     const float* p_invstd;   // EPI 2
     int H, W, K, N;
     long M;
+    int tune;                // experiment knobs (SED_TUNE env var; 0 = shipped configuration)
 };
+
+static int sed_tune() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SED_TUNE"); v = e ? atoi(e) : 0; }
+    return v;
+}
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
@@ -111,6 +119,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
 // applied at LDS-store time (after the MFMA block), so nothing waits on the loads before the MFMAs start
 #define SED_A_FIX(i)                                                                                            \
     if (i < A_LD) {                                                                                             \
+        asm volatile("" : "+v"(areg##i.x), "+v"(areg##i.y), "+v"(areg##i.z), "+v"(areg##i.w));                  \
         if (INT) {                                                                                              \
             areg##i.x = bn_relu(areg##i.x, sc.x, sh.x); areg##i.y = bn_relu(areg##i.y, sc.y, sh.y);             \
             areg##i.z = bn_relu(areg##i.z, sc.z, sh.z); areg##i.w = bn_relu(areg##i.w, sc.w, sh.w);             \
@@ -143,6 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
         SED_B_STORE(BUF, 0) SED_B_STORE(BUF, 1) SED_B_STORE(BUF, 2) SED_B_STORE(BUF, 3)                         \
     }
 
+    if ((p.tune & 2) && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(127);   // experiment: de-phase co-resident workgroups
     gload(0);
     lstore(0);
     __syncthreads();
@@ -154,6 +164,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
         // no "maybe-uninitialised" staging registers in the loop, which is what keeps them out of scratch memory
         gload(it + 1 < KT ? it + 1 : it);
         __builtin_amdgcn_sched_barrier(0);       // keep all global loads ABOVE the MFMA block (latency hidden by it)
+        if (!(p.tune & 1)) __builtin_amdgcn_s_setprio(1);   // +1-2 % (A/B in tools/conv_bench.py)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 af[TM], bf[TN];
@@ -178,6 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (!(p.tune & 1)) __builtin_amdgcn_s_setprio(0);
         __syncthreads();
     }
 #undef gload
@@ -297,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
     }
     // Named staging registers (see conv_igemm_kernel).  Each staged row advances by BKP = 32 pixels per K-step; its
     // (h, w) is tracked incrementally (one 32-bit divide per row per workgroup instead of per step).
-    const int dq = BKP / p.W, dr = BKP % p.W;
+    const int dq = (BKP / p.W) % p.H, dr = BKP % p.W;   // per-step advance of (h, w); dq < H so one wrap suffices
     const long x_tap_off = (long)(dy * p.W + dx) * p.K;
 #define SED_W_META(i)                                                                                           \
     const float* gptr##i = p.gy + (pbeg + g_r + G_RPP * (i < G_LD ? i : 0)) * p.N + co0 + g_c4 * 4;             \
@@ -327,18 +339,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
         xptr##i += (long)BKP * p.K; xpm##i += BKP;                                                              \
         if (NTAPS == 9) {                                                                                       \
             xw##i += dr; xh##i += dq;                                                                           \
-            if (xw##i >= p.W) { xw##i -= p.W; xh##i += 1; }                                                     \
-            while (xh##i >= p.H) xh##i -= p.H;                                                                  \
+            const bool cw = xw##i >= p.W;                                                                       \
+            xw##i = cw ? xw##i - p.W : xw##i; xh##i = cw ? xh##i + 1 : xh##i;                                   \
+            xh##i = xh##i >= p.H ? xh##i - p.H : xh##i;                                                         \
         }                                                                                                       \
     }
+#define SED_PIN(r) asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));
 #define SED_G_STORE(BUF, i)                                                                                     \
     if (i < G_LD) {                                                                                             \
+        SED_PIN(greg##i)                                                                                        \
         float4 v = greg##i;                                                                                     \
         v.x = gv##i ? v.x : 0.f; v.y = gv##i ? v.y : 0.f; v.z = gv##i ? v.z : 0.f; v.w = gv##i ? v.w : 0.f;     \
         *reinterpret_cast<float4*>(&Gs[(BUF)][(g_r + G_RPP * i) * CO_T + g_c4 * 4]) = v;                        \
     }
 #define SED_X_STORE(BUF, i)                                                                                     \
     if (i < X_LD) {                                                                                             \
+        SED_PIN(xreg##i)                                                                                        \
         float4 v = xreg##i;                                                                                     \
         if (INT) {                                                                                              \
             v.x = bn_relu(v.x, xsc.x, xsh.x); v.y = bn_relu(v.y, xsc.y, xsh.y);                                 \
@@ -363,6 +379,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
         const int buf = it & 1;
         wg_load();                               // unconditional prefetch (rows past `pend` are masked to zero)
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
         float af[TM], bf[TN], afn[TM], bfn[TN];
 #pragma unroll
         for (int a = 0; a < TM; ++a) af[a] = Gs[buf][half * CO_T + gcol + a * 32];
@@ -391,8 +408,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
 #pragma unroll
             for (int b = 0; b < TN; ++b) bf[b] = bfn[b];
         }
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
     }
+#undef SED_PIN
 #undef SED_G_LOAD
 #undef SED_X_LOAD
 #undef SED_G_STORE
@@ -654,7 +673,7 @@ SED_API int sed_conv3x3_igemm(const float* x, const float* w_packed, float* y, i
     if ((long)B * H * W * (long)(Cin > Cout ? Cin : Cout) >= (1L << 31) * 16L) return SED_EINVAL;
     if ((long)B * H * W >= (1L << 31)) return SED_EINVAL;
     ConvP p{x, w_packed, y, in_scale, in_shift, partials, yprev, p_scale, p_shift, p_mean, p_invstd, H, W, Cin, Cout,
-            (long)B * H * W};
+            (long)B * H * W, sed_tune()};
     bool in_t = in_scale != nullptr;
     if (Cout >= 128) return launch_igemm<2, 2, 2, 2, 9>(p, in_t, epi, stream);
     return launch_igemm<4, 1, 1, 2, 9>(p, in_t, epi, stream);
@@ -664,7 +683,7 @@ SED_API int sed_conv3x3_igemm(const float* x, const float* w_packed, float* y, i
 SED_API int sed_gemm_nt(const float* x, const float* w, const float* bias, float* y, long M, int N, int K,
                         hipStream_t stream) {
     if (M <= 0 || K % 32 != 0 || N % 64 != 0 || M >= (1L << 31)) return SED_EINVAL;
-    ConvP p{x, w, y, nullptr, nullptr, nullptr, nullptr, nullptr, bias, nullptr, nullptr, 1, 1, K, N, M};
+    ConvP p{x, w, y, nullptr, nullptr, nullptr, nullptr, nullptr, bias, nullptr, nullptr, 1, 1, K, N, M, 0};
     int epi = bias ? 3 : 0;
     if (N % 128 == 0 && M >= 4096) return launch_igemm<2, 2, 2, 2, 1>(p, false, epi, stream);
     return launch_igemm<2, 2, 1, 1, 1>(p, false, epi, stream);

@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the MFMA conv kernels per layer shape (HIP-event timed), for kernel iteration on the GPU box.
+    python tools/conv_bench.py [--batch 64] [--reps 5] [--only igemm|wgrad]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sound_event_detection_dcase2017_task4_amd import ops, _lib
+
+LAYERS = [(64, 64, 1001, 64), (64, 128, 500, 32), (128, 128, 500, 32), (128, 256, 250, 16), (256, 256, 250, 16),
+          (256, 512, 125, 8), (512, 512, 125, 8)]
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--only", type=str, default="")
+    args = ap.parse_args()
+    B = args.batch
+    tot_ms, tot_fl = {}, {}
+    for (ci, co, H, W) in LAYERS:
+        g = torch.Generator(device="cuda").manual_seed(1)
+        x = torch.randn((B, H, W, ci), device="cuda", generator=g)
+        gy = torch.randn((B, H, W, co), device="cuda", generator=g)
+        w = torch.randn((co, ci, 3, 3), device="cuda", generator=g) * 0.05
+        wf, wd = ops._pack(w, True, True)
+        st = ops.BnStats(ci, "cuda"); st.scale.fill_(1.0); st.shift.fill_(0.1); st.mean.fill_(0.0); st.invstd.fill_(1.0)
+        sto = ops.BnStats(ci, "cuda"); sto.scale.fill_(1.0); sto.shift.fill_(0.1); sto.mean.fill_(0.0); sto.invstd.fill_(1.0)
+        L = _lib.lib()
+        M = B * H * W
+        fl = 2.0 * 9 * M * ci * co
+        part = torch.empty((L.sed_conv_num_parts(M, co), 2, co), device="cuda")
+        partb = torch.empty((L.sed_conv_num_parts(M, ci), 2, ci), device="cuda")
+        runs = []
+        if args.only in ("", "igemm"):
+            runs += [("igemm fwd epi1+inT", lambda: ops._conv_igemm(x, wf, B, H, W, ci, co, in_st=st, epi=1, partials=part)),
+                     ("igemm fwd epi0    ", lambda: ops._conv_igemm(x, wf, B, H, W, ci, co)),
+                     ("igemm fwd epi0+inT", lambda: ops._conv_igemm(x, wf, B, H, W, ci, co, in_st=st)),
+                     ("igemm fwd epi1    ", lambda: ops._conv_igemm(x, wf, B, H, W, ci, co, epi=1, partials=part)),
+                     ("igemm dgrad epi2  ", lambda: ops._conv_igemm(gy, wd, B, H, W, co, ci, epi=2, partials=partb, yprev=x, p_st=sto))]
+        if args.only in ("", "wgrad"):
+            runs += [("wgrad +inT        ", lambda: ops._wgrad(x, gy, B, H, W, ci, co, in_st=st)),
+                     ("wgrad             ", lambda: ops._wgrad(x, gy, B, H, W, ci, co))]
+        for name, fn in runs:
+            ms = timeit(fn, args.reps)
+            print("%4d->%-4d %4dx%-3d %s %8.3f ms  %6.1f TFLOP/s" % (ci, co, H, W, name, ms, fl / ms / 1e9))
+            tot_ms[name] = tot_ms.get(name, 0) + ms
+            tot_fl[name] = tot_fl.get(name, 0) + fl
+    for k in tot_ms:
+        print("TOTAL %s %8.3f ms  %6.1f TFLOP/s" % (k, tot_ms[k], tot_fl[k] / tot_ms[k] / 1e9))
+
+
+if __name__ == "__main__":
+    main()
