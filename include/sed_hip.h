@@ -100,14 +100,14 @@ int sed_bn_relu_pool_bwd_apply(const float* y, const float* g_out, int B, int H,
  *   in_scale/in_shift (nullable): the operand is relu(in_scale*x + in_shift) computed on the fly (the
  *     preceding BN+ReLU is never materialised).
  *   epi 0 plain; epi 1 also writes BN statistic partials [sed_conv_num_parts][2][Cout] of y (rows per part =
- *     sed_conv_rows_per_part(Cout)); epi 2 (dgrad) masks y by relu'(p_scale*yprev + p_shift) and writes
+ *     sed_conv_rows_per_part(M, Cout)); epi 2 (dgrad) masks y by relu'(p_scale*yprev + p_shift) and writes
  *     (sum dy, sum dy*xhat) partials for the BN backward of the previous layer.
  * sed_conv3x3_wgrad: dw (OIHW) = sum_p gy[p][co] * a[p + tap][ci]; partial: scratch of
  *   sed_wgrad_partial_floats(B*H*W, Cin, Cout, 9, ...) floats.
  * sed_conv1_*: conv_block1.conv1 (Cin = 1), HBM-bound direct kernels; partials [ceil(M/256)][2][64];
  *   scratch dw_partials ceil(M/1024)*576 floats, tbuf 9*M floats (only when gx0 != null). */
 int sed_pack_conv_weights(const float* w_oihw, int Cout, int Cin, float* wf, float* wd, sed_stream_t stream);
-int sed_conv_rows_per_part(int Cout);
+int sed_conv_rows_per_part(long M, int Cout);
 int sed_conv_num_parts(long M, int Cout);
 int sed_conv3x3_igemm(const float* x, const float* w_packed, float* y, int B, int H, int W, int Cin, int Cout,
                       const float* in_scale, const float* in_shift, int epi, float* partials, const float* yprev,

@@ -63,8 +63,8 @@ template <int WM, int WN, int TM, int TN, int NTAPS, bool INT, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int A_LD = BM * 8 / 256, B_LD = BN * 8 / 256;
-    static_assert(WM * WN == 4, "4 waves");
-    constexpr bool SWZ = (BN == 64 && BM == 128);            // 48 KB -> 3 workgroups per CU for the Cout = 64 layers
+    static_assert(WM * WN == 4 && A_LD <= 8 && B_LD <= 4, "4 waves; staging macros cover 8 A rows / 4 B rows per thread");
+    constexpr bool SWZ = (BN == 64);                         // Cout = 64 layers: unpadded swizzled rows (128x64: 48 KB, 3 WG/CU; 256x64: 80 KB, 2 WG/CU)
     constexpr int ROWF = SWZ ? 32 : LDS_STRIDE;
     __shared__ __attribute__((aligned(16))) float As[2][BM * ROWF];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * ROWF];
@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     float4 areg##i = make_float4(0.f, 0.f, 0.f, 0.f), breg##i = areg##i;                                        \
     bool vld##i = false;
     SED_ROW_META(0) SED_ROW_META(1) SED_ROW_META(2) SED_ROW_META(3)
+    SED_ROW_META(4) SED_ROW_META(5) SED_ROW_META(6) SED_ROW_META(7)
 #undef SED_ROW_META
 
     floatx16 acc[TM][TN];
@@ -142,13 +143,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
         }                                                                                                       \
         SED_B_LOAD(0) SED_B_LOAD(1) SED_B_LOAD(2) SED_B_LOAD(3)                                                 \
         SED_A_LOAD(0) SED_A_LOAD(1) SED_A_LOAD(2) SED_A_LOAD(3)                                                 \
+        SED_A_LOAD(4) SED_A_LOAD(5) SED_A_LOAD(6) SED_A_LOAD(7)                                                 \
     }
 #define SED_A_STORE(BUF, i) if (i < A_LD) *reinterpret_cast<float4*>(&As[(BUF)][lds_off<SWZ>(lrow + 32 * i, c4)]) = areg##i;
 #define SED_B_STORE(BUF, j) if (j < B_LD) *reinterpret_cast<float4*>(&Bs[(BUF)][lds_off<SWZ>(lrow + 32 * j, c4)]) = breg##j;
 #define lstore(BUF)                                                                                             \
     {                                                                                                           \
-        SED_A_FIX(0) SED_A_FIX(1) SED_A_FIX(2) SED_A_FIX(3)                                                     \
+        SED_A_FIX(0) SED_A_FIX(1) SED_A_FIX(2) SED_A_FIX(3) SED_A_FIX(4) SED_A_FIX(5) SED_A_FIX(6) SED_A_FIX(7) \
         SED_A_STORE(BUF, 0) SED_A_STORE(BUF, 1) SED_A_STORE(BUF, 2) SED_A_STORE(BUF, 3)                         \
+        SED_A_STORE(BUF, 4) SED_A_STORE(BUF, 5) SED_A_STORE(BUF, 6) SED_A_STORE(BUF, 7)                         \
         SED_B_STORE(BUF, 0) SED_B_STORE(BUF, 1) SED_B_STORE(BUF, 2) SED_B_STORE(BUF, 3)                         \
     }
 
@@ -658,8 +661,15 @@ int launch_wgrad(const WgradP& p, int nslices, bool in_transform, hipStream_t st
 // ---- C ABI --------------------------------------------------------------------------------------------
 
 // rows covered by one statistics partial of sed_conv3x3_igemm for a given Cout (depends on the tile config)
-SED_API int sed_conv_rows_per_part(int Cout) { return Cout >= 128 ? 64 : 32; }
-SED_API int sed_conv_num_parts(long M, int Cout) { return sed_cdiv(M, 128) * (Cout >= 128 ? 2 : 4); }
+// Statistics partials cover 64 rows each for the 128x128 and 256x64 tiles and 32 rows for the small-M 128x64 tile.
+// The 256x64 tile (80 KB, 2 WG/CU) measured +4 % on epilogue-0 launches but -11 % with the dgrad epilogue 2 (64 extra
+// yprev loads per lane at 2 WG/CU): net zero on the step, so it stays an experiment knob (SED_TUNE bit 2).
+static bool sed_big64(long M) { return M >= 65536 && (sed_tune() & 4); }
+SED_API int sed_conv_rows_per_part(long M, int Cout) { return (Cout >= 128 || sed_big64(M)) ? 64 : 32; }
+SED_API int sed_conv_num_parts(long M, int Cout) {
+    if (Cout >= 128) return sed_cdiv(M, 128) * 2;
+    return sed_big64(M) ? sed_cdiv(M, 256) * 4 : sed_cdiv(M, 128) * 4;
+}
 
 // Forward or dgrad 3x3 conv on fp32 MFMA.  x [B*H*W][Cin], w_packed [9][Cout][Cin], y [B*H*W][Cout].
 //   epi 0: plain store.   epi 1: + BN statistics partials (sum, M2) of y.
@@ -676,6 +686,7 @@ SED_API int sed_conv3x3_igemm(const float* x, const float* w_packed, float* y, i
             (long)B * H * W, sed_tune()};
     bool in_t = in_scale != nullptr;
     if (Cout >= 128) return launch_igemm<2, 2, 2, 2, 9>(p, in_t, epi, stream);
+    if (sed_big64(p.M)) return launch_igemm<4, 1, 2, 2, 9>(p, in_t, epi, stream);   // 256 x 64 tile (experiment)
     return launch_igemm<4, 1, 1, 2, 9>(p, in_t, epi, stream);
 }
 

@@ -278,14 +278,14 @@ class ConvBlockFn(torch.autograd.Function):
             _call("sed_conv1_fwd", _ptr(x), _ptr(w1c), _ptr(y1), B, H, W, _ptr(part1), _stream())
         else:
             wf1, _ = _pack(w1c)
-            rpp1 = L.sed_conv_rows_per_part(Cout)
+            rpp1 = L.sed_conv_rows_per_part(M, Cout)
             np1 = L.sed_conv_num_parts(M, Cout)
             part1 = torch.empty((np1, 2, Cout), dtype=torch.float32, device=dev) if training else None
             y1 = _conv_igemm(x, wf1, B, H, W, Cin, Cout, epi=1 if training else 0, partials=part1)
         st1 = bn_finalize(part1, np1, rpp1, M, g1, b1, rm1, rv1) if training else bn_eval_affine(g1, b1, rm1, rv1)
         # conv2 over relu(bn1(y1)) computed on the fly (+ statistics)
         wf2, _ = _pack(w2c)
-        rpp2 = L.sed_conv_rows_per_part(Cout)
+        rpp2 = L.sed_conv_rows_per_part(M, Cout)
         np2 = L.sed_conv_num_parts(M, Cout)
         part2 = torch.empty((np2, 2, Cout), dtype=torch.float32, device=dev) if training else None
         y2 = _conv_igemm(y1, wf2, B, H, W, Cout, Cout, in_st=st1, epi=1 if training else 0, partials=part2)

@@ -29,7 +29,8 @@ def ops():
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 13, 8, 64, 64), (1, 25, 16, 64, 128), (3, 12, 8, 128, 128),
-                                            (2, 9, 4, 256, 512), (1, 101, 64, 64, 64), (2, 7, 3, 128, 256)])
+                                            (2, 9, 4, 256, 512), (1, 101, 64, 64, 64), (2, 7, 3, 128, 256),
+                                            (2, 601, 64, 64, 64), (3, 701, 32, 128, 64)])   # M >= 65536: 256x64 tile
 def test_conv3x3_igemm_forward_and_grads(ops, B, H, W, Cin, Cout):
     g = torch.Generator().manual_seed(B * 1000 + H)
     x = torch.randn(B, Cin, H, W, generator=g)
@@ -63,7 +64,7 @@ def test_conv_fused_input_bnrelu_and_stats(ops):
     from sound_event_detection_dcase2017_task4_amd import _lib
     L = _lib.lib()
     M = B * H * W
-    nparts, rpp = L.sed_conv_num_parts(M, 128), L.sed_conv_rows_per_part(128)
+    nparts, rpp = L.sed_conv_num_parts(M, 128), L.sed_conv_rows_per_part(M, 128)
     part = torch.zeros((nparts, 2, 128), device="cuda")
     y = ops._conv_igemm(ypd, wf, B, H, W, C, 128, in_st=st, epi=1, partials=part)
     assert rel(nchw(y), y_ref) < 3e-6
