@@ -165,9 +165,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
         const int buf = it & 1;
         // unconditional prefetch (the last iteration re-fetches its own tile into the idle buffer): no branches and
         // no "maybe-uninitialised" staging registers in the loop, which is what keeps them out of scratch memory
+        // All staging loads are issued back to back above the MFMA block.  (Interleaving them one per MFMA with
+        // sched_group_barrier was measured 5 % SLOWER; ablations in DESIGN.md §5.)
         gload(it + 1 < KT ? it + 1 : it);
-        __builtin_amdgcn_sched_barrier(0);       // keep all global loads ABOVE the MFMA block (latency hidden by it)
-        if (!(p.tune & 1)) __builtin_amdgcn_s_setprio(1);   // +1-2 % (A/B in tools/conv_bench.py)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);           // +1-2 % (A/B measured with tools/conv_bench.py)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 af[TM], bf[TN];
@@ -186,13 +188,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
                 }
             if (q == 2) {
                 // stage the next tile into the idle LDS buffer while the MFMA pipe drains the q=2 block: by now the
-                // loads issued at the top have had 3/4 of the K-step to land; only the barrier is left at the end
+                // loads have had most of the K-step to land; only the barrier is left at the end
                 __builtin_amdgcn_sched_barrier(0);
                 lstore(buf ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (!(p.tune & 1)) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
     }
 #undef gload
