@@ -155,7 +155,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
         SED_B_STORE(BUF, 0) SED_B_STORE(BUF, 1) SED_B_STORE(BUF, 2) SED_B_STORE(BUF, 3)                         \
     }
 
-    if ((p.tune & 2) && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(127);   // experiment: de-phase co-resident workgroups
     gload(0);
     lstore(0);
     __syncthreads();

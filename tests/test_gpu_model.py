@@ -263,3 +263,29 @@ def test_int16_waveforms_end_to_end():
     with torch.no_grad():
         ref = om.forward(mt, st, torch.from_numpy((q / 32767.0).astype(np.float32)))["clipwise_output"]
     assert (a - b).abs().max().item() < 1e-6 and (a - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("mt,B,L", [("Cnn_9layers_FrameAvg", 3, 48017), ("Cnn_9layers_Gru_FrameAtt", 5, 20000),
+                                    ("Cnn_9layers_FrameMax", 1, 6400)])
+def test_ragged_shapes_vs_oracle(mt, B, L):
+    """Odd batch sizes and clip lengths that are not multiples of the hop / of the pooling factors (floor-mode pooling
+    drops trailing frames; T = L//320 + 1): eval forward and a no-mixup train forward against the CPU oracle."""
+    m = build(mt)
+    x = waves(B * 7 + L, B, L)
+    st = om.recipe_state(mt, SEEDS[mt])
+    T8 = ((L // 320 + 1) // 8) * 8
+    m.eval()
+    with torch.no_grad():
+        o = m(torch.from_numpy(x).cuda())
+        ref = om.forward(mt, st, torch.from_numpy(x), training=False)
+    assert o["framewise_output"].shape == (B, T8, 17) == tuple(ref["framewise_output"].shape)
+    assert (o["clipwise_output"].cpu() - ref["clipwise_output"]).abs().max().item() < 1e-4
+    assert (o["framewise_output"].cpu() - ref["framewise_output"]).abs().max().item() < 1e-4
+    if B > 1:                                         # batch statistics need more than one value per channel
+        torch.manual_seed(5)
+        stripes = ofe.draw_specaug_stripes(B, L // 320 + 1, 64)
+        m.train()
+        with torch.no_grad():
+            o = m(torch.from_numpy(x).cuda(), None, specaug_stripes=stripes)
+            ref = om.forward(mt, st, torch.from_numpy(x), training=True, mixup_lambda=None, stripes=stripes)
+        assert (o["clipwise_output"].cpu() - ref["clipwise_output"]).abs().max().item() < 1e-4
