@@ -130,6 +130,9 @@ int sed_gemm_nt(const float* x, const float* w, const float* bias, float* y, lon
                 sed_stream_t stream);
 int sed_gemm_tn(const float* x, const float* gy, float* dw, float* partial, long M, int N, int K,
                 sed_stream_t stream);
+/* two independent NT GEMMs of one shape in one launch (the two directions of a BiGRU recurrence step) */
+int sed_gemm_nt_pair(const float* x0, const float* x1, const float* w0, const float* w1, const float* bias0,
+                     const float* bias1, float* y0, float* y1, long M, int N, int K, sed_stream_t stream);
 int sed_reduce_rows(const float* parts, long n, int K, long ld, float* out, int accumulate, float* ws,
                     sed_stream_t stream);
 int sed_transpose(const float* x, int batch, int rows, int cols, float* out, sed_stream_t stream);
@@ -151,11 +154,21 @@ int sed_att_pool_bwd(const float* g_clip, const float* logits, const float* b_at
                      float* g_logits, sed_stream_t stream);
 int sed_interpolate(const float* x, long BT, int ncls, int ratio, float* out, sed_stream_t stream);
 
-/* ---- nn.GRU gate math (models.py:529-530; PyTorch gate order r,z,n, b_hn inside r*(.)) ------------------------- */
-int sed_gru_gate_fwd(const float* gi, long ld_gi, const float* gh, const float* h_prev, int B, int Hd, float* h_out,
-                     long ld_out, float* h_out2, long ld_out2, float* save, sed_stream_t stream);
-int sed_gru_gate_bwd(const float* g_out, long ld_go, const float* dh_rec, const float* save, const float* h_prev,
-                     int B, int Hd, float* dgi, long ld_dgi, float* dgh, float* dh_prev, sed_stream_t stream);
+/* ---- nn.GRU gate math (models.py:529-530; PyTorch gate order r,z,n, b_hn inside r*(.)) -------------------------
+ * Each call handles BOTH directions of one recurrence step (suffix 0 = forward, 1 = reverse; the two directions are at
+ * different time indices, hence explicit pointer pairs).  gi = input projection incl. b_ih (row stride ld_gi), gh =
+ * hidden projection incl. b_hh [B][3H]; h_out / h_out2: the new hidden state, written contiguously for the next step's
+ * GEMM and into the (B,T,2H) output; save [B][4H] = r,z,n,gh_n.  Backward: dh = g_out + dh_direct + dh_gemm (both
+ * nullable; the direct z-path and the W_hh path arriving from the later step) -> dgi, dgh, dh_direct_out = dh*z. */
+int sed_gru_gate_fwd(const float* gi0, const float* gi1, long ld_gi, const float* gh0, const float* gh1,
+                     const float* h_prev0, const float* h_prev1, int B, int Hd, float* h_out0, float* h_out1,
+                     long ld_out, float* h_out2_0, float* h_out2_1, long ld_out2, float* save0, float* save1,
+                     sed_stream_t stream);
+int sed_gru_gate_bwd(const float* g_out0, const float* g_out1, long ld_go, const float* dh_direct0,
+                     const float* dh_direct1, const float* dh_gemm0, const float* dh_gemm1, const float* save0,
+                     const float* save1, const float* h_prev0, const float* h_prev1, int B, int Hd, float* dgi0,
+                     float* dgi1, long ld_dgi, float* dgh0, float* dgh1, float* dh_direct_out0, float* dh_direct_out1,
+                     sed_stream_t stream);
 
 /* ---- loss / mixup of targets / optimiser ---------------------------------------------------------------------
  * sed_clip_bce: losses.py:5-12 (F.binary_cross_entropy, mean, log clamped at -100) + d loss / d p.

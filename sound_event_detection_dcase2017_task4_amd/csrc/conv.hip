@@ -42,6 +42,12 @@ struct ConvP {
     int H, W, K, N;
     long M;
     int tune;                // experiment knobs (SED_TUNE env var; 0 = shipped configuration)
+    // second operand set, selected by blockIdx.z == 1 (NTAPS == 1 only): two independent GEMMs of the same shape in
+    // one launch (the two directions of the BiGRU recurrence)
+    const float* x2;
+    const float* w2;
+    float* y2;
+    const float* b2;
 };
 
 static int sed_tune() {
@@ -61,6 +67,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // after the loads, which exposed the full global-load latency every K-step (measured: 93 -> see DESIGN.md).
 template <int WM, int WN, int TM, int TN, int NTAPS, bool INT, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
+    if (NTAPS == 1 && blockIdx.z == 1) { p.x = p.x2; p.w = p.w2; p.y = p.y2; p.p_shift = p.b2; }
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int A_LD = BM * 8 / 256, B_LD = BN * 8 / 256;
     static_assert(WM * WN == 4 && A_LD <= 8 && B_LD <= 4, "4 waves; staging macros cover 8 A rows / 4 B rows per thread");
@@ -628,10 +635,10 @@ __global__ __launch_bounds__(1024) void conv1_wgrad_reduce_kernel(const float* _
 
 // ---------------------------------------------------------------------------------------------------------
 template <int WM, int WN, int TM, int TN, int NTAPS>
-int launch_igemm(const ConvP& p, bool in_transform, int epi, hipStream_t stream) {
+int launch_igemm(const ConvP& p, bool in_transform, int epi, hipStream_t stream, int nz = 1) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     if (p.N % BN != 0 || p.K % 32 != 0) return SED_EINVAL;
-    dim3 grid((unsigned)(sed_cdiv(p.M, BM) * (p.N / BN))), block(256);
+    dim3 grid((unsigned)(sed_cdiv(p.M, BM) * (p.N / BN)), 1, (unsigned)nz), block(256);
 #define SED_LAUNCH(INT_, EPI_) \
     hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, TM, TN, NTAPS, INT_, EPI_>), grid, block, 0, stream, p)
     if (in_transform) {
@@ -684,7 +691,7 @@ SED_API int sed_conv3x3_igemm(const float* x, const float* w_packed, float* y, i
     if ((long)B * H * W * (long)(Cin > Cout ? Cin : Cout) >= (1L << 31) * 16L) return SED_EINVAL;
     if ((long)B * H * W >= (1L << 31)) return SED_EINVAL;
     ConvP p{x, w_packed, y, in_scale, in_shift, partials, yprev, p_scale, p_shift, p_mean, p_invstd, H, W, Cin, Cout,
-            (long)B * H * W, sed_tune()};
+            (long)B * H * W, sed_tune(), nullptr, nullptr, nullptr, nullptr};
     bool in_t = in_scale != nullptr;
     if (Cout >= 128) return launch_igemm<2, 2, 2, 2, 9>(p, in_t, epi, stream);
     if (sed_big64(p.M)) return launch_igemm<4, 1, 2, 2, 9>(p, in_t, epi, stream);   // 256 x 64 tile (experiment)
@@ -695,10 +702,21 @@ SED_API int sed_conv3x3_igemm(const float* x, const float* w_packed, float* y, i
 SED_API int sed_gemm_nt(const float* x, const float* w, const float* bias, float* y, long M, int N, int K,
                         hipStream_t stream) {
     if (M <= 0 || K % 32 != 0 || N % 64 != 0 || M >= (1L << 31)) return SED_EINVAL;
-    ConvP p{x, w, y, nullptr, nullptr, nullptr, nullptr, nullptr, bias, nullptr, nullptr, 1, 1, K, N, M, 0};
+    ConvP p{x, w, y, nullptr, nullptr, nullptr, nullptr, nullptr, bias, nullptr, nullptr, 1, 1, K, N, M, 0, nullptr, nullptr, nullptr, nullptr};
     int epi = bias ? 3 : 0;
     if (N % 128 == 0 && M >= 4096) return launch_igemm<2, 2, 2, 2, 1>(p, false, epi, stream);
     return launch_igemm<2, 2, 1, 1, 1>(p, false, epi, stream);
+}
+
+// Two independent NT GEMMs of one shape in ONE launch (blockIdx.z picks the operand set): the forward and backward
+// directions of the BiGRU recurrence step.  bias0/bias1 may both be null.
+SED_API int sed_gemm_nt_pair(const float* x0, const float* x1, const float* w0, const float* w1, const float* bias0,
+                             const float* bias1, float* y0, float* y1, long M, int N, int K, hipStream_t stream) {
+    if (M <= 0 || K % 32 != 0 || N % 64 != 0 || M >= (1L << 31) || ((bias0 == nullptr) != (bias1 == nullptr))) return SED_EINVAL;
+    ConvP p{x0, w0, y0, nullptr, nullptr, nullptr, nullptr, nullptr, bias0, nullptr, nullptr, 1, 1, K, N, M, 0, x1, w1, y1, bias1};
+    int epi = bias0 ? 3 : 0;
+    if (N % 128 == 0 && M >= 4096) return launch_igemm<2, 2, 2, 2, 1>(p, false, epi, stream, 2);
+    return launch_igemm<2, 2, 1, 1, 1>(p, false, epi, stream, 2);
 }
 
 SED_API long sed_wgrad_partial_floats(long M, int Cin, int Cout, int ntaps, int* nslices_out, int* pix_per_slice_out) {

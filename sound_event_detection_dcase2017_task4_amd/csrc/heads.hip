@@ -221,18 +221,23 @@ __global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p
     }
 }
 
-// ---- GRU gates (PyTorch order r,z,n; b_hn inside r*(.)), one direction, one time step ---------------------------
-// gi [B][3H] (row stride ld_gi) input projection incl. b_ih; gh [B][3H] hidden projection incl. b_hh.
-// h_out = (1-z)*n + z*h_prev.  Saves r,z,n and gh_n for the backward pass.
-__global__ __launch_bounds__(256) void gru_gate_fwd_kernel(const float* __restrict__ gi, long ld_gi,
-                                                           const float* __restrict__ gh, const float* __restrict__ h_prev,
-                                                           int B, int Hd, float* __restrict__ h_out, long ld_out,
-                                                           float* __restrict__ h_out2, long ld_out2,
-                                                           float* __restrict__ save /*[B][4H]: r,z,n,ghn*/) {
-    long total = (long)B * Hd;
+// ---- GRU gates (PyTorch order r,z,n; b_hn inside r*(.)), BOTH directions of one recurrence step per launch ------
+// (blockIdx.y = direction).  gi [B][3H] (row stride ld_gi) input projection incl. b_ih; gh [B][3H] hidden projection
+// incl. b_hh.  h_out = (1-z)*n + z*h_prev.  Saves r,z,n and gh_n for the backward pass.
+struct GruFwdP {
+    const float* gi[2]; const float* gh[2]; const float* h_prev[2];
+    float* h_out[2]; float* h_out2[2]; float* save[2];
+    long ld_gi, ld_out, ld_out2;
+    int B, Hd;
+};
+__global__ __launch_bounds__(256) void gru_gate_fwd_kernel(GruFwdP p) {
+    const int d = blockIdx.y, Hd = p.Hd;
+    const float* gi = p.gi[d]; const float* gh = p.gh[d]; const float* h_prev = p.h_prev[d];
+    float* h_out = p.h_out[d]; float* h_out2 = p.h_out2[d]; float* save = p.save[d];
+    long total = (long)p.B * Hd;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         int b = (int)(i / Hd), j = (int)(i % Hd);
-        const float* gir = gi + (long)b * ld_gi;
+        const float* gir = gi + (long)b * p.ld_gi;
         const float* ghr = gh + (long)b * 3 * Hd;
         float r = sigmoidf_(gir[j] + ghr[j]);
         float z = sigmoidf_(gir[Hd + j] + ghr[Hd + j]);
@@ -240,8 +245,8 @@ __global__ __launch_bounds__(256) void gru_gate_fwd_kernel(const float* __restri
         float n = tanhf(gir[2 * Hd + j] + r * ghn);
         float hp = h_prev ? h_prev[(long)b * Hd + j] : 0.f;
         float h = (1.0f - z) * n + z * hp;
-        h_out[(long)b * ld_out + j] = h;
-        if (h_out2) h_out2[(long)b * ld_out2 + j] = h;
+        h_out[(long)b * p.ld_out + j] = h;
+        if (h_out2) h_out2[(long)b * p.ld_out2 + j] = h;
         if (save) {
             float* s = save + (long)b * 4 * Hd;
             s[j] = r; s[Hd + j] = z; s[2 * Hd + j] = n; s[3 * Hd + j] = ghn;
@@ -249,33 +254,38 @@ __global__ __launch_bounds__(256) void gru_gate_fwd_kernel(const float* __restri
     }
 }
 
-// dh = (gradient arriving at h_t from the output [row stride ld_go]) + dh_rec (from step t+1, nullable).
-// Produces dgi [B][3H] (row stride ld_dgi), dgh [B][3H], and dh_prev_direct [B][H] = dh*z  (the W_hh path is added
-// by the caller's GEMM).
-__global__ __launch_bounds__(256) void gru_gate_bwd_kernel(const float* __restrict__ g_out, long ld_go,
-                                                           const float* __restrict__ dh_rec,
-                                                           const float* __restrict__ save,
-                                                           const float* __restrict__ h_prev, int B, int Hd,
-                                                           float* __restrict__ dgi, long ld_dgi, float* __restrict__ dgh,
-                                                           float* __restrict__ dh_prev) {
-    long total = (long)B * Hd;
+// dh = g_out (row stride ld_go) + dh_direct (= dh*z of the later step, nullable) + dh_gemm (= dgh x W_hh of the later
+// step, nullable).  Produces dgi [B][3H] (row stride ld_dgi), dgh [B][3H] and dh_direct_out [B][H] = dh*z.
+struct GruBwdP {
+    const float* g_out[2]; const float* dh_direct[2]; const float* dh_gemm[2]; const float* save[2];
+    const float* h_prev[2];
+    float* dgi[2]; float* dgh[2]; float* dh_direct_out[2];
+    long ld_go, ld_dgi;
+    int B, Hd;
+};
+__global__ __launch_bounds__(256) void gru_gate_bwd_kernel(GruBwdP p) {
+    const int d = blockIdx.y, Hd = p.Hd;
+    const float* g_out = p.g_out[d]; const float* dh1 = p.dh_direct[d]; const float* dh2 = p.dh_gemm[d];
+    const float* save = p.save[d]; const float* h_prev = p.h_prev[d];
+    float* dgi = p.dgi[d]; float* dgh = p.dgh[d]; float* dh_out = p.dh_direct_out[d];
+    long total = (long)p.B * Hd;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         int b = (int)(i / Hd), j = (int)(i % Hd);
         const float* s = save + (long)b * 4 * Hd;
         float r = s[j], z = s[Hd + j], n = s[2 * Hd + j], ghn = s[3 * Hd + j];
         float hp = h_prev ? h_prev[(long)b * Hd + j] : 0.f;
-        float dh = g_out[(long)b * ld_go + j] + (dh_rec ? dh_rec[(long)b * Hd + j] : 0.f);
+        float dh = g_out[(long)b * p.ld_go + j] + (dh1 ? dh1[(long)b * Hd + j] : 0.f) + (dh2 ? dh2[(long)b * Hd + j] : 0.f);
         float dn = dh * (1.0f - z);
         float dz = dh * (hp - n);
         float dn_pre = dn * (1.0f - n * n);
         float dr = dn_pre * ghn;
         float dr_pre = dr * r * (1.0f - r);
         float dz_pre = dz * z * (1.0f - z);
-        float* gi_o = dgi + (long)b * ld_dgi;
+        float* gi_o = dgi + (long)b * p.ld_dgi;
         float* gh_o = dgh + (long)b * 3 * Hd;
         gi_o[j] = dr_pre; gi_o[Hd + j] = dz_pre; gi_o[2 * Hd + j] = dn_pre;
         gh_o[j] = dr_pre; gh_o[Hd + j] = dz_pre; gh_o[2 * Hd + j] = dn_pre * r;
-        dh_prev[(long)b * Hd + j] = dh * z;
+        dh_out[(long)b * Hd + j] = dh * z;
     }
 }
 
@@ -391,20 +401,27 @@ SED_API int sed_adam_amsgrad(float* p, const float* g, float* m, float* v, float
     return 0;
 }
 
-SED_API int sed_gru_gate_fwd(const float* gi, long ld_gi, const float* gh, const float* h_prev, int B, int Hd,
-                             float* h_out, long ld_out, float* h_out2, long ld_out2, float* save, hipStream_t stream) {
+SED_API int sed_gru_gate_fwd(const float* gi0, const float* gi1, long ld_gi, const float* gh0, const float* gh1,
+                             const float* h_prev0, const float* h_prev1, int B, int Hd, float* h_out0, float* h_out1,
+                             long ld_out, float* h_out2_0, float* h_out2_1, long ld_out2, float* save0, float* save1,
+                             hipStream_t stream) {
     if (B <= 0 || Hd <= 0) return SED_EINVAL;
-    hipLaunchKernelGGL(gru_gate_fwd_kernel, dim3(grid_for((long)B * Hd)), dim3(256), 0, stream, gi, ld_gi, gh, h_prev, B, Hd,
-                       h_out, ld_out, h_out2, ld_out2, save);
+    GruFwdP p{{gi0, gi1}, {gh0, gh1}, {h_prev0, h_prev1}, {h_out0, h_out1}, {h_out2_0, h_out2_1}, {save0, save1},
+              ld_gi, ld_out, ld_out2, B, Hd};
+    hipLaunchKernelGGL(gru_gate_fwd_kernel, dim3(grid_for((long)B * Hd), 2), dim3(256), 0, stream, p);
     SED_LAUNCH_CHECK();
     return 0;
 }
 
-SED_API int sed_gru_gate_bwd(const float* g_out, long ld_go, const float* dh_rec, const float* save, const float* h_prev,
-                             int B, int Hd, float* dgi, long ld_dgi, float* dgh, float* dh_prev, hipStream_t stream) {
+SED_API int sed_gru_gate_bwd(const float* g_out0, const float* g_out1, long ld_go, const float* dh_direct0,
+                             const float* dh_direct1, const float* dh_gemm0, const float* dh_gemm1, const float* save0,
+                             const float* save1, const float* h_prev0, const float* h_prev1, int B, int Hd, float* dgi0,
+                             float* dgi1, long ld_dgi, float* dgh0, float* dgh1, float* dh_direct_out0,
+                             float* dh_direct_out1, hipStream_t stream) {
     if (B <= 0 || Hd <= 0) return SED_EINVAL;
-    hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3(grid_for((long)B * Hd)), dim3(256), 0, stream, g_out, ld_go, dh_rec, save,
-                       h_prev, B, Hd, dgi, ld_dgi, dgh, dh_prev);
+    GruBwdP p{{g_out0, g_out1}, {dh_direct0, dh_direct1}, {dh_gemm0, dh_gemm1}, {save0, save1}, {h_prev0, h_prev1},
+              {dgi0, dgi1}, {dgh0, dgh1}, {dh_direct_out0, dh_direct_out1}, ld_go, ld_dgi, B, Hd};
+    hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3(grid_for((long)B * Hd), 2), dim3(256), 0, stream, p);
     SED_LAUNCH_CHECK();
     return 0;
 }

@@ -487,9 +487,18 @@ class AttHeadFn(torch.autograd.Function):
                 dwp[ncls:2 * ncls].reshape(ctx.wshape).contiguous(), dbias[ncls:2 * ncls].contiguous())
 
 
+def gemm_nt_pair(x0, x1, w0, w1, b0, b1, y0, y1):
+    """Two independent y = x w^T (+b) of one shape in ONE launch (the two GRU directions)."""
+    M, K = x0.shape
+    N = w0.shape[0]
+    _call("sed_gemm_nt_pair", _ptr(x0), _ptr(x1), _ptr(w0), _ptr(w1), _ptr(b0), _ptr(b1), _ptr(y0), _ptr(y1), M, N, K, _stream())
+
+
 class GruFn(torch.autograd.Function):
     """nn.GRU(512, 256, num_layers=1, bias=True, batch_first=True, bidirectional=True), h0 = 0
-    (models.py:529-530, :565-567).  x (B,T,512) -> (B,T,512) = concat(forward, backward)."""
+    (models.py:529-530, :565-567).  x (B,T,512) -> (B,T,512) = concat(forward, backward).
+    Input projections of both directions = one MFMA GEMM; every recurrence step = one paired GEMM launch + one paired
+    gate launch for BOTH directions (forward at time s, reverse at time T-1-s)."""
 
     @staticmethod
     def forward(ctx, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_b, w_hh_b, b_ih_b, b_hh_b):
@@ -501,26 +510,26 @@ class GruFn(torch.autograd.Function):
         out = torch.empty((B, T, 2 * Hd), dtype=torch.float32, device=dev)
         w_ih = torch.cat([_f32c(w_ih_f), _f32c(w_ih_b)], dim=0).contiguous()          # (6H, I)   device copy
         b_ih = torch.cat([_f32c(b_ih_f), _f32c(b_ih_b)], dim=0).contiguous()
-        gi = gemm_nt(x.view(B * T, I), w_ih, b_ih)                                     # (B*T, 6H)
+        gi = gemm_nt(x.view(B * T, I), w_ih, b_ih).view(B, T, 6 * Hd)                  # (B, T, 6H)
         hs = torch.empty((2, T, B, Hd), dtype=torch.float32, device=dev)
         saves = torch.empty((2, T, B, 4 * Hd), dtype=torch.float32, device=dev)
+        whh = (_f32c(w_hh_f), _f32c(w_hh_b))
+        bhh = (_f32c(b_hh_f), _f32c(b_hh_b))
+        gh0 = torch.stack([bhh[0].view(1, -1).expand(B, -1), bhh[1].view(1, -1).expand(B, -1)]).contiguous()  # h0 = 0
+        gh = torch.empty((2, B, 3 * Hd), dtype=torch.float32, device=dev)
         s = _stream()
-        for d, (w_hh, b_hh) in enumerate(((w_hh_f, b_hh_f), (w_hh_b, b_hh_b))):
-            w_hh, b_hh = _f32c(w_hh), _f32c(b_hh)
-            order = range(T) if d == 0 else range(T - 1, -1, -1)
-            prev = None
-            for t in order:
-                if prev is None:
-                    gh = b_hh.view(1, -1).expand(B, -1).contiguous()
-                else:
-                    gh = gemm_nt(prev, w_hh, b_hh)
-                h_t = hs[d, t]
-                gi_t = gi.view(B, T, 6 * Hd)[:, t, d * 3 * Hd:(d + 1) * 3 * Hd]
-                out_t = out[:, t, d * Hd:(d + 1) * Hd]
-                _call("sed_gru_gate_fwd", _ptr(gi_t), T * 6 * Hd, _ptr(gh), _ptr(prev), B, Hd, _ptr(h_t), Hd, _ptr(out_t),
-                      T * 2 * Hd, _ptr(saves[d, t]), s)
-                prev = h_t
-        ctx.save_for_backward(x, w_ih, _f32c(w_hh_f), _f32c(w_hh_b), hs, saves)
+        for k in range(T):
+            tf, tb = k, T - 1 - k
+            if k == 0:
+                g0, g1, p0, p1 = gh0[0], gh0[1], None, None
+            else:
+                p0, p1 = hs[0, tf - 1], hs[1, tb + 1]
+                gemm_nt_pair(p0, p1, whh[0], whh[1], bhh[0], bhh[1], gh[0], gh[1])
+                g0, g1 = gh[0], gh[1]
+            _call("sed_gru_gate_fwd", _ptr(gi[:, tf, 0:3 * Hd]), _ptr(gi[:, tb, 3 * Hd:6 * Hd]), T * 6 * Hd, _ptr(g0), _ptr(g1),
+                  _ptr(p0), _ptr(p1), B, Hd, _ptr(hs[0, tf]), _ptr(hs[1, tb]), Hd, _ptr(out[:, tf, 0:Hd]),
+                  _ptr(out[:, tb, Hd:2 * Hd]), T * 2 * Hd, _ptr(saves[0, tf]), _ptr(saves[1, tb]), s)
+        ctx.save_for_backward(x, w_ih, whh[0], whh[1], hs, saves)
         return out
 
     @staticmethod
@@ -532,36 +541,40 @@ class GruFn(torch.autograd.Function):
         dev = x.device
         s = _stream()
         dgi = torch.empty((B, T, 6 * Hd), dtype=torch.float32, device=dev)
-        dgh_all = torch.empty((2, T, B, 3 * Hd), dtype=torch.float32, device=dev)
-        hprev_all = torch.zeros((2, T, B, Hd), dtype=torch.float32, device=dev)
-        grads_hh, grads_bhh = [], []
-        for d, w_hh in enumerate((w_hh_f, w_hh_b)):
-            w_hh_t = transpose_b(w_hh.view(1, 3 * Hd, Hd)).view(Hd, 3 * Hd)          # (H, 3H)
-            order = list(range(T)) if d == 0 else list(range(T - 1, -1, -1))
-            dh_rec = None
-            for idx in range(T - 1, -1, -1):
-                t = order[idx]
-                prev = hs[d, order[idx - 1]] if idx > 0 else None
-                if prev is not None:
-                    hprev_all[d, t].copy_(prev)
-                g_t = g_out[:, t, d * Hd:(d + 1) * Hd]
-                dgi_t = dgi[:, t, d * 3 * Hd:(d + 1) * 3 * Hd]
-                dh_prev = torch.empty((B, Hd), dtype=torch.float32, device=dev)
-                _call("sed_gru_gate_bwd", _ptr(g_t), T * 2 * Hd, _ptr(dh_rec), _ptr(saves[d, t]), _ptr(prev), B, Hd,
-                      _ptr(dgi_t), T * 6 * Hd, _ptr(dgh_all[d, t]), _ptr(dh_prev), s)
-                if idx > 0:
-                    rec = gemm_nt(dgh_all[d, t], w_hh_t)                                 # (B, H)
-                    _call("sed_axpy", _ptr(dh_prev), _ptr(rec), B * Hd, s)
-                dh_rec = dh_prev
-            grads_hh.append(gemm_tn(hprev_all[d].view(T * B, Hd), dgh_all[d].view(T * B, 3 * Hd)))
-            grads_bhh.append(col_sums(dgh_all[d].view(T * B, 3 * Hd)))
+        dgh = torch.empty((2, T, B, 3 * Hd), dtype=torch.float32, device=dev)
+        wt = (transpose_b(w_hh_f.view(1, 3 * Hd, Hd)).view(Hd, 3 * Hd),               # (H, 3H): dh = dgh x W_hh
+              transpose_b(w_hh_b.view(1, 3 * Hd, Hd)).view(Hd, 3 * Hd))
+        direct = [torch.empty((2, B, Hd), dtype=torch.float32, device=dev) for _ in range(2)]   # ping-pong
+        rec = [torch.empty((2, B, Hd), dtype=torch.float32, device=dev) for _ in range(2)]
+        have = False
+        for k in range(T - 1, -1, -1):                 # reverse of the forward processing order
+            tf, tb = k, T - 1 - k
+            cur, prv = k & 1, (k & 1) ^ 1
+            p0 = hs[0, tf - 1] if k > 0 else None
+            p1 = hs[1, tb + 1] if k > 0 else None
+            _call("sed_gru_gate_bwd", _ptr(g_out[:, tf, 0:Hd]), _ptr(g_out[:, tb, Hd:2 * Hd]), T * 2 * Hd,
+                  _ptr(direct[prv][0]) if have else None, _ptr(direct[prv][1]) if have else None,
+                  _ptr(rec[prv][0]) if have else None, _ptr(rec[prv][1]) if have else None,
+                  _ptr(saves[0, tf]), _ptr(saves[1, tb]), _ptr(p0), _ptr(p1), B, Hd,
+                  _ptr(dgi[:, tf, 0:3 * Hd]), _ptr(dgi[:, tb, 3 * Hd:6 * Hd]), T * 6 * Hd, _ptr(dgh[0, tf]), _ptr(dgh[1, tb]),
+                  _ptr(direct[cur][0]), _ptr(direct[cur][1]), s)
+            if k > 0:
+                gemm_nt_pair(dgh[0, tf], dgh[1, tb], wt[0], wt[1], None, None, rec[cur][0], rec[cur][1])
+            have = True
+        # weight gradients of the recurrence: dW_hh = sum_t dgh_t^T h_{prev(t)}; h_prev is a shifted view of hs
+        dw_hh_f = gemm_tn(hs[0, 0:T - 1].reshape((T - 1) * B, Hd), dgh[0, 1:T].reshape((T - 1) * B, 3 * Hd)) if T > 1 else \
+            torch.zeros((3 * Hd, Hd), dtype=torch.float32, device=dev)
+        dw_hh_b = gemm_tn(hs[1, 1:T].reshape((T - 1) * B, Hd), dgh[1, 0:T - 1].reshape((T - 1) * B, 3 * Hd)) if T > 1 else \
+            torch.zeros((3 * Hd, Hd), dtype=torch.float32, device=dev)
+        db_hh_f = col_sums(dgh[0].view(T * B, 3 * Hd))
+        db_hh_b = col_sums(dgh[1].view(T * B, 3 * Hd))
         dgi2 = dgi.view(B * T, 6 * Hd)
         w_ih_t = transpose_b(w_ih.view(1, 6 * Hd, I)).view(I, 6 * Hd)
         gx = gemm_nt(dgi2, w_ih_t).view(B, T, I)
         dw_ih = gemm_tn(x.view(B * T, I), dgi2)                                          # (6H, I)
         db_ih = col_sums(dgi2)
-        return (gx, dw_ih[:3 * Hd].contiguous(), grads_hh[0], db_ih[:3 * Hd].contiguous(), grads_bhh[0],
-                dw_ih[3 * Hd:].contiguous(), grads_hh[1], db_ih[3 * Hd:].contiguous(), grads_bhh[1])
+        return (gx, dw_ih[:3 * Hd].contiguous(), dw_hh_f, db_ih[:3 * Hd].contiguous(), db_hh_f,
+                dw_ih[3 * Hd:].contiguous(), dw_hh_b, db_ih[3 * Hd:].contiguous(), db_hh_b)
 
 
 class ClipBceFn(torch.autograd.Function):
