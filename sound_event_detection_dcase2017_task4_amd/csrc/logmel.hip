@@ -8,6 +8,7 @@
 // (T,64) out: 1,536,256 B per 10 s clip (fp32 in) -- the roofline denominator of SURVEY.md §8d.
 #include "common.h"
 #include "sed_hip.h"
+#include <math.h>
 
 namespace {
 
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256, 3) void logmel_kernel(const T* __restrict__ wa
                                                         const int4* __restrict__ tasks,        // [ntasks] {lo, cnt, off, band}
                                                         int ntasks, const int2* __restrict__ bands,   // [64] {first task, #tasks}
                                                         const float* __restrict__ mel_w, int mel_nnz, float amin,
-                                                        float* __restrict__ out) {
+                                                        float floor_db, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* melw_s = reinterpret_cast<float*>(smem_raw);                       // [MELW_MAX]
     float2* tbuf_all = reinterpret_cast<float2*>(melw_s + MELW_MAX);          // 4 x [16*TROW]
@@ -225,8 +226,9 @@ __global__ __launch_bounds__(256, 3) void logmel_kernel(const T* __restrict__ wa
             float ma = 0.f, mb = 0.f;
             for (int j = 0; j < bd.y; ++j) { float2 v = mp[bd.x + j]; ma += v.x; mb += v.y; }
             float* o = out + ((long)b * T_frames + ta) * 64 + lane;
-            o[0] = (float)(10.0 * log10((double)fmaxf(ma, amin)));       // fp64 log: exact -100 dB at the clamp
-            if (ta + 1 < T_frames) o[64] = (float)(10.0 * log10((double)fmaxf(mb, amin)));
+            // fp32 log10 (2 ulp) everywhere except AT the clamp, where the reference yields exactly 10*log10(amin)
+            o[0] = ma > amin ? 10.0f * log10f(ma) : floor_db;
+            if (ta + 1 < T_frames) o[64] = mb > amin ? 10.0f * log10f(mb) : floor_db;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -245,7 +247,7 @@ int launch_logmel(const T* wave, int B2, int L, const float* window, const float
     hipLaunchKernelGGL(logmel_kernel<T>, grid, dim3(256), LOGMEL_SMEM, stream, wave, L, T_frames, window,
                        reinterpret_cast<const float2*>(tw1024t), reinterpret_cast<const float2*>(tw64t),
                        reinterpret_cast<const int4*>(tasks), ntasks, reinterpret_cast<const int2*>(bands), mel_w, mel_nnz,
-                       amin, out);
+                       amin, (float)(10.0 * log10((double)amin)), out);
     SED_LAUNCH_CHECK();
     return 0;
 }
