@@ -20,6 +20,17 @@ constexpr int LDS_STRIDE = 36;   // padded layout: 32 floats + 4 pad: ds_read_b1
 // LDS tile addressing.  SWZ = false: rows padded to 36 floats (conflict-free b128 reads).  SWZ = true: unpadded 128-B
 // rows with the 16-B chunk index XORed by (row & 7): at most 2-way conflicts (irrelevant next to 64-cycle fp32 MFMAs)
 // but 11 % less LDS, which is what lets THREE 128x64 workgroups share a CU.
+// One LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS bytes [dst, dst + 1024) (dst wave-uniform).
+// Inline asm on purpose: with the builtin, hipcc waits vmcnt(0) before EVERY later ds_read of the same __shared__ array
+// (it cannot tell the two halves of the double buffer apart), which exposes the whole load latency each K-step.  The
+// asm form is invisible to that bookkeeping; the kernel drains it with one explicit s_waitcnt vmcnt(0) before the
+// end-of-step barrier.  M0 (the LDS-DMA base) is saved/restored inside the statement.
+__device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_dst_bytes) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_bytes) : "memory");
+}
+
 template <bool SWZ> __device__ __forceinline__ int lds_off(int row, int chunk) {
     return SWZ ? row * 32 + ((chunk ^ (row & 7)) << 2) : row * LDS_STRIDE + (chunk << 2);
 }
@@ -73,8 +84,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     static_assert(WM * WN == 4 && A_LD <= 8 && B_LD <= 4, "4 waves; staging macros cover 8 A rows / 4 B rows per thread");
     constexpr bool SWZ = (BN == 64);                         // Cout = 64 layers: unpadded swizzled rows (128x64: 48 KB, 3 WG/CU; 256x64: 80 KB, 2 WG/CU)
     constexpr int ROWF = SWZ ? 32 : LDS_STRIDE;
+    // The weight tile needs no masking / transform, so it goes global -> LDS directly (global_load_lds_dwordx4: no
+    // staging VGPRs, no ds_write).  An LDS-DMA instruction writes wave-uniform base + lane*16 B, i.e. 8 linear 128-B
+    // rows, so the B tile is always the unpadded swizzled layout with the swizzle applied to the SOURCE chunk.
+    constexpr bool BDMA = true;
+    constexpr int BROWF = BDMA ? 32 : ROWF;
     __shared__ __attribute__((aligned(16))) float As[2][BM * ROWF];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * ROWF];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * BROWF];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv / WN, wn = wv % WN;
@@ -83,6 +99,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     const long m0 = (long)(tile / nt_n) * BM;
     const int n0 = (tile % nt_n) * BN;
     const int c4 = tid & 7, lrow = tid >> 3;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    const unsigned bs_lds_base = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) float*)&Bs[0][0]);
 
     // per-row metadata of the rows this thread stages: A rows lrow + 32*i (i < A_LD), B rows lrow + 32*j (j < B_LD).
     // Rows past M alias row 0 and are always masked.
@@ -98,7 +117,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
             } else { rw##i = 0; rh##i = 0; }                                                                    \
         }                                                                                                       \
     }                                                                                                           \
-    const float* bptr##i = p.w + (long)(n0 + lrow + 32 * (i < B_LD ? i : 0)) * p.K + c4 * 4;                    \
+    const int brow##i = (BN / 4) * wvu + 8 * (i < B_LD ? i : 0) + (lane >> 3);     /* B row staged by DMA i */      \
+    const float* bptr##i = BDMA ? p.w + (long)(n0 + brow##i) * p.K + (((lane & 7) ^ (brow##i & 7)) << 2)            \
+                                : p.w + (long)(n0 + lrow + 32 * (i < B_LD ? i : 0)) * p.K + c4 * 4;                \
     float4 areg##i = make_float4(0.f, 0.f, 0.f, 0.f), breg##i = areg##i;                                        \
     bool vld##i = false;
     SED_ROW_META(0) SED_ROW_META(1) SED_ROW_META(2) SED_ROW_META(3)
@@ -135,8 +156,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
         areg##i.x = vld##i ? areg##i.x : 0.f; areg##i.y = vld##i ? areg##i.y : 0.f;                             \
         areg##i.z = vld##i ? areg##i.z : 0.f; areg##i.w = vld##i ? areg##i.w : 0.f;                             \
     }
-#define SED_B_LOAD(j) if (j < B_LD) breg##j = *reinterpret_cast<const float4*>(bptr##j + b_off);
-#define gload(IT)                                                                                               \
+#define SED_B_LOAD(DST, j)                                                                                      \
+    if (j < B_LD) {                                                                                             \
+        if (BDMA) lds_dma16(bptr##j + b_off, bs_lds_base + (unsigned)(((DST) * BN + (BN / 4) * wvu + 8 * j) * 128));  \
+        else breg##j = *reinterpret_cast<const float4*>(bptr##j + b_off);                                       \
+    }
+#define gload(IT, DST)                                                                                          \
     {                                                                                                           \
         const int it_ = (IT);                                                                                   \
         const int tap = (NTAPS == 9) ? it_ % 9 : 0;                                                             \
@@ -148,12 +173,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
             sc = *reinterpret_cast<const float4*>(p.in_scale + c0 + c4 * 4);                                    \
             sh = *reinterpret_cast<const float4*>(p.in_shift + c0 + c4 * 4);                                    \
         }                                                                                                       \
-        SED_B_LOAD(0) SED_B_LOAD(1) SED_B_LOAD(2) SED_B_LOAD(3)                                                 \
+        SED_B_LOAD(DST, 0) SED_B_LOAD(DST, 1) SED_B_LOAD(DST, 2) SED_B_LOAD(DST, 3)                             \
         SED_A_LOAD(0) SED_A_LOAD(1) SED_A_LOAD(2) SED_A_LOAD(3)                                                 \
         SED_A_LOAD(4) SED_A_LOAD(5) SED_A_LOAD(6) SED_A_LOAD(7)                                                 \
     }
 #define SED_A_STORE(BUF, i) if (i < A_LD) *reinterpret_cast<float4*>(&As[(BUF)][lds_off<SWZ>(lrow + 32 * i, c4)]) = areg##i;
-#define SED_B_STORE(BUF, j) if (j < B_LD) *reinterpret_cast<float4*>(&Bs[(BUF)][lds_off<SWZ>(lrow + 32 * j, c4)]) = breg##j;
+#define SED_B_STORE(BUF, j) if (!BDMA && j < B_LD) *reinterpret_cast<float4*>(&Bs[(BUF)][lds_off<SWZ>(lrow + 32 * j, c4)]) = breg##j;
 #define lstore(BUF)                                                                                             \
     {                                                                                                           \
         SED_A_FIX(0) SED_A_FIX(1) SED_A_FIX(2) SED_A_FIX(3) SED_A_FIX(4) SED_A_FIX(5) SED_A_FIX(6) SED_A_FIX(7) \
@@ -162,8 +187,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
         SED_B_STORE(BUF, 0) SED_B_STORE(BUF, 1) SED_B_STORE(BUF, 2) SED_B_STORE(BUF, 3)                         \
     }
 
-    gload(0);
+    gload(0, 0);
     lstore(0);
+    if (BDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int arow_base = wm * TM * 32 + (lane & 31);
     const int brow_base = wn * TN * 32 + (lane & 31);
@@ -173,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
         // no "maybe-uninitialised" staging registers in the loop, which is what keeps them out of scratch memory
         // All staging loads are issued back to back above the MFMA block.  (Interleaving them one per MFMA with
         // sched_group_barrier was measured 5 % SLOWER; ablations in DESIGN.md §5.)
-        gload(it + 1 < KT ? it + 1 : it);
+        gload(it + 1 < KT ? it + 1 : it, buf ^ 1);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);           // +1-2 % (A/B measured with tools/conv_bench.py)
 #pragma unroll
@@ -182,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
             for (int a = 0; a < TM; ++a) af[a] = lds_frag<SWZ>(&As[buf][0], arow_base + a * 32, q * 2 + (lane >> 5));
 #pragma unroll
-            for (int b = 0; b < TN; ++b) bf[b] = lds_frag<SWZ>(&Bs[buf][0], brow_base + b * 32, q * 2 + (lane >> 5));
+            for (int b = 0; b < TN; ++b) bf[b] = lds_frag<(SWZ || BDMA)>(&Bs[buf][0], brow_base + b * 32, q * 2 + (lane >> 5));
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -201,6 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
             }
         }
         __builtin_amdgcn_s_setprio(0);
+        if (BDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the asm LDS-DMAs of this step have landed
         __syncthreads();
     }
 #undef gload
