@@ -113,6 +113,16 @@ int sed_conv3x3_igemm(const float* x, const float* w_packed, float* y, int B, in
                       const float* in_scale, const float* in_shift, int epi, float* partials, const float* yprev,
                       const float* p_scale, const float* p_shift, const float* p_mean, const float* p_invstd,
                       sed_stream_t stream);
+/* Fused 1-D Winograd F(2,3) (along W) variant of sed_conv3x3_igemm: 1.5x fewer MFMA flops, same fusions and the same
+ * contract, with w_wino = the Winograd pack [3 ky][4 xi][Cout][Cin] from sed_pack_conv_weights_wino (uf: forward,
+ * ud: dgrad with Cin/Cout swapped).  Statistics partials: [ceil(M/128)*2][2][Cout], 64 rows per part.  Needs W even,
+ * W | 128, Cin % 16 == 0, Cout % 64 == 0 (sed_conv3x3_wino_supported). */
+int sed_conv3x3_wino_supported(int H, int W, int Cin, int Cout);
+int sed_pack_conv_weights_wino(const float* w_oihw, int Cout, int Cin, float* uf, float* ud, sed_stream_t stream);
+int sed_conv3x3_wino(const float* x, const float* w_wino, float* y, int B, int H, int W, int Cin, int Cout,
+                     const float* in_scale, const float* in_shift, int epi, float* partials, const float* yprev,
+                     const float* p_scale, const float* p_shift, const float* p_mean, const float* p_invstd,
+                     sed_stream_t stream);
 long sed_wgrad_partial_floats(long M, int Cin, int Cout, int ntaps, int* nslices_out, int* pix_per_slice_out);
 int sed_conv3x3_wgrad(const float* x, const float* gy, float* dw_oihw, float* partial, int B, int H, int W, int Cin,
                       int Cout, const float* in_scale, const float* in_shift, sed_stream_t stream);

@@ -234,6 +234,27 @@ def _conv_igemm(x, w_packed, B, H, W, Cin, Cout, in_st=None, epi=0, partials=Non
     return y
 
 
+def _pack_wino(w, want_f=True, want_d=False):
+    """OIHW -> Winograd-domain packs uf [3][4][Cout][Cin] / ud [3][4][Cin][Cout]."""
+    Cout, Cin = w.shape[0], w.shape[1]
+    uf = torch.empty((3, 4, Cout, Cin), dtype=torch.float32, device=w.device) if want_f else None
+    ud = torch.empty((3, 4, Cin, Cout), dtype=torch.float32, device=w.device) if want_d else None
+    _call("sed_pack_conv_weights_wino", _ptr(w), Cout, Cin, _ptr(uf), _ptr(ud), _stream())
+    return uf, ud
+
+
+def _conv_wino(x, w_wino, B, H, W, Cin, Cout, in_st=None, epi=0, partials=None, yprev=None, p_st=None):
+    y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+    with _timed("conv3x3_wino_mfma(fwd+dgrad)|%d->%d@%dx%d epi%d%s" % (Cin, Cout, H, W, epi, "+inT" if in_st is not None else ""),
+                2.0 * 9 * B * H * W * Cin * Cout):
+        _call("sed_conv3x3_wino", _ptr(x), _ptr(w_wino), _ptr(y), B, H, W, Cin, Cout,
+              _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, epi,
+              _ptr(partials), _ptr(yprev), _ptr(p_st.scale) if p_st is not None else None,
+              _ptr(p_st.shift) if p_st is not None else None, _ptr(p_st.mean) if p_st is not None else None,
+              _ptr(p_st.invstd) if p_st is not None else None, _stream())
+    return y
+
+
 def _pack(w, want_f=True, want_d=False):
     Cout, Cin = w.shape[0], w.shape[1]
     wf = torch.empty((9, Cout, Cin), dtype=torch.float32, device=w.device) if want_f else None

@@ -54,6 +54,13 @@ def main():
                      ("igemm fwd epi0+inT", lambda: ops._conv_igemm(x, wf, B, H, W, ci, co, in_st=st)),
                      ("igemm fwd epi1    ", lambda: ops._conv_igemm(x, wf, B, H, W, ci, co, epi=1, partials=part)),
                      ("igemm dgrad epi2  ", lambda: ops._conv_igemm(gy, wd, B, H, W, co, ci, epi=2, partials=partb, yprev=x, p_st=sto))]
+        if args.only in ("", "wino") and L.sed_conv3x3_wino_supported(H, W, ci, co):
+            uf, ud = ops._pack_wino(w, True, True)
+            npw = ((M + 127) // 128) * 2
+            pw = torch.empty((npw, 2, co), device="cuda"); pwb = torch.empty((npw, 2, ci), device="cuda")
+            runs += [("wino  fwd epi1+inT", lambda: ops._conv_wino(x, uf, B, H, W, ci, co, in_st=st, epi=1, partials=pw)),
+                     ("wino  fwd epi0    ", lambda: ops._conv_wino(x, uf, B, H, W, ci, co)),
+                     ("wino  dgrad epi2  ", lambda: ops._conv_wino(gy, ud, B, H, W, co, ci, epi=2, partials=pwb, yprev=x, p_st=sto))]
         if args.only in ("", "wgrad"):
             runs += [("wgrad +inT        ", lambda: ops._wgrad(x, gy, B, H, W, ci, co, in_st=st)),
                      ("wgrad             ", lambda: ops._wgrad(x, gy, B, H, W, ci, co))]
