@@ -180,11 +180,15 @@ def main():
             print("# %-62s %3d launches  %8.3f ms/launch  %6.1f TFLOP/s" % (tag, v["launches"], v["avg_ms"], v["tflops"]),
                   file=sys.stderr)
     dom = max(kern, key=lambda k: kern[k]["ms_total"]) if kern else None
+    notes = {"conv3x3_wino_mfma(fwd+dgrad)": "fused 1-D Winograd F(2,3) implicit GEMM on fp32 MFMA: 'achieved' counts the "
+                                             "ALGORITHMIC direct-convolution flops (SURVEY.md 8d); the kernel executes 1.5x fewer"}
     roofline = None
     if dom is not None:
         roofline = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                     "launches_per_step": kern[dom]["launches"] // args.steps, "avg_launch_ms": kern[dom]["avg_ms"]}
+        if dom in notes:
+            roofline["note"] = notes[dom]
     conv_ms = sum(v["ms_total"] for v in kern.values())
     clips_per_s = B * world * args.steps / dt
     line = {

@@ -275,6 +275,31 @@ def _wgrad(x, gy, B, H, W, Cin, Cout, in_st=None):
     return dw
 
 
+# The fused 1-D Winograd F(2,3) kernel (csrc/conv_wino.hip) does the same convolution with 1.5x fewer MFMA flops; it is
+# used for forward and dgrad whenever the layer shape allows (W even, W | 128).  False = direct implicit GEMM everywhere.
+USE_WINOGRAD = True
+
+
+def _conv_fwd_like(x, w_oihw, B, H, W, Cin, Cout, dgrad=False, **kw):
+    """3x3 conv of x with the OIHW weights (dgrad=True: the transposed/flipped conv that maps g_y -> g_x; Cin/Cout are
+    then the channel counts of the INPUT/OUTPUT of this call).  Returns (y, nparts, rows_per_part)."""
+    L = _lib.lib()
+    M = B * H * W
+    if USE_WINOGRAD and L.sed_conv3x3_wino_supported(H, W, Cin, Cout):
+        uf, ud = _pack_wino(w_oihw, want_f=not dgrad, want_d=dgrad)
+        return _conv_wino(x, ud if dgrad else uf, B, H, W, Cin, Cout, **kw)
+    wf, wd = _pack(w_oihw, want_f=not dgrad, want_d=dgrad)
+    return _conv_igemm(x, wd if dgrad else wf, B, H, W, Cin, Cout, **kw)
+
+
+def _conv_parts(M, H, W, Cin, Cout):
+    """(number of statistics partials, rows per partial) written by _conv_fwd_like for this shape."""
+    L = _lib.lib()
+    if USE_WINOGRAD and L.sed_conv3x3_wino_supported(H, W, Cin, Cout):
+        return ((M + 127) // 128) * 2, 64
+    return L.sed_conv_num_parts(M, Cout), L.sed_conv_rows_per_part(M, Cout)
+
+
 class ConvBlockFn(torch.autograd.Function):
     """One reference ConvBlock (models.py:99-115, pool_type='avg'), NHWC, training or eval.
     x (B,H,W,Cin) -> (B,H//ph,W//pw,Cout).  Only the two raw conv outputs are saved; BN+ReLU is recomputed
@@ -298,18 +323,14 @@ class ConvBlockFn(torch.autograd.Function):
             y1 = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
             _call("sed_conv1_fwd", _ptr(x), _ptr(w1c), _ptr(y1), B, H, W, _ptr(part1), _stream())
         else:
-            wf1, _ = _pack(w1c)
-            rpp1 = L.sed_conv_rows_per_part(M, Cout)
-            np1 = L.sed_conv_num_parts(M, Cout)
+            np1, rpp1 = _conv_parts(M, H, W, Cin, Cout)
             part1 = torch.empty((np1, 2, Cout), dtype=torch.float32, device=dev) if training else None
-            y1 = _conv_igemm(x, wf1, B, H, W, Cin, Cout, epi=1 if training else 0, partials=part1)
+            y1 = _conv_fwd_like(x, w1c, B, H, W, Cin, Cout, epi=1 if training else 0, partials=part1)
         st1 = bn_finalize(part1, np1, rpp1, M, g1, b1, rm1, rv1) if training else bn_eval_affine(g1, b1, rm1, rv1)
         # conv2 over relu(bn1(y1)) computed on the fly (+ statistics)
-        wf2, _ = _pack(w2c)
-        rpp2 = L.sed_conv_rows_per_part(M, Cout)
-        np2 = L.sed_conv_num_parts(M, Cout)
+        np2, rpp2 = _conv_parts(M, H, W, Cout, Cout)
         part2 = torch.empty((np2, 2, Cout), dtype=torch.float32, device=dev) if training else None
-        y2 = _conv_igemm(y1, wf2, B, H, W, Cout, Cout, in_st=st1, epi=1 if training else 0, partials=part2)
+        y2 = _conv_fwd_like(y1, w2c, B, H, W, Cout, Cout, in_st=st1, epi=1 if training else 0, partials=part2)
         st2 = bn_finalize(part2, np2, rpp2, M, g2, b2, rm2, rv2) if training else bn_eval_affine(g2, b2, rm2, rv2)
         out = torch.empty((B, H // ph, W // pw, Cout), dtype=torch.float32, device=dev)
         _call("sed_bn_relu_pool_fwd", _ptr(y2), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift), _ptr(out), _stream())
@@ -339,11 +360,9 @@ class ConvBlockFn(torch.autograd.Function):
               _ptr(coef2), _ptr(gy2), _stream())
         # conv2: wgrad (operand relu(bn1(y1)) on the fly) and dgrad fused with relu-mask + BN1 backward sums
         dw2 = _wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=st1)
-        _, wd2 = _pack(w2, want_f=False, want_d=True)
-        L = _lib.lib()
-        npb = L.sed_conv_num_parts(M, Cout)
+        npb, _ = _conv_parts(M, H, W, Cout, Cout)
         partb = torch.empty((npb, 2, Cout), dtype=torch.float32, device=dev)
-        gy1 = _conv_igemm(gy2, wd2, B, H, W, Cout, Cout, epi=2, partials=partb, yprev=y1, p_st=st1)
+        gy1 = _conv_fwd_like(gy2, w2, B, H, W, Cout, Cout, dgrad=True, epi=2, partials=partb, yprev=y1, p_st=st1)
         del gy2
         dg1, db1, coef1 = bn_bwd_finalize(partb, npb, M, st1, batch_stats=ctx.training)
         _call("sed_bn_bwd_apply", _ptr(gy1), _ptr(y1), M, Cout, _ptr(coef1), _stream())
@@ -360,8 +379,7 @@ class ConvBlockFn(torch.autograd.Function):
         else:
             dw1 = _wgrad(x, gy1, B, H, W, Cin, Cout)
             if ctx.needs_input_grad[0]:
-                _, wd1 = _pack(w1, want_f=False, want_d=True)
-                gx = _conv_igemm(gy1, wd1, B, H, W, Cout, Cin, epi=0)
+                gx = _conv_fwd_like(gy1, w1, B, H, W, Cout, Cin, dgrad=True, epi=0)
         return gx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, None, None, None
 
 
