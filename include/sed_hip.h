@@ -123,6 +123,11 @@ int sed_conv3x3_wino(const float* x, const float* w_wino, float* y, int B, int H
                      const float* in_scale, const float* in_shift, int epi, float* partials, const float* yprev,
                      const float* p_scale, const float* p_shift, const float* p_mean, const float* p_invstd,
                      sed_stream_t stream);
+/* Winograd-domain weight gradient (12 instead of 18 MACs per output pair); same contract as sed_conv3x3_wgrad.
+ * Needs W a power of two <= 64 and Cin, Cout % 64 == 0; partial: sed_wgrad_wino_partial_floats(...) floats. */
+long sed_wgrad_wino_partial_floats(long M, int Cin, int Cout, int* nslices_out, int* pix_per_slice_out);
+int sed_conv3x3_wgrad_wino(const float* x, const float* gy, float* dw_oihw, float* partial, int B, int H, int W, int Cin,
+                           int Cout, const float* in_scale, const float* in_shift, sed_stream_t stream);
 long sed_wgrad_partial_floats(long M, int Cin, int Cout, int ntaps, int* nslices_out, int* pix_per_slice_out);
 int sed_conv3x3_wgrad(const float* x, const float* gy, float* dw_oihw, float* partial, int B, int H, int W, int Cin,
                       int Cout, const float* in_scale, const float* in_shift, sed_stream_t stream);

@@ -270,6 +270,169 @@ __global__ __launch_bounds__(256) void pack_wino_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient in the Winograd domain:  dU_xi[ky][co][ci] = sum over output pairs t of dM_xi[t][co] * V_xi[t@ky][ci]
+// with dM = (g0, g0+g1, g0-g1, -g1) from the output-gradient pair and V = (d0-d2, d1+d2, d2-d1, d1-d3) from the input
+// row h+ky-1; the reduce kernel maps dU back to the three horizontal taps (dg0 = dU0 + (dU1+dU2)/2,
+// dg1 = (dU1-dU2)/2, dg2 = (dU1+dU2)/2 + dU3).  12 MACs per pair instead of 18.  One workgroup = one ky, 64 co x 64 ci,
+// all four positions (4 accumulators per wave), K = the pairs of a pixel slice, 64 pixels per K-step.
+struct WWinoP {
+    const float* x;
+    const float* gy;
+    float* partial;          // [nslices][3 ky][4 xi][N][K]
+    const float* in_scale;
+    const float* in_shift;
+    int H, W, logW, K, N;
+    long M;
+    int pix_per_slice, ids_per_slice;
+};
+constexpr int WXROWS = 80;   // (64 / W) * (W + 2) <= 8 * 10
+
+template <bool INT>
+__global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WWinoP p) {
+    __shared__ __attribute__((aligned(16))) float Gs[2][64 * 64];
+    __shared__ __attribute__((aligned(16))) float Xs[2][WXROWS * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int W = p.W, W2 = W + 2;
+    const int ci_tiles = p.K / 64;
+    const int logical = xcd_remap_w(blockIdx.x, gridDim.x);
+    const int slice = logical / p.ids_per_slice;
+    int id = logical % p.ids_per_slice;
+    const int ky = id % 3;
+    id /= 3;
+    const int ci0 = (id % ci_tiles) * 64, co0 = (id / ci_tiles) * 64;
+    const int dy = ky - 1;
+    const long pbeg = (long)slice * p.pix_per_slice;
+    long pend = pbeg + p.pix_per_slice;
+    if (pend > p.M) pend = p.M;
+
+    for (int i = tid; i < 2 * WXROWS * 64 / 4; i += 256) reinterpret_cast<float4*>(&Xs[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    floatx16 acc[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+
+    const int c4 = tid & 15, r0 = tid >> 4;            // staged pixel r0 + 16*i (i < 4), 16-B chunk c4
+    float4 xsc = make_float4(0.f, 0.f, 0.f, 0.f), xsh = xsc;
+    if (INT) {
+        xsc = *reinterpret_cast<const float4*>(p.in_scale + ci0 + c4 * 4);
+        xsh = *reinterpret_cast<const float4*>(p.in_shift + ci0 + c4 * 4);
+    }
+    const int dq = (64 >> p.logW) % p.H;               // image rows per K-step (mod H); 64 % W == 0 so w never changes
+    const long x_off = (long)dy * W * p.K;
+#define SED_WW_META(i)                                                                                          \
+    long pm##i = pbeg + r0 + 16 * i;                                                                            \
+    const float* gptr##i = p.gy + pm##i * p.N + co0 + c4 * 4;                                                   \
+    const float* xptr##i = p.x + pm##i * p.K + ci0 + c4 * 4;                                                    \
+    int xh##i = (int)(((unsigned)(pm##i < p.M ? pm##i : 0) >> p.logW) % (unsigned)p.H);                         \
+    const int xslot##i = ((r0 + 16 * i) >> p.logW) * W2 + ((r0 + 16 * i) & (W - 1)) + 1;                        \
+    float4 greg##i = make_float4(0.f, 0.f, 0.f, 0.f), xreg##i = greg##i;                                        \
+    bool gv##i = false, xv##i = false;
+    SED_WW_META(0) SED_WW_META(1) SED_WW_META(2) SED_WW_META(3)
+#undef SED_WW_META
+    const float* g_safe = p.gy + pbeg * p.N + co0 + c4 * 4;
+    const float* x_safe = p.x + pbeg * p.K + ci0 + c4 * 4;
+#define SED_WW_LOAD(i)                                                                                          \
+    {                                                                                                           \
+        gv##i = pm##i < pend;                                                                                   \
+        xv##i = gv##i && (unsigned)(xh##i + dy) < (unsigned)p.H;                                                \
+        greg##i = *reinterpret_cast<const float4*>(gv##i ? gptr##i : g_safe);                                   \
+        xreg##i = *reinterpret_cast<const float4*>(xv##i ? xptr##i + x_off : x_safe);                           \
+        gptr##i += 64L * p.N; xptr##i += 64L * p.K; pm##i += 64;                                                \
+        xh##i += dq; xh##i = xh##i >= p.H ? xh##i - p.H : xh##i;                                                \
+    }
+#define SED_WW_PIN(r) asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));
+#define SED_WW_STORE(BUF, i)                                                                                    \
+    {                                                                                                           \
+        SED_WW_PIN(greg##i) SED_WW_PIN(xreg##i)                                                                 \
+        float4 g = greg##i, v = xreg##i;                                                                        \
+        g.x = gv##i ? g.x : 0.f; g.y = gv##i ? g.y : 0.f; g.z = gv##i ? g.z : 0.f; g.w = gv##i ? g.w : 0.f;     \
+        if (INT) {                                                                                              \
+            v.x = bn_relu(v.x, xsc.x, xsh.x); v.y = bn_relu(v.y, xsc.y, xsh.y);                                 \
+            v.z = bn_relu(v.z, xsc.z, xsh.z); v.w = bn_relu(v.w, xsc.w, xsh.w);                                 \
+        }                                                                                                       \
+        v.x = xv##i ? v.x : 0.f; v.y = xv##i ? v.y : 0.f; v.z = xv##i ? v.z : 0.f; v.w = xv##i ? v.w : 0.f;     \
+        *reinterpret_cast<float4*>(&Gs[(BUF)][(r0 + 16 * i) * 64 + c4 * 4]) = g;                                \
+        *reinterpret_cast<float4*>(&Xs[(BUF)][xslot##i * 64 + c4 * 4]) = v;                                     \
+    }
+#define ww_load() { SED_WW_LOAD(0) SED_WW_LOAD(1) SED_WW_LOAD(2) SED_WW_LOAD(3) }
+#define ww_store(BUF) { SED_WW_STORE(BUF, 0) SED_WW_STORE(BUF, 1) SED_WW_STORE(BUF, 2) SED_WW_STORE(BUF, 3) }
+
+    const int nsteps = (int)((pend - pbeg + 63) / 64);
+    __syncthreads();                                   // zero fill (halo columns) visible
+    if (nsteps > 0) {
+        ww_load();
+        ww_store(0);
+    }
+    __syncthreads();
+    const int half = lane >> 5;
+    const int gcol = wm * 32 + (lane & 31), xcol = wn * 32 + (lane & 31);
+    for (int it = 0; it < nsteps; ++it) {
+        const int buf = it & 1;
+        ww_load();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int px = 4 * j + 2 * half;           // first pixel of this lane-half's pair (within the 64 of the step)
+            const int slot = (px >> p.logW) * W2 + (px & (W - 1));
+            const float g0 = Gs[buf][px * 64 + gcol], g1 = Gs[buf][(px + 1) * 64 + gcol];
+            const float* xp = &Xs[buf][slot * 64 + xcol];
+            const float d0 = xp[0], d1 = xp[64], d2 = xp[128], d3 = xp[192];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, d0 - d2, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0 + g1, d1 + d2, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0 - g1, d2 - d1, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(-g1, d1 - d3, acc[3], 0, 0, 0);
+            if (j == 11) {
+                __builtin_amdgcn_sched_barrier(0);
+                ww_store(buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+    }
+#undef SED_WW_LOAD
+#undef SED_WW_PIN
+#undef SED_WW_STORE
+#undef ww_load
+#undef ww_store
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        float* out = p.partial + (((long)slice * 3 + ky) * 4 + x) * p.N * p.K;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            int ci = ci0 + wn * 32 + (lane & 31);
+            out[(long)co * p.K + ci] = acc[x][r];
+        }
+    }
+}
+
+// sum the slices in fp64, map the four Winograd positions back to the three horizontal taps, scatter to OIHW
+__global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const float* __restrict__ partial, int nslices, int N,
+                                                                int K, float* __restrict__ out) {
+    const long nk = (long)N * K;
+    const long total = 3 * nk;
+    const long per_slice = 12 * nk;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int ky = (int)(i / nk);
+        long e = i % nk;                               // co * K + ci
+        double u[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int sl = 0; sl < nslices; ++sl) {
+            const float* q = partial + (long)sl * per_slice + ((long)ky * 4) * nk + e;
+            u[0] += (double)q[0]; u[1] += (double)q[nk]; u[2] += (double)q[2 * nk]; u[3] += (double)q[3 * nk];
+        }
+        float* o = out + e * 9 + ky * 3;
+        o[0] = (float)(u[0] + 0.5 * (u[1] + u[2]));
+        o[1] = (float)(0.5 * (u[1] - u[2]));
+        o[2] = (float)(0.5 * (u[1] + u[2]) + u[3]);
+    }
+}
+
 }  // namespace
 
 // 1 if the Winograd kernel supports this layer shape (W even and dividing 128, channel multiples), else 0.
@@ -300,6 +463,47 @@ SED_API int sed_conv3x3_wino(const float* x, const float* w_wino, float* y, int 
     if (in_t) { if (epi == 0) SED_WL(true, 0); else if (epi == 1) SED_WL(true, 1); else return SED_EINVAL; }
     else { if (epi == 0) SED_WL(false, 0); else if (epi == 1) SED_WL(false, 1); else if (epi == 2) SED_WL(false, 2); else return SED_EINVAL; }
 #undef SED_WL
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// Pixel slices of the Winograd wgrad (multiples of 64 pixels, <= 16384 per slice, grid = whole rounds of 512 workgroups).
+SED_API long sed_wgrad_wino_partial_floats(long M, int Cin, int Cout, int* nslices_out, int* pix_per_slice_out) {
+    const long tiles = 3L * (Cout / 64) * (Cin / 64);
+    const long capacity = 512;
+    long ns_min = (M + 16383) / 16384;
+    long fill = (2 * capacity + tiles - 1) / tiles;
+    if (fill > ns_min) ns_min = fill;
+    long rounds = (tiles * ns_min + capacity - 1) / capacity;
+    long ns = rounds * capacity / tiles;
+    if (ns < ns_min) ns = ns_min;
+    long pps = ((M + ns - 1) / ns + 63) / 64 * 64;
+    if (pps < 256) pps = 256;
+    ns = (M + pps - 1) / pps;
+    if (nslices_out) *nslices_out = (int)ns;
+    if (pix_per_slice_out) *pix_per_slice_out = (int)pps;
+    return ns * 12L * Cin * Cout;
+}
+
+// dW (OIHW) via the Winograd domain; same contract as sed_conv3x3_wgrad.  partial: sed_wgrad_wino_partial_floats floats.
+// Additionally needs W to be a power of two dividing 64 and Cin % 64 == 0.
+SED_API int sed_conv3x3_wgrad_wino(const float* x, const float* gy, float* dw_oihw, float* partial, int B, int H, int W,
+                                   int Cin, int Cout, const float* in_scale, const float* in_shift, hipStream_t stream) {
+    int logW = 0;
+    while ((1 << logW) < W) ++logW;
+    if (B <= 0 || (1 << logW) != W || W < 2 || W > 64 || (64 / W) * (W + 2) > WXROWS || Cin % 64 != 0 || Cout % 64 != 0 ||
+        (long)B * H * W >= (1L << 31))
+        return SED_EINVAL;
+    long M = (long)B * H * W;
+    int ns, pps;
+    sed_wgrad_wino_partial_floats(M, Cin, Cout, &ns, &pps);
+    WWinoP p{x, gy, partial, in_scale, in_shift, H, W, logW, Cin, Cout, M, pps, 3 * (Cout / 64) * (Cin / 64)};
+    dim3 grid((unsigned)((long)p.ids_per_slice * ns)), block(256);
+    if (in_scale) hipLaunchKernelGGL((wgrad_wino_kernel<true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((wgrad_wino_kernel<false>), grid, block, 0, stream, p);
+    long total = 3L * Cin * Cout;
+    hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3(sed_cdiv(total, 256) > 4096 ? 4096 : sed_cdiv(total, 256)), dim3(256), 0,
+                       stream, partial, ns, Cout, Cin, dw_oihw);
     SED_LAUNCH_CHECK();
     return 0;
 }

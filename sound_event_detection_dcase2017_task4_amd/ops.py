@@ -15,6 +15,10 @@ from . import _lib
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
+# The fused 1-D Winograd F(2,3) kernels (csrc/conv_wino.hip) do the same convolutions with 1.5x fewer MFMA flops; they are
+# used for forward, dgrad and wgrad whenever the layer shape allows.  False = direct implicit GEMM everywhere.
+USE_WINOGRAD = True
+
 # bench.py sets this to a dict to HIP-event-time the MFMA kernels inside its timed region:
 # {tag: [(start_event, end_event, algorithmic_flops), ...]}.  None = no instrumentation.
 TIMING = None
@@ -263,7 +267,29 @@ def _pack(w, want_f=True, want_d=False):
     return wf, wd
 
 
+def _wgrad_wino_ok(W, Cin, Cout):
+    return W in (8, 16, 32, 64) and Cin % 64 == 0 and Cout % 64 == 0
+
+
+def _wgrad_wino(x, gy, B, H, W, Cin, Cout, in_st=None):
+    ns, pps = ctypes.c_int(0), ctypes.c_int(0)
+    nfl = _lib.lib().sed_wgrad_wino_partial_floats(B * H * W, Cin, Cout, ctypes.byref(ns), ctypes.byref(pps))
+    partial = torch.empty((nfl,), dtype=torch.float32, device=x.device)
+    dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
+    with _timed("conv3x3_wgrad_wino_mfma(+slice reduce)|%d->%d@%dx%d%s" % (Cin, Cout, H, W, "+inT" if in_st is not None else ""),
+                2.0 * 9 * B * H * W * Cin * Cout):
+        _call("sed_conv3x3_wgrad_wino", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
+              _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, _stream())
+    return dw
+
+
 def _wgrad(x, gy, B, H, W, Cin, Cout, in_st=None):
+    if USE_WINOGRAD and _wgrad_wino_ok(W, Cin, Cout):
+        return _wgrad_wino(x, gy, B, H, W, Cin, Cout, in_st=in_st)
+    return _wgrad_direct(x, gy, B, H, W, Cin, Cout, in_st=in_st)
+
+
+def _wgrad_direct(x, gy, B, H, W, Cin, Cout, in_st=None):
     ns, pps = ctypes.c_int(0), ctypes.c_int(0)
     nfl = _lib.lib().sed_wgrad_partial_floats(B * H * W, Cin, Cout, 9, ctypes.byref(ns), ctypes.byref(pps))
     partial = torch.empty((nfl,), dtype=torch.float32, device=x.device)
@@ -274,10 +300,6 @@ def _wgrad(x, gy, B, H, W, Cin, Cout, in_st=None):
               _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, _stream())
     return dw
 
-
-# The fused 1-D Winograd F(2,3) kernel (csrc/conv_wino.hip) does the same convolution with 1.5x fewer MFMA flops; it is
-# used for forward and dgrad whenever the layer shape allows (W even, W | 128).  False = direct implicit GEMM everywhere.
-USE_WINOGRAD = True
 
 
 def _conv_fwd_like(x, w_oihw, B, H, W, Cin, Cout, dgrad=False, **kw):

@@ -62,8 +62,10 @@ def main():
                      ("wino  fwd epi0    ", lambda: ops._conv_wino(x, uf, B, H, W, ci, co)),
                      ("wino  dgrad epi2  ", lambda: ops._conv_wino(gy, ud, B, H, W, co, ci, epi=2, partials=pwb, yprev=x, p_st=sto))]
         if args.only in ("", "wgrad"):
-            runs += [("wgrad +inT        ", lambda: ops._wgrad(x, gy, B, H, W, ci, co, in_st=st)),
-                     ("wgrad             ", lambda: ops._wgrad(x, gy, B, H, W, ci, co))]
+            runs += [("wgrad +inT        ", lambda: ops._wgrad_direct(x, gy, B, H, W, ci, co, in_st=st)),
+                     ("wgrad             ", lambda: ops._wgrad_direct(x, gy, B, H, W, ci, co)),
+                     ("wgrad wino +inT   ", lambda: ops._wgrad_wino(x, gy, B, H, W, ci, co, in_st=st)),
+                     ("wgrad wino        ", lambda: ops._wgrad_wino(x, gy, B, H, W, ci, co))]
         for name, fn in runs:
             ms = timeit(fn, args.reps)
             print("%4d->%-4d %4dx%-3d %s %8.3f ms  %6.1f TFLOP/s" % (ci, co, H, W, name, ms, fl / ms / 1e9))
