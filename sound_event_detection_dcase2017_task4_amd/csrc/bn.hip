@@ -82,15 +82,26 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restri
 
 // stage 2 (training): mean / invstd / folded scale,shift / running-stat update.  nn.BatchNorm2d semantics:
 // biased variance normalises, unbiased variance is tracked, momentum 0.1 (reference models.py:87-88, :264).
+// Both finalize kernels: one 16-lane group per channel sums the <= 1024 chunk rows of ws (a serial loop per channel
+// made these "tiny" kernels 0.2 ms each, 3 ms per training step), fixed-order xor-shuffle tree -> deterministic.
+__device__ __forceinline__ void chunk_sums16(const double* __restrict__ ws, int nchunks, int C, int c, int sub,
+                                             double& s1, double& s2) {
+    s1 = 0.0; s2 = 0.0;
+    for (int k = sub; k < nchunks; k += 16) { s1 += ws[(long)k * 2 * C + c]; s2 += ws[(long)k * 2 * C + C + c]; }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+}
+
 __global__ void bn_finalize_kernel(const double* __restrict__ ws, int nchunks, int C, long N,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                    float* __restrict__ scale_out, float* __restrict__ shift_out) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;   // 256 threads = 16 channels x 16 lanes
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nchunks; ++k) { s1 += ws[(long)k * 2 * C + c]; s2 += ws[(long)k * 2 * C + C + c]; }
+    double s1, s2;
+    chunk_sums16(ws, nchunks, C, c, sub, s1, s2);
+    if (sub != 0) return;
     double mean = s1 / (double)N;
     double var = s2 / (double)N - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -124,10 +135,11 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int nchunk
                                        const float* __restrict__ scale, int batch_stats,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ coef /*[3][C]*/) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nchunks; ++k) { s1 += ws[(long)k * 2 * C + c]; s2 += ws[(long)k * 2 * C + C + c]; }
+    double s1, s2;
+    chunk_sums16(ws, nchunks, C, c, sub, s1, s2);
+    if (sub != 0) return;
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
     if (coef) {
@@ -390,7 +402,7 @@ SED_API int sed_bn_finalize(const float* partials, int nparts, int rows_per_part
     int ppc = reduce_chunks(nparts), nchunks = sed_cdiv(nparts, ppc), K = 2 * C;
     hipLaunchKernelGGL(reduce_parts_kernel<1>, dim3(nchunks, sed_cdiv(K, 256)), dim3(256), 0, stream, partials, nparts, K,
                        ppc, N, rows_per_part, ws);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(sed_cdiv(C, 64)), dim3(64), 0, stream, ws, nchunks, C, N, gamma, beta, eps,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(sed_cdiv(C, 16)), dim3(256), 0, stream, ws, nchunks, C, N, gamma, beta, eps,
                        momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out);
     SED_LAUNCH_CHECK();
     return 0;
@@ -413,7 +425,7 @@ SED_API int sed_bn_bwd_finalize(const float* partials, int nparts, long N, int C
     int ppc = reduce_chunks(nparts), nchunks = sed_cdiv(nparts, ppc), K = 2 * C;
     hipLaunchKernelGGL(reduce_parts_kernel<0>, dim3(nchunks, sed_cdiv(K, 256)), dim3(256), 0, stream, partials, nparts, K,
                        ppc, N, 0, ws);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sed_cdiv(C, 64)), dim3(64), 0, stream, ws, nchunks, C, N, mean, invstd,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sed_cdiv(C, 16)), dim3(256), 0, stream, ws, nchunks, C, N, mean, invstd,
                        scale, batch_stats, dgamma, dbeta, coef);
     SED_LAUNCH_CHECK();
     return 0;
