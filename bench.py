@@ -76,6 +76,23 @@ def cpu_baseline(batch=32, clips=64, seconds=10, threads=0):
                       "CPU oracle (torch fp32, %d threads); first step warm-up, %d timed" % (len(times), batch, threads, len(timed))}
 
 
+def pmc_traffic(family):
+    """HBM bytes per launch of a timed kernel family, from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
+    gfx950 correction + WRITE_SIZE; tools/pmc_digest.py).  PMC collection needs rocprofv3 around the process, so it cannot
+    be sampled live: the figure is valid for the default workload only, otherwise null."""
+    sub = {"conv3x3_wino_mfma(fwd+dgrad)": "conv_wino_kernel", "conv3x3_wgrad_wino_mfma(+slice reduce)": "wgrad_wino_",
+           "conv3x3_igemm_mfma(fwd+dgrad)": "conv_igemm_kernel", "conv3x3_wgrad_mfma(+slice reduce)": "wgrad_kernel"}.get(family)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_traffic.json")
+    if sub is None or not os.path.exists(path):
+        return None, None
+    tot, n = 0.0, 0
+    for k, v in json.load(open(path)).items():
+        if sub in k:
+            tot += (v["fetch_bytes_x2_per_launch"] + v["write_bytes_per_launch"]) * v["launches"]
+            n += v["launches"] if "reduce" not in k else 0
+    return (round(tot / n) if n else None), "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes/launch)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,14 +198,21 @@ def main():
                   file=sys.stderr)
     dom = max(kern, key=lambda k: kern[k]["ms_total"]) if kern else None
     notes = {"conv3x3_wino_mfma(fwd+dgrad)": "fused 1-D Winograd F(2,3) implicit GEMM on fp32 MFMA: 'achieved' counts the "
-                                             "ALGORITHMIC direct-convolution flops (SURVEY.md 8d); the kernel executes 1.5x fewer"}
+                                             "ALGORITHMIC direct-convolution flops (SURVEY.md 8d); the kernel executes 1.5x fewer",
+             "conv3x3_wgrad_wino_mfma(+slice reduce)": "Winograd-domain F(2,3) weight gradient on fp32 MFMA: 'achieved' counts the "
+                                                       "ALGORITHMIC direct-convolution flops; the kernel executes 1.5x fewer"}
     roofline = None
     if dom is not None:
         roofline = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                     "launches_per_step": kern[dom]["launches"] // args.steps, "avg_launch_ms": kern[dom]["avg_ms"]}
-        if dom in notes:
+        if dom in notes:                           # Winograd kernels issue 2/3 of the direct-convolution MACs
             roofline["note"] = notes[dom]
+            roofline["executed_tflops"] = round(kern[dom]["tflops"] / 1.5, 2)
+            roofline["executed_frac"] = round(kern[dom]["tflops"] / 1.5 / FP32_MFMA_PEAK_TFLOPS, 4)
+        roofline["traffic"], src = pmc_traffic(dom)
+        if src:
+            roofline["traffic_source"] = src
     conv_ms = sum(v["ms_total"] for v in kern.values())
     clips_per_s = B * world * args.steps / dt
     line = {

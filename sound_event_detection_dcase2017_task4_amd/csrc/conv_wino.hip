@@ -19,7 +19,8 @@
 namespace {
 
 constexpr int WBK = 16;            // channels per K-step
-constexpr int WAS = 20;            // A row stride in floats (16 + 4 pad)
+constexpr int WAS = 16;            // A row stride in floats: unpadded 64-B rows, 16-B chunk index XOR ((row >> 1) & 3)
+__device__ __forceinline__ int wa_off(int row, int chunk) { return row * WAS + ((chunk ^ ((row >> 1) & 3)) << 2); }
 constexpr int WMAXROWS = 160;      // RPT*(W+2) <= 16*10
 
 struct WinoP {
@@ -53,7 +54,7 @@ __device__ __forceinline__ void lds_dma16_w(const float* gsrc, unsigned lds_dst_
 // 128 output pixels (= 64 horizontal pairs) x 64 output channels per workgroup; 4 waves as 2 (pairs) x 2 (channels),
 // each wave 32 pairs x 32 channels x 4 Winograd positions = 4 MFMA accumulators.
 template <bool INT, int EPI>
-__global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
+__global__ __launch_bounds__(256, 3) void conv_wino_kernel(WinoP p) {
     __shared__ __attribute__((aligned(16))) float As[2][WMAXROWS * WAS];   // raw rows incl. halo columns
     __shared__ __attribute__((aligned(16))) float Bs[2][4 * 64 * WBK];     // [xi][n][k], unpadded, source-swizzled
 
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
             v.z = bn_relu(v.z, sc.z, sh.z); v.w = bn_relu(v.w, sc.w, sh.w);                                     \
         }                                                                                                       \
         v.x = vld##i ? v.x : 0.f; v.y = vld##i ? v.y : 0.f; v.z = vld##i ? v.z : 0.f; v.w = vld##i ? v.w : 0.f; \
-        *reinterpret_cast<float4*>(&As[(BUF)][lrow##i * WAS + c4 * 4]) = v;                                     \
+        *reinterpret_cast<float4*>(&As[(BUF)][wa_off(lrow##i, c4)]) = v;                                        \
     }
 #define wlstore(BUF) { SED_WA_STORE(BUF, 0) SED_WA_STORE(BUF, 1) }
 
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
 
     // fragment addressing: lane (i = lane & 31) owns pair t = wm*32 + i of the tile -> LDS rows base .. base+3
     const int t = wm * 32 + (lane & 31);
-    const int abase = ((t / halfW) * W2 + 2 * (t % halfW)) * WAS + (lane >> 5) * 4;
+    const int arow0 = (t / halfW) * W2 + 2 * (t % halfW);
     const int brow = wn * 32 + (lane & 31);
 
     for (int it = 0; it < KT; ++it) {
@@ -156,13 +157,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const float* ap = &As[buf][abase + q * 8];
-            float4 d0 = *reinterpret_cast<const float4*>(ap);
-            float4 d1 = *reinterpret_cast<const float4*>(ap + WAS);
-            float4 d2 = *reinterpret_cast<const float4*>(ap + 2 * WAS);
-            float4 d3 = *reinterpret_cast<const float4*>(ap + 3 * WAS);
-            float4 bf[4];
             const int chunk = q * 2 + (lane >> 5);
+            float4 d0 = *reinterpret_cast<const float4*>(&As[buf][wa_off(arow0, chunk)]);
+            float4 d1 = *reinterpret_cast<const float4*>(&As[buf][wa_off(arow0 + 1, chunk)]);
+            float4 d2 = *reinterpret_cast<const float4*>(&As[buf][wa_off(arow0 + 2, chunk)]);
+            float4 d3 = *reinterpret_cast<const float4*>(&As[buf][wa_off(arow0 + 3, chunk)]);
+            float4 bf[4];
 #pragma unroll
             for (int x = 0; x < 4; ++x)
                 bf[x] = *reinterpret_cast<const float4*>(&Bs[buf][(x * 64 + brow) * WBK + ((chunk ^ ((brow >> 2) & 3)) << 2)]);
