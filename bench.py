@@ -80,7 +80,8 @@ def pmc_traffic(family):
     """HBM bytes per launch of a timed kernel family, from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
     gfx950 correction + WRITE_SIZE; tools/pmc_digest.py).  PMC collection needs rocprofv3 around the process, so it cannot
     be sampled live: the figure is valid for the default workload only, otherwise null."""
-    sub = {"conv3x3_wino_mfma(fwd+dgrad)": "conv_wino_kernel", "conv3x3_wgrad_wino_mfma(+slice reduce)": "wgrad_wino_",
+    sub = {"conv3x3_wino_mfma(fwd+dgrad)": "conv_wino_kernel", "conv3x3_wino2d_mfma(fwd+dgrad)": "conv_wino2_kernel",
+           "conv3x3_wgrad_wino2d_mfma(+slice reduce)": "wgrad_wino2_", "conv3x3_wgrad_wino_mfma(+slice reduce)": "wgrad_wino_",
            "conv3x3_igemm_mfma(fwd+dgrad)": "conv_igemm_kernel", "conv3x3_wgrad_mfma(+slice reduce)": "wgrad_kernel"}.get(family)
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_traffic.json")
     if sub is None or not os.path.exists(path):
@@ -197,19 +198,22 @@ def main():
             print("# %-62s %3d launches  %8.3f ms/launch  %6.1f TFLOP/s" % (tag, v["launches"], v["avg_ms"], v["tflops"]),
                   file=sys.stderr)
     dom = max(kern, key=lambda k: kern[k]["ms_total"]) if kern else None
-    notes = {"conv3x3_wino_mfma(fwd+dgrad)": "fused 1-D Winograd F(2,3) implicit GEMM on fp32 MFMA: 'achieved' counts the "
-                                             "ALGORITHMIC direct-convolution flops (SURVEY.md 8d); the kernel executes 1.5x fewer",
-             "conv3x3_wgrad_wino_mfma(+slice reduce)": "Winograd-domain F(2,3) weight gradient on fp32 MFMA: 'achieved' counts the "
-                                                       "ALGORITHMIC direct-convolution flops; the kernel executes 1.5x fewer"}
+    # Winograd kernels issue fewer MACs than the direct convolution whose flops 'achieved' counts
+    notes = {"conv3x3_wino_mfma(fwd+dgrad)": ("fused 1-D Winograd F(2,3) implicit GEMM on fp32 MFMA", 1.5),
+             "conv3x3_wino2d_mfma(fwd+dgrad)": ("fused 2-D Winograd F(2x2,3x3) implicit GEMM on fp32 MFMA", 2.25),
+             "conv3x3_wgrad_wino_mfma(+slice reduce)": ("Winograd-domain F(2,3) weight gradient on fp32 MFMA", 1.5),
+             "conv3x3_wgrad_wino2d_mfma(+slice reduce)": ("Winograd-domain F(2x2,3x3) weight gradient on fp32 MFMA", 2.25)}
     roofline = None
     if dom is not None:
         roofline = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                     "launches_per_step": kern[dom]["launches"] // args.steps, "avg_launch_ms": kern[dom]["avg_ms"]}
-        if dom in notes:                           # Winograd kernels issue 2/3 of the direct-convolution MACs
-            roofline["note"] = notes[dom]
-            roofline["executed_tflops"] = round(kern[dom]["tflops"] / 1.5, 2)
-            roofline["executed_frac"] = round(kern[dom]["tflops"] / 1.5 / FP32_MFMA_PEAK_TFLOPS, 4)
+        if dom in notes:
+            what, fewer = notes[dom]
+            roofline["note"] = ("%s: 'achieved' counts the ALGORITHMIC direct-convolution flops (SURVEY.md 8d); the kernel "
+                                "executes %.4gx fewer" % (what, fewer))
+            roofline["executed_tflops"] = round(kern[dom]["tflops"] / fewer, 2)
+            roofline["executed_frac"] = round(kern[dom]["tflops"] / fewer / FP32_MFMA_PEAK_TFLOPS, 4)
         roofline["traffic"], src = pmc_traffic(dom)
         if src:
             roofline["traffic_source"] = src

@@ -49,7 +49,8 @@ int sed_logmel_i16(const short* wave, int B2, int L, const float* window, const 
  * sed_chan_stats: per-channel (sum, M2) partials of x [N][C] in tiles of sed_stats_rows_per_part() rows;
  * partials [ceil(N/rows)][2][C].  sed_bn_finalize merges partials (from sed_chan_stats, sed_conv1_fwd or
  * sed_conv3x3_igemm epi 1) into mean / invstd / folded scale = gamma*invstd, shift = beta - mean*scale and
- * updates the running statistics (unbiased variance).  ws: >= 2048*C doubles.
+ * updates the running statistics (unbiased variance).  ws: >= 2048*C doubles.  rows_per_part = -1: the parts hold
+ * varying row counts, given as nparts floats appended after the [nparts][2][C] partials (sed_conv3x3_wino2).
  * sed_bn_eval_affine: eval mode, fold the running statistics instead. */
 int sed_chan_stats(const float* x, long N, int C, float* partials, sed_stream_t stream);
 int sed_stats_rows_per_part(void);
@@ -123,6 +124,18 @@ int sed_conv3x3_wino(const float* x, const float* w_wino, float* y, int B, int H
                      const float* in_scale, const float* in_shift, int epi, float* partials, const float* yprev,
                      const float* p_scale, const float* p_shift, const float* p_mean, const float* p_invstd,
                      sed_stream_t stream);
+/* Fused 2-D Winograd F(2x2,3x3) variant (16 instead of 36 MACs per 2x2 output tile): same fusions and contract, with
+ * w_wino2 = the k-step-major pack [Cin/8][16][Cout][8] from sed_pack_conv_weights_wino2 (uf: forward, ud: dgrad with
+ * Cin/Cout swapped).  Statistics parts: P = sed_conv_wino2_num_parts(B,H,W), one per wave (<= 64 pixels);
+ * partials = [P][2][Cout] floats followed (epi 1) by P per-part pixel counts -> pass rows_per_part = -1 to
+ * sed_bn_finalize.  Needs W in {8,16,32,64}, Cin % 8 == 0, Cout % 32 == 0 (sed_conv3x3_wino2_supported). */
+int sed_conv3x3_wino2_supported(int H, int W, int Cin, int Cout);
+long sed_conv_wino2_num_parts(int B, int H, int W);
+int sed_pack_conv_weights_wino2(const float* w_oihw, int Cout, int Cin, float* uf, float* ud, sed_stream_t stream);
+int sed_conv3x3_wino2(const float* x, const float* w_wino2, float* y, int B, int H, int W, int Cin, int Cout,
+                      const float* in_scale, const float* in_shift, int epi, float* partials, const float* yprev,
+                      const float* p_scale, const float* p_shift, const float* p_mean, const float* p_invstd,
+                      sed_stream_t stream);
 /* Winograd-domain weight gradient (12 instead of 18 MACs per output pair); same contract as sed_conv3x3_wgrad.
  * Needs W a power of two <= 64 and Cin, Cout % 64 == 0; partial: sed_wgrad_wino_partial_floats(...) floats. */
 long sed_wgrad_wino_partial_floats(long M, int Cin, int Cout, int* nslices_out, int* pix_per_slice_out);

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const float* __restrict
 // ---------------------------------------------------------------------------------------------------------
 // stage 1 of the deterministic fp64 merge: [nparts][K] fp32 -> ws[nchunks][K] fp64.
 // MODE 0: plain column sums.  MODE 1: K = 2C laid out [sum | M2] per part -> [S1 | S2] raw moments,
-// part i holds n_i = min(rows_per_part, N - i*rows_per_part) rows.
+// part i holds n_i = min(rows_per_part, N - i*rows_per_part) rows (rows_per_part < 0: n_i = parts[nparts*K + i]).
 template <int MODE>
 __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ parts, int nparts, int K,
                                                            int parts_per_chunk, long N, int rows_per_part,
@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restri
             for (int p = p0; p < p1; ++p) acc += (double)parts[(long)p * K + col];
         } else {
             for (int p = p0; p < p1; ++p) {
-                double n = (double)min((long)rows_per_part, N - (long)p * rows_per_part);
+                double n = rows_per_part < 0 ? (double)parts[(long)nparts * K + p]       // explicit per-part counts
+                                             : (double)min((long)rows_per_part, N - (long)p * rows_per_part);
                 if (n <= 0.0) continue;              // tile rows past the end of the tensor
                 double s = (double)parts[(long)p * K + col - C];
                 acc += (double)parts[(long)p * K + col] + s * s / n;

@@ -17,7 +17,7 @@ BN_MOMENTUM = 0.1
 
 # The fused 1-D Winograd F(2,3) kernels (csrc/conv_wino.hip) do the same convolutions with 1.5x fewer MFMA flops; they are
 # used for forward, dgrad and wgrad whenever the layer shape allows.  False = direct implicit GEMM everywhere.
-USE_WINOGRAD = True
+USE_WINOGRAD = 2          # 2: 2-D F(2x2,3x3) where supported, else 1-D F(2,3), else direct; 1: 1-D; 0: direct only
 
 # bench.py sets this to a dict to HIP-event-time the MFMA kernels inside its timed region:
 # {tag: [(start_event, end_event, algorithmic_flops), ...]}.  None = no instrumentation.
@@ -259,6 +259,33 @@ def _conv_wino(x, w_wino, B, H, W, Cin, Cout, in_st=None, epi=0, partials=None, 
     return y
 
 
+def _pack_wino2(w, want_f=True, want_d=False):
+    """OIHW -> 2-D Winograd packs uf [Cin/8][16][Cout][8] / ud [Cout/8][16][Cin][8]."""
+    Cout, Cin = w.shape[0], w.shape[1]
+    uf = torch.empty((Cin // 8, 16, Cout, 8), dtype=torch.float32, device=w.device) if want_f else None
+    ud = torch.empty((Cout // 8, 16, Cin, 8), dtype=torch.float32, device=w.device) if want_d else None
+    _call("sed_pack_conv_weights_wino2", _ptr(w), Cout, Cin, _ptr(uf), _ptr(ud), _stream())
+    return uf, ud
+
+
+def _wino2_partials(B, H, W, C, device):
+    """(buffer, nparts) for the statistics epilogues of sed_conv3x3_wino2: [P][2][C] floats + P counts."""
+    P = int(_lib.lib().sed_conv_wino2_num_parts(B, H, W))
+    return torch.empty((P * 2 * C + P,), dtype=torch.float32, device=device), P
+
+
+def _conv_wino2(x, w_wino2, B, H, W, Cin, Cout, in_st=None, epi=0, partials=None, yprev=None, p_st=None):
+    y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+    with _timed("conv3x3_wino2d_mfma(fwd+dgrad)|%d->%d@%dx%d epi%d%s" % (Cin, Cout, H, W, epi, "+inT" if in_st is not None else ""),
+                2.0 * 9 * B * H * W * Cin * Cout):
+        _call("sed_conv3x3_wino2", _ptr(x), _ptr(w_wino2), _ptr(y), B, H, W, Cin, Cout,
+              _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, epi,
+              _ptr(partials), _ptr(yprev), _ptr(p_st.scale) if p_st is not None else None,
+              _ptr(p_st.shift) if p_st is not None else None, _ptr(p_st.mean) if p_st is not None else None,
+              _ptr(p_st.invstd) if p_st is not None else None, _stream())
+    return y
+
+
 def _pack(w, want_f=True, want_d=False):
     Cout, Cin = w.shape[0], w.shape[1]
     wf = torch.empty((9, Cout, Cin), dtype=torch.float32, device=w.device) if want_f else None
@@ -302,24 +329,44 @@ def _wgrad_direct(x, gy, B, H, W, Cin, Cout, in_st=None):
 
 
 
+def _conv_algo(H, W, Cin, Cout):
+    """2 = fused 2-D Winograd F(2x2,3x3), 1 = fused 1-D Winograd F(2,3), 0 = direct implicit GEMM."""
+    L = _lib.lib()
+    if USE_WINOGRAD >= 2 and L.sed_conv3x3_wino2_supported(H, W, Cin, Cout):
+        return 2
+    if USE_WINOGRAD >= 1 and L.sed_conv3x3_wino_supported(H, W, Cin, Cout):
+        return 1
+    return 0
+
+
 def _conv_fwd_like(x, w_oihw, B, H, W, Cin, Cout, dgrad=False, **kw):
     """3x3 conv of x with the OIHW weights (dgrad=True: the transposed/flipped conv that maps g_y -> g_x; Cin/Cout are
-    then the channel counts of the INPUT/OUTPUT of this call).  Returns (y, nparts, rows_per_part)."""
-    L = _lib.lib()
-    M = B * H * W
-    if USE_WINOGRAD and L.sed_conv3x3_wino_supported(H, W, Cin, Cout):
+    then the channel counts of the INPUT/OUTPUT of this call)."""
+    algo = _conv_algo(H, W, Cin, Cout)
+    if algo == 2:
+        uf, ud = _pack_wino2(w_oihw, want_f=not dgrad, want_d=dgrad)
+        return _conv_wino2(x, ud if dgrad else uf, B, H, W, Cin, Cout, **kw)
+    if algo == 1:
         uf, ud = _pack_wino(w_oihw, want_f=not dgrad, want_d=dgrad)
         return _conv_wino(x, ud if dgrad else uf, B, H, W, Cin, Cout, **kw)
     wf, wd = _pack(w_oihw, want_f=not dgrad, want_d=dgrad)
     return _conv_igemm(x, wd if dgrad else wf, B, H, W, Cin, Cout, **kw)
 
 
-def _conv_parts(M, H, W, Cin, Cout):
-    """(number of statistics partials, rows per partial) written by _conv_fwd_like for this shape."""
+def _conv_parts(B, H, W, Cin, Cout):
+    """(number of statistics partials, rows per partial [-1: counts appended], floats to allocate) written by
+    _conv_fwd_like for this shape."""
     L = _lib.lib()
-    if USE_WINOGRAD and L.sed_conv3x3_wino_supported(H, W, Cin, Cout):
-        return ((M + 127) // 128) * 2, 64
-    return L.sed_conv_num_parts(M, Cout), L.sed_conv_rows_per_part(M, Cout)
+    M = B * H * W
+    algo = _conv_algo(H, W, Cin, Cout)
+    if algo == 2:
+        P = int(L.sed_conv_wino2_num_parts(B, H, W))
+        return P, -1, P * 2 * Cout + P
+    if algo == 1:
+        P = ((M + 127) // 128) * 2
+        return P, 64, P * 2 * Cout
+    P = L.sed_conv_num_parts(M, Cout)
+    return P, L.sed_conv_rows_per_part(M, Cout), P * 2 * Cout
 
 
 class ConvBlockFn(torch.autograd.Function):
@@ -345,13 +392,13 @@ class ConvBlockFn(torch.autograd.Function):
             y1 = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
             _call("sed_conv1_fwd", _ptr(x), _ptr(w1c), _ptr(y1), B, H, W, _ptr(part1), _stream())
         else:
-            np1, rpp1 = _conv_parts(M, H, W, Cin, Cout)
-            part1 = torch.empty((np1, 2, Cout), dtype=torch.float32, device=dev) if training else None
+            np1, rpp1, nf1 = _conv_parts(B, H, W, Cin, Cout)
+            part1 = torch.empty((nf1,), dtype=torch.float32, device=dev) if training else None
             y1 = _conv_fwd_like(x, w1c, B, H, W, Cin, Cout, epi=1 if training else 0, partials=part1)
         st1 = bn_finalize(part1, np1, rpp1, M, g1, b1, rm1, rv1) if training else bn_eval_affine(g1, b1, rm1, rv1)
         # conv2 over relu(bn1(y1)) computed on the fly (+ statistics)
-        np2, rpp2 = _conv_parts(M, H, W, Cout, Cout)
-        part2 = torch.empty((np2, 2, Cout), dtype=torch.float32, device=dev) if training else None
+        np2, rpp2, nf2 = _conv_parts(B, H, W, Cout, Cout)
+        part2 = torch.empty((nf2,), dtype=torch.float32, device=dev) if training else None
         y2 = _conv_fwd_like(y1, w2c, B, H, W, Cout, Cout, in_st=st1, epi=1 if training else 0, partials=part2)
         st2 = bn_finalize(part2, np2, rpp2, M, g2, b2, rm2, rv2) if training else bn_eval_affine(g2, b2, rm2, rv2)
         out = torch.empty((B, H // ph, W // pw, Cout), dtype=torch.float32, device=dev)
@@ -382,8 +429,8 @@ class ConvBlockFn(torch.autograd.Function):
               _ptr(coef2), _ptr(gy2), _stream())
         # conv2: wgrad (operand relu(bn1(y1)) on the fly) and dgrad fused with relu-mask + BN1 backward sums
         dw2 = _wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=st1)
-        npb, _ = _conv_parts(M, H, W, Cout, Cout)
-        partb = torch.empty((npb, 2, Cout), dtype=torch.float32, device=dev)
+        npb, _, nfb = _conv_parts(B, H, W, Cout, Cout)
+        partb = torch.empty((nfb,), dtype=torch.float32, device=dev)
         gy1 = _conv_fwd_like(gy2, w2, B, H, W, Cout, Cout, dgrad=True, epi=2, partials=partb, yprev=y1, p_st=st1)
         del gy2
         dg1, db1, coef1 = bn_bwd_finalize(partb, npb, M, st1, batch_stats=ctx.training)

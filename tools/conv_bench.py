@@ -61,6 +61,13 @@ def main():
             runs += [("wino  fwd epi1+inT", lambda: ops._conv_wino(x, uf, B, H, W, ci, co, in_st=st, epi=1, partials=pw)),
                      ("wino  fwd epi0    ", lambda: ops._conv_wino(x, uf, B, H, W, ci, co)),
                      ("wino  dgrad epi2  ", lambda: ops._conv_wino(gy, ud, B, H, W, co, ci, epi=2, partials=pwb, yprev=x, p_st=sto))]
+        if args.only in ("", "wino2") and L.sed_conv3x3_wino2_supported(H, W, ci, co):
+            uf2, ud2 = ops._pack_wino2(w, True, True)
+            pw2, _ = ops._wino2_partials(B, H, W, co, "cuda")
+            pwb2, _ = ops._wino2_partials(B, H, W, ci, "cuda")
+            runs += [("wino2 fwd epi1+inT", lambda: ops._conv_wino2(x, uf2, B, H, W, ci, co, in_st=st, epi=1, partials=pw2)),
+                     ("wino2 fwd epi0    ", lambda: ops._conv_wino2(x, uf2, B, H, W, ci, co)),
+                     ("wino2 dgrad epi2  ", lambda: ops._conv_wino2(gy, ud2, B, H, W, co, ci, epi=2, partials=pwb2, yprev=x, p_st=sto))]
         if args.only in ("", "wgrad"):
             runs += [("wgrad +inT        ", lambda: ops._wgrad_direct(x, gy, B, H, W, ci, co, in_st=st)),
                      ("wgrad             ", lambda: ops._wgrad_direct(x, gy, B, H, W, ci, co)),
