@@ -136,6 +136,12 @@ int sed_conv3x3_wino2(const float* x, const float* w_wino2, float* y, int B, int
                       const float* in_scale, const float* in_shift, int epi, float* partials, const float* yprev,
                       const float* p_scale, const float* p_shift, const float* p_mean, const float* p_invstd,
                       sed_stream_t stream);
+/* 2-D Winograd-domain weight gradient (16 instead of 36 MACs per 2x2 tile); same contract as sed_conv3x3_wgrad.
+ * Needs W in {8,16,32,64}, Cin % 32 == 0, Cout % 64 == 0 (else -22 / 0 floats);
+ * partial: sed_wgrad_wino2_partial_floats(...) floats. */
+long sed_wgrad_wino2_partial_floats(int B, int H, int W, int Cin, int Cout, int* nslices_out, int* units_per_slice_out);
+int sed_conv3x3_wgrad_wino2(const float* x, const float* gy, float* dw_oihw, float* partial, int B, int H, int W, int Cin,
+                            int Cout, const float* in_scale, const float* in_shift, sed_stream_t stream);
 /* Winograd-domain weight gradient (12 instead of 18 MACs per output pair); same contract as sed_conv3x3_wgrad.
  * Needs W a power of two <= 64 and Cin, Cout % 64 == 0; partial: sed_wgrad_wino_partial_floats(...) floats. */
 long sed_wgrad_wino_partial_floats(long M, int Cin, int Cout, int* nslices_out, int* pix_per_slice_out);

@@ -373,3 +373,309 @@ SED_API int sed_conv3x3_wino2(const float* x, const float* w_wino2, float* y, in
     SED_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient in the 2-D Winograd domain:
+//     dU[eta][xi][co][ci] = sum over tiles of dM[eta][xi][tile][co] * V[eta][xi][tile][ci],
+//     dM = A dY A^T (4x4 from the 2x2 output-gradient tile, A rows (1,0),(1,1),(1,-1),(0,-1)),  V = B^T d B as above,
+// and the reduce kernel maps dU back to the taps, dg = G^T dU G.  16 MACs per tile instead of 36.
+// Workgroup = 64 co x 32 ci, four waves = 2 co blocks x 2 eta halves (8 accumulators each); K = tiles, streamed in
+// units of 16 tiles (RPK row pairs x TCK tile columns = 64 output pixels): the raw gy pixels [64][64 co] and the raw
+// x patch region [(2*RPK+2) x (2*TCK+2)][32 ci] are staged per unit, both operands are transformed in registers from
+// scalar LDS reads (lane = channel).  The two lane halves of an MFMA read adjacent tile columns, i.e. addresses two
+// pixels apart; a 32-float swizzle keyed on the tile-column parity keeps them on different banks.
+namespace {
+
+struct WWino2P {
+    const float* x;          // [B][H][W][K]
+    const float* gy;         // [B][H][W][N]
+    float* partial;          // [nslices][16][N][K]
+    const float* in_scale;
+    const float* in_shift;
+    int B, H, W, K, N;
+    int nrg, nsg;            // unit grid per image: row-pair groups x tile-column segments
+    long U;                  // units in total
+    int units_per_slice, ids_per_slice;
+};
+
+template <bool INT, bool W8>
+__global__ __launch_bounds__(256, 2) void wgrad_wino2_kernel(WWino2P p) {
+    constexpr int TCK = W8 ? 4 : 8, RPK = 16 / TCK, CW = 2 * TCK + 2, XR = 2 * RPK + 2, GW = 2 * TCK;
+    constexpr int XPIX = XR * CW;                      // 100 / 108 patch pixels
+    constexpr int XSTAGE = ((XPIX + 1) / 2) * 64;      // floats: two pixels per 64-float line
+    constexpr int GSTAGE = 64 * 64;
+    __shared__ __attribute__((aligned(16))) float Gs[2][GSTAGE];
+    __shared__ __attribute__((aligned(16))) float Xs[2][XSTAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int eh = wvu & 1, cob = wvu >> 1;
+    const int logical = xcd_remap2(blockIdx.x, gridDim.x);
+    const int slice = logical / p.ids_per_slice;
+    const int id = logical % p.ids_per_slice;
+    const int ci_tiles = p.K >> 5;
+    const int ci0 = (id % ci_tiles) * 32, co0 = (id / ci_tiles) * 64;
+    const int W = p.W;
+
+    long u = (long)slice * p.units_per_slice;
+    long uend = u + p.units_per_slice;
+    if (uend > p.U) uend = p.U;
+    const int nsteps = (int)(uend > u ? uend - u : 0);
+    int sg = (int)(u % p.nsg);
+    long tq = u / p.nsg;
+    int rg = (int)(tq % p.nrg);
+    int b = (int)(tq / p.nrg);
+
+    floatx16 acc[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    // ---- staging maps (fixed per thread): x item e = tid + 256*i -> patch pixel e >> 3, chunk e & 7;
+    //      gy item e -> pixel e >> 4 of the 64, chunk e & 15
+    const int xch = tid & 7, gch = tid & 15;
+    float4 xsc = make_float4(0.f, 0.f, 0.f, 0.f), xsh = xsc;
+    if (INT) {
+        xsc = *reinterpret_cast<const float4*>(p.in_scale + ci0 + xch * 4);
+        xsh = *reinterpret_cast<const float4*>(p.in_shift + ci0 + xch * 4);
+    }
+#define SED_WW2_META(i)                                                                                         \
+    const int xpx##i = (tid + 256 * i) >> 3;                                                                    \
+    const bool xit##i = xpx##i < XPIX;                                                                          \
+    const int xr##i = xpx##i / CW, xc##i = xpx##i % CW;                                                         \
+    const int xls##i = (xpx##i >> 1) * 64 + 32 * ((xpx##i & 1) ^ ((xc##i >> 1) & 1)) + xch * 4;                 \
+    const int gpx##i = (tid + 256 * i) >> 4;                                                                    \
+    const int gr##i = gpx##i / GW, gc##i = gpx##i % GW;                                                         \
+    const int gls##i = gpx##i * 64 + ((gch * 4) ^ (32 * ((gc##i >> 1) & 1)));                                   \
+    float4 xreg##i = make_float4(0.f, 0.f, 0.f, 0.f), greg##i = xreg##i;                                        \
+    bool xv##i = false, gv##i = false;
+    SED_WW2_META(0) SED_WW2_META(1) SED_WW2_META(2) SED_WW2_META(3)
+#undef SED_WW2_META
+    const float* x_safe = p.x + ci0 + xch * 4;
+    const float* g_safe = p.gy + co0 + gch * 4;
+
+#define SED_WW2_LOAD(i)                                                                                         \
+    {                                                                                                           \
+        const int h = h0 + xr##i, w = w0 + xc##i;                                                               \
+        xv##i = live && xit##i && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)W;                     \
+        xreg##i = *reinterpret_cast<const float4*>(xv##i ? x_safe + (((long)b * p.H + h) * W + w) * p.K : x_safe); \
+        const int hg = h0 + 1 + gr##i;                                                                          \
+        gv##i = live && hg < p.H;                                                                               \
+        greg##i = *reinterpret_cast<const float4*>(gv##i ? g_safe + (((long)b * p.H + hg) * W + (w0 + 1 + gc##i)) * p.N : g_safe); \
+    }
+#define ww2_load(LIVE)                                                                                          \
+    {                                                                                                           \
+        const bool live = (LIVE);                                                                               \
+        const int h0 = 2 * rg * RPK - 1, w0 = 2 * sg * TCK - 1;                                                 \
+        SED_WW2_LOAD(0) SED_WW2_LOAD(1) SED_WW2_LOAD(2) SED_WW2_LOAD(3)                                         \
+        if (++sg == p.nsg) { sg = 0; if (++rg == p.nrg) { rg = 0; ++b; } }                                      \
+    }
+#define SED_WW2_PIN(r) asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));
+#define SED_WW2_STORE(BUF, i)                                                                                   \
+    {                                                                                                           \
+        SED_WW2_PIN(greg##i) SED_WW2_PIN(xreg##i)                                                               \
+        float4 g = greg##i, v = xreg##i;                                                                        \
+        g.x = gv##i ? g.x : 0.f; g.y = gv##i ? g.y : 0.f; g.z = gv##i ? g.z : 0.f; g.w = gv##i ? g.w : 0.f;     \
+        if (INT) {                                                                                              \
+            v.x = bn_relu(v.x, xsc.x, xsh.x); v.y = bn_relu(v.y, xsc.y, xsh.y);                                 \
+            v.z = bn_relu(v.z, xsc.z, xsh.z); v.w = bn_relu(v.w, xsc.w, xsh.w);                                 \
+        }                                                                                                       \
+        v.x = xv##i ? v.x : 0.f; v.y = xv##i ? v.y : 0.f; v.z = xv##i ? v.z : 0.f; v.w = xv##i ? v.w : 0.f;     \
+        *reinterpret_cast<float4*>(&Gs[(BUF)][gls##i]) = g;                                                     \
+        if (xit##i) *reinterpret_cast<float4*>(&Xs[(BUF)][xls##i]) = v;                                         \
+    }
+#define ww2_store(BUF) { SED_WW2_STORE(BUF, 0) SED_WW2_STORE(BUF, 1) SED_WW2_STORE(BUF, 2) SED_WW2_STORE(BUF, 3) }
+
+    ww2_load(nsteps > 0);
+    ww2_store(0);
+    __syncthreads();
+
+    // ---- fragment addressing: lane = channel (lane & 31), lane half = second tile of the k pair (next tile column)
+    const int half = lane >> 5, cl = lane & 31;
+    const int gbase = half * 128 + ((cob * 32 + cl) ^ (32 * half));
+    const int xbase0 = half * 64 + 32 * half + cl;          // patch columns with (jj & 1) ^ (jj >> 1) == 0
+    const int xbase1 = half * 64 + 32 * (1 ^ half) + cl;    // ... == 1
+    // eta half 0: dM rows (d0, d0 + d1), V rows (r0 - r2, r1 + r2); half 1: (d0 - d1, -d1), (r2 - r1, r1 - r3)
+    const float al = eh ? -1.f : 0.f, be = eh ? 0.f : 1.f, ga = eh ? -1.f : 1.f, sgn = eh ? -1.f : 1.f;
+    const int ra = (eh ? 2 : 0) * (CW / 2) * 64, rbw = (eh ? 3 : 1) * (CW / 2) * 64, rc = (eh ? 1 : 2) * (CW / 2) * 64;
+
+    for (int it = 0; it < nsteps; ++it) {
+        const int buf = it & 1;
+        ww2_load(it + 1 < nsteps);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        const float* Gb = &Gs[buf][gbase];
+        const float* Xa0 = &Xs[buf][xbase0 + ra], *Xa1 = &Xs[buf][xbase1 + ra];
+        const float* Xq0 = &Xs[buf][xbase0 + rbw], *Xq1 = &Xs[buf][xbase1 + rbw];
+        const float* Xc0 = &Xs[buf][xbase0 + rc], *Xc1 = &Xs[buf][xbase1 + rc];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int rp_k = (2 * j) / TCK, tcb = (2 * j) % TCK;
+            // output-gradient tile -> this wave's two eta rows of dM, then the four xi columns
+            const float* gp = Gb + ((2 * rp_k) * GW + 2 * tcb) * 64;
+            const float d00 = gp[0], d01 = gp[64], d10 = gp[GW * 64], d11 = gp[GW * 64 + 64];
+            const float ea0 = fmaf(al, d10, d00), ea1 = fmaf(al, d11, d01);
+            const float eb0 = fmaf(ga, d10, be * d00), eb1 = fmaf(ga, d11, be * d01);
+            // input patch -> this wave's two eta rows of V
+            float ca[4], cb[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const bool s1_ = ((jj & 1) ^ (jj >> 1)) != 0;
+                const int eo = (rp_k * CW + tcb + (jj >> 1)) * 64;       // line of patch row 2*rp_k, column 2*tcb + jj
+                const float va = (s1_ ? Xa1 : Xa0)[eo];
+                const float vb = (s1_ ? Xq1 : Xq0)[eo];
+                const float vc = (s1_ ? Xc1 : Xc0)[eo];
+                ca[jj] = va - vc;
+                cb[jj] = fmaf(sgn, vb, vc);
+            }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ea0, ca[0] - ca[2], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ea0 + ea1, ca[1] + ca[2], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(ea0 - ea1, ca[2] - ca[1], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(-ea1, ca[1] - ca[3], acc[3], 0, 0, 0);
+            acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(eb0, cb[0] - cb[2], acc[4], 0, 0, 0);
+            acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(eb0 + eb1, cb[1] + cb[2], acc[5], 0, 0, 0);
+            acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(eb0 - eb1, cb[2] - cb[1], acc[6], 0, 0, 0);
+            acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(-eb1, cb[1] - cb[3], acc[7], 0, 0, 0);
+            if (j == 5) {
+                __builtin_amdgcn_sched_barrier(0);
+                ww2_store(buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+    }
+#undef SED_WW2_LOAD
+#undef SED_WW2_PIN
+#undef SED_WW2_STORE
+#undef ww2_load
+#undef ww2_store
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        float* out = p.partial + ((long)slice * 16 + eh * 8 + a) * p.N * p.K;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + cob * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            out[(long)co * p.K + ci0 + cl] = acc[a][r];
+        }
+    }
+}
+
+// Slice reduction, two stages so that layers with few (co, ci) pairs but hundreds of slices still fill the chip:
+// stage A sums a chunk of slices in fp64 (block = 64 consecutive (co,ci) elements x 4 groups of 4 coordinates);
+// stage B sums the chunks, applies dg = G^T dU G and scatters to OIHW.
+__global__ __launch_bounds__(256) void wgrad_wino2_reduce_a_kernel(const float* __restrict__ partial, int nslices,
+                                                                   int slices_per_chunk, long nk, double* __restrict__ ws) {
+    const long e = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ag = threadIdx.x >> 6;
+    if (e >= nk) return;
+    const int s0 = blockIdx.y * slices_per_chunk;
+    const int s1 = min(nslices, s0 + slices_per_chunk);
+    double u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0;
+    for (int sl = s0; sl < s1; ++sl) {
+        const float* q = partial + ((long)sl * 16 + ag * 4) * nk + e;
+        u0 += (double)q[0]; u1 += (double)q[nk]; u2 += (double)q[2 * nk]; u3 += (double)q[3 * nk];
+    }
+    double* o = ws + ((long)blockIdx.y * 16 + ag * 4) * nk + e;
+    o[0] = u0; o[nk] = u1; o[2 * nk] = u2; o[3 * nk] = u3;
+}
+
+__global__ __launch_bounds__(256) void wgrad_wino2_reduce_b_kernel(const double* __restrict__ ws, int nchunks, long nk,
+                                                                   float* __restrict__ out) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nk; e += (long)gridDim.x * 256) {
+        double u[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) u[a] = 0.0;
+        for (int c = 0; c < nchunks; ++c) {
+            const double* q = ws + (long)c * 16 * nk + e;
+#pragma unroll
+            for (int a = 0; a < 16; ++a) u[a] += q[a * nk];
+        }
+        double t[3][4];
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+            const double u0 = u[xi], u1 = u[4 + xi], u2 = u[8 + xi], u3 = u[12 + xi];
+            t[0][xi] = u0 + 0.5 * (u1 + u2);
+            t[1][xi] = 0.5 * (u1 - u2);
+            t[2][xi] = 0.5 * (u1 + u2) + u3;
+        }
+        float* o = out + e * 9;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            o[ky * 3 + 0] = (float)(t[ky][0] + 0.5 * (t[ky][1] + t[ky][2]));
+            o[ky * 3 + 1] = (float)(0.5 * (t[ky][1] - t[ky][2]));
+            o[ky * 3 + 2] = (float)(0.5 * (t[ky][1] + t[ky][2]) + t[ky][3]);
+        }
+    }
+}
+
+__host__ int wwino2_chunks(long ns, int* slices_per_chunk) {
+    long spc = (ns + 15) / 16;            // <= 16 chunks ...
+    if (spc < 32) spc = 32;               // ... of >= 32 slices (keeps the fp64 workspace small when slices are few)
+    if (spc > ns) spc = ns;
+    *slices_per_chunk = (int)spc;
+    return (int)((ns + spc - 1) / spc);
+}
+
+__host__ bool wwino2_geometry(int B, int H, int W, int Cin, int Cout, int* nrg, int* nsg, long* U) {
+    if (B <= 0 || H < 1 || !(W == 8 || W == 16 || W == 32 || W == 64) || Cin <= 0 || Cin % 32 || Cout <= 0 || Cout % 64) return false;
+    const int TCK = W == 8 ? 4 : 8, RPK = 16 / TCK, TH = (H + 1) / 2;
+    *nrg = (TH + RPK - 1) / RPK;
+    *nsg = (W / 2) / TCK;
+    *U = (long)B * (*nrg) * (*nsg);
+    return true;
+}
+
+}  // namespace
+
+// Unit slices of the 2-D Winograd wgrad (a unit = 16 tiles = 64 output pixels; <= 512 units per slice bounds the fp32
+// accumulation chains; the slice count fills whole rounds of 512 resident workgroups).  Returns the scratch size in floats.
+SED_API long sed_wgrad_wino2_partial_floats(int B, int H, int W, int Cin, int Cout, int* nslices_out, int* units_per_slice_out) {
+    int nrg, nsg;
+    long U;
+    if (!wwino2_geometry(B, H, W, Cin, Cout, &nrg, &nsg, &U)) return 0;
+    const long ids = (long)(Cout / 64) * (Cin / 32);
+    const long capacity = 512;
+    long ns_min = (U + 511) / 512;
+    long fill = (2 * capacity + ids - 1) / ids;
+    if (fill > ns_min) ns_min = fill;
+    long rounds = (ids * ns_min + capacity - 1) / capacity;
+    long ns = rounds * capacity / ids;
+    if (ns < ns_min) ns = ns_min;
+    long ups = (U + ns - 1) / ns;
+    if (ups < 4) ups = 4;
+    ns = (U + ups - 1) / ups;
+    if (nslices_out) *nslices_out = (int)ns;
+    if (units_per_slice_out) *units_per_slice_out = (int)ups;
+    int spc;
+    const int nchunks = wwino2_chunks(ns, &spc);
+    return ns * 16L * Cin * Cout + 2L * nchunks * 16L * Cin * Cout;      // fp32 slices + fp64 chunk sums
+}
+
+// dW (OIHW) via the 2-D Winograd domain; same contract as sed_conv3x3_wgrad.  partial: sed_wgrad_wino2_partial_floats
+// floats.  Needs W in {8,16,32,64}, Cin % 32 == 0, Cout % 64 == 0.
+SED_API int sed_conv3x3_wgrad_wino2(const float* x, const float* gy, float* dw_oihw, float* partial, int B, int H, int W,
+                                    int Cin, int Cout, const float* in_scale, const float* in_shift, hipStream_t stream) {
+    int nrg, nsg, ns, ups;
+    long U;
+    if (!wwino2_geometry(B, H, W, Cin, Cout, &nrg, &nsg, &U) || (long)B * H * W >= (1L << 31)) return SED_EINVAL;
+    sed_wgrad_wino2_partial_floats(B, H, W, Cin, Cout, &ns, &ups);
+    WWino2P p{x, gy, partial, in_scale, in_shift, B, H, W, Cin, Cout, nrg, nsg, U, ups, (Cout / 64) * (Cin / 32)};
+    dim3 grid((unsigned)((long)p.ids_per_slice * ns)), block(256);
+    const bool in_t = in_scale != nullptr, w8 = W == 8;
+    if (in_t) { if (w8) hipLaunchKernelGGL((wgrad_wino2_kernel<true, true>), grid, block, 0, stream, p);
+                else hipLaunchKernelGGL((wgrad_wino2_kernel<true, false>), grid, block, 0, stream, p); }
+    else { if (w8) hipLaunchKernelGGL((wgrad_wino2_kernel<false, true>), grid, block, 0, stream, p);
+           else hipLaunchKernelGGL((wgrad_wino2_kernel<false, false>), grid, block, 0, stream, p); }
+    const long nk = (long)Cin * Cout;
+    int spc;
+    const int nchunks = wwino2_chunks(ns, &spc);
+    double* ws = reinterpret_cast<double*>(partial + (long)ns * 16 * nk);      // 8-byte aligned: 16*nk floats per slice
+    hipLaunchKernelGGL(wgrad_wino2_reduce_a_kernel, dim3((unsigned)sed_cdiv(nk, 64), nchunks), dim3(256), 0, stream, partial, ns,
+                       spc, nk, ws);
+    hipLaunchKernelGGL(wgrad_wino2_reduce_b_kernel, dim3(sed_cdiv(nk, 256) > 4096 ? 4096 : sed_cdiv(nk, 256)), dim3(256), 0,
+                       stream, ws, nchunks, nk, dw_oihw);
+    SED_LAUNCH_CHECK();
+    return 0;
+}

@@ -310,7 +310,23 @@ def _wgrad_wino(x, gy, B, H, W, Cin, Cout, in_st=None):
     return dw
 
 
+def _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=None):
+    ns, ups = ctypes.c_int(0), ctypes.c_int(0)
+    nfl = _lib.lib().sed_wgrad_wino2_partial_floats(B, H, W, Cin, Cout, ctypes.byref(ns), ctypes.byref(ups))
+    if nfl <= 0:
+        raise RuntimeError("sed_conv3x3_wgrad_wino2 does not support this shape")
+    partial = torch.empty((nfl,), dtype=torch.float32, device=x.device)
+    dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
+    with _timed("conv3x3_wgrad_wino2d_mfma(+slice reduce)|%d->%d@%dx%d%s" % (Cin, Cout, H, W, "+inT" if in_st is not None else ""),
+                2.0 * 9 * B * H * W * Cin * Cout):
+        _call("sed_conv3x3_wgrad_wino2", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
+              _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, _stream())
+    return dw
+
+
 def _wgrad(x, gy, B, H, W, Cin, Cout, in_st=None):
+    if USE_WINOGRAD >= 2 and W in (8, 16, 32, 64) and Cin % 32 == 0 and Cout % 64 == 0:
+        return _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=in_st)
     if USE_WINOGRAD and _wgrad_wino_ok(W, Cin, Cout):
         return _wgrad_wino(x, gy, B, H, W, Cin, Cout, in_st=in_st)
     return _wgrad_direct(x, gy, B, H, W, Cin, Cout, in_st=in_st)

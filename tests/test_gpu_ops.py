@@ -387,6 +387,29 @@ def test_conv3x3_winograd2d_fusions_match_direct_kernel(ops):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,inT", [(2, 13, 8, 64, 64, False), (1, 25, 16, 64, 128, True), (3, 12, 32, 128, 128, False),
+                                                (2, 101, 64, 64, 64, True), (5, 7, 8, 256, 512, False), (2, 300, 32, 32, 64, False),
+                                                (1, 1, 8, 32, 64, True)])
+def test_conv3x3_winograd2d_wgrad(ops, B, H, W, Cin, Cout, inT):
+    """2-D Winograd-domain weight gradient vs torch autograd (odd heights, BN+ReLU input transform, ragged slices)."""
+    g = torch.Generator().manual_seed(B * 10 + W + 3)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    gy = torch.randn(B, Cout, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).requires_grad_(True)
+    st = None
+    a = x
+    if inT:
+        sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+        a = F.relu(x * sc[None, :, None, None] + sh[None, :, None, None])
+        st = ops.BnStats(Cin, "cuda"); st.scale.copy_(sc); st.shift.copy_(sh)
+    F.conv2d(a, w, padding=1).backward(gy)
+    xd, gyd = nhwc(x), nhwc(gy)
+    dw = ops._wgrad_wino2(xd, gyd, B, H, W, Cin, Cout, in_st=st).cpu()
+    assert rel(dw, w.grad) < 1e-5
+    dwd = ops._wgrad_direct(xd, gyd, B, H, W, Cin, Cout, in_st=st).cpu() if Cin % 64 == 0 else w.grad
+    assert rel(dw, dwd) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,inT", [(2, 13, 8, 64, 64, False), (1, 25, 16, 64, 128, True), (3, 12, 32, 128, 128, False),
                                                 (2, 101, 64, 64, 64, True), (5, 7, 8, 256, 512, False), (2, 300, 32, 128, 64, False)])
 def test_conv3x3_winograd_wgrad(ops, B, H, W, Cin, Cout, inT):
     """Winograd-domain weight gradient vs torch autograd (incl. the on-the-fly BN+ReLU input transform, ragged slices)."""

@@ -71,6 +71,8 @@ def main():
         if args.only in ("", "wgrad"):
             runs += [("wgrad +inT        ", lambda: ops._wgrad_direct(x, gy, B, H, W, ci, co, in_st=st)),
                      ("wgrad             ", lambda: ops._wgrad_direct(x, gy, B, H, W, ci, co)),
+                     ("wgrad wino2 +inT  ", lambda: ops._wgrad_wino2(x, gy, B, H, W, ci, co, in_st=st)),
+                     ("wgrad wino2       ", lambda: ops._wgrad_wino2(x, gy, B, H, W, ci, co)),
                      ("wgrad wino +inT   ", lambda: ops._wgrad_wino(x, gy, B, H, W, ci, co, in_st=st)),
                      ("wgrad wino        ", lambda: ops._wgrad_wino(x, gy, B, H, W, ci, co))]
         for name, fn in runs:
