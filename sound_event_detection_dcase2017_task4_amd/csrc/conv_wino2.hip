@@ -85,8 +85,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2P p) {
     const int hbase = 2 * th0 - 1;                   // image row of block row 0
     const int nrows = 2 * RP + 2;
 
-    for (int i = tid; i < 2 * W2_ASTAGE / 4; i += 256) reinterpret_cast<float4*>(As)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-
     // ---- A staging: item e = tid + 256*i -> pixel e >> 1 of the block's rows, 16-byte chunk e & 1
     const int c2 = tid & 1;
 #define SED_W2META(i)                                                                                           \
@@ -145,6 +143,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2P p) {
     }
 #define w2lstore(BUF) { SED_W2A_STORE(BUF, 0) SED_W2A_STORE(BUF, 1) SED_W2A_STORE(BUF, 2) }
 
+    // halo entries and rows outside the image are never stored: zero both A stages once
+    for (int i = tid; i < 2 * W2_ASTAGE / 4; i += 256) reinterpret_cast<float4*>(As)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();                                   // zero fill visible before the first stores
     w2gload(0, 0);
     w2lstore(0);
@@ -231,12 +231,23 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2P p) {
         mine[2 * r] = eh ? -(z00 + z10) : (z00 + z10);
         mine[2 * r + 1] = eh ? -(z01 + z11) : (z01 + z11);
     }
-    __syncthreads();
     const int half = lane >> 5;
     const int col = n0 + (lane & 31);
     float s1 = 0.f, s2 = 0.f, cnt = 0.f;
     float e_sc = 0.f, e_sh = 0.f, e_mu = 0.f, e_is = 0.f;
-    if (EPI == 2) { e_sc = p.p_scale[col]; e_sh = p.p_shift[col]; e_mu = p.p_mean[col]; e_is = p.p_invstd[col]; }
+    float yp[EPI == 2 ? 32 : 1];
+    if (EPI == 2) {                                    // previous-layer activations: loads overlap the LDS exchange
+        e_sc = p.p_scale[col]; e_sh = p.p_shift[col]; e_mu = p.p_mean[col]; e_is = p.p_invstd[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int tl = tb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int h = 2 * (th0 + (tl >> logTW)) + eh;
+            const long pix = ((long)b * p.H + (h < p.H ? h : 0)) * W + 2 * (tl & (TW - 1));
+            yp[2 * r] = p.yprev[pix * p.N + col];
+            yp[2 * r + 1] = p.yprev[(pix + 1) * p.N + col];
+        }
+    }
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int tl = tb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2P p) {
         float y0 = mine[2 * r] + xch[((wvu ^ 1) * 32 + 2 * r) * 64 + lane];
         float y1 = mine[2 * r + 1] + xch[((wvu ^ 1) * 32 + 2 * r + 1) * 64 + lane];
         if (EPI == 2 && ok) {
-            float a0 = p.yprev[pix * p.N + col], a1 = p.yprev[(pix + 1) * p.N + col];
+            float a0 = yp[(EPI == 2 ? 2 * r : 0)], a1 = yp[(EPI == 2 ? 2 * r + 1 : 0)];
             y0 = bn_relu_active(a0, e_sc, e_sh) ? y0 : 0.f;
             y1 = bn_relu_active(a1, e_sc, e_sh) ? y1 : 0.f;
             s1 += y0 + y1;
@@ -448,6 +459,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino2_kernel(WWino2P p) {
     const int gpx##i = (tid + 256 * i) >> 4;                                                                    \
     const int gr##i = gpx##i / GW, gc##i = gpx##i % GW;                                                         \
     const int gls##i = gpx##i * 64 + ((gch * 4) ^ (32 * ((gc##i >> 1) & 1)));                                   \
+    const int xoff##i = (xr##i * W + xc##i) * p.K + ci0 + xch * 4;                                              \
+    const int goff##i = (gr##i * W + gc##i) * p.N + co0 + gch * 4;                                              \
     float4 xreg##i = make_float4(0.f, 0.f, 0.f, 0.f), greg##i = xreg##i;                                        \
     bool xv##i = false, gv##i = false;
     SED_WW2_META(0) SED_WW2_META(1) SED_WW2_META(2) SED_WW2_META(3)
@@ -459,15 +472,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino2_kernel(WWino2P p) {
     {                                                                                                           \
         const int h = h0 + xr##i, w = w0 + xc##i;                                                               \
         xv##i = live && xit##i && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)W;                     \
-        xreg##i = *reinterpret_cast<const float4*>(xv##i ? x_safe + (((long)b * p.H + h) * W + w) * p.K : x_safe); \
+        xreg##i = *reinterpret_cast<const float4*>(xv##i ? x_unit + xoff##i : x_safe);                         \
         const int hg = h0 + 1 + gr##i;                                                                          \
         gv##i = live && hg < p.H;                                                                               \
-        greg##i = *reinterpret_cast<const float4*>(gv##i ? g_safe + (((long)b * p.H + hg) * W + (w0 + 1 + gc##i)) * p.N : g_safe); \
+        greg##i = *reinterpret_cast<const float4*>(gv##i ? g_unit + goff##i : g_safe);                         \
     }
 #define ww2_load(LIVE)                                                                                          \
     {                                                                                                           \
         const bool live = (LIVE);                                                                               \
         const int h0 = 2 * rg * RPK - 1, w0 = 2 * sg * TCK - 1;                                                 \
+        const float* x_unit = p.x + (((long)b * p.H + h0) * W + w0) * p.K;          /* uniform; only valid offsets used */ \
+        const float* g_unit = p.gy + (((long)b * p.H + h0 + 1) * W + w0 + 1) * p.N;                             \
         SED_WW2_LOAD(0) SED_WW2_LOAD(1) SED_WW2_LOAD(2) SED_WW2_LOAD(3)                                         \
         if (++sg == p.nsg) { sg = 0; if (++rg == p.nrg) { rg = 0; ++b; } }                                      \
     }
@@ -509,25 +524,42 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino2_kernel(WWino2P p) {
         const float* Xa0 = &Xs[buf][xbase0 + ra], *Xa1 = &Xs[buf][xbase1 + ra];
         const float* Xq0 = &Xs[buf][xbase0 + rbw], *Xq1 = &Xs[buf][xbase1 + rbw];
         const float* Xc0 = &Xs[buf][xbase0 + rc], *Xc1 = &Xs[buf][xbase1 + rc];
+        // raw LDS values of k pair J: 2x2 output-gradient tile (dq) and the three patch rows this eta half needs
+#define SED_WW2_RAW(J, DQ, XA, XB, XC)                                                                          \
+    {                                                                                                           \
+        constexpr int rp_k = (2 * (J)) / TCK, tcb = (2 * (J)) % TCK;                                            \
+        const float* gp = Gb + ((2 * rp_k) * GW + 2 * tcb) * 64;                                                \
+        DQ[0] = gp[0]; DQ[1] = gp[64]; DQ[2] = gp[GW * 64]; DQ[3] = gp[GW * 64 + 64];                           \
+        _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                      \
+            const bool s1_ = ((jj & 1) ^ (jj >> 1)) != 0;                                                       \
+            const int eo = (rp_k * CW + tcb + (jj >> 1)) * 64;   /* line of patch row 2*rp_k, column 2*tcb+jj */ \
+            XA[jj] = (s1_ ? Xa1 : Xa0)[eo];                                                                     \
+            XB[jj] = (s1_ ? Xq1 : Xq0)[eo];                                                                     \
+            XC[jj] = (s1_ ? Xc1 : Xc0)[eo];                                                                     \
+        }                                                                                                       \
+    }
+        float dq[4], xa[4], xb[4], xc[4], dqn[4], xan[4], xbn[4], xcn[4];
+        SED_WW2_RAW(0, dq, xa, xb, xc)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int rp_k = (2 * j) / TCK, tcb = (2 * j) % TCK;
+            // reads of the NEXT k pair are in flight while this pair's MFMAs run
+            if (j == 0) SED_WW2_RAW(1, dqn, xan, xbn, xcn)
+            if (j == 1) SED_WW2_RAW(2, dqn, xan, xbn, xcn)
+            if (j == 2) SED_WW2_RAW(3, dqn, xan, xbn, xcn)
+            if (j == 3) SED_WW2_RAW(4, dqn, xan, xbn, xcn)
+            if (j == 4) SED_WW2_RAW(5, dqn, xan, xbn, xcn)
+            if (j == 5) SED_WW2_RAW(6, dqn, xan, xbn, xcn)
+            if (j == 6) SED_WW2_RAW(7, dqn, xan, xbn, xcn)
+            __builtin_amdgcn_sched_barrier(0);
             // output-gradient tile -> this wave's two eta rows of dM, then the four xi columns
-            const float* gp = Gb + ((2 * rp_k) * GW + 2 * tcb) * 64;
-            const float d00 = gp[0], d01 = gp[64], d10 = gp[GW * 64], d11 = gp[GW * 64 + 64];
-            const float ea0 = fmaf(al, d10, d00), ea1 = fmaf(al, d11, d01);
-            const float eb0 = fmaf(ga, d10, be * d00), eb1 = fmaf(ga, d11, be * d01);
+            const float ea0 = fmaf(al, dq[2], dq[0]), ea1 = fmaf(al, dq[3], dq[1]);
+            const float eb0 = fmaf(ga, dq[2], be * dq[0]), eb1 = fmaf(ga, dq[3], be * dq[1]);
             // input patch -> this wave's two eta rows of V
             float ca[4], cb[4];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                const bool s1_ = ((jj & 1) ^ (jj >> 1)) != 0;
-                const int eo = (rp_k * CW + tcb + (jj >> 1)) * 64;       // line of patch row 2*rp_k, column 2*tcb + jj
-                const float va = (s1_ ? Xa1 : Xa0)[eo];
-                const float vb = (s1_ ? Xq1 : Xq0)[eo];
-                const float vc = (s1_ ? Xc1 : Xc0)[eo];
-                ca[jj] = va - vc;
-                cb[jj] = fmaf(sgn, vb, vc);
+                ca[jj] = xa[jj] - xc[jj];
+                cb[jj] = fmaf(sgn, xb[jj], xc[jj]);
             }
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ea0, ca[0] - ca[2], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ea0 + ea1, ca[1] + ca[2], acc[1], 0, 0, 0);
@@ -537,12 +569,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino2_kernel(WWino2P p) {
             acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(eb0 + eb1, cb[1] + cb[2], acc[5], 0, 0, 0);
             acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(eb0 - eb1, cb[2] - cb[1], acc[6], 0, 0, 0);
             acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(-eb1, cb[1] - cb[3], acc[7], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
             if (j == 5) {
-                __builtin_amdgcn_sched_barrier(0);
                 ww2_store(buf ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) { dq[jj] = dqn[jj]; xa[jj] = xan[jj]; xb[jj] = xbn[jj]; xc[jj] = xcn[jj]; }
         }
+#undef SED_WW2_RAW
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();
     }

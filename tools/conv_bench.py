@@ -31,10 +31,12 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--layers", type=str, default="", help="comma-separated indices into LAYERS (default: all)")
     args = ap.parse_args()
     B = args.batch
     tot_ms, tot_fl = {}, {}
-    for (ci, co, H, W) in LAYERS:
+    layers = [LAYERS[int(i)] for i in args.layers.split(",")] if args.layers else LAYERS
+    for (ci, co, H, W) in layers:
         g = torch.Generator(device="cuda").manual_seed(1)
         x = torch.randn((B, H, W, ci), device="cuda", generator=g)
         gy = torch.randn((B, H, W, co), device="cuda", generator=g)
