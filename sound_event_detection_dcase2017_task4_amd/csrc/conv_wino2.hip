@@ -60,11 +60,70 @@ __device__ __forceinline__ void lds_dma16_2(const float* gsrc, unsigned lds_dst_
 // float offset of 16-byte chunk `chunk` (0/1) of 32-byte LDS row `row`
 __device__ __forceinline__ int sw_off(int row, int chunk) { return row * 8 + ((chunk ^ ((row >> 3) & 1)) << 2); }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4fma(float s, float4 a, float4 b) {
     return make_float4(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z), fmaf(s, a.w, b.w));
 }
+
+// Input transform of one eta row for the forward kernel, on 4-channel fragments held as float pairs: column values
+// c_j = a_j - r_j (SUB) or s*a_j + r_j (FMA), then the xi columns v0 = c0-c2, v1 = c1+c2, v2 = c2-c1, v3 = c1-c3.
+// 16 packed-fp32 instructions in ONE asm block: hipcc scalarises the equivalent vector code (2x the VALU instructions,
+// plus register-pair moves), and every VALU instruction issued costs MFMA time here.  The trailing s_nop covers the
+// VALU-write -> MFMA-read wait states the compiler cannot see through the asm.
+#define SED_XF_TAIL                                                                                             \
+        "v_pk_add_f32 %8, %4, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"   /* t = c2 - c1 */                            \
+        "v_pk_add_f32 %9, %5, %3 neg_lo:[0,1] neg_hi:[0,1]\n\t"                                                \
+        "v_pk_add_f32 %0, %0, %4 neg_lo:[0,1] neg_hi:[0,1]\n\t"   /* v0 = c0 - c2 */                           \
+        "v_pk_add_f32 %1, %1, %5 neg_lo:[0,1] neg_hi:[0,1]\n\t"                                                \
+        "v_pk_add_f32 %6, %2, %6 neg_lo:[0,1] neg_hi:[0,1]\n\t"   /* v3 = c1 - c3 */                           \
+        "v_pk_add_f32 %7, %3, %7 neg_lo:[0,1] neg_hi:[0,1]\n\t"                                                \
+        "v_pk_add_f32 %2, %2, %4\n\t"                             /* v1 = c1 + c2 */                           \
+        "v_pk_add_f32 %3, %3, %5\n\t"                                                                          \
+        "s_nop 1"
+#define SED_XF_OUTS "=&v"(v0l), "=&v"(v0h), "=&v"(v1l), "=&v"(v1h), "=&v"(c2l), "=&v"(c2h), "=&v"(v3l), "=&v"(v3h), "=&v"(v2l), "=&v"(v2h)
+#define SED_XF_INS "v"(f2{a[0].x, a[0].y}), "v"(f2{a[0].z, a[0].w}), "v"(f2{a[1].x, a[1].y}), "v"(f2{a[1].z, a[1].w}),     \
+                   "v"(f2{a[2].x, a[2].y}), "v"(f2{a[2].z, a[2].w}), "v"(f2{a[3].x, a[3].y}), "v"(f2{a[3].z, a[3].w}),     \
+                   "v"(f2{r[0].x, r[0].y}), "v"(f2{r[0].z, r[0].w}), "v"(f2{r[1].x, r[1].y}), "v"(f2{r[1].z, r[1].w}),     \
+                   "v"(f2{r[2].x, r[2].y}), "v"(f2{r[2].z, r[2].w}), "v"(f2{r[3].x, r[3].y}), "v"(f2{r[3].z, r[3].w})
+#define SED_XF_PACK                                                                                             \
+    v[0] = f4v{v0l.x, v0l.y, v0h.x, v0h.y}; v[1] = f4v{v1l.x, v1l.y, v1h.x, v1h.y};                             \
+    v[2] = f4v{v2l.x, v2l.y, v2h.x, v2h.y}; v[3] = f4v{v3l.x, v3l.y, v3h.x, v3h.y};
+__device__ __forceinline__ void wino2_xf_sub(const f4v (&a)[4], const f4v (&r)[4], f4v (&v)[4]) {
+    f2 v0l, v0h, v1l, v1h, c2l, c2h, v3l, v3h, v2l, v2h;
+    asm("v_pk_add_f32 %0, %10, %18 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %1, %11, %19 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %2, %12, %20 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %3, %13, %21 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %4, %14, %22 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %5, %15, %23 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %6, %16, %24 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %7, %17, %25 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        SED_XF_TAIL
+        : SED_XF_OUTS : SED_XF_INS);
+    SED_XF_PACK
+}
+__device__ __forceinline__ void wino2_xf_fma(f2 sg, const f4v (&a)[4], const f4v (&r)[4], f4v (&v)[4]) {
+    f2 v0l, v0h, v1l, v1h, c2l, c2h, v3l, v3h, v2l, v2h;
+    asm("v_pk_fma_f32 %0, %26, %10, %18\n\t"
+        "v_pk_fma_f32 %1, %26, %11, %19\n\t"
+        "v_pk_fma_f32 %2, %26, %12, %20\n\t"
+        "v_pk_fma_f32 %3, %26, %13, %21\n\t"
+        "v_pk_fma_f32 %4, %26, %14, %22\n\t"
+        "v_pk_fma_f32 %5, %26, %15, %23\n\t"
+        "v_pk_fma_f32 %6, %26, %16, %24\n\t"
+        "v_pk_fma_f32 %7, %26, %17, %25\n\t"
+        SED_XF_TAIL
+        : SED_XF_OUTS : SED_XF_INS, "s"(sg));
+    SED_XF_PACK
+}
+#undef SED_XF_TAIL
+#undef SED_XF_OUTS
+#undef SED_XF_INS
+#undef SED_XF_PACK
 
 template <bool INT, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2P p) {
@@ -85,12 +144,20 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2P p) {
     const int hbase = 2 * th0 - 1;                   // image row of block row 0
     const int nrows = 2 * RP + 2;
 
-    // ---- A staging: item e = tid + 256*i -> pixel e >> 1 of the block's rows, 16-byte chunk e & 1
+    // ---- A staging: item e = tid + 256*i -> pixel e >> 1 of the block's rows, 16-byte chunk e & 1.
+    // Raw buffer loads over this workgroup's image: thread-constant byte offset + a scalar k offset, no per-step
+    // address arithmetic on the vector unit (every VALU instruction issued costs MFMA time on this chip).
     const int c2 = tid & 1;
+    constexpr int OOB = (int)0x80000000;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x) + (long)b * p.H * W * p.K, 0, (int)((unsigned)p.H * W * p.K * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(INT ? p.in_scale : p.x), 0, p.K * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(INT ? p.in_shift : p.x), 0, p.K * 4, 0x00020000);
 #define SED_W2META(i)                                                                                           \
     bool sok##i;                                                                                                \
-    int lso##i;                                                                                                 \
-    const float* aptr##i;                                                                                       \
+    int lso##i, aoff##i;                                                                                        \
     float4 areg##i = make_float4(0.f, 0.f, 0.f, 0.f);                                                           \
     {                                                                                                           \
         const int pix = (tid + 256 * i) >> 1;                                                                   \
@@ -98,13 +165,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2P p) {
         const int h = hbase + r;                                                                                \
         sok##i = r < nrows && (unsigned)h < (unsigned)p.H;                                                      \
         lso##i = sw_off((r * 2 + ((w + 1) & 1)) * S + ((w + 1) >> 1), c2);                                      \
-        aptr##i = p.x + (sok##i ? (((long)b * p.H + h) * W + w) * p.K : 0L) + c2 * 4;                           \
+        aoff##i = sok##i ? ((h * W + w) * p.K + c2 * 4) * 4 : OOB;                                              \
     }
     SED_W2META(0) SED_W2META(1) SED_W2META(2)
 #undef SED_W2META
-    // ---- B DMA: wave wv stages coordinates 4*wv .. 4*wv+3, one instruction (64 lanes x 16 B = 32 rows) each
+    // ---- B DMA: wave wv stages coordinates 4*wv .. 4*wv+3, one instruction (64 lanes x 16 B = 32 rows) each;
+    // scalar base (k-step, coordinate) + thread-constant 32-bit offset
     const int brow_in = lane >> 1;
-    const float* bptr = p.wu + ((long)(wvu * 4) * p.N + n0 + brow_in) * 8 + (((lane & 1) ^ ((brow_in >> 3) & 1)) << 2);
+    const int boff = ((n0 + brow_in) * 8 + (((lane & 1) ^ ((brow_in >> 3) & 1)) << 2)) * 4;
+    const float* const bw = p.wu + (long)(wvu * 4) * p.N * 8;
     const long b_xi_stride = (long)p.N * 8;          // next Winograd coordinate
     const long b_k_stride = 16L * p.N * 8;           // next k-step
     const unsigned bs_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)Bs);
@@ -116,17 +185,26 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2P p) {
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
     const int KT = p.K >> 3;
-    float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
+    f2 sc01 = {0.f, 0.f}, sc23 = sc01, sh01 = sc01, sh23 = sc01;
 
-#define SED_W2A_LOAD(i) areg##i = *reinterpret_cast<const float4*>(aptr##i + (sok##i ? a_off : 0));
-#define SED_W2B_LOAD(DST, j) lds_dma16_2(bptr + b_off + (j) * b_xi_stride, bs_base + (unsigned)(((DST) * W2_BSTAGE + (wvu * 4 + (j)) * 256) * 4));
+#define SED_W2A_LOAD(i) areg##i = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, aoff##i, k_off, 0));
+#define SED_W2B_LOAD(DST, j)                                                                                    \
+    {                                                                                                           \
+        unsigned keep_;                                                                                         \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_)                                                                             \
+                     : "v"(boff), "s"(bs_base + (unsigned)(((DST) * W2_BSTAGE + (wvu * 4 + (j)) * 256) * 4)),   \
+                       "s"(bsrc + (j) * b_xi_stride)                                                            \
+                     : "memory");                                                                               \
+    }
 #define w2gload(IT, DST)                                                                                        \
     {                                                                                                           \
-        const int a_off = (IT) * 8;                                                                             \
-        const long b_off = (long)(IT) * b_k_stride;                                                             \
+        const int k_off = (IT) * 32;                                   /* bytes */                              \
+        const float* bsrc = bw + (long)(IT) * b_k_stride;                                                       \
         if (INT) {                                                                                              \
-            sc = *reinterpret_cast<const float4*>(p.in_scale + a_off + c2 * 4);                                 \
-            sh = *reinterpret_cast<const float4*>(p.in_shift + a_off + c2 * 4);                                 \
+            const float4 s4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(srs, c2 * 16, k_off, 0)); \
+            const float4 h4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(hrs, c2 * 16, k_off, 0)); \
+            sc01 = f2{s4.x, s4.y}; sc23 = f2{s4.z, s4.w}; sh01 = f2{h4.x, h4.y}; sh23 = f2{h4.z, h4.w};         \
         }                                                                                                       \
         SED_W2B_LOAD(DST, 0) SED_W2B_LOAD(DST, 1) SED_W2B_LOAD(DST, 2) SED_W2B_LOAD(DST, 3)                     \
         SED_W2A_LOAD(0) SED_W2A_LOAD(1) SED_W2A_LOAD(2)                                                         \
@@ -136,8 +214,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2P p) {
         asm volatile("" : "+v"(areg##i.x), "+v"(areg##i.y), "+v"(areg##i.z), "+v"(areg##i.w));                  \
         float4 v = areg##i;                                                                                     \
         if (INT) {                                                                                              \
-            v.x = bn_relu(v.x, sc.x, sh.x); v.y = bn_relu(v.y, sc.y, sh.y);                                     \
-            v.z = bn_relu(v.z, sc.z, sh.z); v.w = bn_relu(v.w, sc.w, sh.w);                                     \
+            f2 v01 = f2{v.x, v.y} * sc01 + sh01, v23 = f2{v.z, v.w} * sc23 + sh23;                              \
+            v01 = __builtin_elementwise_max(v01, f2{0.f, 0.f}); v23 = __builtin_elementwise_max(v23, f2{0.f, 0.f}); \
+            v = make_float4(v01.x, v01.y, v23.x, v23.y);                                                        \
         }                                                                                                       \
         if (sok##i) *reinterpret_cast<float4*>(&As[(BUF) * W2_ASTAGE + lso##i]) = v;                            \
     }
@@ -158,58 +237,62 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2P p) {
     // eta half 0 combines rows (0,2) and (1,2) of the patch; half 1 rows (2,1) and (1,3):  eta_a = ra - rc,
     // eta_b = rc + sgn*rb with sgn = +1 / -1.
     const int ra = 2 * rp_l + (eh ? 2 : 0), rbw = 2 * rp_l + (eh ? 3 : 1), rc = 2 * rp_l + (eh ? 1 : 2);
-    const float sgn = eh ? -1.f : 1.f;
-    int oa[4], ob[4], oc[4];
+    const f2 sgn2 = eh ? f2{-1.f, -1.f} : f2{1.f, 1.f};
+    const float* pa[4], *pb[4], *pc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        oa[j] = sw_off((ra * 2 + (j & 1)) * S + tw_l + (j >> 1), chunk);
-        ob[j] = sw_off((rbw * 2 + (j & 1)) * S + tw_l + (j >> 1), chunk);
-        oc[j] = sw_off((rc * 2 + (j & 1)) * S + tw_l + (j >> 1), chunk);
+        pa[j] = As + sw_off((ra * 2 + (j & 1)) * S + tw_l + (j >> 1), chunk);
+        pb[j] = As + sw_off((rbw * 2 + (j & 1)) * S + tw_l + (j >> 1), chunk);
+        pc[j] = As + sw_off((rc * 2 + (j & 1)) * S + tw_l + (j >> 1), chunk);
     }
-    const int bo = eh * 8 * 256 + sw_off(lane & 31, chunk);          // + (e*4 + xi) * 256
+    const float* const pbf = Bs + eh * 8 * 256 + sw_off(lane & 31, chunk);          // + (e*4 + xi) * 256
 
-    for (int it = 0; it < KT; ++it) {
-        const int buf = it & 1;
-        const float* Ab = As + buf * W2_ASTAGE;
-        const float* Bb = Bs + buf * W2_BSTAGE + bo;
-        w2gload(it + 1 < KT ? it + 1 : it, buf ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-        float4 xa[4], xb[4], xc[4], bf[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            xa[j] = *reinterpret_cast<const float4*>(Ab + oa[j]);
-            xc[j] = *reinterpret_cast<const float4*>(Ab + oc[j]);
-        }
-#pragma unroll
-        for (int a = 0; a < 4; ++a) bf[a] = *reinterpret_cast<const float4*>(Bb + a * 256);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) xb[j] = *reinterpret_cast<const float4*>(Ab + ob[j]);
-#pragma unroll
-        for (int a = 4; a < 8; ++a) bf[a] = *reinterpret_cast<const float4*>(Bb + a * 256);
+    // one K-step on stage BUF (compile-time, so every LDS access is base register + immediate) while step ITN is
+    // fetched into the other stage
 #define SED_W2MMA(A_, VV)                                                                                       \
     acc[A_] = __builtin_amdgcn_mfma_f32_32x32x2f32(VV.x, bf[A_].x, acc[A_], 0, 0, 0);                            \
     acc[A_] = __builtin_amdgcn_mfma_f32_32x32x2f32(VV.y, bf[A_].y, acc[A_], 0, 0, 0);                            \
     acc[A_] = __builtin_amdgcn_mfma_f32_32x32x2f32(VV.z, bf[A_].z, acc[A_], 0, 0, 0);                            \
     acc[A_] = __builtin_amdgcn_mfma_f32_32x32x2f32(VV.w, bf[A_].w, acc[A_], 0, 0, 0);
-        {
-            float4 c0 = f4sub(xa[0], xc[0]), c1 = f4sub(xa[1], xc[1]), c2_ = f4sub(xa[2], xc[2]), c3 = f4sub(xa[3], xc[3]);
-            float4 v0 = f4sub(c0, c2_), v1 = f4add(c1, c2_), v2 = f4sub(c2_, c1), v3 = f4sub(c1, c3);
-            SED_W2MMA(0, v0) SED_W2MMA(1, v1) SED_W2MMA(2, v2) SED_W2MMA(3, v3)
-        }
-        {
-            float4 c0 = f4fma(sgn, xb[0], xc[0]), c1 = f4fma(sgn, xb[1], xc[1]), c2_ = f4fma(sgn, xb[2], xc[2]),
-                   c3 = f4fma(sgn, xb[3], xc[3]);
-            float4 v0 = f4sub(c0, c2_), v1 = f4add(c1, c2_), v2 = f4sub(c2_, c1), v3 = f4sub(c1, c3);
-            SED_W2MMA(4, v0) SED_W2MMA(5, v1) SED_W2MMA(6, v2) SED_W2MMA(7, v3)
-        }
-#undef SED_W2MMA
-        __builtin_amdgcn_sched_barrier(0);
-        w2lstore(buf ^ 1);
-        __builtin_amdgcn_s_setprio(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+#define W2_STEP(BUF, ITN)                                                                                       \
+    {                                                                                                           \
+        w2gload(ITN, (BUF) ^ 1);                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        __builtin_amdgcn_s_setprio(1);                                                                          \
+        f4v xa[4], xb[4], xc[4], bf[8];                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
+            xa[j] = *reinterpret_cast<const f4v*>(pa[j] + (BUF) * W2_ASTAGE);                                   \
+            xc[j] = *reinterpret_cast<const f4v*>(pc[j] + (BUF) * W2_ASTAGE);                                   \
+        }                                                                                                       \
+        _Pragma("unroll") for (int a = 0; a < 4; ++a) bf[a] = *reinterpret_cast<const f4v*>(pbf + (BUF) * W2_BSTAGE + a * 256); \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) xb[j] = *reinterpret_cast<const f4v*>(pb[j] + (BUF) * W2_ASTAGE); \
+        _Pragma("unroll") for (int a = 4; a < 8; ++a) bf[a] = *reinterpret_cast<const f4v*>(pbf + (BUF) * W2_BSTAGE + a * 256); \
+        {                                                                                                       \
+            f4v v[4];                                                                                           \
+            wino2_xf_sub(xa, xc, v);                                                                            \
+            SED_W2MMA(0, v[0]) SED_W2MMA(1, v[1]) SED_W2MMA(2, v[2]) SED_W2MMA(3, v[3])                         \
+        }                                                                                                       \
+        {                                                                                                       \
+            f4v v[4];                                                                                           \
+            wino2_xf_fma(sgn2, xb, xc, v);                                                                      \
+            SED_W2MMA(4, v[0]) SED_W2MMA(5, v[1]) SED_W2MMA(6, v[2]) SED_W2MMA(7, v[3])                         \
+        }                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        w2lstore((BUF) ^ 1);                                                                                    \
+        __builtin_amdgcn_s_setprio(0);                                                                          \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
+        __syncthreads();                                                                                        \
     }
+    {
+        int it = 0;
+        for (; it + 1 < KT; it += 2) {
+            W2_STEP(0, it + 1)
+            W2_STEP(1, it + 2 < KT ? it + 2 : it + 1)
+        }
+        if (it < KT) W2_STEP(0, it)
+    }
+#undef W2_STEP
+#undef SED_W2MMA
 #undef w2gload
 #undef w2lstore
 #undef SED_W2A_LOAD
@@ -371,7 +454,8 @@ SED_API int sed_conv3x3_wino2(const float* x, const float* w_wino2, float* y, in
                               hipStream_t stream) {
     int lw, rp, nrb, s;
     if (B <= 0 || !sed_conv3x3_wino2_supported(H, W, Cin, Cout) || !wino2_geometry(H, W, &lw, &rp, &nrb, &s) ||
-        (long)B * H * W >= (1L << 31) || (long)B * nrb * (Cout / 32) >= (1L << 31))
+        (long)B * H * W >= (1L << 31) || (long)B * nrb * (Cout / 32) >= (1L << 31) ||
+        (long)H * W * Cin * 4 >= (1L << 31))           // one image must fit a 31-bit buffer-descriptor range
         return SED_EINVAL;
     Wino2P p{x, w_wino2, y, in_scale, in_shift, partials, yprev, p_scale, p_shift, p_mean, p_invstd,
              B, H, W, Cin, Cout, lw, rp, nrb, s, (long)B * nrb * 4};
@@ -409,6 +493,31 @@ struct WWino2P {
     int units_per_slice, ids_per_slice;
 };
 
+// The 13 packed-fp32 instructions that turn the raw LDS values of one k pair into the 8 + 8 MFMA operands of an eta half.
+// Written as ONE asm block because hipcc scalarises most v2f32 expressions with swizzles (28 VALU instead of 13), and on
+// this chip every VALU instruction issued costs MFMA time (measured: kernel time ~ 64*MFMAs + 4*VALUs cycles per SIMD).
+// The trailing s_nop covers the VALU-write -> MFMA-read wait states the compiler cannot see through the asm.
+__device__ __forceinline__ void wgrad_wino2_transforms(f2 d0, f2 d1, f2 a03, f2 a12, f2 b03, f2 b12, f2 c03, f2 c12, f2 al,
+                                                       f2 be, f2 ga, f2& ea, f2& eb, f2& ma, f2& mb, f2& va03, f2& va12,
+                                                       f2& vb03, f2& vb12) {
+    asm("v_pk_fma_f32 %0, %16, %9, %8\n\t"                                                  // ea = al*d1 + d0
+        "v_pk_mul_f32 %1, %17, %8\n\t"                                                      // eb = be*d0
+        "v_pk_fma_f32 %1, %18, %9, %1\n\t"                                                  //    + ga*d1
+        "v_pk_add_f32 %4, %10, %14 neg_lo:[0,1] neg_hi:[0,1]\n\t"                           // ca03 = a03 - c03
+        "v_pk_add_f32 %5, %11, %15 neg_lo:[0,1] neg_hi:[0,1]\n\t"                           // ca12 = a12 - c12
+        "v_pk_fma_f32 %6, %18, %12, %14\n\t"                                                // cb03 = ga*b03 + c03
+        "v_pk_fma_f32 %7, %18, %13, %15\n\t"                                                // cb12 = ga*b12 + c12
+        "v_pk_add_f32 %2, %0, %0 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"             // ma = (ea.x+ea.y, ea.x-ea.y)
+        "v_pk_add_f32 %3, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"             // mb
+        "v_pk_add_f32 %4, %4, %5 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" // va03 = (c0-c2, c3-c1)
+        "v_pk_add_f32 %5, %5, %5 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"             // va12 = (c2+c1, c2-c1)
+        "v_pk_add_f32 %6, %6, %7 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" // vb03
+        "v_pk_add_f32 %7, %7, %7 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"             // vb12
+        "s_nop 1"
+        : "=&v"(ea), "=&v"(eb), "=&v"(ma), "=&v"(mb), "=&v"(va03), "=&v"(va12), "=&v"(vb03), "=&v"(vb12)
+        : "v"(d0), "v"(d1), "v"(a03), "v"(a12), "v"(b03), "v"(b12), "v"(c03), "v"(c12), "s"(al), "s"(be), "s"(ga));
+}
+
 template <bool INT, bool W8>
 __global__ __launch_bounds__(256, 2) void wgrad_wino2_kernel(WWino2P p) {
     constexpr int TCK = W8 ? 4 : 8, RPK = 16 / TCK, CW = 2 * TCK + 2, XR = 2 * RPK + 2, GW = 2 * TCK;
@@ -444,13 +553,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino2_kernel(WWino2P p) {
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
     // ---- staging maps (fixed per thread): x item e = tid + 256*i -> patch pixel e >> 3, chunk e & 7;
-    //      gy item e -> pixel e >> 4 of the 64, chunk e & 15
+    //      gy item e -> pixel e >> 4 of the 64, chunk e & 15.
+    // Loads are raw BUFFER loads over one image (descriptor rebuilt per unit on the scalar unit): rows above / below the
+    // image fall outside [0, num_records) and return 0 without any per-lane masking; the only explicit test is the
+    // patch's halo column at the left / right image edge (offset forced out of range).
     const int xch = tid & 7, gch = tid & 15;
-    float4 xsc = make_float4(0.f, 0.f, 0.f, 0.f), xsh = xsc;
+    f2 xsc01 = {0.f, 0.f}, xsc23 = xsc01, xsh01 = xsc01, xsh23 = xsc01;
     if (INT) {
-        xsc = *reinterpret_cast<const float4*>(p.in_scale + ci0 + xch * 4);
-        xsh = *reinterpret_cast<const float4*>(p.in_shift + ci0 + xch * 4);
+        const float4 sc4 = *reinterpret_cast<const float4*>(p.in_scale + ci0 + xch * 4);
+        const float4 sh4 = *reinterpret_cast<const float4*>(p.in_shift + ci0 + xch * 4);
+        xsc01 = f2{sc4.x, sc4.y}; xsc23 = f2{sc4.z, sc4.w}; xsh01 = f2{sh4.x, sh4.y}; xsh23 = f2{sh4.z, sh4.w};
     }
+    constexpr int OOB = (int)0x80000000;
+    const unsigned x_img_bytes = (unsigned)p.H * W * p.K * 4u, g_img_bytes = (unsigned)p.H * W * p.N * 4u;
 #define SED_WW2_META(i)                                                                                         \
     const int xpx##i = (tid + 256 * i) >> 3;                                                                    \
     const bool xit##i = xpx##i < XPIX;                                                                          \
@@ -459,30 +574,33 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino2_kernel(WWino2P p) {
     const int gpx##i = (tid + 256 * i) >> 4;                                                                    \
     const int gr##i = gpx##i / GW, gc##i = gpx##i % GW;                                                         \
     const int gls##i = gpx##i * 64 + ((gch * 4) ^ (32 * ((gc##i >> 1) & 1)));                                   \
-    const int xoff##i = (xr##i * W + xc##i) * p.K + ci0 + xch * 4;                                              \
-    const int goff##i = (gr##i * W + gc##i) * p.N + co0 + gch * 4;                                              \
+    const int xoffb##i = xit##i ? ((xr##i * W + xc##i) * p.K + ci0 + xch * 4) * 4 : OOB;                        \
+    const int xe0##i = xc##i == 0 ? OOB : 0, xe1##i = xc##i == CW - 1 ? OOB : 0;   /* halo columns of the patch */ \
+    const int goffb##i = ((gr##i * W + gc##i) * p.N + co0 + gch * 4) * 4;                                       \
     float4 xreg##i = make_float4(0.f, 0.f, 0.f, 0.f), greg##i = xreg##i;                                        \
-    bool xv##i = false, gv##i = false;
+    bool xv##i = false;
     SED_WW2_META(0) SED_WW2_META(1) SED_WW2_META(2) SED_WW2_META(3)
 #undef SED_WW2_META
-    const float* x_safe = p.x + ci0 + xch * 4;
-    const float* g_safe = p.gy + co0 + gch * 4;
 
 #define SED_WW2_LOAD(i)                                                                                         \
     {                                                                                                           \
-        const int h = h0 + xr##i, w = w0 + xc##i;                                                               \
-        xv##i = live && xit##i && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)W;                     \
-        xreg##i = *reinterpret_cast<const float4*>(xv##i ? x_unit + xoff##i : x_safe);                         \
-        const int hg = h0 + 1 + gr##i;                                                                          \
-        gv##i = live && hg < p.H;                                                                               \
-        greg##i = *reinterpret_cast<const float4*>(gv##i ? g_unit + goff##i : g_safe);                         \
+        const int vo = (xu + xoffb##i) | (xe0##i & mfirst) | (xe1##i & mlast);                                  \
+        if (INT) xv##i = (unsigned)vo < x_img_bytes;                                                            \
+        xreg##i = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, 0, 0));             \
+        greg##i = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(grs, gu + goffb##i, 0, 0));  \
     }
 #define ww2_load(LIVE)                                                                                          \
     {                                                                                                           \
         const bool live = (LIVE);                                                                               \
         const int h0 = 2 * rg * RPK - 1, w0 = 2 * sg * TCK - 1;                                                 \
-        const float* x_unit = p.x + (((long)b * p.H + h0) * W + w0) * p.K;          /* uniform; only valid offsets used */ \
-        const float* g_unit = p.gy + (((long)b * p.H + h0 + 1) * W + w0 + 1) * p.N;                             \
+        const int bb = b < p.B ? b : p.B - 1;                                                                   \
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(                                   \
+            const_cast<float*>(p.x) + (long)bb * p.H * W * p.K, 0, (int)x_img_bytes, 0x00020000);               \
+        const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(                                   \
+            const_cast<float*>(p.gy) + (long)bb * p.H * W * p.N, 0, (int)g_img_bytes, 0x00020000);              \
+        const int xu = live ? (h0 * W + w0) * p.K * 4 : OOB;            /* unit origin within the image, bytes */ \
+        const int gu = live ? ((h0 + 1) * W + w0 + 1) * p.N * 4 : OOB;                                          \
+        const int mfirst = sg == 0 ? -1 : 0, mlast = sg == p.nsg - 1 ? -1 : 0;                                  \
         SED_WW2_LOAD(0) SED_WW2_LOAD(1) SED_WW2_LOAD(2) SED_WW2_LOAD(3)                                         \
         if (++sg == p.nsg) { sg = 0; if (++rg == p.nrg) { rg = 0; ++b; } }                                      \
     }
@@ -490,15 +608,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino2_kernel(WWino2P p) {
 #define SED_WW2_STORE(BUF, i)                                                                                   \
     {                                                                                                           \
         SED_WW2_PIN(greg##i) SED_WW2_PIN(xreg##i)                                                               \
-        float4 g = greg##i, v = xreg##i;                                                                        \
-        g.x = gv##i ? g.x : 0.f; g.y = gv##i ? g.y : 0.f; g.z = gv##i ? g.z : 0.f; g.w = gv##i ? g.w : 0.f;     \
+        float4 v = xreg##i;                                                                                     \
         if (INT) {                                                                                              \
-            v.x = bn_relu(v.x, xsc.x, xsh.x); v.y = bn_relu(v.y, xsc.y, xsh.y);                                 \
-            v.z = bn_relu(v.z, xsc.z, xsh.z); v.w = bn_relu(v.w, xsc.w, xsh.w);                                 \
+            f2 v01 = f2{v.x, v.y} * xsc01 + xsh01, v23 = f2{v.z, v.w} * xsc23 + xsh23;                          \
+            v01 = __builtin_elementwise_max(v01, f2{0.f, 0.f}); v23 = __builtin_elementwise_max(v23, f2{0.f, 0.f}); \
+            v.x = xv##i ? v01.x : 0.f; v.y = xv##i ? v01.y : 0.f; v.z = xv##i ? v23.x : 0.f; v.w = xv##i ? v23.y : 0.f; \
         }                                                                                                       \
-        v.x = xv##i ? v.x : 0.f; v.y = xv##i ? v.y : 0.f; v.z = xv##i ? v.z : 0.f; v.w = xv##i ? v.w : 0.f;     \
-        *reinterpret_cast<float4*>(&Gs[(BUF)][gls##i]) = g;                                                     \
-        if (xit##i) *reinterpret_cast<float4*>(&Xs[(BUF)][xls##i]) = v;                                         \
+        *reinterpret_cast<float4*>(&Gs[(BUF)][gls##i]) = greg##i;                                               \
+        if (xit##i) *reinterpret_cast<float4*>(&Xs[(BUF)][xls##i]) = v;                                        \
     }
 #define ww2_store(BUF) { SED_WW2_STORE(BUF, 0) SED_WW2_STORE(BUF, 1) SED_WW2_STORE(BUF, 2) SED_WW2_STORE(BUF, 3) }
 
@@ -509,10 +626,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino2_kernel(WWino2P p) {
     // ---- fragment addressing: lane = channel (lane & 31), lane half = second tile of the k pair (next tile column)
     const int half = lane >> 5, cl = lane & 31;
     const int gbase = half * 128 + ((cob * 32 + cl) ^ (32 * half));
-    const int xbase0 = half * 64 + 32 * half + cl;          // patch columns with (jj & 1) ^ (jj >> 1) == 0
-    const int xbase1 = half * 64 + 32 * (1 ^ half) + cl;    // ... == 1
-    // eta half 0: dM rows (d0, d0 + d1), V rows (r0 - r2, r1 + r2); half 1: (d0 - d1, -d1), (r2 - r1, r1 - r3)
-    const float al = eh ? -1.f : 0.f, be = eh ? 0.f : 1.f, ga = eh ? -1.f : 1.f, sgn = eh ? -1.f : 1.f;
+    const int xbase0 = half * 64 + 32 * half + cl;          // patch columns 0 and 3 of a tile
+    const int xbase1 = half * 64 + 32 * (1 ^ half) + cl;    // patch columns 1 and 2
+    // eta half 0: dM rows (d0, d0 + d1), V rows (r0 - r2, r1 + r2); half 1: (d0 - d1, -d1), (r2 - r1, r1 - r3).
+    // All transforms run on float PAIRS (v_pk_*_f32: one VALU instruction per two values): the pairs are the two
+    // horizontal outputs of a tile row (dq) and the patch columns (0,3) / (1,2) as the paired LDS reads deliver them.
+    const f2 al2 = eh ? f2{-1.f, -1.f} : f2{0.f, 0.f}, be2 = eh ? f2{0.f, 0.f} : f2{1.f, 1.f};
+    const f2 ga2 = eh ? f2{-1.f, -1.f} : f2{1.f, 1.f};
     const int ra = (eh ? 2 : 0) * (CW / 2) * 64, rbw = (eh ? 3 : 1) * (CW / 2) * 64, rc = (eh ? 1 : 2) * (CW / 2) * 64;
 
     for (int it = 0; it < nsteps; ++it) {
@@ -524,58 +644,50 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino2_kernel(WWino2P p) {
         const float* Xa0 = &Xs[buf][xbase0 + ra], *Xa1 = &Xs[buf][xbase1 + ra];
         const float* Xq0 = &Xs[buf][xbase0 + rbw], *Xq1 = &Xs[buf][xbase1 + rbw];
         const float* Xc0 = &Xs[buf][xbase0 + rc], *Xc1 = &Xs[buf][xbase1 + rc];
-        // raw LDS values of k pair J: 2x2 output-gradient tile (dq) and the three patch rows this eta half needs
-#define SED_WW2_RAW(J, DQ, XA, XB, XC)                                                                          \
+        // raw LDS values of k pair J: the 2x2 output-gradient tile (rows D0, D1) and the three patch rows this eta
+        // half needs, each as the column pairs (0,3) and (1,2)
+#define SED_WW2_RAW(J, D0, D1, A03, A12, B03, B12, C03, C12)                                                    \
     {                                                                                                           \
         constexpr int rp_k = (2 * (J)) / TCK, tcb = (2 * (J)) % TCK;                                            \
         const float* gp = Gb + ((2 * rp_k) * GW + 2 * tcb) * 64;                                                \
-        DQ[0] = gp[0]; DQ[1] = gp[64]; DQ[2] = gp[GW * 64]; DQ[3] = gp[GW * 64 + 64];                           \
-        _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                      \
-            const bool s1_ = ((jj & 1) ^ (jj >> 1)) != 0;                                                       \
-            const int eo = (rp_k * CW + tcb + (jj >> 1)) * 64;   /* line of patch row 2*rp_k, column 2*tcb+jj */ \
-            XA[jj] = (s1_ ? Xa1 : Xa0)[eo];                                                                     \
-            XB[jj] = (s1_ ? Xq1 : Xq0)[eo];                                                                     \
-            XC[jj] = (s1_ ? Xc1 : Xc0)[eo];                                                                     \
-        }                                                                                                       \
+        D0 = f2{gp[0], gp[64]}; D1 = f2{gp[GW * 64], gp[GW * 64 + 64]};                                         \
+        constexpr int eo = (rp_k * CW + tcb) * 64;          /* line of patch row 2*rp_k, column 2*tcb */         \
+        A03 = f2{Xa0[eo], Xa0[eo + 64]}; A12 = f2{Xa1[eo], Xa1[eo + 64]};                                       \
+        B03 = f2{Xq0[eo], Xq0[eo + 64]}; B12 = f2{Xq1[eo], Xq1[eo + 64]};                                       \
+        C03 = f2{Xc0[eo], Xc0[eo + 64]}; C12 = f2{Xc1[eo], Xc1[eo + 64]};                                       \
     }
-        float dq[4], xa[4], xb[4], xc[4], dqn[4], xan[4], xbn[4], xcn[4];
-        SED_WW2_RAW(0, dq, xa, xb, xc)
+        f2 d0, d1, a03, a12, b03, b12, c03, c12, d0n, d1n, a03n, a12n, b03n, b12n, c03n, c12n;
+        SED_WW2_RAW(0, d0, d1, a03, a12, b03, b12, c03, c12)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             // reads of the NEXT k pair are in flight while this pair's MFMAs run
-            if (j == 0) SED_WW2_RAW(1, dqn, xan, xbn, xcn)
-            if (j == 1) SED_WW2_RAW(2, dqn, xan, xbn, xcn)
-            if (j == 2) SED_WW2_RAW(3, dqn, xan, xbn, xcn)
-            if (j == 3) SED_WW2_RAW(4, dqn, xan, xbn, xcn)
-            if (j == 4) SED_WW2_RAW(5, dqn, xan, xbn, xcn)
-            if (j == 5) SED_WW2_RAW(6, dqn, xan, xbn, xcn)
-            if (j == 6) SED_WW2_RAW(7, dqn, xan, xbn, xcn)
+            if (j == 0) SED_WW2_RAW(1, d0n, d1n, a03n, a12n, b03n, b12n, c03n, c12n)
+            if (j == 1) SED_WW2_RAW(2, d0n, d1n, a03n, a12n, b03n, b12n, c03n, c12n)
+            if (j == 2) SED_WW2_RAW(3, d0n, d1n, a03n, a12n, b03n, b12n, c03n, c12n)
+            if (j == 3) SED_WW2_RAW(4, d0n, d1n, a03n, a12n, b03n, b12n, c03n, c12n)
+            if (j == 4) SED_WW2_RAW(5, d0n, d1n, a03n, a12n, b03n, b12n, c03n, c12n)
+            if (j == 5) SED_WW2_RAW(6, d0n, d1n, a03n, a12n, b03n, b12n, c03n, c12n)
+            if (j == 6) SED_WW2_RAW(7, d0n, d1n, a03n, a12n, b03n, b12n, c03n, c12n)
             __builtin_amdgcn_sched_barrier(0);
-            // output-gradient tile -> this wave's two eta rows of dM, then the four xi columns
-            const float ea0 = fmaf(al, dq[2], dq[0]), ea1 = fmaf(al, dq[3], dq[1]);
-            const float eb0 = fmaf(ga, dq[2], be * dq[0]), eb1 = fmaf(ga, dq[3], be * dq[1]);
-            // input patch -> this wave's two eta rows of V
-            float ca[4], cb[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                ca[jj] = xa[jj] - xc[jj];
-                cb[jj] = fmaf(sgn, xb[jj], xc[jj]);
-            }
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ea0, ca[0] - ca[2], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ea0 + ea1, ca[1] + ca[2], acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(ea0 - ea1, ca[2] - ca[1], acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(-ea1, ca[1] - ca[3], acc[3], 0, 0, 0);
-            acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(eb0, cb[0] - cb[2], acc[4], 0, 0, 0);
-            acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(eb0 + eb1, cb[1] + cb[2], acc[5], 0, 0, 0);
-            acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(eb0 - eb1, cb[2] - cb[1], acc[6], 0, 0, 0);
-            acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(-eb1, cb[1] - cb[3], acc[7], 0, 0, 0);
+            // dM: eta rows ea = d0 + al*d1, eb = be*d0 + ga*d1 (pairs over the two tile columns q), then the xi columns
+            // (e.x, e.x + e.y, e.x - e.y, -e.y); the sign of the last one is moved into the V operand.
+            // V: eta rows ca = ra - rc, cb = rc +- rb; xi columns (c0 - c2, c1 + c2, c2 - c1, c3 - c1).
+            f2 ea, eb, ma, mb, va03, va12, vb03, vb12;
+            wgrad_wino2_transforms(d0, d1, a03, a12, b03, b12, c03, c12, al2, be2, ga2, ea, eb, ma, mb, va03, va12, vb03, vb12);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ea.x, va03.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ma.x, va12.x, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(ma.y, va12.y, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(ea.y, va03.y, acc[3], 0, 0, 0);
+            acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(eb.x, vb03.x, acc[4], 0, 0, 0);
+            acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(mb.x, vb12.x, acc[5], 0, 0, 0);
+            acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(mb.y, vb12.y, acc[6], 0, 0, 0);
+            acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(eb.y, vb03.y, acc[7], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (j == 5) {
                 ww2_store(buf ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) { dq[jj] = dqn[jj]; xa[jj] = xan[jj]; xb[jj] = xbn[jj]; xc[jj] = xcn[jj]; }
+            d0 = d0n; d1 = d1n; a03 = a03n; a12 = a12n; b03 = b03n; b12 = b12n; c03 = c03n; c12 = c12n;
         }
 #undef SED_WW2_RAW
         __builtin_amdgcn_s_setprio(0);
@@ -694,7 +806,9 @@ SED_API int sed_conv3x3_wgrad_wino2(const float* x, const float* gy, float* dw_o
                                     int Cin, int Cout, const float* in_scale, const float* in_shift, hipStream_t stream) {
     int nrg, nsg, ns, ups;
     long U;
-    if (!wwino2_geometry(B, H, W, Cin, Cout, &nrg, &nsg, &U) || (long)B * H * W >= (1L << 31)) return SED_EINVAL;
+    if (!wwino2_geometry(B, H, W, Cin, Cout, &nrg, &nsg, &U) || (long)B * H * W >= (1L << 31) ||
+        (long)H * W * (Cin > Cout ? Cin : Cout) * 4 >= (1L << 31))      // one image must fit a 31-bit buffer-descriptor range
+        return SED_EINVAL;
     sed_wgrad_wino2_partial_floats(B, H, W, Cin, Cout, &ns, &ups);
     WWino2P p{x, gy, partial, in_scale, in_shift, B, H, W, Cin, Cout, nrg, nsg, U, ups, (Cout / 64) * (Cin / 32)};
     dim3 grid((unsigned)((long)p.ids_per_slice * ns)), block(256);
