@@ -301,75 +301,123 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2P p) {
 
     // ---- epilogue.  z[e][q] = column inverse transform of this wave's two eta rows; the wave keeps
     // mine[q] = +-(z[0][q] + z[1][q]) and hands z[1] (half 0) / z[0] (half 1) to its partner wave through LDS
-    // (the staging buffers are free after the loop's last barrier).
+    // (the staging buffers are free after the loop's last barrier).  Kept lean on the vector unit (float pairs over
+    // adjacent accumulator rows, buffer-descriptor addressing with out-of-range rows dropped by the hardware): for the
+    // 64-channel layers the K loop is only 8 steps long and the epilogue is a third of the workgroup's instructions.
     float* xch = smem;                                 // [4 waves][32][64 lanes]
-    float mine[32];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float z00 = acc[0][r] + acc[1][r] + acc[2][r], z01 = acc[1][r] - acc[2][r] - acc[3][r];
-        float z10 = acc[4][r] + acc[5][r] + acc[6][r], z11 = acc[5][r] - acc[6][r] - acc[7][r];
-        float g0 = eh ? z00 : z10, g1 = eh ? z01 : z11;
-        xch[(wvu * 32 + 2 * r) * 64 + lane] = g0;
-        xch[(wvu * 32 + 2 * r + 1) * 64 + lane] = g1;
-        mine[2 * r] = eh ? -(z00 + z10) : (z00 + z10);
-        mine[2 * r + 1] = eh ? -(z01 + z11) : (z01 + z11);
-    }
     const int half = lane >> 5;
     const int col = n0 + (lane & 31);
-    float s1 = 0.f, s2 = 0.f, cnt = 0.f;
+    f2 mine[16];                                       // [row pair rp][q]: accumulator rows 2rp, 2rp+1
+#define SED_AP(a) f2{acc[a][2 * rp], acc[a][2 * rp + 1]}
+#define SED_GIVE(G0, G1)                                                                                        \
+    xch[(wvu * 32 + 4 * rp + 0) * 64 + lane] = G0.x; xch[(wvu * 32 + 4 * rp + 1) * 64 + lane] = G1.x;           \
+    xch[(wvu * 32 + 4 * rp + 2) * 64 + lane] = G0.y; xch[(wvu * 32 + 4 * rp + 3) * 64 + lane] = G1.y;
+    if (eh) {
+#pragma unroll
+        for (int rp = 0; rp < 8; ++rp) {
+            const f2 z00 = SED_AP(0) + SED_AP(1) + SED_AP(2), z01 = SED_AP(1) - SED_AP(2) - SED_AP(3);
+            const f2 z10 = SED_AP(4) + SED_AP(5) + SED_AP(6), z11 = SED_AP(5) - SED_AP(6) - SED_AP(7);
+            SED_GIVE(z00, z01)
+            mine[2 * rp] = -z00 - z10; mine[2 * rp + 1] = -z01 - z11;
+        }
+    } else {
+#pragma unroll
+        for (int rp = 0; rp < 8; ++rp) {
+            const f2 z00 = SED_AP(0) + SED_AP(1) + SED_AP(2), z01 = SED_AP(1) - SED_AP(2) - SED_AP(3);
+            const f2 z10 = SED_AP(4) + SED_AP(5) + SED_AP(6), z11 = SED_AP(5) - SED_AP(6) - SED_AP(7);
+            SED_GIVE(z10, z11)
+            mine[2 * rp] = z00 + z10; mine[2 * rp + 1] = z01 + z11;
+        }
+    }
+#undef SED_AP
+#undef SED_GIVE
+    // byte offset (within the image) of output pixel (2*th+eh, 2*tw) of block tile tl, channel col:
+    //   pixel = (2*th0+eh)*W + 2*(tl + (tl & ~(TW-1)));  rows past the image land beyond num_records
+    const unsigned y_img_bytes = (unsigned)p.H * W * p.N * 4u;
+    const __amdgpu_buffer_rsrc_t yrs =
+        __builtin_amdgcn_make_buffer_rsrc(p.y + (long)b * p.H * W * p.N, 0, (int)y_img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(EPI == 2 ? p.yprev + (long)b * p.H * W * p.N : p.x), 0, (int)y_img_bytes, 0x00020000);
+    const int n4 = p.N * 4;
+    const unsigned n8 = (unsigned)p.N * 8u;
+    const int t0 = tb * 32 + 4 * half;
+    const unsigned lane_off = (unsigned)(((2 * th0 + eh) * W * p.N + col) * 4);
+    unsigned yoff[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned tl = (unsigned)(t0 + (r & 3) + 8 * (r >> 2));
+        yoff[r] = __umul24(tl + (tl & ~(unsigned)(TW - 1)), n8) + lane_off;
+    }
+    float s1 = 0.f, s2 = 0.f;
+    f2 s1p = {0.f, 0.f}, s2p = {0.f, 0.f};
     float e_sc = 0.f, e_sh = 0.f, e_mu = 0.f, e_is = 0.f;
-    float yp[EPI == 2 ? 32 : 1];
-    if (EPI == 2) {                                    // previous-layer activations: loads overlap the LDS exchange
+    // everything below works on pairs over the accumulator rows (2rp, 2rp+1), separately for q = 0 and q = 1
+    f2 yp0[EPI == 2 ? 8 : 1], yp1[EPI == 2 ? 8 : 1];   // previous-layer activations
+    if (EPI == 2) {                                    // ... their loads overlap the LDS exchange
         e_sc = p.p_scale[col]; e_sh = p.p_shift[col]; e_mu = p.p_mean[col]; e_is = p.p_invstd[col];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int tl = tb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int h = 2 * (th0 + (tl >> logTW)) + eh;
-            const long pix = ((long)b * p.H + (h < p.H ? h : 0)) * W + 2 * (tl & (TW - 1));
-            yp[2 * r] = p.yprev[pix * p.N + col];
-            yp[2 * r + 1] = p.yprev[(pix + 1) * p.N + col];
+        for (int rp = 0; rp < 8; ++rp) {
+            yp0[EPI == 2 ? rp : 0] = f2{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, (int)yoff[2 * rp], 0, 0)),
+                                        __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, (int)yoff[2 * rp + 1], 0, 0))};
+            yp1[EPI == 2 ? rp : 0] = f2{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, (int)yoff[2 * rp], n4, 0)),
+                                        __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, (int)yoff[2 * rp + 1], n4, 0))};
         }
     }
     __syncthreads();
+    const float* rx = xch + ((wvu ^ 1) * 32) * 64 + lane;
+    f2 yq0[8], yq1[8];                                 // outputs
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int tl = tb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int h = 2 * (th0 + (tl >> logTW)) + eh;
-        const bool ok = h < p.H;
-        const long pix = ((long)b * p.H + h) * W + 2 * (tl & (TW - 1));
-        float y0 = mine[2 * r] + xch[((wvu ^ 1) * 32 + 2 * r) * 64 + lane];
-        float y1 = mine[2 * r + 1] + xch[((wvu ^ 1) * 32 + 2 * r + 1) * 64 + lane];
-        if (EPI == 2 && ok) {
-            float a0 = yp[(EPI == 2 ? 2 * r : 0)], a1 = yp[(EPI == 2 ? 2 * r + 1 : 0)];
-            y0 = bn_relu_active(a0, e_sc, e_sh) ? y0 : 0.f;
-            y1 = bn_relu_active(a1, e_sc, e_sh) ? y1 : 0.f;
-            s1 += y0 + y1;
-            s2 = fmaf(y0, (a0 - e_mu) * e_is, s2);
-            s2 = fmaf(y1, (a1 - e_mu) * e_is, s2);
-        }
-        if (ok) {
-            p.y[pix * p.N + col] = y0;
-            p.y[(pix + 1) * p.N + col] = y1;
-            if (EPI == 1) { s1 += y0 + y1; cnt += 2.f; }
-        }
-        mine[2 * r] = y0; mine[2 * r + 1] = y1;
-    }
-    if (EPI == 1) {
-        s1 += __shfl_xor(s1, 32, 64);
-        cnt += __shfl_xor(cnt, 32, 64);
-        const float mean = cnt > 0.f ? s1 / cnt : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int tl = tb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (2 * (th0 + (tl >> logTW)) + eh < p.H) {
-                float da = mine[2 * r] - mean, db = mine[2 * r + 1] - mean;
-                s2 = fmaf(da, da, s2);
-                s2 = fmaf(db, db, s2);
+    for (int rp = 0; rp < 8; ++rp) {
+        f2 y0 = mine[2 * rp] + f2{rx[(4 * rp + 0) * 64], rx[(4 * rp + 2) * 64]};      // q = 0 of rows 2rp, 2rp+1
+        f2 y1 = mine[2 * rp + 1] + f2{rx[(4 * rp + 1) * 64], rx[(4 * rp + 3) * 64]};  // q = 1
+        if (EPI == 1 || EPI == 2) {
+            const bool oka = yoff[2 * rp] < y_img_bytes, okb = yoff[2 * rp + 1] < y_img_bytes;
+            if (EPI == 2) {
+                const f2 a0 = yp0[EPI == 2 ? rp : 0], a1 = yp1[EPI == 2 ? rp : 0];
+                const f2 t0_ = a0 * f2{e_sc, e_sc} + f2{e_sh, e_sh}, t1_ = a1 * f2{e_sc, e_sc} + f2{e_sh, e_sh};
+                y0.x = (oka && t0_.x > 0.f) ? y0.x : 0.f; y0.y = (okb && t0_.y > 0.f) ? y0.y : 0.f;
+                y1.x = (oka && t1_.x > 0.f) ? y1.x : 0.f; y1.y = (okb && t1_.y > 0.f) ? y1.y : 0.f;
+                s2p = y0 * ((a0 - f2{e_mu, e_mu}) * f2{e_is, e_is}) + s2p;
+                s2p = y1 * ((a1 - f2{e_mu, e_mu}) * f2{e_is, e_is}) + s2p;
+            } else {
+                y0.x = oka ? y0.x : 0.f; y0.y = okb ? y0.y : 0.f;
+                y1.x = oka ? y1.x : 0.f; y1.y = okb ? y1.y : 0.f;
             }
+            s1p += y0 + y1;
         }
+        yq0[rp] = y0; yq1[rp] = y1;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y0.x), yrs, (int)yoff[2 * rp], 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y1.x), yrs, (int)yoff[2 * rp], n4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y0.y), yrs, (int)yoff[2 * rp + 1], 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y1.y), yrs, (int)yoff[2 * rp + 1], n4, 0);
+    }
+    float cnt = 0.f;
+    if (EPI == 1) {
+        // valid pixels of this wave's 32 tiles (scalar): row pairs th < ceil((H - eh) / 2)
+        const int rp_cnt = TW >= 32 ? 1 : (32 >> logTW), per_rp = TW >= 32 ? 32 : TW;
+        int nv = (p.H - eh + 1) / 2 - (th0 + ((tb * 32) >> logTW));
+        nv = nv < 0 ? 0 : (nv > rp_cnt ? rp_cnt : nv);
+        cnt = (float)(2 * nv * per_rp);
+        s1 = s1p.x + s1p.y;
+        s1 += __shfl_xor(s1, 32, 64);
+        const float mean = cnt > 0.f ? s1 / cnt : 0.f;
+        const f2 mean2 = {mean, mean};
+#pragma unroll
+        for (int rp = 0; rp < 8; ++rp) {
+            const bool oka = yoff[2 * rp] < y_img_bytes, okb = yoff[2 * rp + 1] < y_img_bytes;
+            f2 d0 = yq0[rp] - mean2, d1 = yq1[rp] - mean2;
+            d0.x = oka ? d0.x : 0.f; d0.y = okb ? d0.y : 0.f;
+            d1.x = oka ? d1.x : 0.f; d1.y = okb ? d1.y : 0.f;
+            s2p = d0 * d0 + s2p;
+            s2p = d1 * d1 + s2p;
+        }
+        s2 = s2p.x + s2p.y;
         s2 += __shfl_xor(s2, 32, 64);
     }
-    if (EPI == 2) { s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64); }
+    if (EPI == 2) {
+        s1 = s1p.x + s1p.y; s2 = s2p.x + s2p.y;
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+    }
     if ((EPI == 1 || EPI == 2) && half == 0) {
         const long part = (long)tblk * 4 + wvu;
         p.partials[(part * 2 + 0) * p.N + col] = s1;
@@ -455,7 +503,7 @@ SED_API int sed_conv3x3_wino2(const float* x, const float* w_wino2, float* y, in
     int lw, rp, nrb, s;
     if (B <= 0 || !sed_conv3x3_wino2_supported(H, W, Cin, Cout) || !wino2_geometry(H, W, &lw, &rp, &nrb, &s) ||
         (long)B * H * W >= (1L << 31) || (long)B * nrb * (Cout / 32) >= (1L << 31) ||
-        (long)H * W * Cin * 4 >= (1L << 31))           // one image must fit a 31-bit buffer-descriptor range
+        (long)H * W * (Cin > Cout ? Cin : Cout) * 4 >= (1L << 31))   // one image must fit a 31-bit buffer-descriptor range
         return SED_EINVAL;
     Wino2P p{x, w_wino2, y, in_scale, in_shift, partials, yprev, p_scale, p_shift, p_mean, p_invstd,
              B, H, W, Cin, Cout, lw, rp, nrb, s, (long)B * nrb * 4};
