@@ -571,8 +571,12 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 // backward of the Cin=1 conv: one pass over gy produces (i) per-block dW partials [nblk][9][64] and
 // (ii) t[p][tap] = <gy[p][:], w[:, tap]> (the scatter form of dgrad); conv1_dgrad_gather then sums 9 neighbours.
 constexpr int C1B_ROWS = 1024;
+// AFF: gy is the masked dgrad output dz of the NEXT conv and the BatchNorm backward g = a*dz + b*y + c (coef [3][64])
+// is applied on load, which saves the separate sed_bn_bwd_apply pass over the two largest tensors of the model.
+template <bool AFF>
 __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict__ x0, const float* __restrict__ w,
-                                                        const float* __restrict__ gy, long M, int H, int W,
+                                                        const float* __restrict__ gy, const float* __restrict__ yraw,
+                                                        const float* __restrict__ coef, long M, int H, int W,
                                                         float* __restrict__ dw_partials, float* __restrict__ tbuf) {
     __shared__ float red[16][9 * 64 + 4];
     const int c4 = threadIdx.x & 15, pl = threadIdx.x >> 4;
@@ -586,11 +590,21 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int k = 0; k < 4; ++k) dw[t][k] = 0.f;
+    float4 ca = make_float4(0.f, 0.f, 0.f, 0.f), cb = ca, cc = ca;
+    if (AFF) {
+        ca = reinterpret_cast<const float4*>(coef)[c4]; cb = reinterpret_cast<const float4*>(coef)[16 + c4];
+        cc = reinterpret_cast<const float4*>(coef)[32 + c4];
+    }
     const long base = (long)blockIdx.x * C1B_ROWS;
     const long nrows = min((long)C1B_ROWS, M - base);
     for (int r = pl; r < nrows; r += 16) {
         long pm = base + r;
         float4 g = reinterpret_cast<const float4*>(gy)[pm * 16 + c4];
+        if (AFF) {
+            const float4 v = reinterpret_cast<const float4*>(yraw)[pm * 16 + c4];
+            g.x = fmaf(ca.x, g.x, fmaf(cb.x, v.x, cc.x)); g.y = fmaf(ca.y, g.y, fmaf(cb.y, v.y, cc.y));
+            g.z = fmaf(ca.z, g.z, fmaf(cb.z, v.z, cc.z)); g.w = fmaf(ca.w, g.w, fmaf(cb.w, v.w, cc.w));
+        }
         float xs[9];
         c1_taps(x0, pm, H, W, xs);
         float tp[9];
@@ -830,13 +844,19 @@ SED_API int sed_conv1_rows_per_part(void) { return C1_ROWS; }
 
 // backward of conv_block1.conv1: dw [64][1][3][3]; gx0 [M] (nullable: skip the input gradient).
 // scratch: dw_partials ceil(M/1024)*576 floats; tbuf M*9 floats (only if gx0).
-SED_API int sed_conv1_bwd(const float* x0, const float* w_oihw, const float* gy, int B, int H, int W, float* dw,
-                          float* gx0, float* dw_partials, float* tbuf, hipStream_t stream) {
+// bn_y / bn_coef (both or neither): gy is then the masked dgrad output dz and g = a*dz + b*bn_y + c is formed on load
+// (coef [3][64] from sed_bn_bwd_finalize), replacing a sed_bn_bwd_apply pass.
+SED_API int sed_conv1_bwd(const float* x0, const float* w_oihw, const float* gy, const float* bn_y, const float* bn_coef,
+                          int B, int H, int W, float* dw, float* gx0, float* dw_partials, float* tbuf, hipStream_t stream) {
     long M = (long)B * H * W;
-    if (M <= 0 || M >= (1L << 31) / 9) return SED_EINVAL;
+    if (M <= 0 || M >= (1L << 31) / 9 || ((bn_y == nullptr) != (bn_coef == nullptr))) return SED_EINVAL;
     int nblk = sed_cdiv(M, C1B_ROWS);
-    hipLaunchKernelGGL(conv1_bwd_kernel, dim3(nblk), dim3(256), 0, stream, x0, w_oihw, gy, M, H, W, dw_partials,
-                       gx0 ? tbuf : (float*)nullptr);
+    if (bn_coef)
+        hipLaunchKernelGGL(conv1_bwd_kernel<true>, dim3(nblk), dim3(256), 0, stream, x0, w_oihw, gy, bn_y, bn_coef, M, H, W,
+                           dw_partials, gx0 ? tbuf : (float*)nullptr);
+    else
+        hipLaunchKernelGGL(conv1_bwd_kernel<false>, dim3(nblk), dim3(256), 0, stream, x0, w_oihw, gy, bn_y, bn_coef, M, H, W,
+                           dw_partials, gx0 ? tbuf : (float*)nullptr);
     hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(9), dim3(1024), 0, stream, dw_partials, nblk, dw);
     if (gx0) {
         int g = sed_cdiv(M, 256);

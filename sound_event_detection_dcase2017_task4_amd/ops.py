@@ -450,17 +450,19 @@ class ConvBlockFn(torch.autograd.Function):
         gy1 = _conv_fwd_like(gy2, w2, B, H, W, Cout, Cout, dgrad=True, epi=2, partials=partb, yprev=y1, p_st=st1)
         del gy2
         dg1, db1, coef1 = bn_bwd_finalize(partb, npb, M, st1, batch_stats=ctx.training)
-        _call("sed_bn_bwd_apply", _ptr(gy1), _ptr(y1), M, Cout, _ptr(coef1), _stream())
         # conv1
         gx = None
-        if Cin == 1:
+        if Cin != 1:
+            _call("sed_bn_bwd_apply", _ptr(gy1), _ptr(y1), M, Cout, _ptr(coef1), _stream())
+        if Cin == 1:                                   # BN1 backward g = a*dz + b*y1 + c is applied on load by the kernel
             nblk = (M + 1023) // 1024
             dwp = torch.empty((nblk, 576), dtype=torch.float32, device=dev)
             dw1 = torch.empty((Cout, 1, 3, 3), dtype=torch.float32, device=dev)
             want_gx = ctx.needs_input_grad[0]
             tbuf = torch.empty((M, 9), dtype=torch.float32, device=dev) if want_gx else None
             gx = torch.empty((B, H, W, 1), dtype=torch.float32, device=dev) if want_gx else None
-            _call("sed_conv1_bwd", _ptr(x), _ptr(w1), _ptr(gy1), B, H, W, _ptr(dw1), _ptr(gx), _ptr(dwp), _ptr(tbuf), _stream())
+            _call("sed_conv1_bwd", _ptr(x), _ptr(w1), _ptr(gy1), _ptr(y1), _ptr(coef1), B, H, W, _ptr(dw1), _ptr(gx), _ptr(dwp),
+                  _ptr(tbuf), _stream())
         else:
             dw1 = _wgrad(x, gy1, B, H, W, Cin, Cout)
             if ctx.needs_input_grad[0]:

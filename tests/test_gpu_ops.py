@@ -101,10 +101,21 @@ def test_conv1_direct_fwd_bwd(ops):
     assert rel(st.invstd.cpu(), 1 / torch.sqrt(y_ref.var(dim=(0, 2, 3), unbiased=False) + 1e-5)) < 1e-5
     dw = torch.empty((64, 1, 3, 3), device="cuda"); gx = torch.empty((B, H, W, 1), device="cuda")
     dwp = torch.empty(((M + 1023) // 1024, 576), device="cuda"); tb = torch.empty((M, 9), device="cuda")
-    ops._call("sed_conv1_bwd", ops._ptr(xd), ops._ptr(wdev), ops._ptr(gyd), B, H, W, ops._ptr(dw), ops._ptr(gx),
+    ops._call("sed_conv1_bwd", ops._ptr(xd), ops._ptr(wdev), ops._ptr(gyd), None, None, B, H, W, ops._ptr(dw), ops._ptr(gx),
               ops._ptr(dwp), ops._ptr(tb), ops._stream())
     assert rel(dw.cpu(), wr.grad) < 1e-5
     assert rel(nchw(gx), xr.grad) < 1e-5
+    # fused BatchNorm-backward apply: gy = a*dz + b*yraw + c formed on load must equal the two-pass result
+    g = torch.Generator().manual_seed(77)
+    dz = torch.randn(B, H, W, 64, generator=g).cuda(); yraw = torch.randn(B, H, W, 64, generator=g).cuda()
+    coef = torch.randn(3, 64, generator=g).cuda()
+    gfull = (coef[0] * dz + coef[1] * yraw + coef[2]).contiguous()
+    dw2 = torch.empty_like(dw); gx2 = torch.empty_like(gx); dw3 = torch.empty_like(dw); gx3 = torch.empty_like(gx)
+    ops._call("sed_conv1_bwd", ops._ptr(xd), ops._ptr(wdev), ops._ptr(gfull), None, None, B, H, W, ops._ptr(dw2), ops._ptr(gx2),
+              ops._ptr(dwp), ops._ptr(tb), ops._stream())
+    ops._call("sed_conv1_bwd", ops._ptr(xd), ops._ptr(wdev), ops._ptr(dz), ops._ptr(yraw), ops._ptr(coef), B, H, W,
+              ops._ptr(dw3), ops._ptr(gx3), ops._ptr(dwp), ops._ptr(tb), ops._stream())
+    assert rel(dw3.cpu(), dw2.cpu()) < 1e-5 and rel(gx3.cpu(), gx2.cpu()) < 1e-5
 
 
 @pytest.mark.parametrize("Cin,Cout,H,W,ph,pw,training", [(1, 64, 21, 64, 2, 2, True), (64, 128, 11, 32, 2, 2, True),
