@@ -192,7 +192,11 @@ def main():
         frontend = {"kernel": "logmel_kernel (STFT+mel+log, K1)", "bound": "hbm", "achieved": round(gbps, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None,
                     "avg_launch_ms": round(ms / len(fe), 4),
-                    "bytes_per_waveform": int(fe[0][2] / B2)}
+                    "bytes_per_waveform": int(fe[0][2] / B2),
+                    # ~34 kflop per frame (FFT 25.6k + unpack/power 6.5k + window/mel 2k), 1001 frames at 10 s: the
+                    # kernel is bound by the fp32 vector unit (22 flop/B), see DESIGN.md section 5
+                    "valu_tflops": round(B2 * len(fe) * (args.seconds * 100 + 1) * 34.1e3 / (ms * 1e-3) / 1e12, 2),
+                    "valu_peak_tflops": 78.6}
     if args.by_shape:
         for tag, v in sorted(summarise(timing).items()):
             print("# %-62s %3d launches  %8.3f ms/launch  %6.1f TFLOP/s" % (tag, v["launches"], v["avg_ms"], v["tflops"]),

@@ -544,20 +544,19 @@ struct WWino2P {
     int units_per_slice, ids_per_slice;
 };
 
-// The 13 packed-fp32 instructions that turn the raw LDS values of one k pair into the 8 + 8 MFMA operands of an eta half.
-// Written as ONE asm block because hipcc scalarises most v2f32 expressions with swizzles (28 VALU instead of 13), and on
+// The 12 packed-fp32 instructions that turn the raw LDS values of one k pair into the 8 + 8 MFMA operands of an eta half.
+// Written as ONE asm block because hipcc scalarises most v2f32 expressions with swizzles (28 VALU instead of 12), and on
 // this chip every VALU instruction issued costs MFMA time (measured: kernel time ~ 64*MFMAs + 4*VALUs cycles per SIMD).
 // The trailing s_nop covers the VALU-write -> MFMA-read wait states the compiler cannot see through the asm.
 __device__ __forceinline__ void wgrad_wino2_transforms(f2 d0, f2 d1, f2 a03, f2 a12, f2 b03, f2 b12, f2 c03, f2 c12, f2 al,
                                                        f2 be, f2 ga, f2& ea, f2& eb, f2& ma, f2& mb, f2& va03, f2& va12,
                                                        f2& vb03, f2& vb12) {
     asm("v_pk_fma_f32 %0, %16, %9, %8\n\t"                                                  // ea = al*d1 + d0
-        "v_pk_mul_f32 %1, %17, %8\n\t"                                                      // eb = be*d0
-        "v_pk_fma_f32 %1, %18, %9, %1\n\t"                                                  //    + ga*d1
+        "v_pk_fma_f32 %1, %17, %8, %9\n\t"                                                  // eb = be*d0 + d1 (sign of half 1 moved into cb)
         "v_pk_add_f32 %4, %10, %14 neg_lo:[0,1] neg_hi:[0,1]\n\t"                           // ca03 = a03 - c03
         "v_pk_add_f32 %5, %11, %15 neg_lo:[0,1] neg_hi:[0,1]\n\t"                           // ca12 = a12 - c12
-        "v_pk_fma_f32 %6, %18, %12, %14\n\t"                                                // cb03 = ga*b03 + c03
-        "v_pk_fma_f32 %7, %18, %13, %15\n\t"                                                // cb12 = ga*b12 + c12
+        "v_pk_fma_f32 %6, %18, %14, %12\n\t"                                                // cb03 = ga*c03 + b03
+        "v_pk_fma_f32 %7, %18, %15, %13\n\t"                                                // cb12 = ga*c12 + b12
         "v_pk_add_f32 %2, %0, %0 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"             // ma = (ea.x+ea.y, ea.x-ea.y)
         "v_pk_add_f32 %3, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"             // mb
         "v_pk_add_f32 %4, %4, %5 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" // va03 = (c0-c2, c3-c1)
@@ -679,7 +678,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino2_kernel(WWino2P p) {
     const int gbase = half * 128 + ((cob * 32 + cl) ^ (32 * half));
     const int xbase0 = half * 64 + 32 * half + cl;          // patch columns 0 and 3 of a tile
     const int xbase1 = half * 64 + 32 * (1 ^ half) + cl;    // patch columns 1 and 2
-    // eta half 0: dM rows (d0, d0 + d1), V rows (r0 - r2, r1 + r2); half 1: (d0 - d1, -d1), (r2 - r1, r1 - r3).
+    // eta half 0: dM rows (d0, d0 + d1), V rows (r0 - r2, r1 + r2); half 1: (d0 - d1, +d1), (r2 - r1, r3 - r1)
+    // (the -d1 * (r1 - r3) product of the fourth eta row is carried as (+d1) * (r3 - r1): one instruction less).
     // All transforms run on float PAIRS (v_pk_*_f32: one VALU instruction per two values): the pairs are the two
     // horizontal outputs of a tile row (dq) and the patch columns (0,3) / (1,2) as the paired LDS reads deliver them.
     const f2 al2 = eh ? f2{-1.f, -1.f} : f2{0.f, 0.f}, be2 = eh ? f2{0.f, 0.f} : f2{1.f, 1.f};
