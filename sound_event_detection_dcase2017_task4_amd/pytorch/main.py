@@ -7,8 +7,9 @@ workspace layout (:72-110, :297-324) and checkpoint format (`{'iteration', 'mode
 
 Differences, all additive: one process per GPU under torchrun (RCCL all-reduce of one flat gradient buffer) instead
 of nn.DataParallel; `--synthetic N` trains on N synthetic clips when no packed data exists; `--print_every` (the
-reference prints, i.e. synchronises, every iteration).  The every-1000-iterations evaluation branch needs the
-reference's sed_eval-based Evaluator, which is out of scope: it is skipped with a log line.
+reference prints, i.e. synchronises, every iteration).  The every-1000-iterations evaluation branch (main.py:188-209)
+runs `evaluate.Evaluator` on the test / evaluation packs when they and their strong-label csv files exist (rank 0), with
+the segment-based metrics restated in utils/utilities.py because sed_eval is not installed; otherwise it logs and skips.
 """
 import argparse
 import logging
@@ -24,7 +25,8 @@ from .. import parallel
 from ..optim import FusedAdamAmsgrad
 from ..utils.config import (sample_rate, classes_num, mel_bins, fmin, fmax, window_size, hop_size)
 from ..utils.data_generator import DCASE2017Task4Dataset, TrainSampler, TestSampler, collate_fn
-from ..utils.utilities import create_folder, get_filename, create_logging, Mixup
+from ..utils.utilities import create_folder, get_filename, create_logging, Mixup, StatisticsContainer
+from .evaluate import Evaluator
 from . import models as _models
 from .losses import get_loss_func
 from .models import *  # noqa: F401,F403  (model lookup by name, like the reference's `eval(model_type)`)
@@ -91,10 +93,45 @@ def train(args):
     mixup_augmenter = Mixup(mixup_alpha=1., random_seed=1234 + rank) if mix else None
     train_bgn_time = time.time()
 
+    # evaluation sets of the every-1000-iterations branch (main.py:78-89, :150-176): used when present
+    eval_sets = []
+    if rank == 0 and not args.synthetic:
+        _, _, predictions_dir = _paths(args, prefix)
+        for data_type, pack, csv in (('test', '{}testing.h5'.format(prefix), 'groundtruth_strong_label_testing_set.csv'),
+                                     ('evaluate', 'evaluation.h5', 'groundtruth_strong_label_evaluation_set.csv')):
+            pack_path = os.path.join(args.workspace, 'hdf5s', pack)
+            if not os.path.exists(pack_path) and os.path.isdir(pack_path[:-3]):
+                pack_path = pack_path[:-3]
+            csv_path = os.path.join(args.dataset_dir, 'metadata', csv)
+            if os.path.exists(pack_path) and os.path.exists(csv_path):
+                sampler = TestSampler(hdf5_path=pack_path, batch_size=args.batch_size)
+                loader = torch.utils.data.DataLoader(dataset=DCASE2017Task4Dataset(), batch_sampler=sampler,
+                                                     collate_fn=collate_fn, num_workers=8, pin_memory=True)
+                eval_sets.append((data_type, loader, csv_path))
+        if eval_sets:
+            create_folder(predictions_dir)
+            statistics_path = os.path.join(args.workspace, 'statistics', os.path.relpath(checkpoints_dir, os.path.join(
+                args.workspace, 'checkpoints')), 'statistics.pickle')
+            create_folder(os.path.dirname(statistics_path))
+            statistics_container = StatisticsContainer(statistics_path)
+            evaluator = Evaluator(model=model)
+
     for batch_data_dict in train_loader:
         if iteration % 1000 == 0 and iteration > (args.resume_iteration or 0) and rank == 0:
-            logging.info('Iteration: {}  train time: {:.3f} s  (evaluation branch out of scope, skipped)'.format(
-                iteration, time.time() - train_bgn_time))
+            train_fin_time = time.time()
+            for data_type, loader, csv_path in eval_sets:
+                statistics, _ = evaluator.evaluate(loader, csv_path, os.path.join(predictions_dir, '_tmp_submission.csv'))
+                logging.info('{} statistics:'.format(data_type))
+                logging.info('    Clipwise mAP: {:.3f}'.format(np.mean(statistics['clipwise_ap'])))
+                if 'framewise_ap' in statistics:
+                    logging.info('    Framewise mAP: {:.3f}'.format(np.mean(statistics['framewise_ap'])))
+                logging.info('    {}'.format(statistics['sed_metrics']['overall']['error_rate']))
+                statistics_container.append(data_type, iteration, statistics)
+            if eval_sets:
+                statistics_container.dump()
+            logging.info('Iteration: {}  train time: {:.3f} s, validate time: {:.3f} s{}'.format(
+                iteration, train_fin_time - train_bgn_time, time.time() - train_fin_time,
+                '' if eval_sets else '  (no test / evaluation packs with strong-label csv found: evaluation skipped)'))
             train_bgn_time = time.time()
         if iteration % 10000 == 0 and rank == 0:
             checkpoint = {'iteration': iteration, 'model': model.state_dict(), 'optimizer': optimizer.state_dict()}
