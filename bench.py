@@ -107,6 +107,10 @@ def main():
     ap.add_argument("--int16", action="store_true", help="feed int16 waveforms (the HDF5 storage dtype)")
     ap.add_argument("--by_shape", action="store_true", help="print a per-layer MFMA kernel table to stderr")
     ap.add_argument("--cpu_threads", type=int, default=0)
+    ap.add_argument("--inference", action="store_true",
+                    help="secondary metric (SURVEY.md 8d): eval-mode forward only, clips/s over --batch_size waveforms per step")
+    ap.add_argument("--h2d", action="store_true",
+                    help="secondary: each step first copies its int16 waveforms from pinned host memory (PCIe-inclusive rate)")
     args = ap.parse_args()
 
     rank, world, local_rank = parallel.init_from_env()
@@ -130,11 +134,33 @@ def main():
     loss_func = get_loss_func("clip_bce")
     mixup = Mixup(mixup_alpha=1., random_seed=1234 + rank)
     pool = [synth_batch(B2, L, 1000 * rank + i, dev) for i in range(2)]
-    if args.int16:
+    if args.int16 or args.h2d:
         pool = [((w * 32767.0).round().to(torch.int16), t) for (w, t) in pool]
+    host_pool = [w.cpu().pin_memory() for (w, _) in pool] if args.h2d else None
+    if args.h2d:                       # double-buffered upload on a copy stream, one batch ahead of the compute
+        copy_stream = torch.cuda.Stream()
+        dbuf = [torch.empty_like(pool[0][0]) for _ in range(2)]
+        dev_ready = [torch.cuda.Event() for _ in range(2)]
+
+        def upload(i):
+            copy_stream.wait_stream(torch.cuda.current_stream())     # the buffer's previous reader (step i-2) is done
+            with torch.cuda.stream(copy_stream):
+                dbuf[i % 2].copy_(host_pool[i % len(host_pool)], non_blocking=True)
+                dev_ready[i % 2].record(copy_stream)
+        upload(0)
+    if args.inference:
+        model.eval()
 
     def step(i):
         wave, target = pool[i % len(pool)]
+        if args.h2d:
+            torch.cuda.current_stream().wait_event(dev_ready[i % 2])
+            wave = dbuf[i % 2]
+            upload(i + 1)
+        if args.inference:
+            with torch.no_grad():
+                out = model(wave[:B], None)
+            return out["clipwise_output"].sum()
         if mix:
             lam = torch.from_numpy(mixup.get_lambda(B2).astype(np.float32)).to(dev, non_blocking=True)
             out = model(wave, lam)
@@ -224,8 +250,9 @@ def main():
     conv_ms = sum(v["ms_total"] for v in kern.values())
     clips_per_s = B * world * args.steps / dt
     line = {
-        "metric": "training clips/sec (10s@32kHz) Cnn_9layers_FrameAvg" if args.model_type == "Cnn_9layers_FrameAvg"
-                  else "training clips/sec (10s@32kHz) " + args.model_type,
+        "metric": ("inference clips/sec (10s@32kHz, eval mode) " + args.model_type) if args.inference else
+                  ("training clips/sec (10s@32kHz) Cnn_9layers_FrameAvg" if args.model_type == "Cnn_9layers_FrameAvg"
+                   else "training clips/sec (10s@32kHz) " + args.model_type),
         "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -233,7 +260,8 @@ def main():
                                "SpecAugment on, clip_bce, Adam-amsgrad; BASELINE.json configs[1]%s"
                                % (args.model_type, B, ", mixup (%d waveforms/step/GPU)" % B2 if mix else ", no mixup",
                                   args.seconds, "int16" if args.int16 else "fp32",
-                                  "" if (B == 256 and mix and args.model_type == "Cnn_9layers_FrameAvg") else " (modified by flags)"),
+                                  "" if (B == 256 and mix and args.model_type == "Cnn_9layers_FrameAvg" and not args.inference
+                                         and not args.h2d) else " (modified by flags)"),
                    "global_batch": B * world, "waveforms_per_step": B2 * world, "parallelism": "dp%d" % world},
         "waveforms_per_s": round(B2 * world * args.steps / dt, 2),
         "loss": round(float(loss.item()), 5),
