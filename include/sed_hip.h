@@ -206,6 +206,21 @@ int sed_gru_gate_bwd(const float* g_out0, const float* g_out1, long ld_go, const
                      float* dgi1, long ld_dgi, float* dgh0, float* dgh1, float* dh_direct_out0, float* dh_direct_out1,
                      sed_stream_t stream);
 
+/* ---- multi-head self-attention of the Transformer heads (models.py:587-665; 8 heads x 64) ----------------------
+ * q, k, v, o, g_*: [B*T][512] fp32, head h in columns 64h..64h+63 (the Linear outputs of w_qs / w_ks / w_vs, no
+ * permutes).  keep: attention-dropout KEEP mask, bytes [8*B][T][T] with row index h*B + b (the (n*b) layout of
+ * :651-657), or null in eval mode; p_drop = 0.1 (:590).  stats: [B][8][T][4] floats (row max, row sum, D, -) written by
+ * the forward and completed / consumed by the backward.
+ *   sed_mha_fwd: O = dropout(softmax(Q K^T / 8)) V            sed_mha_bwd: g_q, g_k, g_v from g_o
+ * sed_drop_relu_*: y = relu(dropout(x)) of the output projection (:664), keep bytes [n] or null, p_drop = 0.2. */
+int sed_mha_fwd(const float* q, const float* k, const float* v, const unsigned char* keep, float p_drop, int B, int T,
+                float* o, float* stats, sed_stream_t stream);
+int sed_mha_bwd(const float* q, const float* k, const float* v, const float* o, const float* g_o, const unsigned char* keep,
+                float p_drop, int B, int T, float* stats, float* g_q, float* g_k, float* g_v, sed_stream_t stream);
+int sed_drop_relu_fwd(const float* x, const unsigned char* keep, float p_drop, long n, float* y, sed_stream_t stream);
+int sed_drop_relu_bwd(const float* g_y, const float* y, const unsigned char* keep, float p_drop, long n, float* g_x,
+                      sed_stream_t stream);
+
 /* ---- loss / mixup of targets / optimiser ---------------------------------------------------------------------
  * sed_clip_bce: losses.py:5-12 (F.binary_cross_entropy, mean, log clamped at -100) + d loss / d p.
  * sed_mixup_rows: pytorch_utils.py:80-93 on a [B2][D] matrix (the targets, main.py:246).

@@ -2,7 +2,8 @@
 
 Functional restatement of `/root/reference/pytorch/models.py` (ConvBlock :72-115,
 AttBlock :118-149, Cnn_9layers_FrameMax :152, _FrameAvg :237-319, _FrameAtt :322-400,
-_Gru_FrameAvg :403, _Gru_FrameAtt :495-581), `losses.py:5-12`, `pytorch_utils.py:80-93`
+_Gru_FrameAvg :403, _Gru_FrameAtt :495-581, MultiHead :587-665, _Transformer_FrameAvg :668-759,
+_Transformer_FrameAtt :762-853), `losses.py:5-12`, `pytorch_utils.py:80-93`
 and `optim.Adam(amsgrad=True)` as configured at `main.py:144-145`.  State is a flat dict
 keyed exactly like the reference `state_dict()`.
 """
@@ -16,7 +17,10 @@ import torch.nn.functional as F
 from . import frontend
 
 MODEL_TYPES = ("Cnn_9layers_FrameMax", "Cnn_9layers_FrameAvg", "Cnn_9layers_FrameAtt",
-               "Cnn_9layers_Gru_FrameAvg", "Cnn_9layers_Gru_FrameAtt")
+               "Cnn_9layers_Gru_FrameAvg", "Cnn_9layers_Gru_FrameAtt",
+               "Cnn_9layers_Transformer_FrameAvg", "Cnn_9layers_Transformer_FrameAtt")
+N_HEAD, D_HEAD = 8, 64                   # MultiHead(n_head=8, d_model=512, d_k=d_v=64, dropout=0.2), models.py:702-707
+P_DROP_ATTN, P_DROP_FC = 0.1, 0.2        # ScaledDotProductAttention(attn_dropout=0.1) :590; MultiHead dropout :638
 CLASSES = 17
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -44,6 +48,11 @@ def state_layout(model_type):
         for sfx in ("", "_reverse"):
             lay += [("gru.weight_ih_l0" + sfx, (768, 512)), ("gru.weight_hh_l0" + sfx, (768, 256)),
                     ("gru.bias_ih_l0" + sfx, (768,)), ("gru.bias_hh_l0" + sfx, (768,))]
+    if "Transformer" in model_type:
+        for nm in ("w_qs", "w_ks", "w_vs"):
+            lay += [("multihead.%s.weight" % nm, (512, 512)), ("multihead.%s.bias" % nm, (512,))]
+        lay += [("multihead.layer_norm.weight", (512,)), ("multihead.layer_norm.bias", (512,)),      # never used (:660-665)
+                ("multihead.fc.weight", (512, 512)), ("multihead.fc.bias", (512,))]
     if model_type.endswith("FrameAtt"):
         lay += [("att_block.att.weight", (CLASSES, 512, 1)), ("att_block.att.bias", (CLASSES,)),
                 ("att_block.cla.weight", (CLASSES, 512, 1)), ("att_block.cla.bias", (CLASSES,))]
@@ -81,7 +90,7 @@ def recipe_state(model_type, seed=0):
             v = (rs.randn(*shape) * 0.2 + (-20.0 if key.startswith("bn0") else 0.1)).astype(np.float32)
         elif key.endswith("running_var"):
             v = ((0.5 + rs.rand(*shape)) * (60.0 if key.startswith("bn0") else 1.0)).astype(np.float32)
-        elif ".bn" in key or key.startswith("bn0"):
+        elif ".bn" in key or key.startswith("bn0") or ".layer_norm" in key:
             v = (1.0 + 0.1 * rs.randn(*shape)).astype(np.float32) if key.endswith("weight") \
                 else (0.1 * rs.randn(*shape)).astype(np.float32)
         elif key.endswith("bias") or "bias_" in key:
@@ -153,6 +162,33 @@ def att_block(x, st):
     return torch.sum(norm_att * cla, dim=2), norm_att, cla
 
 
+def dropout_masks(seed, B, T):
+    """Seeded KEEP masks of the two dropouts of MultiHead in training mode: attention (N_HEAD*B, T, T) with row index
+    head*B + b (the (n*b) layout of models.py:651-657) and fc output (B, T, 512).  The reference draws them from torch's
+    RNG; tests fix them (here, in the golden generator and in the product) so that training parity is checkable."""
+    rs = np.random.RandomState(seed)
+    return (torch.from_numpy(rs.rand(N_HEAD * B, T, T) >= P_DROP_ATTN), torch.from_numpy(rs.rand(B, T, 512) >= P_DROP_FC))
+
+
+def multihead(x, st, training=False, masks=None):
+    """MultiHead.forward(x, x, x) (models.py:641-665) + ScaledDotProductAttention (:596-609): per-head scaled
+    dot-product self-attention, output projection, dropout, ReLU; no residual, no layer norm.  x (B,T,512) -> (B,T,512)."""
+    B, T, _ = x.shape
+    def proj(nm):
+        y = F.linear(x, st["multihead.%s.weight" % nm], st["multihead.%s.bias" % nm]).view(B, T, N_HEAD, D_HEAD)
+        return y.permute(2, 0, 1, 3).reshape(N_HEAD * B, T, D_HEAD)
+    q, k, v = proj("w_qs"), proj("w_ks"), proj("w_vs")
+    attn = torch.softmax(torch.bmm(q, k.transpose(1, 2)) / math.sqrt(D_HEAD), dim=2)
+    if training:
+        assert masks is not None, "training-mode MultiHead needs explicit dropout masks (oracle.model.dropout_masks)"
+        attn = attn * masks[0].to(attn.dtype) / (1.0 - P_DROP_ATTN)
+    out = torch.bmm(attn, v).view(N_HEAD, B, T, D_HEAD).permute(1, 2, 0, 3).reshape(B, T, N_HEAD * D_HEAD)
+    out = F.linear(out, st["multihead.fc.weight"], st["multihead.fc.bias"])
+    if training:
+        out = out * masks[1].to(out.dtype) / (1.0 - P_DROP_FC)
+    return F.relu(out)
+
+
 def interpolate(x, ratio):
     """models.py:58-69: pure repeat along time."""
     (b, t, c) = x.shape
@@ -176,15 +212,17 @@ def trunk(logmel, st, training, mixup_lambda=None, stripes=None, track=True):
     return torch.mean(x, dim=3)
 
 
-def head(model_type, x, st):
+def head(model_type, x, st, training=False, masks=None):
     """x (B,512,T') -> output dict.  FrameAvg models.py:306-319, FrameMax :221-234,
-    FrameAtt :388-400, Gru_* :565-581."""
+    FrameAtt :388-400, Gru_* :565-581, Transformer_* :740-759 / :834-853."""
     if "Gru" in model_type:
         x = gru_bidir(x.transpose(1, 2), st).transpose(1, 2)
+    if "Transformer" in model_type:
+        x = multihead(x.transpose(1, 2), st, training, masks).transpose(1, 2)
     if model_type.endswith("FrameAtt"):
         clip, _, cla = att_block(x, st)
         return {"framewise_output": interpolate(cla.transpose(1, 2), 8), "clipwise_output": clip,
-                "embedding": cla}
+                "embedding": x if "Transformer" in model_type else cla}      # :398/:579 return cla, :851 returns x
     frame = torch.sigmoid(F.linear(x.transpose(1, 2), st["fc.weight"], st["fc.bias"]))
     frame = interpolate(frame, 8)
     if model_type.endswith("FrameMax"):
@@ -194,10 +232,16 @@ def head(model_type, x, st):
     return {"framewise_output": frame, "clipwise_output": clip, "embedding": x}
 
 
-def forward(model_type, st, waveform, training=False, mixup_lambda=None, stripes=None, track=True):
-    """Whole-model forward == `Model.forward(input, mixup_lambda)` (models.py:279-319 etc.)."""
+def forward(model_type, st, waveform, training=False, mixup_lambda=None, stripes=None, track=True, dropout_seed=None):
+    """Whole-model forward == `Model.forward(input, mixup_lambda)` (models.py:279-319 etc.).  `dropout_seed` fixes the
+    MultiHead dropout masks of the Transformer models in training mode (dropout_masks)."""
     lm = frontend.logmel(waveform)
-    return head(model_type, trunk(lm, st, training, mixup_lambda, stripes, track), st)
+    x = trunk(lm, st, training, mixup_lambda, stripes, track)
+    masks = None
+    if training and "Transformer" in model_type:
+        assert dropout_seed is not None, "Transformer models in training mode need dropout_seed"
+        masks = dropout_masks(dropout_seed, x.shape[0], x.shape[2])
+    return head(model_type, x, st, training, masks)
 
 
 def clip_bce(output_dict, target_dict):
@@ -207,6 +251,14 @@ def clip_bce(output_dict, target_dict):
 
 def trainable_keys(model_type):
     return [k for k, _ in state_layout(model_type) if k not in FROZEN_KEYS and not is_buffer(k)]
+
+
+def unused_keys(model_type):
+    """Trainable parameters that never receive a gradient (the reference's Adam skips them: .grad is None)."""
+    out = ["att_block.bn_att.weight", "att_block.bn_att.bias"] if model_type.endswith("FrameAtt") else []
+    if "Transformer" in model_type:
+        out += ["multihead.layer_norm.weight", "multihead.layer_norm.bias"]
+    return out
 
 
 def adam_amsgrad_step(p, g, m, v, vmax, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):

@@ -613,6 +613,56 @@ class AttHeadFn(torch.autograd.Function):
                 dwp[ncls:2 * ncls].reshape(ctx.wshape).contiguous(), dbias[ncls:2 * ncls].contiguous())
 
 
+class MultiHeadFn(torch.autograd.Function):
+    """MultiHead(n_head=8, d_model=512, d_k=d_v=64).forward(x, x, x) of the Transformer heads (models.py:641-665):
+    q/k/v projections (MFMA GEMMs), scaled dot-product attention with attention dropout, output projection, dropout,
+    ReLU.  x (B,T,512) -> (B,T,512).  `keep_attn` (8*B,T,T) / `keep_fc` (B,T,512) are bool KEEP masks (None = no dropout)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo, keep_attn, keep_fc, p_attn, p_fc):
+        _chk_dev(x, wq)
+        x = _f32c(x)
+        B, T, C = x.shape
+        M = B * T
+        x2 = x.view(M, C)
+        q, k, v = gemm_nt(x2, _f32c(wq), _f32c(bq)), gemm_nt(x2, _f32c(wk), _f32c(bk)), gemm_nt(x2, _f32c(wv), _f32c(bv))
+        o = torch.empty((M, C), dtype=torch.float32, device=x.device)
+        stats = torch.empty((B, 8, T, 4), dtype=torch.float32, device=x.device)
+        ka = keep_attn.contiguous() if keep_attn is not None else None
+        kf = keep_fc.contiguous() if keep_fc is not None else None
+        if ka is not None and (ka.dtype not in (torch.bool, torch.uint8) or tuple(ka.shape) != (8 * B, T, T)):
+            raise RuntimeError("attention keep mask must be bool/uint8 of shape (8*B, T, T)")
+        if kf is not None and (kf.dtype not in (torch.bool, torch.uint8) or kf.numel() != M * C):
+            raise RuntimeError("fc keep mask must be bool/uint8 of shape (B, T, 512)")
+        _call("sed_mha_fwd", _ptr(q), _ptr(k), _ptr(v), _ptr(ka), float(p_attn), B, T, _ptr(o), _ptr(stats), _stream())
+        y = gemm_nt(o, _f32c(wo), _f32c(bo))
+        out = torch.empty_like(y)
+        _call("sed_drop_relu_fwd", _ptr(y), _ptr(kf), float(p_fc), M * C, _ptr(out), _stream())
+        ctx.save_for_backward(x2, q, k, v, o, stats, out, wq, wk, wv, wo, ka, kf)
+        ctx.dims, ctx.p = (B, T, C), (float(p_attn), float(p_fc))
+        return out.view(B, T, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, q, k, v, o, stats, out, wq, wk, wv, wo, ka, kf = ctx.saved_tensors
+        B, T, C = ctx.dims
+        M = B * T
+        g = _f32c(g).view(M, C)
+        gy = torch.empty_like(g)
+        _call("sed_drop_relu_bwd", _ptr(g), _ptr(out), _ptr(kf), ctx.p[1], M * C, _ptr(gy), _stream())
+        dwo, dbo = gemm_tn(o, gy), col_sums(gy)
+        go = gemm_nt(gy, transpose_b(_f32c(wo).view(1, C, C)).view(C, C))
+        gq, gk, gv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        _call("sed_mha_bwd", _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(go), _ptr(ka), ctx.p[0], B, T, _ptr(stats), _ptr(gq),
+              _ptr(gk), _ptr(gv), _stream())
+        gx = gemm_nt(gq, transpose_b(_f32c(wq).view(1, C, C)).view(C, C))
+        for gt, w in ((gk, wk), (gv, wv)):
+            t = gemm_nt(gt, transpose_b(_f32c(w).view(1, C, C)).view(C, C))
+            _call("sed_axpy", _ptr(gx), _ptr(t), M * C, _stream())
+        return (gx.view(B, T, C), gemm_tn(x2, gq), col_sums(gq), gemm_tn(x2, gk), col_sums(gk), gemm_tn(x2, gv), col_sums(gv),
+                dwo, dbo, None, None, None, None)
+
+
 def gemm_nt_pair(x0, x1, w0, w1, b0, b1, y0, y1):
     """Two independent y = x w^T (+b) of one shape in ONE launch (the two GRU directions)."""
     M, K = x0.shape

@@ -7,8 +7,8 @@ as PARAMETER CONTAINERS so that keys, shapes, `.to()`, `.train()/.eval()` behave
 their own forward methods are never called.
 
 Covered: Cnn_9layers_FrameMax (:152), Cnn_9layers_FrameAvg (:237), Cnn_9layers_FrameAtt (:322),
-Cnn_9layers_Gru_FrameAvg (:403), Cnn_9layers_Gru_FrameAtt (:495).  The two Transformer variants are out of
-scope.
+Cnn_9layers_Gru_FrameAvg (:403), Cnn_9layers_Gru_FrameAtt (:495), Cnn_9layers_Transformer_FrameAvg (:668),
+Cnn_9layers_Transformer_FrameAtt (:762) -- every model type of the reference.
 """
 import math
 
@@ -20,7 +20,8 @@ from .. import ops
 from ..utils.augmentation import draw_specaug_stripes
 
 __all__ = ['Cnn_9layers_FrameMax', 'Cnn_9layers_FrameAvg', 'Cnn_9layers_FrameAtt', 'Cnn_9layers_Gru_FrameAvg',
-           'Cnn_9layers_Gru_FrameAtt', 'ConvBlock', 'AttBlock', 'init_layer', 'init_bn', 'init_gru', 'interpolate']
+           'Cnn_9layers_Gru_FrameAtt', 'Cnn_9layers_Transformer_FrameAvg', 'Cnn_9layers_Transformer_FrameAtt', 'ConvBlock',
+           'AttBlock', 'MultiHead', 'init_layer', 'init_bn', 'init_gru', 'interpolate']
 
 
 def init_layer(layer):
@@ -188,6 +189,47 @@ class AttBlock(nn.Module):
         return clip, natt.transpose(1, 2), cla.transpose(1, 2)
 
 
+class MultiHead(nn.Module):
+    """Multi-head self-attention block of the Transformer models (models.py:611-665): parameter container with the
+    reference's keys (w_qs, w_ks, w_vs, layer_norm [never used], fc) and inits; forward(x (B,T,d_model), dropout_masks)
+    -> (B,T,d_model).  In training mode the two dropouts (attention 0.1, output `dropout`) use the given KEEP masks
+    `(attn (n_head*B,T,T), fc (B,T,d_model))` or, when None, masks drawn on the device from torch's generator."""
+
+    def __init__(self, n_head, d_model, d_k, d_v, dropout=0.1):
+        super(MultiHead, self).__init__()
+        if (n_head, d_model, d_k, d_v) != (8, 512, 64, 64):
+            raise Exception('Incorrect argument!')   # the attention kernel is specialised for the reference's sizes
+        self.n_head, self.d_k, self.d_v = n_head, d_k, d_v
+        self.w_qs = nn.Linear(d_model, n_head * d_k)
+        self.w_ks = nn.Linear(d_model, n_head * d_k)
+        self.w_vs = nn.Linear(d_model, n_head * d_v)
+        nn.init.normal_(self.w_qs.weight, mean=0, std=np.sqrt(2.0 / (d_model + d_k)))
+        nn.init.normal_(self.w_ks.weight, mean=0, std=np.sqrt(2.0 / (d_model + d_k)))
+        nn.init.normal_(self.w_vs.weight, mean=0, std=np.sqrt(2.0 / (d_model + d_v)))
+        self.w_qs.bias.data.fill_(0)
+        self.w_ks.bias.data.fill_(0)
+        self.w_vs.bias.data.fill_(0)
+        self.attn_dropout_p = 0.1                      # ScaledDotProductAttention(attn_dropout=0.1), models.py:590
+        self.layer_norm = nn.LayerNorm(d_model)        # in the state_dict, never applied (models.py:660-665)
+        self.fc = nn.Linear(n_head * d_v, d_model)
+        nn.init.xavier_normal_(self.fc.weight)
+        self.fc.bias.data.fill_(0)
+        self.dropout_p = dropout
+
+    def forward(self, x_btc, dropout_masks=None):
+        keep_attn = keep_fc = None
+        if self.training:
+            B, T, C = x_btc.shape
+            if dropout_masks is None:
+                keep_attn = torch.rand((self.n_head * B, T, T), device=x_btc.device) >= self.attn_dropout_p
+                keep_fc = torch.rand((B, T, C), device=x_btc.device) >= self.dropout_p
+            else:
+                keep_attn, keep_fc = (m.to(device=x_btc.device, dtype=torch.bool) for m in dropout_masks)
+        return ops.MultiHeadFn.apply(x_btc, self.w_qs.weight, self.w_qs.bias, self.w_ks.weight, self.w_ks.bias,
+                                     self.w_vs.weight, self.w_vs.bias, self.fc.weight, self.fc.bias, keep_attn, keep_fc,
+                                     self.attn_dropout_p, self.dropout_p)
+
+
 # ---- models ---------------------------------------------------------------------------------------------------------
 
 class _Cnn9Base(nn.Module):
@@ -265,16 +307,17 @@ class _FcHead(_Cnn9Base):
     def _make_mid(self):
         pass
 
-    def _mid(self, feat):
+    def _mid(self, feat, dropout_masks=None):
         return feat
 
     def init_weights(self):
         init_bn(self.bn0)
         init_layer(self.fc)
 
-    def forward(self, input, mixup_lambda=None, specaug_stripes=None):
-        """Input: (batch_size, data_length).  `specaug_stripes` (optional, extension) fixes the SpecAugment draws."""
-        feat = self._mid(self.trunk(input, mixup_lambda, specaug_stripes))
+    def forward(self, input, mixup_lambda=None, specaug_stripes=None, dropout_masks=None):
+        """Input: (batch_size, data_length).  `specaug_stripes` (optional, extension) fixes the SpecAugment draws,
+        `dropout_masks` (optional, extension, Transformer models) the two MultiHead dropout keep masks."""
+        feat = self._mid(self.trunk(input, mixup_lambda, specaug_stripes), dropout_masks)
         frame, clip = ops.FcHeadFn.apply(feat, self.fc.weight, self.fc.bias, self._mode)
         return {'framewise_output': interpolate(frame, self.interpolate_ratio), 'clipwise_output': clip,
                 'embedding': feat.transpose(1, 2)}
@@ -294,7 +337,7 @@ class _GruMixin(object):
     def _make_mid(self):
         self.gru = nn.GRU(input_size=512, hidden_size=256, num_layers=1, bias=True, batch_first=True, bidirectional=True)
 
-    def _mid(self, feat):
+    def _mid(self, feat, dropout_masks=None):
         g = self.gru
         return ops.GruFn.apply(feat, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0, g.weight_ih_l0_reverse,
                                g.weight_hh_l0_reverse, g.bias_ih_l0_reverse, g.bias_hh_l0_reverse)
@@ -317,20 +360,23 @@ class _AttHead(_Cnn9Base):
         self.att_block = AttBlock(n_in=512, n_out=17, activation='sigmoid')
         self.init_weights()
 
+    _embedding_is_cla = True                          # models.py:398 / :579 return cla; the Transformer variant (:851) x
+
     def _make_mid(self):
         pass
 
-    def _mid(self, feat):
+    def _mid(self, feat, dropout_masks=None):
         return feat
 
     def init_weights(self):
         init_bn(self.bn0)
 
-    def forward(self, input, mixup_lambda=None, specaug_stripes=None):
-        feat = self._mid(self.trunk(input, mixup_lambda, specaug_stripes))
+    def forward(self, input, mixup_lambda=None, specaug_stripes=None, dropout_masks=None):
+        feat = self._mid(self.trunk(input, mixup_lambda, specaug_stripes), dropout_masks)
         (clipwise_output, norm_att, cla) = self.att_block(feat)
         framewise_output = interpolate(cla.transpose(1, 2), self.interpolate_ratio)
-        return {'framewise_output': framewise_output, 'clipwise_output': clipwise_output, 'embedding': cla}
+        return {'framewise_output': framewise_output, 'clipwise_output': clipwise_output,
+                'embedding': cla if self._embedding_is_cla else feat.transpose(1, 2)}
 
 
 class Cnn_9layers_FrameAtt(_AttHead):
@@ -343,3 +389,21 @@ class Cnn_9layers_Gru_FrameAtt(_GruMixin, _AttHead):
     def init_weights(self):
         init_bn(self.bn0)
         init_gru(self.gru)
+
+
+class _TransformerMixin(object):
+    def _make_mid(self):
+        self.multihead = MultiHead(n_head=8, d_model=512, d_k=64, d_v=64, dropout=0.2)
+
+    def _mid(self, feat, dropout_masks=None):
+        return self.multihead(feat, dropout_masks)
+
+
+class Cnn_9layers_Transformer_FrameAvg(_TransformerMixin, _FcHead):
+    """models.py:668-759."""
+    _mode = 0
+
+
+class Cnn_9layers_Transformer_FrameAtt(_TransformerMixin, _AttHead):
+    """models.py:762-853."""
+    _embedding_is_cla = False

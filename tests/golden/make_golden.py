@@ -51,8 +51,33 @@ def summarize(t):
                     [0.0] * max(0, 14 - f.numel()), dtype=np.float64)[:16]
 
 
+class FixedDropout(torch.nn.Module):
+    """Stand-in for the two nn.Dropout modules of MultiHead: applies a GIVEN keep mask in training mode (same scaling as
+    nn.Dropout), so that training-mode fixtures of the Transformer models are reproducible by the oracle / product."""
+
+    def __init__(self, p):
+        super().__init__()
+        self.p, self.mask = p, None
+
+    def forward(self, x):
+        if not self.training:
+            return x
+        assert self.mask is not None and self.mask.shape == x.shape, (None if self.mask is None else self.mask.shape, x.shape)
+        return x * self.mask.to(x.dtype) / (1.0 - self.p)
+
+
+def set_dropout(m, seed, B, T):
+    if hasattr(m, "multihead"):
+        ma, mf = om.dropout_masks(seed, B, T)
+        m.multihead.attention.dropout.mask, m.multihead.dropout.mask = ma, mf
+
+
 def build(model_type, seed):
     m = getattr(ref_models, model_type)(*CTOR)
+    if hasattr(m, "multihead"):
+        assert abs(m.multihead.attention.dropout.p - om.P_DROP_ATTN) < 1e-12 and abs(m.multihead.dropout.p - om.P_DROP_FC) < 1e-12
+        m.multihead.attention.dropout = FixedDropout(om.P_DROP_ATTN)
+        m.multihead.dropout = FixedDropout(om.P_DROP_FC)
     st = om.recipe_state(model_type, seed)
     assert list(m.state_dict().keys()) == list(st.keys()), model_type
     for k, v in m.state_dict().items():
@@ -113,6 +138,8 @@ def model_fixture(model_type, seed, long_case=False):
     out["train_stripes"] = ofe.draw_specaug_stripes(6, 101, 64)         # same draw order as the package
     m = build(model_type, seed)
     m.train()
+    out["train_dropout_seed"] = np.array(4000 + seed)
+    set_dropout(m, 4000 + seed, 3, 12)
     torch.manual_seed(500 + seed)
     with torch.no_grad():
         o = m(xt, torch.from_numpy(lam))
@@ -136,6 +163,7 @@ def model_fixture(model_type, seed, long_case=False):
         stripes_all.append(ofe.draw_specaug_stripes(8, 101, 64))
         torch.manual_seed(900 + 10 * seed + it)
         m.train()
+        set_dropout(m, 5000 + 10 * seed + it, 4, 12)
         o = m(xw, lam_t)
         tgt = {'target': ref_utils.do_mixup(tg, lam_t)}
         loss = loss_func(o, tgt)
@@ -146,7 +174,8 @@ def model_fixture(model_type, seed, long_case=False):
                 if p.grad is not None:
                     out["grad0/" + k] = summarize(p.grad)
                     if k in ("fc.weight", "bn0.weight", "bn0.bias", "conv_block1.conv1.weight",
-                             "att_block.att.weight", "att_block.cla.bias", "gru.bias_hh_l0"):
+                             "att_block.att.weight", "att_block.cla.bias", "gru.bias_hh_l0",
+                             "multihead.w_ks.bias", "multihead.fc.bias"):
                         out["gradfull0/" + k] = p.grad.numpy().copy()
             out["grad0_none_keys"] = np.array([k for k, p in m.named_parameters()
                                                if p.requires_grad and p.grad is None])
@@ -154,6 +183,7 @@ def model_fixture(model_type, seed, long_case=False):
         losses.append(loss.item())
     out["step_losses"] = np.array(losses)
     out["step_stripes"] = np.stack(stripes_all)
+    out["step_dropout_seeds"] = np.array([5000 + 10 * seed + it for it in range(3)])
     for k, v in m.state_dict().items():
         if k not in om.FROZEN_KEYS:
             out["after3/" + k] = summarize(v.float())
@@ -176,9 +206,13 @@ def misc_fixture():
 
 
 if __name__ == "__main__":
-    np.savez_compressed(os.path.join(HERE, "frontend.npz"), **frontend_fixture())
-    np.savez_compressed(os.path.join(HERE, "misc.npz"), **misc_fixture())
+    only = sys.argv[1:]                     # optional: model types to (re)generate; default everything
+    if not only:
+        np.savez_compressed(os.path.join(HERE, "frontend.npz"), **frontend_fixture())
+        np.savez_compressed(os.path.join(HERE, "misc.npz"), **misc_fixture())
     for i, mt in enumerate(om.MODEL_TYPES):
+        if only and mt not in only:
+            continue
         fx = model_fixture(mt, seed=i + 1, long_case=(mt == "Cnn_9layers_FrameAvg"))
         np.savez_compressed(os.path.join(HERE, mt + ".npz"), **fx)
         print(mt, "losses", fx["step_losses"])

@@ -37,7 +37,15 @@ def check_summary(got, want, rtol, what, slack=0.0):
     np.testing.assert_allclose(got[2:], want[2:], rtol=rtol * 50, atol=rtol * scale / 10 + slack, err_msg=what)
 
 
-def fp64_oracle_grads(mt, seed, stripes, unused):
+def dropout_kw(mt, seed, B, T):
+    """Product keyword for the fixed MultiHead dropout masks of the Transformer models (same recipe as the fixtures)."""
+    if "Transformer" not in mt:
+        return {}
+    ma, mf = om.dropout_masks(seed, B, T)
+    return {"dropout_masks": (ma.cuda(), mf.cuda())}
+
+
+def fp64_oracle_grads(mt, seed, stripes, unused, dropout_seed=None):
     """Step-0 gradients of the golden training recipe evaluated by the CPU oracle in float64 (ground truth)."""
     st = {k: (v.double() if v.is_floating_point() else v) for k, v in om.recipe_state(mt, seed).items()}
     ofe._CACHE.clear()
@@ -52,7 +60,7 @@ def fp64_oracle_grads(mt, seed, stripes, unused):
         xw = torch.from_numpy(waves(700 + 10 * seed, 8, 32000)).double()
         tg = torch.from_numpy(targets(800 + 10 * seed, 8)).double()
         lam = torch.from_numpy(ofe.mixup_lambdas(8, rs).astype(np.float32)).double()
-        o = om.forward(mt, st, xw, training=True, mixup_lambda=lam, stripes=stripes)
+        o = om.forward(mt, st, xw, training=True, mixup_lambda=lam, stripes=stripes, dropout_seed=dropout_seed)
         loss = om.clip_bce(o, {"target": om.do_mixup(tg, lam)})
         grads = torch.autograd.grad(loss, [st[k] for k in keys])
         return {k: g.numpy() for k, g in zip(keys, grads)}
@@ -79,7 +87,7 @@ def test_eval_forward_matches_reference(mt, golden_dir):
     fw = o["framewise_output"].cpu().numpy()
     assert np.array_equal(fw[:, 0::8], fw[:, 7::8])                   # x8 repeat
     check_summary(summarize(o["embedding"].contiguous()), fx["eval_embedding"], 1e-4, "embedding")
-    assert o["embedding"].shape == ((4, 17, 12) if mt.endswith("Att") else (4, 512, 12))
+    assert o["embedding"].shape == ((4, 17, 12) if (mt.endswith("Att") and "Transformer" not in mt) else (4, 512, 12))
 
 
 def test_eval_forward_10s_clip(golden_dir):
@@ -101,7 +109,7 @@ def test_train_forward_matches_reference(mt, golden_dir):
     lam = torch.from_numpy(fx["train_lambda"]).cuda()
     torch.manual_seed(500 + seed)                                      # same global-RNG stream as the reference run
     with torch.no_grad():
-        o = m(torch.from_numpy(waves(300 + seed, 6, 32000)).cuda(), lam)
+        o = m(torch.from_numpy(waves(300 + seed, 6, 32000)).cuda(), lam, **dropout_kw(mt, int(fx["train_dropout_seed"]), 3, 12))
     assert o["clipwise_output"].shape == (3, 17)
     assert np.abs(o["clipwise_output"].cpu().numpy() - fx["train_clip"]).max() < 1e-4
     assert np.abs(o["framewise_output"].cpu().numpy()[:, ::8] - fx["train_frame"]).max() < 1e-4
@@ -130,7 +138,7 @@ def test_three_train_steps_match_reference(mt, golden_dir):
         lam = move_data_to_device(ofe.mixup_lambdas(8, rs), "cuda")
         torch.manual_seed(900 + 10 * seed + it)
         m.train()
-        o = m(xw, lam)
+        o = m(xw, lam, **dropout_kw(mt, int(fx["step_dropout_seeds"][it]), 4, 12))
         loss = loss_func(o, {"target": do_mixup(tg, lam)})
         # step 0 is a pure forward (1e-4 gate); later steps inherit Adam's sign-like amplification of gradient noise
         assert abs(loss.item() - fx["step_losses"][it]) < (1e-4 if it == 0 else 2e-3), (it, loss.item(), fx["step_losses"][it])
@@ -146,7 +154,7 @@ def test_three_train_steps_match_reference(mt, golden_dir):
             # agrees with fp64 to 3e-6 on every tensor (Gru_FrameAvg fixture).  The yardstick is thus the fp64 oracle
             # with a statistical gate: relative L2 error <= 1e-2 and max error <= 4e-2 of the tensor max (~2.5x the
             # reference's own jitter).  The strict per-kernel gradient checks (<= 3e-4) live in tests/test_gpu_ops.py.
-            g64 = fp64_oracle_grads(mt, seed, fx["step_stripes"][0], sorted(unused))
+            g64 = fp64_oracle_grads(mt, seed, fx["step_stripes"][0], sorted(unused), int(fx["step_dropout_seeds"][0]))
             report, bad = {}, {}
             for k, p in m.named_parameters():
                 if not p.requires_grad or k in unused:

@@ -440,3 +440,45 @@ def test_conv3x3_winograd_wgrad(ops, B, H, W, Cin, Cout, inT):
     assert rel(dw, w.grad) < 1e-5
     dwd = ops._wgrad_direct(xd, gyd, B, H, W, Cin, Cout, in_st=st).cpu()
     assert rel(dw, dwd) < 1e-5
+
+
+@pytest.mark.parametrize("B,T,train", [(3, 12, False), (2, 125, True), (1, 130, True), (4, 12, True)])
+def test_multihead_attention_forward_backward(ops, B, T, train):
+    """MultiHeadFn (q/k/v projections, scaled dot-product attention with dropout, output projection, dropout, ReLU) vs
+    the same computation in torch autograd (models.py:641-665), incl. T > 128 (two row chunks) and T not a multiple of
+    the 64-key staging chunk."""
+    g = torch.Generator().manual_seed(T * 10 + B)
+    x = torch.randn(B, T, 512, generator=g)
+    W = {n: (torch.randn(512, 512, generator=g) * 0.04) for n in "qkvo"}
+    bias = {n: torch.randn(512, generator=g) * 0.05 for n in "qkvo"}
+    keep_a = (torch.rand(8 * B, T, T, generator=g) >= 0.1) if train else None
+    keep_f = (torch.rand(B, T, 512, generator=g) >= 0.2) if train else None
+    gout = torch.randn(B, T, 512, generator=g)
+
+    def ref(x, W, bias):
+        def proj(n):
+            return F.linear(x, W[n], bias[n]).view(B, T, 8, 64).permute(2, 0, 1, 3).reshape(8 * B, T, 64)
+        q, k, v = proj("q"), proj("k"), proj("v")
+        a = torch.softmax(torch.bmm(q, k.transpose(1, 2)) / 8.0, dim=2)
+        if train:
+            a = a * keep_a / 0.9
+        o = torch.bmm(a, v).view(8, B, T, 64).permute(1, 2, 0, 3).reshape(B, T, 512)
+        y = F.linear(o, W["o"], bias["o"])
+        if train:
+            y = y * keep_f / 0.8
+        return F.relu(y)
+
+    leaves = [x.clone().requires_grad_(True)] + [W[n].clone().requires_grad_(True) for n in "qkvo"] + \
+             [bias[n].clone().requires_grad_(True) for n in "qkvo"]
+    yr = ref(leaves[0], dict(zip("qkvo", leaves[1:5])), dict(zip("qkvo", leaves[5:9])))
+    yr.backward(gout)
+    dev = [t.detach().clone().cuda().requires_grad_(True) for t in leaves]
+    y = ops.MultiHeadFn.apply(dev[0], dev[1], dev[5], dev[2], dev[6], dev[3], dev[7], dev[4], dev[8],
+                              keep_a.cuda() if train else None, keep_f.cuda() if train else None, 0.1, 0.2)
+    assert rel(y.detach().cpu(), yr.detach()) < 5e-6
+    y.backward(gout.cuda())
+    for name, a, b in zip(["x", "wq", "wk", "wv", "wo", "bq", "bk", "bv", "bo"], dev, leaves):
+        if name == "bk":        # structurally zero: a constant added to every key shifts all logits of a row alike
+            assert a.grad.abs().max().item() < 1e-4 * leaves[5].grad.abs().max().item() and b.grad.abs().max().item() < 1e-4 * leaves[5].grad.abs().max().item()
+            continue
+        assert rel(a.grad.cpu(), b.grad) < 3e-5, name

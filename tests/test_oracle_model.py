@@ -43,7 +43,8 @@ def test_state_layout_matches_survey_counts(mt):
     n_train = sum(st[k].numel() for k in om.trainable_keys(mt))
     n_frozen = sum(st[k].numel() for k in om.FROZEN_KEYS)
     want = {"Cnn_9layers_FrameMax": 4694993, "Cnn_9layers_FrameAvg": 4694993, "Cnn_9layers_FrameAtt": 4703748,
-            "Cnn_9layers_Gru_FrameAvg": 5877713, "Cnn_9layers_Gru_FrameAtt": 5886468}[mt]
+            "Cnn_9layers_Gru_FrameAvg": 5877713, "Cnn_9layers_Gru_FrameAtt": 5886468,
+            "Cnn_9layers_Transformer_FrameAvg": 5746641, "Cnn_9layers_Transformer_FrameAtt": 5755396}[mt]
     assert n_train == want and n_frozen == 1083456
 
 
@@ -79,7 +80,7 @@ def test_train_forward_matches_reference(mt, golden_dir):
     lam = torch.from_numpy(fx["train_lambda"])
     with torch.no_grad():
         o = om.forward(mt, st, torch.from_numpy(waves(300 + seed, 6, 32000)), training=True,
-                       mixup_lambda=lam, stripes=fx["train_stripes"])
+                       mixup_lambda=lam, stripes=fx["train_stripes"], dropout_seed=int(fx["train_dropout_seed"]))
     assert o["clipwise_output"].shape == (3, 17)
     np.testing.assert_allclose(o["clipwise_output"].numpy(), fx["train_clip"], atol=1e-5)
     np.testing.assert_allclose(o["framewise_output"].numpy()[:, ::8], fx["train_frame"], atol=1e-5)
@@ -105,7 +106,8 @@ def test_three_train_steps_match_reference(mt, golden_dir):
         xw = torch.from_numpy(waves(700 + 10 * seed + it, 8, 32000))
         tg = torch.from_numpy(targets(800 + 10 * seed + it, 8))
         lam = torch.from_numpy(ofe.mixup_lambdas(8, rs).astype(np.float32))
-        o = om.forward(mt, st, xw, training=True, mixup_lambda=lam, stripes=fx["step_stripes"][it])
+        o = om.forward(mt, st, xw, training=True, mixup_lambda=lam, stripes=fx["step_stripes"][it],
+                       dropout_seed=int(fx["step_dropout_seeds"][it]))
         loss = om.clip_bce(o, {"target": om.do_mixup(tg, lam)})
         assert abs(loss.item() - fx["step_losses"][it]) < 2e-5, (it, loss.item(), fx["step_losses"][it])
         used = [k for k in keys if k not in unused]
@@ -119,7 +121,7 @@ def test_three_train_steps_match_reference(mt, golden_dir):
                         np.testing.assert_allclose(g.numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max() + 1e-7)
                 m, v, vmax = opt_state[k]
                 om.adam_amsgrad_step(st[k], g, m, v, vmax, it + 1, 1e-3)
-    assert unused == ({"att_block.bn_att.weight", "att_block.bn_att.bias"} if mt.endswith("Att") else set())
+    assert unused == set(om.unused_keys(mt))
     for k, _ in om.state_layout(mt):
         if k in om.FROZEN_KEYS:
             continue
