@@ -16,6 +16,9 @@ Pinning status
   reference's own `pytorch/models.py`, `losses.py`, `pytorch_utils.py` imported
   unmodified (`tests/golden/make_golden.py`; fixtures in `tests/golden/*.npz`;
   checked by `tests/test_oracle_*.py`).
+* Transformer heads (`MultiHead`, `models.py:587-665`): PINNED the same way; the two `nn.Dropout`s of `MultiHead` are
+  replaced in the generator by a module applying SEEDED keep masks (`oracle.model.dropout_masks`), which the oracle and
+  the product take as explicit inputs, so training-mode parity is checkable (the reference draws them from torch's RNG).
 * Front-end (rows F1, F2, F4 = third-party `torchlibrosa==0.0.4` + `librosa`,
   absent from /root/reference and from this image): **parity unpinned** by any
   reference test.  Restated from the published 0.0.4 algorithm, anchored on the
