@@ -82,10 +82,12 @@ int sed_bn0_aug_mix_bwd(const float* logmel, const float* g_out, int B2, int T, 
 
 /* ---- ConvBlock tail: BN (folded) + ReLU + avg_pool2d (models.py:102-107), and torch.mean(dim=3) (:303) as the
  * (1, W) pool of block 4.  y [B][H][W][C] raw conv output -> out [B][H/ph][W/pw][C] (floor mode).
- * Backward: pass 1 reduces (sum dy, sum dy*xhat) partials [ceil(B*H*W/1024)][2][C]; pass 2 writes
+ * Backward: pass 1 reduces (sum dy, sum dy*xhat) partials [ceil(B*H*W / sed_pool_bwd_rows_per_block(B*H*W))][2][C];
+ * pass 2 writes
  * g_y = a*dy + b*y + c with dy = relu-mask * g_out/(ph*pw). */
 int sed_bn_relu_pool_fwd(const float* y, int B, int H, int W, int C, int ph, int pw, const float* scale,
                          const float* shift, float* out, sed_stream_t stream);
+int sed_pool_bwd_rows_per_block(long M);
 int sed_bn_relu_pool_bwd_reduce(const float* y, const float* g_out, int B, int H, int W, int C, int ph, int pw,
                                 const float* scale, const float* shift, const float* mean, const float* invstd,
                                 float* partials, int* nparts_out, sed_stream_t stream);

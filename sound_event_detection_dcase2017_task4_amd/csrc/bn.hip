@@ -465,14 +465,23 @@ SED_API int sed_bn_relu_pool_fwd(const float* y, int B, int H, int W, int C, int
     return 0;
 }
 
-// pass 1: partials must hold ceil(B*H*W/1024)*2*C floats
+// rows of y per workgroup of the two pool-backward passes: 1024 for big tensors, fewer (>= 64) for small ones so that the
+// grid still holds ~2048 workgroups (at batch 32 a fixed 1024 left block 4 with 31 workgroups on 256 CUs)
+SED_API int sed_pool_bwd_rows_per_block(long M) {
+    long r = (M + 2047) / 2048;
+    r = (r + 63) / 64 * 64;
+    return (int)(r < 64 ? 64 : (r > 1024 ? 1024 : r));
+}
+
+// pass 1: partials must hold ceil(B*H*W / sed_pool_bwd_rows_per_block(B*H*W)) * 2*C floats
 SED_API int sed_bn_relu_pool_bwd_reduce(const float* y, const float* g_out, int B, int H, int W, int C, int ph, int pw,
                                         const float* scale, const float* shift, const float* mean,
                                         const float* invstd, float* partials, int* nparts_out, hipStream_t stream) {
     if (B <= 0 || C < 64 || C > 512 || (256 % (C / 4)) != 0) return SED_EINVAL;
-    int nblk = sed_cdiv((long)B * H * W, 1024);
+    const int rpb = sed_pool_bwd_rows_per_block((long)B * H * W);
+    int nblk = sed_cdiv((long)B * H * W, rpb);
     hipLaunchKernelGGL(bn_relu_pool_bwd_kernel<1>, dim3(nblk), dim3(256), 0, stream, y, g_out, B, H, W, C, ph, pw, scale, shift,
-                       mean, invstd, (const float*)nullptr, 1024, partials, (float*)nullptr);
+                       mean, invstd, (const float*)nullptr, rpb, partials, (float*)nullptr);
     if (nparts_out) *nparts_out = nblk;
     SED_LAUNCH_CHECK();
     return 0;
@@ -483,9 +492,10 @@ SED_API int sed_bn_relu_pool_bwd_apply(const float* y, const float* g_out, int B
                                        const float* scale, const float* shift, const float* coef, float* gy,
                                        hipStream_t stream) {
     if (B <= 0 || C < 64 || C > 512 || (256 % (C / 4)) != 0) return SED_EINVAL;
-    int nblk = sed_cdiv((long)B * H * W, 1024);
+    const int rpb = sed_pool_bwd_rows_per_block((long)B * H * W);
+    int nblk = sed_cdiv((long)B * H * W, rpb);
     hipLaunchKernelGGL(bn_relu_pool_bwd_kernel<2>, dim3(nblk), dim3(256), 0, stream, y, g_out, B, H, W, C, ph, pw, scale, shift,
-                       (const float*)nullptr, (const float*)nullptr, coef, 1024, (float*)nullptr, gy);
+                       (const float*)nullptr, (const float*)nullptr, coef, rpb, (float*)nullptr, gy);
     SED_LAUNCH_CHECK();
     return 0;
 }

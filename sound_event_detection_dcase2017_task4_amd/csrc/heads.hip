@@ -305,11 +305,11 @@ int grid_for(long n) {
 
 // ---- C ABI --------------------------------------------------------------------------------------------------
 
-// out[K] (=|+=) column sums of parts [n][K] with row stride ld.  ws: scratch of 256*K floats when n > 4096 (else unused).
+// out[K] (=|+=) column sums of parts [n][K] with row stride ld.  ws: scratch of 256*K floats when n > 512 (else unused).
 SED_API int sed_reduce_rows(const float* parts, long n, int K, long ld, float* out, int accumulate, float* ws,
                             hipStream_t stream) {
     if (n <= 0 || K <= 0) return SED_EINVAL;
-    if (n > 4096 && ws) {
+    if (n > 512 && ws) {
         long rpc = (n + 255) / 256;
         int chunks = (int)((n + rpc - 1) / rpc);
         hipLaunchKernelGGL(reduce_rows_chunk_kernel, dim3(sed_cdiv(K, 256), chunks), dim3(256), 0, stream, parts, n, K, ld, rpc, ws);

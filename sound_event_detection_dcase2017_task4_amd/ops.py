@@ -434,7 +434,8 @@ class ConvBlockFn(torch.autograd.Function):
         dev = x.device
         M = B * H * W
         # BN2 + ReLU + pool backward
-        npmax = (M + 1023) // 1024
+        rpb = _lib.lib().sed_pool_bwd_rows_per_block(M)
+        npmax = (M + rpb - 1) // rpb
         part = torch.empty((npmax, 2, Cout), dtype=torch.float32, device=dev)
         n = ctypes.c_int(0)
         _call("sed_bn_relu_pool_bwd_reduce", _ptr(y2), _ptr(g_out), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift),
@@ -498,7 +499,7 @@ def col_sums(x2d, ncols=None):
     n, ld = x2d.shape
     K = ld if ncols is None else ncols
     out = torch.empty((K,), dtype=torch.float32, device=x2d.device)
-    ws = torch.empty((256 * K,), dtype=torch.float32, device=x2d.device) if n > 4096 else None
+    ws = torch.empty((256 * K,), dtype=torch.float32, device=x2d.device) if n > 512 else None
     _call("sed_reduce_rows", _ptr(x2d), n, K, ld, _ptr(out), 0, _ptr(ws), _stream())
     return out
 
