@@ -504,8 +504,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 // Also emits BN partial statistics (sum, M2) per 256-pixel tile via pivot-shifted sums.
 constexpr int C1_ROWS = 256;
 
-__device__ __forceinline__ void c1_taps(const float* __restrict__ x0, long pm, int H, int W, float (&xs)[9]) {
-    int w = (int)(pm % W), h = (int)((pm / W) % H);
+// the 3x3 neighbourhood of pixel pm = (.., h, w) of the single-channel input, zero outside the image
+__device__ __forceinline__ void c1_taps(const float* __restrict__ x0, long pm, int h, int w, int H, int W, float (&xs)[9]) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         int dy = t / 3 - 1, dx = t % 3 - 1;
@@ -513,6 +513,17 @@ __device__ __forceinline__ void c1_taps(const float* __restrict__ x0, long pm, i
         xs[t] = valid ? x0[pm + dy * W + dx] : 0.f;
     }
 }
+
+// (h, w) of a pixel index walked in fixed steps: one division at the start, then carried along (a 64-bit div/mod per row
+// and lane made the Cin = 1 kernels VALU-bound)
+struct C1Walk {
+    int h, w;
+    __device__ __forceinline__ C1Walk(long pm, int H, int W) : h((int)((pm / W) % H)), w((int)(pm % W)) {}
+    __device__ __forceinline__ void advance(int step, int H, int W) {
+        w += step;
+        while (w >= W) { w -= W; if (++h == H) h = 0; }
+    }
+};
 
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x0, const float* __restrict__ w,
                                                         long M, int H, int W, float* __restrict__ y,
@@ -529,17 +540,19 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     float piv[4] = {0, 0, 0, 0};
     {
         float xs[9];
-        c1_taps(x0, base, H, W, xs);
+        const C1Walk p0(base, H, W);
+        c1_taps(x0, base, p0.h, p0.w, H, W, xs);
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int k = 0; k < 4; ++k) piv[k] = fmaf(xs[t], wr[t][k], piv[k]);
     }
     float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-    for (int r = pl; r < nrows; r += 16) {
+    C1Walk pos(base + pl, H, W);
+    for (int r = pl; r < nrows; r += 16, pos.advance(16, H, W)) {
         long pm = base + r;
         float xs[9], o[4] = {0, 0, 0, 0};
-        c1_taps(x0, pm, H, W, xs);
+        c1_taps(x0, pm, pos.h, pos.w, H, W, xs);
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -597,7 +610,8 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
     }
     const long base = (long)blockIdx.x * C1B_ROWS;
     const long nrows = min((long)C1B_ROWS, M - base);
-    for (int r = pl; r < nrows; r += 16) {
+    C1Walk pos(base + pl, H, W);
+    for (int r = pl; r < nrows; r += 16, pos.advance(16, H, W)) {
         long pm = base + r;
         float4 g = reinterpret_cast<const float4*>(gy)[pm * 16 + c4];
         if (AFF) {
@@ -606,7 +620,7 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
             g.z = fmaf(ca.z, g.z, fmaf(cb.z, v.z, cc.z)); g.w = fmaf(ca.w, g.w, fmaf(cb.w, v.w, cc.w));
         }
         float xs[9];
-        c1_taps(x0, pm, H, W, xs);
+        c1_taps(x0, pm, pos.h, pos.w, H, W, xs);
         float tp[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
