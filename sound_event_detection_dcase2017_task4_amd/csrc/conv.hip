@@ -581,6 +581,16 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     }
 }
 
+// sum over the 16 lanes of a DPP row, result in every lane: four v_add_f32 with DPP operands (xor 1, xor 2 inside the
+// quads, then half-mirror and mirror), no LDS crossbar traffic (__shfl_xor = ds_bpermute made this kernel LDS-issue-bound)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+}
+
 // backward of the Cin=1 conv: one pass over gy produces (i) per-block dW partials [nblk][9][64] and
 // (ii) t[p][tap] = <gy[p][:], w[:, tap]> (the scatter form of dgrad); conv1_dgrad_gather then sums 9 neighbours.
 constexpr int C1B_ROWS = 1024;
@@ -630,11 +640,7 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
         }
         if (tbuf) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                float v = tp[t];
-                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-                tp[t] = v;
-            }
+            for (int t = 0; t < 9; ++t) tp[t] = row16_sum(tp[t]);     // all 16 lanes of a pixel end up with the channel sum
             if (c4 < 9) {
                 float v = tp[0];
 #pragma unroll
