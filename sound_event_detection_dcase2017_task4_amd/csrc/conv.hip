@@ -593,7 +593,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 // backward of the Cin=1 conv: one pass over gy produces (i) per-block dW partials [nblk][9][64] and
 // (ii) t[p][tap] = <gy[p][:], w[:, tap]> (the scatter form of dgrad); conv1_dgrad_gather then sums 9 neighbours.
-constexpr int C1B_ROWS = 1024;
+constexpr int C1B_ROWS = 4096;      // rows per workgroup (scratch sized for 1024 by the callers: an upper bound)
 // AFF: gy is the masked dgrad output dz of the NEXT conv and the BatchNorm backward g = a*dz + b*y + c (coef [3][64])
 // is applied on load, which saves the separate sed_bn_bwd_apply pass over the two largest tensors of the model.
 template <bool AFF>
