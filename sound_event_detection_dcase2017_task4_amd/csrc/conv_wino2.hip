@@ -272,13 +272,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2P p) {
             wino2_xf_sub(xa, xc, v);                                                                            \
             SED_W2MMA(0, v[0]) SED_W2MMA(1, v[1]) SED_W2MMA(2, v[2]) SED_W2MMA(3, v[3])                         \
         }                                                                                                       \
+        /* the next step's A tile goes to LDS mid-step, behind 16 queued MFMAs: in front of the barrier its   */ \
+        /* BN-affine + ReLU instructions sat on every wave's critical path (3-5 % on the fused-input layers)  */ \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        w2lstore((BUF) ^ 1);                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
         {                                                                                                       \
             f4v v[4];                                                                                           \
             wino2_xf_fma(sgn2, xb, xc, v);                                                                      \
             SED_W2MMA(4, v[0]) SED_W2MMA(5, v[1]) SED_W2MMA(6, v[2]) SED_W2MMA(7, v[3])                         \
         }                                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-        w2lstore((BUF) ^ 1);                                                                                    \
         __builtin_amdgcn_s_setprio(0);                                                                          \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
         __syncthreads();                                                                                        \
@@ -734,7 +738,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino2_kernel(WWino2P p) {
             acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(mb.y, vb12.y, acc[6], 0, 0, 0);
             acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(eb.y, vb03.y, acc[7], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (j == 5) {
+            if (j == 6) {                                  // measured best of j = 2..7
                 ww2_store(buf ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
