@@ -208,6 +208,20 @@ int sed_gru_gate_bwd(const float* g_out0, const float* g_out1, long ld_go, const
                      float* dgi1, long ld_dgi, float* dgh0, float* dgh1, float* dh_direct_out0, float* dh_direct_out1,
                      sed_stream_t stream);
 
+/* ---- nn.GRU recurrence, fused (models.py:529-530, :565-567): one launch per time step does the hidden projection
+ * h_prev x W_hh^T (fp32 MFMA) AND the gate math for both directions; the whole T-step loop is enqueued by one call.
+ * Built for Hd = 256 (sed_gru_seq_supported); layouts: gi [B][T][6H] (forward gates r,z,n then reverse gates, incl.
+ * b_ih), hs [2][T][B][H] hidden states, saves [2][T][B][4H] = r,z,n,gh_n, out [B][T][2H] = concat(forward, reverse).
+ * Backward: g_out [B][T][2H]; wt_* = W_hh^T [H][3H]; produces dgi [B][T][6H] and dgh [2][T][B][3H] (the gate
+ * pre-activation gradients on the input / hidden side; the weight and bias gradients are plain GEMMs / column sums
+ * over them); ws = 4*B*H floats of scratch. */
+int sed_gru_seq_supported(int Hd);
+int sed_gru_seq_fwd(const float* gi, const float* w_hh_f, const float* w_hh_b, const float* b_hh_f,
+                    const float* b_hh_b, int B, int T, int Hd, float* hs, float* saves, float* out,
+                    sed_stream_t stream);
+int sed_gru_seq_bwd(const float* g_out, const float* wt_f, const float* wt_b, const float* hs, const float* saves,
+                    int B, int T, int Hd, float* dgi, float* dgh, float* ws, sed_stream_t stream);
+
 /* ---- multi-head self-attention of the Transformer heads (models.py:587-665; 8 heads x 64) ----------------------
  * q, k, v, o, g_*: [B*T][512] fp32, head h in columns 64h..64h+63 (the Linear outputs of w_qs / w_ks / w_vs, no
  * permutes).  keep: attention-dropout KEEP mask, bytes [8*B][T][T] with row index h*B + b (the (n*b) layout of

@@ -18,6 +18,7 @@ BN_MOMENTUM = 0.1
 # The fused 1-D Winograd F(2,3) kernels (csrc/conv_wino.hip) do the same convolutions with 1.5x fewer MFMA flops; they are
 # used for forward, dgrad and wgrad whenever the layer shape allows.  False = direct implicit GEMM everywhere.
 USE_WINOGRAD = 2          # 2: 2-D F(2x2,3x3) where supported, else 1-D F(2,3), else direct; 1: 1-D; 0: direct only
+USE_FUSED_GRU = True        # False: per-step GEMM + gate launches (any hidden size; the fused step kernels are built for 256)
 
 # bench.py sets this to a dict to HIP-event-time the MFMA kernels inside its timed region:
 # {tag: [(start_event, end_event, algorithmic_flops), ...]}.  None = no instrumentation.
@@ -692,6 +693,12 @@ class GruFn(torch.autograd.Function):
         saves = torch.empty((2, T, B, 4 * Hd), dtype=torch.float32, device=dev)
         whh = (_f32c(w_hh_f), _f32c(w_hh_b))
         bhh = (_f32c(b_hh_f), _f32c(b_hh_b))
+        if USE_FUSED_GRU and _lib.lib().sed_gru_seq_supported(Hd):
+            # fused recurrence: one launch per step (hidden projection on MFMA + gates), enqueued from C
+            _call("sed_gru_seq_fwd", _ptr(gi), _ptr(whh[0]), _ptr(whh[1]), _ptr(bhh[0]), _ptr(bhh[1]), B, T, Hd,
+                  _ptr(hs), _ptr(saves), _ptr(out), _stream())
+            ctx.save_for_backward(x, w_ih, whh[0], whh[1], hs, saves)
+            return out
         gh0 = torch.stack([bhh[0].view(1, -1).expand(B, -1), bhh[1].view(1, -1).expand(B, -1)]).contiguous()  # h0 = 0
         gh = torch.empty((2, B, 3 * Hd), dtype=torch.float32, device=dev)
         s = _stream()
@@ -721,10 +728,15 @@ class GruFn(torch.autograd.Function):
         dgh = torch.empty((2, T, B, 3 * Hd), dtype=torch.float32, device=dev)
         wt = (transpose_b(w_hh_f.view(1, 3 * Hd, Hd)).view(Hd, 3 * Hd),               # (H, 3H): dh = dgh x W_hh
               transpose_b(w_hh_b.view(1, 3 * Hd, Hd)).view(Hd, 3 * Hd))
+        fused = USE_FUSED_GRU and _lib.lib().sed_gru_seq_supported(Hd)
+        if fused:
+            ws = torch.empty((4, B, Hd), dtype=torch.float32, device=dev)
+            _call("sed_gru_seq_bwd", _ptr(g_out), _ptr(wt[0]), _ptr(wt[1]), _ptr(hs), _ptr(saves), B, T, Hd,
+                  _ptr(dgi), _ptr(dgh), _ptr(ws), s)
         direct = [torch.empty((2, B, Hd), dtype=torch.float32, device=dev) for _ in range(2)]   # ping-pong
         rec = [torch.empty((2, B, Hd), dtype=torch.float32, device=dev) for _ in range(2)]
         have = False
-        for k in range(T - 1, -1, -1):                 # reverse of the forward processing order
+        for k in (() if fused else range(T - 1, -1, -1)):   # reverse of the forward processing order
             tf, tb = k, T - 1 - k
             cur, prv = k & 1, (k & 1) ^ 1
             p0 = hs[0, tf - 1] if k > 0 else None

@@ -237,9 +237,13 @@ def test_att_head(ops):
         assert (d.grad.cpu() - r).abs().max().item() < 2e-4 * r.abs().max().item() + 1e-7
 
 
-def test_gru_vs_torch(ops):
+@pytest.mark.parametrize("fused,B,T", [(True, 3, 7), (True, 37, 5), (True, 64, 1), (False, 3, 7)])
+def test_gru_vs_torch(ops, monkeypatch, fused, B, T):
+    """GruFn against torch.nn.GRU (the layer the reference instantiates, models.py:529-530): fused per-step recurrence
+    kernels (ragged batch: 37 rows = one full + one partial 32-row block; T = 1: no recurrent term at all) and the
+    per-step GEMM + gate launches kept for other hidden sizes."""
+    monkeypatch.setattr(ops, "USE_FUSED_GRU", fused)
     g = torch.Generator().manual_seed(6)
-    B, T = 3, 7
     gru = torch.nn.GRU(512, 256, num_layers=1, bias=True, batch_first=True, bidirectional=True)
     for p in gru.parameters():
         p.data = torch.randn(p.shape, generator=g) * 0.05
