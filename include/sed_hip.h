@@ -208,16 +208,20 @@ int sed_gru_gate_bwd(const float* g_out0, const float* g_out1, long ld_go, const
                      float* dgi1, long ld_dgi, float* dgh0, float* dgh1, float* dh_direct_out0, float* dh_direct_out1,
                      sed_stream_t stream);
 
-/* ---- nn.GRU recurrence, fused (models.py:529-530, :565-567): one launch per time step does the hidden projection
- * h_prev x W_hh^T (fp32 MFMA) AND the gate math for both directions; the whole T-step loop is enqueued by one call.
- * Built for Hd = 256 (sed_gru_seq_supported); layouts: gi [B][T][6H] (forward gates r,z,n then reverse gates, incl.
- * b_ih), hs [2][T][B][H] hidden states, saves [2][T][B][4H] = r,z,n,gh_n, out [B][T][2H] = concat(forward, reverse).
- * Backward: g_out [B][T][2H]; wt_* = W_hh^T [H][3H]; produces dgi [B][T][6H] and dgh [2][T][B][3H] (the gate
- * pre-activation gradients on the input / hidden side; the weight and bias gradients are plain GEMMs / column sums
- * over them); ws = 4*B*H floats of scratch. */
-int sed_gru_seq_supported(int Hd);
+/* ---- nn.GRU recurrence, fused (models.py:529-530, :565-567): ONE persistent launch per pass runs all T steps of both
+ * directions -- hidden projection h_prev x W_hh^T on fp32 MFMA with the weight slice resident in registers, gate math,
+ * and a per-(direction, 32-row block) counter in `ws` that orders the steps among the 8 workgroups sharing the rows
+ * (bounded spin, no grid-wide barrier).  Built for Hd = 256 and B <= 512 (all workgroups must be co-resident):
+ * sed_gru_seq_supported; callers use the per-step GEMM + sed_gru_gate_* launches otherwise.
+ * Layouts: gi [B][T][6H] (forward gates r,z,n then reverse gates, incl. b_ih), hs [2][T][B][H] hidden states,
+ * saves [2][T][B][4H] = r,z,n,gh_n, out [B][T][2H] = concat(forward, reverse).  Backward: g_out [B][T][2H];
+ * wt_* = W_hh^T [H][3H]; produces dgi [B][T][6H] and dgh [2][T][B][3H] (gate pre-activation gradients on the input /
+ * hidden side; weight and bias gradients are plain GEMMs / column sums over them).
+ * ws: sed_gru_seq_ws_floats() floats of scratch (counters; zeroed by the call). */
+int sed_gru_seq_supported(int B, int Hd);
+long sed_gru_seq_ws_floats(void);
 int sed_gru_seq_fwd(const float* gi, const float* w_hh_f, const float* w_hh_b, const float* b_hh_f,
-                    const float* b_hh_b, int B, int T, int Hd, float* hs, float* saves, float* out,
+                    const float* b_hh_b, int B, int T, int Hd, float* hs, float* saves, float* out, float* ws,
                     sed_stream_t stream);
 int sed_gru_seq_bwd(const float* g_out, const float* wt_f, const float* wt_b, const float* hs, const float* saves,
                     int B, int T, int Hd, float* dgi, float* dgh, float* ws, sed_stream_t stream);

@@ -22,200 +22,270 @@
 
 namespace {
 
-constexpr int GH = 256;                                // hidden size the fused kernels are built for
+constexpr int GH = 256;                                // hidden size the kernels are built for
+constexpr int GRU_FLAG_INTS = 1024;                    // counters (one per (direction, row block) group) + error word
+constexpr int GRU_MAX_GROUPS = GRU_FLAG_INTS - 1;
 
 __device__ __forceinline__ float gru_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // accumulator register r of a 32x32 MFMA tile holds row (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), column lane & 31
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-struct GruStepFwdP {
-    const float* gi[2];        // [B] rows (stride ld_gi) x [3H]: input projection incl. b_ih at this direction's time index
-    const float* h_prev[2];    // [B][H] or null (h0 = 0)
-    const float* w[2];         // W_hh [3H][H]
-    const float* bhh[2];       // [3H]
-    float* h_out[2];           // [B][H]
-    float* out2[2];            // rows (stride ld_out2): the (B,T,2H) output slice
-    float* save[2];            // [B][4H] = r, z, n, gh_n
-    long ld_gi, ld_out2;
-    int B;
-};
-
-__global__ __launch_bounds__(512) void gru_step_fwd_kernel(GruStepFwdP p) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 3 * 16 * 64];      // 48 KB
-    const int d = blockIdx.z, r0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int hf = lane >> 5, l31 = lane & 31;
-    const float* h_prev = p.h_prev[d];
-
-    floatx16 acc[3];
+// Data exchanged between workgroups DURING the kernel (h_t forward, dgh_t backward) is written and read with
+// agent-scope relaxed atomics (64-bit): they go to the coherence point, so the step synchronisation needs no L2
+// write-back / invalidate (an agent-scope fence pair cost ~10 us per step on the 8-XCD part: measured).
+__device__ __forceinline__ void st_coherent(float* ptr, float2 v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(ptr), __builtin_bit_cast(unsigned long long, v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// 16-byte coherent load (system-scope cache policy bits; atomicity is not needed: the data was completed before the
+// counter the reader waited on).  The result is valid only after ld_coherent_wait on the same registers.
+typedef float f4r __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ld_coherent4(f4r& dst, const float* ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(dst) : "v"(ptr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void ld_coherent_wait(f4r (&v)[N]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
-    if (h_prev) {
-        const int kb = wave * 32 + hf * 16;            // this lane's 16 consecutive k
-        const int row = min(r0 + l31, p.B - 1);
-        float4 a[4], b[3][4];
-        const float4* ap = reinterpret_cast<const float4*>(h_prev + (long)row * GH + kb);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a[q] = ap[q];
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            const float4* bp = reinterpret_cast<const float4*>(p.w[d] + (long)(g * GH + j0 + l31) * GH + kb);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) b[g][q] = bp[q];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, b[g][q].x, acc[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, b[g][q].y, acc[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, b[g][q].z, acc[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, b[g][q].w, acc[g], 0, 0, 0);
-            }
-        // two-phase reduction over the 8 waves: 4..7 -> LDS -> added by 0..3 -> LDS -> summed by the output threads
-        if (wave >= 4) {
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) red[(((wave - 4) * 3 + g) * 16 + r) * 64 + lane] = acc[g][r];
-        }
-        __syncthreads();
-        if (wave < 4) {
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[g][r] += red[((wave * 3 + g) * 16 + r) * 64 + lane];
-        }
-        __syncthreads();
-        if (wave < 4) {
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) red[((wave * 3 + g) * 16 + r) * 64 + lane] = acc[g][r];
-        }
-        __syncthreads();
-    }
-    // thread -> accumulator register r = tid >> 5 of the lane pair (2q, 2q+1), q = tid & 31: two adjacent hidden units
-    const int r = tid >> 5, lp = (tid & 31) * 2;
-    const int row = r0 + acc_row(r, lp >> 5);
-    if (row >= p.B) return;
-    const int j = j0 + (lp & 31);
-    float2 gh[3];
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
-        float2 s = *reinterpret_cast<const float2*>(p.bhh[d] + g * GH + j);
-        if (h_prev) {
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const float2 v = *reinterpret_cast<const float2*>(&red[((w * 3 + g) * 16 + r) * 64 + lp]);
-                s.x += v.x; s.y += v.y;
-            }
-        }
-        gh[g] = s;
-    }
-    const float* gir = p.gi[d] + (long)row * p.ld_gi + j;
-    const float2 gr = *reinterpret_cast<const float2*>(gir);
-    const float2 gz = *reinterpret_cast<const float2*>(gir + GH);
-    const float2 gn = *reinterpret_cast<const float2*>(gir + 2 * GH);
-    float2 hp = make_float2(0.f, 0.f);
-    if (h_prev) hp = *reinterpret_cast<const float2*>(h_prev + (long)row * GH + j);
-    float2 rr, zz, nn, hh;
-    rr.x = gru_sigmoid(gr.x + gh[0].x); rr.y = gru_sigmoid(gr.y + gh[0].y);
-    zz.x = gru_sigmoid(gz.x + gh[1].x); zz.y = gru_sigmoid(gz.y + gh[1].y);
-    nn.x = tanhf(gn.x + rr.x * gh[2].x); nn.y = tanhf(gn.y + rr.y * gh[2].y);
-    hh.x = (1.0f - zz.x) * nn.x + zz.x * hp.x; hh.y = (1.0f - zz.y) * nn.y + zz.y * hp.y;
-    *reinterpret_cast<float2*>(p.h_out[d] + (long)row * GH + j) = hh;
-    *reinterpret_cast<float2*>(p.out2[d] + (long)row * p.ld_out2 + j) = hh;
-    float* s = p.save[d] + (long)row * 4 * GH + j;
-    *reinterpret_cast<float2*>(s) = rr;
-    *reinterpret_cast<float2*>(s + GH) = zz;
-    *reinterpret_cast<float2*>(s + 2 * GH) = nn;
-    *reinterpret_cast<float2*>(s + 3 * GH) = gh[2];
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));
 }
 
-struct GruStepBwdP {
-    const float* g_out[2];     // rows (stride ld_go) x [H]: gradient of this direction's output at this time index
-    const float* dh_direct[2]; // [B][H] = dh * z of the later step, or null
-    const float* dgh_next[2];  // [B][3H] = dgh of the later step (its W_hh path is contracted here), or null
-    const float* wt[2];        // W_hh^T [H][3H]
-    const float* save[2];      // [B][4H]
-    const float* h_prev[2];    // [B][H] or null
-    float* dgi[2];             // rows (stride ld_dgi) x [3H]
-    float* dgh[2];             // [B][3H]
-    float* dh_direct_out[2];   // [B][H]
-    long ld_go, ld_dgi;
-    int B;
+// Group synchronisation.  arrive: every thread's coherent stores of the step are complete at the barrier (HIP's
+// __syncthreads waits for outstanding memory operations), then one thread bumps the
+// counter.  wait: one thread spins (bounded) until all `target` arrivals are visible, then releases the block.
+__device__ __forceinline__ void group_arrive(int* counter) {
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void group_wait(int* counter, int target, int* err) {
+    if (threadIdx.x == 0) {
+        long spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 1023) == 0 &&
+                (spins > (1L << 23) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // give up everywhere, never hang
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+struct GruSeqFwdP {
+    const float* gi;           // [B][T][6H]: input projections incl. b_ih, forward gates then reverse gates
+    const float* w[2];         // W_hh [3H][H]
+    const float* bhh[2];       // [3H]
+    float* hs;                 // [2][T][B][H]
+    float* saves;              // [2][T][B][4H] = r, z, n, gh_n
+    float* out;                // [B][T][2H]
+    int* flags;                // [ngroups] arrival counters (zeroed by the launcher) + error word at [GRU_MAX_GROUPS]
+    int B, T, ngroups;
 };
 
-__global__ __launch_bounds__(512) void gru_step_bwd_kernel(GruStepBwdP p) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];          // 16 KB
-    const int d = blockIdx.z, r0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+__global__ __launch_bounds__(512) void gru_seq_fwd_kernel(GruSeqFwdP p) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 3 * 16 * 64];      // 48 KB
+    const int group = blockIdx.x % p.ngroups, jb = blockIdx.x / p.ngroups;   // group members: ids group + ngroups*jb
+    const int d = group & 1, r0 = (group >> 1) * 32, j0 = jb * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hf = lane >> 5, l31 = lane & 31;
-    const float* dgh_next = p.dgh_next[d];
+    const int B = p.B, T = p.T;
+    const long bh = (long)B * GH;
+    int* const counter = p.flags + group;
+    int* const err = p.flags + GRU_MAX_GROUPS;
 
-    if (dgh_next) {
-        // dh_gemm[b][j] = sum_c dgh_next[b][c] * W_hh[c][j], c over 3H = 768: 96 per wave, 48 consecutive per lane
-        floatx16 acc;
+    // this lane's part of the weight slice, resident for the whole sequence: gate g, hidden unit j0 + l31, 16 consecutive k
+    const int kb = wave * 32 + hf * 16;
+    float4 b[3][4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const int kb = wave * 96 + hf * 48;
-        const int row = min(r0 + l31, p.B - 1);
-        float4 a[12], b[12];
-        const float4* ap = reinterpret_cast<const float4*>(dgh_next + (long)row * 3 * GH + kb);
-        const float4* bp = reinterpret_cast<const float4*>(p.wt[d] + (long)(j0 + l31) * 3 * GH + kb);
+    for (int g = 0; g < 3; ++g) {
+        const float4* bp = reinterpret_cast<const float4*>(p.w[d] + (long)(g * GH + j0 + l31) * GH + kb);
 #pragma unroll
-        for (int q = 0; q < 12; ++q) { a[q] = ap[q]; b[q] = bp[q]; }
-#pragma unroll
-        for (int q = 0; q < 12; ++q) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, b[q].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, b[q].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, b[q].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, b[q].w, acc, 0, 0, 0);
-        }
-        if (wave >= 4) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red[((wave - 4) * 16 + r) * 64 + lane] = acc[r];
-        }
-        __syncthreads();
-        if (wave < 4) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += red[(wave * 16 + r) * 64 + lane];
-        }
-        __syncthreads();
-        if (wave < 4) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
-        }
-        __syncthreads();
+        for (int q = 0; q < 4; ++q) b[g][q] = bp[q];
     }
+    const int arow = min(r0 + l31, B - 1);             // operand row of this lane (clamped: ragged last row block)
+    // output role: accumulator register r = tid >> 5 of the lane pair (2q, 2q+1), q = tid & 31: two adjacent hidden units
     const int r = tid >> 5, lp = (tid & 31) * 2;
     const int row = r0 + acc_row(r, lp >> 5);
-    if (row >= p.B) return;
+    const bool live = row < B;
+    const int rowc = live ? row : B - 1;
     const int j = j0 + (lp & 31);
-    float2 dh = *reinterpret_cast<const float2*>(p.g_out[d] + (long)row * p.ld_go + j);
-    if (p.dh_direct[d]) {
-        const float2 v = *reinterpret_cast<const float2*>(p.dh_direct[d] + (long)row * GH + j);
-        dh.x += v.x; dh.y += v.y;
-    }
-    if (dgh_next) {
-        float2 sum = make_float2(0.f, 0.f);
+    float2 bias[3];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float2 v = *reinterpret_cast<const float2*>(&red[(w * 16 + r) * 64 + lp]);
-            sum.x += v.x; sum.y += v.y;
+    for (int g = 0; g < 3; ++g) bias[g] = *reinterpret_cast<const float2*>(p.bhh[d] + g * GH + j);
+
+    float2 hlast = make_float2(0.f, 0.f);
+    for (int k = 0; k < T; ++k) {
+        const int t = d ? T - 1 - k : k;
+        const float* h_prev = p.hs + ((long)d * T + (d ? t + 1 : t - 1)) * bh;
+        // independent of the previous step: this thread's input-projection values
+        const float* gir = p.gi + ((long)rowc * T + t) * 6 * GH + d * 3 * GH + j;
+        const float2 gr = *reinterpret_cast<const float2*>(gir);
+        const float2 gz = *reinterpret_cast<const float2*>(gir + GH);
+        const float2 gn = *reinterpret_cast<const float2*>(gir + 2 * GH);
+        float2 gh[3] = {bias[0], bias[1], bias[2]};
+        float2 hp = make_float2(0.f, 0.f);
+        if (k > 0) {
+            group_wait(counter, 8 * k, err);
+            f4r a[4];
+            const float* ap = h_prev + (long)arow * GH + kb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ld_coherent4(a[q], ap + 4 * q);
+            ld_coherent_wait(a);
+            hp = hlast;                                // this thread wrote h_{t-1}[row][j, j+1] itself
+            floatx16 acc[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, b[g][q].x, acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, b[g][q].y, acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, b[g][q].z, acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, b[g][q].w, acc[g], 0, 0, 0);
+                }
+            // two-phase reduction over the 8 waves: 4..7 -> LDS -> added by 0..3 -> LDS -> summed by the output threads
+            if (wave >= 4) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) red[(((wave - 4) * 3 + g) * 16 + i) * 64 + lane] = acc[g][i];
+            }
+            __syncthreads();
+            if (wave < 4) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[g][i] += red[((wave * 3 + g) * 16 + i) * 64 + lane];
+            }
+            __syncthreads();
+            if (wave < 4) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) red[((wave * 3 + g) * 16 + i) * 64 + lane] = acc[g][i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const float2 v = *reinterpret_cast<const float2*>(&red[((w * 3 + g) * 16 + r) * 64 + lp]);
+                    gh[g].x += v.x; gh[g].y += v.y;
+                }
         }
-        dh.x += sum.x; dh.y += sum.y;
+        if (live) {
+            float2 rr, zz, nn, hh;
+            rr.x = gru_sigmoid(gr.x + gh[0].x); rr.y = gru_sigmoid(gr.y + gh[0].y);
+            zz.x = gru_sigmoid(gz.x + gh[1].x); zz.y = gru_sigmoid(gz.y + gh[1].y);
+            nn.x = tanhf(gn.x + rr.x * gh[2].x); nn.y = tanhf(gn.y + rr.y * gh[2].y);
+            hh.x = (1.0f - zz.x) * nn.x + zz.x * hp.x; hh.y = (1.0f - zz.y) * nn.y + zz.y * hp.y;
+            st_coherent(p.hs + ((long)d * T + t) * bh + (long)row * GH + j, hh);
+            hlast = hh;
+            *reinterpret_cast<float2*>(p.out + ((long)row * T + t) * 2 * GH + d * GH + j) = hh;
+            float* s = p.saves + ((long)d * T + t) * 4 * bh + (long)row * 4 * GH + j;
+            *reinterpret_cast<float2*>(s) = rr;
+            *reinterpret_cast<float2*>(s + GH) = zz;
+            *reinterpret_cast<float2*>(s + 2 * GH) = nn;
+            *reinterpret_cast<float2*>(s + 3 * GH) = gh[2];
+        }
+        if (k + 1 < T) group_arrive(counter);
     }
-    const float* s = p.save[d] + (long)row * 4 * GH + j;
-    const float2 rr = *reinterpret_cast<const float2*>(s), zz = *reinterpret_cast<const float2*>(s + GH);
-    const float2 nn = *reinterpret_cast<const float2*>(s + 2 * GH), ghn = *reinterpret_cast<const float2*>(s + 3 * GH);
-    float2 hp = make_float2(0.f, 0.f);
-    if (p.h_prev[d]) hp = *reinterpret_cast<const float2*>(p.h_prev[d] + (long)row * GH + j);
-    float2 dr_pre, dz_pre, dn_pre, dn_r, dhz;
+}
+
+struct GruSeqBwdP {
+    const float* g_out;        // [B][T][2H]
+    const float* wt[2];        // W_hh^T [H][3H]
+    const float* hs;           // [2][T][B][H]
+    const float* saves;        // [2][T][B][4H]
+    float* dgi;                // [B][T][6H]
+    float* dgh;                // [2][T][B][3H]
+    int* flags;
+    int B, T, ngroups;
+};
+
+__global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqBwdP p) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];          // 16 KB
+    const int group = blockIdx.x % p.ngroups, jb = blockIdx.x / p.ngroups;
+    const int d = group & 1, r0 = (group >> 1) * 32, j0 = jb * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hf = lane >> 5, l31 = lane & 31;
+    const int B = p.B, T = p.T;
+    const long bh = (long)B * GH;
+    int* const counter = p.flags + group;
+    int* const err = p.flags + GRU_MAX_GROUPS;
+
+    // dh_gemm[b][j] = sum_c dgh_later[b][c] * W_hh[c][j], c over 3H = 768: 96 per wave, 48 consecutive per lane;
+    // this lane's run of row j0 + l31 of W_hh^T is resident for the whole sequence
+    const int kb = wave * 96 + hf * 48;
+    float4 b[12];
+    {
+        const float4* bp = reinterpret_cast<const float4*>(p.wt[d] + (long)(j0 + l31) * 3 * GH + kb);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) b[q] = bp[q];
+    }
+    const int arow = min(r0 + l31, B - 1);
+    const int r = tid >> 5, lp = (tid & 31) * 2;
+    const int row = r0 + acc_row(r, lp >> 5);
+    const bool live = row < B;
+    const int rowc = live ? row : B - 1;
+    const int j = j0 + (lp & 31);
+    float2 dhz = make_float2(0.f, 0.f);                // dh * z of the step processed before (the later time step)
+
+    for (int k = T - 1, done = 0; k >= 0; --k, ++done) {
+        const int t = d ? T - 1 - k : k;
+        // independent of the later step: output gradient, saved gates, previous hidden state
+        float2 dh = *reinterpret_cast<const float2*>(p.g_out + ((long)rowc * T + t) * 2 * GH + d * GH + j);
+        const float* s = p.saves + ((long)d * T + t) * 4 * bh + (long)rowc * 4 * GH + j;
+        const float2 rr = *reinterpret_cast<const float2*>(s), zz = *reinterpret_cast<const float2*>(s + GH);
+        const float2 nn = *reinterpret_cast<const float2*>(s + 2 * GH), ghn = *reinterpret_cast<const float2*>(s + 3 * GH);
+        float2 hp = make_float2(0.f, 0.f);
+        if (k > 0) hp = *reinterpret_cast<const float2*>(p.hs + ((long)d * T + (d ? t + 1 : t - 1)) * bh + (long)rowc * GH + j);
+        dh.x += dhz.x; dh.y += dhz.y;
+        if (done > 0) {
+            group_wait(counter, 8 * done, err);
+            const float* dgh_later = p.dgh + ((long)d * T + (d ? t - 1 : t + 1)) * 3 * bh;
+            f4r a[12];
+            const float* ap = dgh_later + (long)arow * 3 * GH + kb;
+#pragma unroll
+            for (int q = 0; q < 12; ++q) ld_coherent4(a[q], ap + 4 * q);
+            ld_coherent_wait(a);
+            floatx16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, b[q].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, b[q].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, b[q].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, b[q].w, acc, 0, 0, 0);
+            }
+            if (wave >= 4) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) red[((wave - 4) * 16 + i) * 64 + lane] = acc[i];
+            }
+            __syncthreads();
+            if (wave < 4) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] += red[(wave * 16 + i) * 64 + lane];
+            }
+            __syncthreads();
+            if (wave < 4) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = acc[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float2 v = *reinterpret_cast<const float2*>(&red[(w * 16 + r) * 64 + lp]);
+                dh.x += v.x; dh.y += v.y;
+            }
+        }
+        float2 dr_pre, dz_pre, dn_pre, dn_r;
 #define SED_GRU_BWD(c)                                                                                          \
     {                                                                                                           \
         const float dn = dh.c * (1.0f - zz.c);                                                                  \
@@ -227,71 +297,50 @@ __global__ __launch_bounds__(512) void gru_step_bwd_kernel(GruStepBwdP p) {
         dn_r.c = dn_pre.c * rr.c;                                                                               \
         dhz.c = dh.c * zz.c;                                                                                    \
     }
-    SED_GRU_BWD(x) SED_GRU_BWD(y)
+        SED_GRU_BWD(x) SED_GRU_BWD(y)
 #undef SED_GRU_BWD
-    float* gi_o = p.dgi[d] + (long)row * p.ld_dgi + j;
-    float* gh_o = p.dgh[d] + (long)row * 3 * GH + j;
-    *reinterpret_cast<float2*>(gi_o) = dr_pre;
-    *reinterpret_cast<float2*>(gi_o + GH) = dz_pre;
-    *reinterpret_cast<float2*>(gi_o + 2 * GH) = dn_pre;
-    *reinterpret_cast<float2*>(gh_o) = dr_pre;
-    *reinterpret_cast<float2*>(gh_o + GH) = dz_pre;
-    *reinterpret_cast<float2*>(gh_o + 2 * GH) = dn_r;
-    *reinterpret_cast<float2*>(p.dh_direct_out[d] + (long)row * GH + j) = dhz;
+        if (live) {
+            float* gi_o = p.dgi + ((long)row * T + t) * 6 * GH + d * 3 * GH + j;
+            float* gh_o = p.dgh + ((long)d * T + t) * 3 * bh + (long)row * 3 * GH + j;
+            *reinterpret_cast<float2*>(gi_o) = dr_pre;
+            *reinterpret_cast<float2*>(gi_o + GH) = dz_pre;
+            *reinterpret_cast<float2*>(gi_o + 2 * GH) = dn_pre;
+            st_coherent(gh_o, dr_pre);
+            st_coherent(gh_o + GH, dz_pre);
+            st_coherent(gh_o + 2 * GH, dn_r);
+        }
+        if (k > 0) group_arrive(counter);
+    }
 }
 
 }  // namespace
 
-SED_API int sed_gru_seq_supported(int Hd) { return Hd == GH; }
+SED_API int sed_gru_seq_supported(int B, int Hd) { return Hd == GH && B > 0 && 2 * sed_cdiv(B, 32) * (GH / 32) <= 256; }
+SED_API long sed_gru_seq_ws_floats(void) { return GRU_FLAG_INTS; }
 
-// Whole forward recurrence, T launches enqueued from here.  Direction 0 walks t = 0..T-1, direction 1 walks t = T-1..0.
+// Whole forward recurrence in one launch.  Direction 0 walks t = 0..T-1, direction 1 walks t = T-1..0.
 SED_API int sed_gru_seq_fwd(const float* gi, const float* w_hh_f, const float* w_hh_b, const float* b_hh_f,
-                            const float* b_hh_b, int B, int T, int Hd, float* hs, float* saves, float* out,
+                            const float* b_hh_b, int B, int T, int Hd, float* hs, float* saves, float* out, float* ws,
                             hipStream_t stream) {
-    if (B <= 0 || T <= 0 || Hd != GH) return SED_EINVAL;
-    const long bh = (long)B * GH;
-    for (int k = 0; k < T; ++k) {
-        const int tf = k, tb = T - 1 - k;
-        GruStepFwdP p;
-        p.gi[0] = gi + (long)tf * 6 * GH;            p.gi[1] = gi + (long)tb * 6 * GH + 3 * GH;
-        p.h_prev[0] = k ? hs + (long)(tf - 1) * bh : nullptr;
-        p.h_prev[1] = k ? hs + ((long)T + tb + 1) * bh : nullptr;
-        p.w[0] = w_hh_f; p.w[1] = w_hh_b; p.bhh[0] = b_hh_f; p.bhh[1] = b_hh_b;
-        p.h_out[0] = hs + (long)tf * bh;             p.h_out[1] = hs + ((long)T + tb) * bh;
-        p.out2[0] = out + (long)tf * 2 * GH;         p.out2[1] = out + (long)tb * 2 * GH + GH;
-        p.save[0] = saves + (long)tf * 4 * bh;       p.save[1] = saves + ((long)T + tb) * 4 * bh;
-        p.ld_gi = (long)T * 6 * GH; p.ld_out2 = (long)T * 2 * GH; p.B = B;
-        hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(GH / 32, sed_cdiv(B, 32), 2), dim3(512), 0, stream, p);
-    }
+    const int ngroups = 2 * sed_cdiv(B, 32);
+    if (B <= 0 || T <= 0 || Hd != GH || ngroups > GRU_MAX_GROUPS || ngroups * (GH / 32) > 256) return SED_EINVAL;
+    hipError_t e = hipMemsetAsync(ws, 0, GRU_FLAG_INTS * sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
+    GruSeqFwdP p{gi, {w_hh_f, w_hh_b}, {b_hh_f, b_hh_b}, hs, saves, out, reinterpret_cast<int*>(ws), B, T, ngroups};
+    hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3(ngroups * (GH / 32)), dim3(512), 0, stream, p);
     SED_LAUNCH_CHECK();
     return 0;
 }
 
-// Whole backward recurrence (reverse processing order).  ws: 4*B*H floats (ping-pong dh*z buffers, both directions).
+// Whole backward recurrence in one launch (reverse processing order).
 SED_API int sed_gru_seq_bwd(const float* g_out, const float* wt_f, const float* wt_b, const float* hs, const float* saves,
                             int B, int T, int Hd, float* dgi, float* dgh, float* ws, hipStream_t stream) {
-    if (B <= 0 || T <= 0 || Hd != GH) return SED_EINVAL;
-    const long bh = (long)B * GH;
-    for (int k = T - 1; k >= 0; --k) {
-        const int tf = k, tb = T - 1 - k;
-        const bool later = k < T - 1;
-        float* cur = ws + (long)(k & 1) * 2 * bh;
-        const float* prv = ws + (long)((k & 1) ^ 1) * 2 * bh;
-        GruStepBwdP p;
-        p.g_out[0] = g_out + (long)tf * 2 * GH;      p.g_out[1] = g_out + (long)tb * 2 * GH + GH;
-        p.dh_direct[0] = later ? prv : nullptr;      p.dh_direct[1] = later ? prv + bh : nullptr;
-        p.dgh_next[0] = later ? dgh + (long)(tf + 1) * 3 * bh : nullptr;
-        p.dgh_next[1] = later ? dgh + ((long)T + tb - 1) * 3 * bh : nullptr;
-        p.wt[0] = wt_f; p.wt[1] = wt_b;
-        p.save[0] = saves + (long)tf * 4 * bh;       p.save[1] = saves + ((long)T + tb) * 4 * bh;
-        p.h_prev[0] = k ? hs + (long)(tf - 1) * bh : nullptr;
-        p.h_prev[1] = k ? hs + ((long)T + tb + 1) * bh : nullptr;
-        p.dgi[0] = dgi + (long)tf * 6 * GH;          p.dgi[1] = dgi + (long)tb * 6 * GH + 3 * GH;
-        p.dgh[0] = dgh + (long)tf * 3 * bh;          p.dgh[1] = dgh + ((long)T + tb) * 3 * bh;
-        p.dh_direct_out[0] = cur;                    p.dh_direct_out[1] = cur + bh;
-        p.ld_go = (long)T * 2 * GH; p.ld_dgi = (long)T * 6 * GH; p.B = B;
-        hipLaunchKernelGGL(gru_step_bwd_kernel, dim3(GH / 32, sed_cdiv(B, 32), 2), dim3(512), 0, stream, p);
-    }
+    const int ngroups = 2 * sed_cdiv(B, 32);
+    if (B <= 0 || T <= 0 || Hd != GH || ngroups > GRU_MAX_GROUPS || ngroups * (GH / 32) > 256) return SED_EINVAL;
+    hipError_t e = hipMemsetAsync(ws, 0, GRU_FLAG_INTS * sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
+    GruSeqBwdP p{g_out, {wt_f, wt_b}, hs, saves, dgi, dgh, reinterpret_cast<int*>(ws), B, T, ngroups};
+    hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(ngroups * (GH / 32)), dim3(512), 0, stream, p);
     SED_LAUNCH_CHECK();
     return 0;
 }

@@ -693,10 +693,11 @@ class GruFn(torch.autograd.Function):
         saves = torch.empty((2, T, B, 4 * Hd), dtype=torch.float32, device=dev)
         whh = (_f32c(w_hh_f), _f32c(w_hh_b))
         bhh = (_f32c(b_hh_f), _f32c(b_hh_b))
-        if USE_FUSED_GRU and _lib.lib().sed_gru_seq_supported(Hd):
-            # fused recurrence: one launch per step (hidden projection on MFMA + gates), enqueued from C
+        if USE_FUSED_GRU and _lib.lib().sed_gru_seq_supported(B, Hd):
+            # fused recurrence: ONE persistent launch for all T steps of both directions (csrc/gru.hip)
+            ws = torch.empty((_lib.lib().sed_gru_seq_ws_floats(),), dtype=torch.float32, device=dev)
             _call("sed_gru_seq_fwd", _ptr(gi), _ptr(whh[0]), _ptr(whh[1]), _ptr(bhh[0]), _ptr(bhh[1]), B, T, Hd,
-                  _ptr(hs), _ptr(saves), _ptr(out), _stream())
+                  _ptr(hs), _ptr(saves), _ptr(out), _ptr(ws), _stream())
             ctx.save_for_backward(x, w_ih, whh[0], whh[1], hs, saves)
             return out
         gh0 = torch.stack([bhh[0].view(1, -1).expand(B, -1), bhh[1].view(1, -1).expand(B, -1)]).contiguous()  # h0 = 0
@@ -728,9 +729,9 @@ class GruFn(torch.autograd.Function):
         dgh = torch.empty((2, T, B, 3 * Hd), dtype=torch.float32, device=dev)
         wt = (transpose_b(w_hh_f.view(1, 3 * Hd, Hd)).view(Hd, 3 * Hd),               # (H, 3H): dh = dgh x W_hh
               transpose_b(w_hh_b.view(1, 3 * Hd, Hd)).view(Hd, 3 * Hd))
-        fused = USE_FUSED_GRU and _lib.lib().sed_gru_seq_supported(Hd)
+        fused = USE_FUSED_GRU and _lib.lib().sed_gru_seq_supported(B, Hd)
         if fused:
-            ws = torch.empty((4, B, Hd), dtype=torch.float32, device=dev)
+            ws = torch.empty((_lib.lib().sed_gru_seq_ws_floats(),), dtype=torch.float32, device=dev)
             _call("sed_gru_seq_bwd", _ptr(g_out), _ptr(wt[0]), _ptr(wt[1]), _ptr(hs), _ptr(saves), B, T, Hd,
                   _ptr(dgi), _ptr(dgh), _ptr(ws), s)
         direct = [torch.empty((2, B, Hd), dtype=torch.float32, device=dev) for _ in range(2)]   # ping-pong
