@@ -87,6 +87,24 @@ int sed_bn0_aug_mix_bwd(const float* logmel, const float* g_out, int B2, int T, 
  * g_y = a*dy + b*y + c with dy = relu-mask * g_out/(ph*pw). */
 int sed_bn_relu_pool_fwd(const float* y, int B, int H, int W, int C, int ph, int pw, const float* scale,
                          const float* shift, float* out, sed_stream_t stream);
+/* forward that also writes cnt [B][H/ph][W/pw][C] bytes = how many of the ph*pw window inputs passed the ReLU; with
+ * it and the pooled output, backward pass 1 runs at POOLED resolution (sum dy = sum g*cnt/n, sum dy*xhat =
+ * sum g*(p - beta*cnt/n)/gamma, n = ph*pw) and never touches y.  The 1/gamma amplifies fp32 rounding of p: use the
+ * full-resolution sed_bn_relu_pool_bwd_reduce when some |gamma| is small. */
+int sed_bn_relu_pool_fwd_cnt(const float* y, int B, int H, int W, int C, int ph, int pw, const float* scale,
+                             const float* shift, float* out, unsigned char* cnt, sed_stream_t stream);
+int sed_bn_relu_pool_bwd_reduce_win(const float* g_out, const float* pooled, const unsigned char* cnt, long Mp, int C,
+                                    int window, const float* gamma, const float* beta, float* partials,
+                                    int* nparts_out, sed_stream_t stream);
+/* pass 1 with the windowed / exact choice made on the device from this step's gamma (windowed when every |gamma[c]| >=
+ * gamma_min; the other kernel returns at once).  partials: sed_bn_relu_pool_bwd_reduce_auto_parts(...) * 2*C floats,
+ * zeroed by the call; *nparts_out = that part count. */
+long sed_bn_relu_pool_bwd_reduce_auto_parts(int B, int H, int W, int ph, int pw);
+int sed_bn_relu_pool_bwd_reduce_auto(const float* y, const float* g_out, const float* pooled, const unsigned char* cnt,
+                                     int B, int H, int W, int C, int ph, int pw, const float* scale,
+                                     const float* shift, const float* mean, const float* invstd, const float* gamma,
+                                     const float* beta, float gamma_min, float* partials, int* nparts_out,
+                                     sed_stream_t stream);
 int sed_pool_bwd_rows_per_block(long M);
 int sed_bn_relu_pool_bwd_reduce(const float* y, const float* g_out, int B, int H, int W, int C, int ph, int pw,
                                 const float* scale, const float* shift, const float* mean, const float* invstd,

@@ -251,12 +251,23 @@ __global__ __launch_bounds__(256) void bn0_aug_mix_bwd_kernel(const float* __res
     }
 }
 
+// block-wide "some |gamma[c]| < gmin" (every block evaluates it redundantly: C <= 512 loads and one barrier)
+__device__ __forceinline__ bool any_small_gamma(const float* __restrict__ gamma, int C, float gmin) {
+    bool small = false;
+    for (int c = threadIdx.x; c < C; c += 256) small |= fabsf(gamma[c]) < gmin;
+    return __syncthreads_or(small ? 1 : 0) != 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // BN(folded)+ReLU+avg-pool forward.  y [B][H][W][C] -> out [B][H/ph][W/pw][C]  (floor mode: trailing rows dropped)
+// CNT: also write, per pooled element, how many of its ph*pw inputs passed the ReLU (one byte per channel, packed 4 to a
+// word like the float4 lanes) -- with the pooled output itself that is all backward pass 1 needs (see
+// pool_bwd_reduce_win_kernel).
+template <bool CNT>
 __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __restrict__ y, int B, int H, int W, int C,
                                                                int ph, int pw, const float* __restrict__ scale,
                                                                const float* __restrict__ shift,
-                                                               float* __restrict__ out) {
+                                                               float* __restrict__ out, unsigned* __restrict__ cnt4) {
     const int Ho = H / ph, Wo = W / pw, c4n = C >> 2;
     const long total = (long)B * Ho * Wo * c4n;
     const float inv = 1.0f / (float)(ph * pw);
@@ -269,14 +280,19 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __re
         int b = (int)(q / Ho);
         float4 sc = reinterpret_cast<const float4*>(scale)[c4], sh = reinterpret_cast<const float4*>(shift)[c4];
         float4 acc = make_float4(0, 0, 0, 0);
+        unsigned n4 = 0;
         for (int dh = 0; dh < ph; ++dh)
             for (int dw = 0; dw < pw; ++dw) {
                 long src = (((long)b * H + ho * ph + dh) * W + wo * pw + dw) * c4n + c4;
                 float4 v = reinterpret_cast<const float4*>(y)[src];
                 acc.x += bn_relu(v.x, sc.x, sh.x); acc.y += bn_relu(v.y, sc.y, sh.y);
                 acc.z += bn_relu(v.z, sc.z, sh.z); acc.w += bn_relu(v.w, sc.w, sh.w);
+                if (CNT)
+                    n4 += (bn_relu_active(v.x, sc.x, sh.x) ? 1u : 0u) + (bn_relu_active(v.y, sc.y, sh.y) ? 0x100u : 0u) +
+                          (bn_relu_active(v.z, sc.z, sh.z) ? 0x10000u : 0u) + (bn_relu_active(v.w, sc.w, sh.w) ? 0x1000000u : 0u);
             }
         reinterpret_cast<float4*>(out)[i] = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+        if (CNT) cnt4[i] = n4;
     }
 }
 
@@ -291,8 +307,11 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const float* __re
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ invstd,
                                                                const float* __restrict__ coef, int rows_per_block,
-                                                               float* __restrict__ partials, float* __restrict__ gy) {
+                                                               float* __restrict__ partials, float* __restrict__ gy,
+                                                               const float* __restrict__ gamma, float gmin) {
     __shared__ float4 red_a[256], red_b[256];
+    // PASS 1 with a gamma pointer is the exact fallback of the windowed pass: it runs only when that one declines
+    if (PASS == 1 && gamma && !any_small_gamma(gamma, C, gmin)) return;
     const int Ho = H / ph, Wo = W / pw, c4n = C >> 2;
     const int rpp = 256 / c4n;
     const int c4 = threadIdx.x % c4n, r0 = threadIdx.x / c4n;
@@ -347,6 +366,53 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const float* __re
             po[c4] = sa;
             po[c4n + c4] = sb;
         }
+    }
+}
+
+// Backward pass 1 at POOLED resolution.  The pool gradient is constant over a window, so with n = ph*pw,
+// cnt = number of active inputs of the window and p = the pooled output (n*p = sum over the window of mask*(gamma*xhat +
+// beta)):   sum dy = sum_windows g*cnt/n,   sum dy*xhat = sum_windows g*(p - beta*cnt/n)/gamma.
+// Reads g, p and one byte per element instead of the full-resolution y: 0.52 instead of 1.25 tensor sizes for 2x2.
+// The division by gamma amplifies p's rounding by 1/|gamma|: callers use the exact full-resolution pass when any
+// |gamma| is small (ops.py keeps a per-layer guard).
+__global__ __launch_bounds__(256) void pool_bwd_reduce_win_kernel(const float* __restrict__ gout,
+                                                                  const float* __restrict__ pooled,
+                                                                  const unsigned* __restrict__ cnt4, long nrows, int C,
+                                                                  float inv, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, int rows_per_block,
+                                                                  float* __restrict__ partials, float gmin) {
+    __shared__ float4 red_a[256], red_b[256];
+    if (gmin > 0.f && any_small_gamma(gamma, C, gmin)) return;     // the exact pass takes over (partials pre-zeroed)
+    const int c4n = C >> 2;
+    const int rpp = 256 / c4n;
+    const int c4 = threadIdx.x % c4n, r0 = threadIdx.x / c4n;
+    const long row_base = (long)blockIdx.x * rows_per_block;
+    const long row_end = min(nrows, row_base + rows_per_block);
+    const float4 ga = reinterpret_cast<const float4*>(gamma)[c4], be = reinterpret_cast<const float4*>(beta)[c4];
+    const float4 gi = make_float4(1.0f / ga.x, 1.0f / ga.y, 1.0f / ga.z, 1.0f / ga.w);
+    float4 sa = make_float4(0, 0, 0, 0), sb = make_float4(0, 0, 0, 0);
+    for (long r = row_base + r0; r < row_end; r += rpp) {
+        const float4 g = reinterpret_cast<const float4*>(gout)[r * c4n + c4];
+        const float4 p = reinterpret_cast<const float4*>(pooled)[r * c4n + c4];
+        const unsigned n4 = cnt4[r * c4n + c4];
+        float4 gc;
+        gc.x = g.x * ((float)(n4 & 255u) * inv); gc.y = g.y * ((float)((n4 >> 8) & 255u) * inv);
+        gc.z = g.z * ((float)((n4 >> 16) & 255u) * inv); gc.w = g.w * ((float)(n4 >> 24) * inv);
+        sa.x += gc.x; sa.y += gc.y; sa.z += gc.z; sa.w += gc.w;
+        sb.x = fmaf(fmaf(g.x, p.x, -gc.x * be.x), gi.x, sb.x); sb.y = fmaf(fmaf(g.y, p.y, -gc.y * be.y), gi.y, sb.y);
+        sb.z = fmaf(fmaf(g.z, p.z, -gc.z * be.z), gi.z, sb.z); sb.w = fmaf(fmaf(g.w, p.w, -gc.w * be.w), gi.w, sb.w);
+    }
+    red_a[threadIdx.x] = sa; red_b[threadIdx.x] = sb;
+    __syncthreads();
+    if (threadIdx.x < c4n) {
+        for (int j = 1; j < rpp; ++j) {
+            float4 a2 = red_a[threadIdx.x + j * c4n], b2 = red_b[threadIdx.x + j * c4n];
+            sa.x += a2.x; sa.y += a2.y; sa.z += a2.z; sa.w += a2.w;
+            sb.x += b2.x; sb.y += b2.y; sb.z += b2.z; sb.w += b2.w;
+        }
+        float4* po = reinterpret_cast<float4*>(partials + (long)blockIdx.x * 2 * C);
+        po[c4] = sa;
+        po[c4n + c4] = sb;
     }
 }
 
@@ -459,8 +525,65 @@ SED_API int sed_bn_relu_pool_fwd(const float* y, int B, int H, int W, int C, int
                                  const float* shift, float* out, hipStream_t stream) {
     if (B <= 0 || (C & 3) || ph <= 0 || pw <= 0 || H / ph <= 0 || W / pw <= 0) return SED_EINVAL;
     long total = (long)B * (H / ph) * (W / pw) * (C / 4);
-    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(stream_grid(total)), dim3(256), 0, stream, y, B, H, W, C, ph, pw, scale,
-                       shift, out);
+    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<false>, dim3(stream_grid(total)), dim3(256), 0, stream, y, B, H, W, C, ph, pw,
+                       scale, shift, out, (unsigned*)nullptr);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// Same, also writing cnt [B][H/ph][W/pw][C] bytes = number of window inputs that passed the ReLU (ph*pw <= 255).
+SED_API int sed_bn_relu_pool_fwd_cnt(const float* y, int B, int H, int W, int C, int ph, int pw, const float* scale,
+                                     const float* shift, float* out, unsigned char* cnt, hipStream_t stream) {
+    if (B <= 0 || (C & 3) || ph <= 0 || pw <= 0 || H / ph <= 0 || W / pw <= 0 || ph * pw > 255 || !cnt) return SED_EINVAL;
+    long total = (long)B * (H / ph) * (W / pw) * (C / 4);
+    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<true>, dim3(stream_grid(total)), dim3(256), 0, stream, y, B, H, W, C, ph, pw,
+                       scale, shift, out, reinterpret_cast<unsigned*>(cnt));
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// Backward pass 1 from the pooled tensors: g_out, pooled, cnt [B*Ho*Wo][C]; gamma / beta = the BatchNorm weight / bias.
+// partials must hold ceil(M' / sed_pool_bwd_rows_per_block(M')) * 2*C floats, M' = B*Ho*Wo.
+SED_API int sed_bn_relu_pool_bwd_reduce_win(const float* g_out, const float* pooled, const unsigned char* cnt, long Mp,
+                                            int C, int window, const float* gamma, const float* beta, float* partials,
+                                            int* nparts_out, hipStream_t stream) {
+    if (Mp <= 0 || C < 64 || C > 512 || (256 % (C / 4)) != 0 || window <= 0 || window > 255) return SED_EINVAL;
+    const int rpb = sed_pool_bwd_rows_per_block(Mp);
+    int nblk = sed_cdiv(Mp, rpb);
+    hipLaunchKernelGGL(pool_bwd_reduce_win_kernel, dim3(nblk), dim3(256), 0, stream, g_out, pooled,
+                       reinterpret_cast<const unsigned*>(cnt), Mp, C, 1.0f / (float)window, gamma, beta, rpb, partials, 0.f);
+    if (nparts_out) *nparts_out = nblk;
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// Pass 1 with the choice made ON THE DEVICE, in stream order, from this step's gamma: the windowed kernel runs when every
+// |gamma[c]| >= gamma_min, otherwise it returns at once and the full-resolution kernel (which returns at once in the
+// common case) produces the sums.  partials: max(parts of either) * 2*C floats, zeroed here; *nparts_out = that maximum.
+SED_API long sed_bn_relu_pool_bwd_reduce_auto_parts(int B, int H, int W, int ph, int pw) {
+    if (B <= 0 || ph <= 0 || pw <= 0 || H / ph <= 0 || W / pw <= 0) return SED_EINVAL;
+    const long M = (long)B * H * W, Mp = (long)B * (H / ph) * (W / pw);
+    const long a = sed_cdiv(M, sed_pool_bwd_rows_per_block(M)), b = sed_cdiv(Mp, sed_pool_bwd_rows_per_block(Mp));
+    return a > b ? a : b;
+}
+SED_API int sed_bn_relu_pool_bwd_reduce_auto(const float* y, const float* g_out, const float* pooled,
+                                             const unsigned char* cnt, int B, int H, int W, int C, int ph, int pw,
+                                             const float* scale, const float* shift, const float* mean,
+                                             const float* invstd, const float* gamma, const float* beta,
+                                             float gamma_min, float* partials, int* nparts_out, hipStream_t stream) {
+    if (B <= 0 || C < 64 || C > 512 || (256 % (C / 4)) != 0 || ph * pw > 255 || !(gamma_min > 0.f)) return SED_EINVAL;
+    const long nparts = sed_bn_relu_pool_bwd_reduce_auto_parts(B, H, W, ph, pw);
+    if (nparts <= 0) return SED_EINVAL;
+    hipError_t e = hipMemsetAsync(partials, 0, (size_t)nparts * 2 * C * sizeof(float), stream);
+    if (e != hipSuccess) return (int)e;
+    const long M = (long)B * H * W, Mp = (long)B * (H / ph) * (W / pw);
+    const int rpb = sed_pool_bwd_rows_per_block(M), rpbw = sed_pool_bwd_rows_per_block(Mp);
+    hipLaunchKernelGGL(pool_bwd_reduce_win_kernel, dim3(sed_cdiv(Mp, rpbw)), dim3(256), 0, stream, g_out, pooled,
+                       reinterpret_cast<const unsigned*>(cnt), Mp, C, 1.0f / (float)(ph * pw), gamma, beta, rpbw, partials,
+                       gamma_min);
+    hipLaunchKernelGGL(bn_relu_pool_bwd_kernel<1>, dim3(sed_cdiv(M, rpb)), dim3(256), 0, stream, y, g_out, B, H, W, C, ph, pw,
+                       scale, shift, mean, invstd, (const float*)nullptr, rpb, partials, (float*)nullptr, gamma, gamma_min);
+    if (nparts_out) *nparts_out = (int)nparts;
     SED_LAUNCH_CHECK();
     return 0;
 }
@@ -481,7 +604,7 @@ SED_API int sed_bn_relu_pool_bwd_reduce(const float* y, const float* g_out, int 
     const int rpb = sed_pool_bwd_rows_per_block((long)B * H * W);
     int nblk = sed_cdiv((long)B * H * W, rpb);
     hipLaunchKernelGGL(bn_relu_pool_bwd_kernel<1>, dim3(nblk), dim3(256), 0, stream, y, g_out, B, H, W, C, ph, pw, scale, shift,
-                       mean, invstd, (const float*)nullptr, rpb, partials, (float*)nullptr);
+                       mean, invstd, (const float*)nullptr, rpb, partials, (float*)nullptr, (const float*)nullptr, 0.f);
     if (nparts_out) *nparts_out = nblk;
     SED_LAUNCH_CHECK();
     return 0;
@@ -495,7 +618,7 @@ SED_API int sed_bn_relu_pool_bwd_apply(const float* y, const float* g_out, int B
     const int rpb = sed_pool_bwd_rows_per_block((long)B * H * W);
     int nblk = sed_cdiv((long)B * H * W, rpb);
     hipLaunchKernelGGL(bn_relu_pool_bwd_kernel<2>, dim3(nblk), dim3(256), 0, stream, y, g_out, B, H, W, C, ph, pw, scale, shift,
-                       (const float*)nullptr, (const float*)nullptr, coef, rpb, (float*)nullptr, gy);
+                       (const float*)nullptr, (const float*)nullptr, coef, rpb, (float*)nullptr, gy, (const float*)nullptr, 0.f);
     SED_LAUNCH_CHECK();
     return 0;
 }

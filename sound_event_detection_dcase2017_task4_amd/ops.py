@@ -18,6 +18,11 @@ BN_MOMENTUM = 0.1
 # The fused 1-D Winograd F(2,3) kernels (csrc/conv_wino.hip) do the same convolutions with 1.5x fewer MFMA flops; they are
 # used for forward, dgrad and wgrad whenever the layer shape allows.  False = direct implicit GEMM everywhere.
 USE_WINOGRAD = 2          # 2: 2-D F(2x2,3x3) where supported, else 1-D F(2,3), else direct; 1: 1-D; 0: direct only
+# ConvBlock backward: BN2's (sum dy, sum dy*xhat) from the pooled output + per-window ReLU counts instead of a pass over
+# the full-resolution conv output.  The identity divides by gamma, so the kernels themselves fall back to the exact pass
+# (on the device, from this step's weights) whenever some |gamma| < POOL_BWD_GAMMA_MIN.
+POOL_BWD_WINDOWED = True
+POOL_BWD_GAMMA_MIN = 1e-2
 USE_FUSED_GRU = True        # False: per-step GEMM + gate launches (any hidden size; the fused step kernels are built for 256)
 
 # bench.py sets this to a dict to HIP-event-time the MFMA kernels inside its timed region:
@@ -419,14 +424,25 @@ class ConvBlockFn(torch.autograd.Function):
         y2 = _conv_fwd_like(y1, w2c, B, H, W, Cout, Cout, in_st=st1, epi=1 if training else 0, partials=part2)
         st2 = bn_finalize(part2, np2, rpp2, M, g2, b2, rm2, rv2) if training else bn_eval_affine(g2, b2, rm2, rv2)
         out = torch.empty((B, H // ph, W // pw, Cout), dtype=torch.float32, device=dev)
-        _call("sed_bn_relu_pool_fwd", _ptr(y2), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift), _ptr(out), _stream())
-        ctx.save_for_backward(x, y1, y2, w1c, w2c)
+        cnt = None
+        if training and POOL_BWD_WINDOWED and ph * pw > 1:
+            # per-window ReLU counts: with them backward pass 1 runs on the pooled tensors and never reads y2
+            cnt = torch.empty((B, H // ph, W // pw, Cout), dtype=torch.uint8, device=dev)
+            _call("sed_bn_relu_pool_fwd_cnt", _ptr(y2), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift), _ptr(out),
+                  _ptr(cnt), _stream())
+        else:
+            _call("sed_bn_relu_pool_fwd", _ptr(y2), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift), _ptr(out), _stream())
+        if cnt is not None:
+            ctx.save_for_backward(x, y1, y2, w1c, w2c, out, cnt, _f32c(g2), _f32c(b2))
+        else:
+            ctx.save_for_backward(x, y1, y2, w1c, w2c)
         ctx.st1, ctx.st2, ctx.pool, ctx.training = st1, st2, (ph, pw), bool(training)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        x, y1, y2, w1, w2 = ctx.saved_tensors
+        x, y1, y2, w1, w2 = ctx.saved_tensors[:5]
+        win = ctx.saved_tensors[5:] if len(ctx.saved_tensors) > 5 else None
         st1, st2 = ctx.st1, ctx.st2
         ph, pw = ctx.pool
         g_out = _f32c(g_out)
@@ -435,12 +451,21 @@ class ConvBlockFn(torch.autograd.Function):
         dev = x.device
         M = B * H * W
         # BN2 + ReLU + pool backward
-        rpb = _lib.lib().sed_pool_bwd_rows_per_block(M)
-        npmax = (M + rpb - 1) // rpb
-        part = torch.empty((npmax, 2, Cout), dtype=torch.float32, device=dev)
         n = ctypes.c_int(0)
-        _call("sed_bn_relu_pool_bwd_reduce", _ptr(y2), _ptr(g_out), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift),
-              _ptr(st2.mean), _ptr(st2.invstd), _ptr(part), ctypes.byref(n), _stream())
+        if win is not None:
+            pooled, cnt, gam, bet = win
+            npmax = _lib.lib().sed_bn_relu_pool_bwd_reduce_auto_parts(B, H, W, ph, pw)
+            part = torch.empty((npmax, 2, Cout), dtype=torch.float32, device=dev)
+            _call("sed_bn_relu_pool_bwd_reduce_auto", _ptr(y2), _ptr(g_out), _ptr(pooled), _ptr(cnt), B, H, W, Cout, ph, pw,
+                  _ptr(st2.scale), _ptr(st2.shift), _ptr(st2.mean), _ptr(st2.invstd), _ptr(gam), _ptr(bet), POOL_BWD_GAMMA_MIN,
+                  _ptr(part), ctypes.byref(n), _stream())
+            del pooled, cnt, win
+        else:
+            rpb = _lib.lib().sed_pool_bwd_rows_per_block(M)
+            npmax = (M + rpb - 1) // rpb
+            part = torch.empty((npmax, 2, Cout), dtype=torch.float32, device=dev)
+            _call("sed_bn_relu_pool_bwd_reduce", _ptr(y2), _ptr(g_out), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift),
+                  _ptr(st2.mean), _ptr(st2.invstd), _ptr(part), ctypes.byref(n), _stream())
         dg2, db2, coef2 = bn_bwd_finalize(part, n.value, M, st2, batch_stats=ctx.training)
         gy2 = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
         _call("sed_bn_relu_pool_bwd_apply", _ptr(y2), _ptr(g_out), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift),

@@ -237,6 +237,70 @@ def test_att_head(ops):
         assert (d.grad.cpu() - r).abs().max().item() < 2e-4 * r.abs().max().item() + 1e-7
 
 
+@pytest.mark.parametrize("ph,pw,H,W,C,small", [(2, 2, 11, 16, 64, False), (1, 8, 5, 8, 512, False), (2, 2, 8, 8, 128, True)])
+def test_pool_bwd_windowed_pass1_matches_full_resolution_pass(ops, ph, pw, H, W, C, small):
+    """Backward pass 1 of the ConvBlock tail (BN2 sums for models.py:102-107) from the pooled output + per-window ReLU
+    counts against the full-resolution pass over y; odd H (floor-mode pooling drops a row); and the on-device fallback
+    when a |gamma| is below the guard (the auto entry point must then give the exact pass bit for bit)."""
+    import ctypes
+    g = torch.Generator().manual_seed(11)
+    B = 3
+    y = torch.randn(B, H, W, C, generator=g).cuda()
+    gamma = (torch.rand(C, generator=g) + 0.5) * torch.where(torch.rand(C, generator=g) < 0.3, -1.0, 1.0)
+    if small:
+        gamma[5] = 1e-4
+    beta = torch.randn(C, generator=g) * 0.3
+    mean = y.mean(dim=(0, 1, 2)).cpu()
+    var = y.var(dim=(0, 1, 2), unbiased=False).cpu()
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    gamma, beta, mean, invstd, scale, shift = [t.float().contiguous().cuda() for t in (gamma, beta, mean, invstd, scale, shift)]
+    Ho, Wo = H // ph, W // pw
+    gout = torch.randn(B, Ho, Wo, C, generator=g).cuda()
+    L = ops._lib.lib()
+    s = ops._stream()
+    out = torch.empty(B, Ho, Wo, C, device="cuda")
+    cnt = torch.empty(B, Ho, Wo, C, dtype=torch.uint8, device="cuda")
+    ops._call("sed_bn_relu_pool_fwd_cnt", ops._ptr(y), B, H, W, C, ph, pw, ops._ptr(scale), ops._ptr(shift), ops._ptr(out),
+              ops._ptr(cnt), s)
+    act = (y * scale + shift) > 0
+    ref_cnt = act[:, :Ho * ph, :Wo * pw].view(B, Ho, ph, Wo, pw, C).sum(dim=(2, 4))
+    assert torch.equal(cnt.long(), ref_cnt.long())
+    out0 = torch.empty_like(out)
+    ops._call("sed_bn_relu_pool_fwd", ops._ptr(y), B, H, W, C, ph, pw, ops._ptr(scale), ops._ptr(shift), ops._ptr(out0), s)
+    assert torch.equal(out, out0)
+
+    def sums(part, n):
+        return part[:n].double().sum(dim=0).cpu()
+
+    M = B * H * W
+    rpb = L.sed_pool_bwd_rows_per_block(M)
+    pe = torch.empty(((M + rpb - 1) // rpb, 2, C), device="cuda")
+    n = ctypes.c_int(0)
+    ops._call("sed_bn_relu_pool_bwd_reduce", ops._ptr(y), ops._ptr(gout), B, H, W, C, ph, pw, ops._ptr(scale), ops._ptr(shift),
+              ops._ptr(mean), ops._ptr(invstd), ops._ptr(pe), ctypes.byref(n), s)
+    exact = sums(pe, n.value)
+    na = L.sed_bn_relu_pool_bwd_reduce_auto_parts(B, H, W, ph, pw)
+    pa = torch.full((na, 2, C), float("nan"), device="cuda")
+    ops._call("sed_bn_relu_pool_bwd_reduce_auto", ops._ptr(y), ops._ptr(gout), ops._ptr(out), ops._ptr(cnt), B, H, W, C, ph, pw,
+              ops._ptr(scale), ops._ptr(shift), ops._ptr(mean), ops._ptr(invstd), ops._ptr(gamma), ops._ptr(beta), 1e-2,
+              ops._ptr(pa), ctypes.byref(n), s)
+    assert n.value == na
+    auto = sums(pa, na)
+    if small:
+        assert torch.equal(auto, exact)               # the exact kernel produced them
+    else:
+        tol = 2e-5 * exact.abs().max()
+        assert (auto - exact).abs().max() < tol
+        Mp = B * Ho * Wo
+        rpw = L.sed_pool_bwd_rows_per_block(Mp)
+        pw_ = torch.empty(((Mp + rpw - 1) // rpw, 2, C), device="cuda")
+        ops._call("sed_bn_relu_pool_bwd_reduce_win", ops._ptr(gout), ops._ptr(out), ops._ptr(cnt), Mp, C, ph * pw,
+                  ops._ptr(gamma), ops._ptr(beta), ops._ptr(pw_), ctypes.byref(n), s)
+        assert torch.equal(sums(pw_, n.value), auto)
+
+
 @pytest.mark.parametrize("fused,B,T", [(True, 3, 7), (True, 37, 5), (True, 64, 1), (False, 3, 7)])
 def test_gru_vs_torch(ops, monkeypatch, fused, B, T):
     """GruFn against torch.nn.GRU (the layer the reference instantiates, models.py:529-530): fused per-step recurrence
