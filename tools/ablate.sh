@@ -1,5 +1,6 @@
 #!/bin/bash
 # GPU-box helper: rebuild one source with extra -D flags and time it (kernel experiments / ablations).
+# BENCH=tools/elem_bench.py selects another micro-benchmark.
 # usage: tools/ablate.sh <source.hip> "<conv_bench args>" <variant...>   variant = base | <N> (-DSED_ABL=N) | D<macro> (-D<macro>)
 SRC=$1; ARGS=$2; shift 2
 P=sound_event_detection_dcase2017_task4_amd
@@ -7,5 +8,5 @@ for A in "$@"; do
   case "$A" in base) D="";; D*) D="-D${A#D}";; *) D="-DSED_ABL=$A";; esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -I include $D -c $P/csrc/$SRC -o $P/build/${SRC%.hip}.o || exit 1
   g++ -shared -fPIC -o $P/libsed_hip.so $P/build/*.o
-  echo "=== variant $A"; python tools/conv_bench.py $ARGS 2>/dev/null | grep -v TOTAL
+  echo "=== variant $A"; python ${BENCH:-tools/conv_bench.py} $ARGS 2>/dev/null | grep -v TOTAL
 done

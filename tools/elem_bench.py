@@ -1,0 +1,64 @@
+"""Micro-benchmark of the HBM-bound elementwise kernels at the training shapes (B=256): GB/s of algorithmic traffic.
+    python tools/elem_bench.py [--batch 256] [--reps 10]"""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sound_event_detection_dcase2017_task4_amd import ops  # noqa: E402
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--reps", type=int, default=10)
+    args = ap.parse_args()
+    B = args.batch
+    s = ops._stream()
+    tot = {}
+    for (H, W, C, ph, pw) in [(1001, 64, 64, 2, 2), (500, 32, 128, 2, 2), (250, 16, 256, 2, 2), (125, 8, 512, 1, 8)]:
+        M = B * H * W
+        y = torch.randn(B, H, W, C, device="cuda")
+        d = torch.randn(B, H, W, C, device="cuda")
+        Ho, Wo = H // ph, W // pw
+        gp = torch.randn(B, Ho, Wo, C, device="cuda")
+        sc = torch.rand(C, device="cuda") + 0.5
+        sh = torch.randn(C, device="cuda") * 0.1
+        coef = torch.randn(3, C, device="cuda")
+        out = torch.empty(B, Ho, Wo, C, device="cuda")
+        cnt = torch.empty(B, Ho, Wo, C, dtype=torch.uint8, device="cuda")
+        gy = torch.empty_like(y)
+        S = M * C * 4 / 1e9
+        Sp = B * Ho * Wo * C * 4 / 1e9
+        runs = [
+            ("bn_bwd_apply     ", 3 * S, lambda: ops._call("sed_bn_bwd_apply", ops._ptr(d), ops._ptr(y), M, C, ops._ptr(coef), s)),
+            ("pool_bwd_apply   ", 2 * S + Sp, lambda: ops._call("sed_bn_relu_pool_bwd_apply", ops._ptr(y), ops._ptr(gp), B, H, W, C, ph, pw,
+                                                                 ops._ptr(sc), ops._ptr(sh), ops._ptr(coef), ops._ptr(gy), s)),
+            ("pool_fwd_cnt     ", S + 1.25 * Sp, lambda: ops._call("sed_bn_relu_pool_fwd_cnt", ops._ptr(y), B, H, W, C, ph, pw, ops._ptr(sc),
+                                                                   ops._ptr(sh), ops._ptr(out), ops._ptr(cnt), s)),
+        ]
+        for name, gb, fn in runs:
+            ms = timeit(fn, args.reps)
+            tot[name] = tot.get(name, 0.0) + ms
+            print("%4dx%-3d C=%-3d %s %7.3f ms  %6.0f GB/s" % (H, W, C, name, ms, gb / ms * 1e3))
+    for k, v in tot.items():
+        print("TOTAL %s %.3f ms" % (k, v))
+
+
+if __name__ == "__main__":
+    main()
