@@ -52,7 +52,27 @@ def build(force=False, verbose=False):
         # libamdhip64.so (soname without version), and a second runtime from /opt/rocm would not know torch's streams
         # and allocations.  _lib.py loads torch's runtime RTLD_GLOBAL first; a plain-C consumer links libamdhip64 itself.
         run([os.environ.get("CXX", "g++"), "-shared", "-fPIC", "-o", LIB] + objs)
+    build_c_example(force=force or bool(jobs), run=run)
     return LIB
+
+
+C_EXAMPLE = os.path.join(HERE, "build", "capi_conv")
+
+
+def build_c_example(force=False, run=None):
+    """examples/capi_conv.c: a plain-C host of the ABI (gcc, no Python / torch / C++), linked against libsed_hip.so and
+    the ROCm HIP runtime.  Run by tests/test_gpu_ops.py on the GPU box."""
+    src = os.path.join(os.path.dirname(HERE), "examples", "capi_conv.c")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    if not (force or _stale(C_EXAMPLE, [src, LIB, os.path.join(INCLUDE, "sed_hip.h")])):
+        return C_EXAMPLE
+    cmd = [os.environ.get("CC", "gcc"), "-O2", "-std=c11", "-Wall", src, "-I", INCLUDE, "-I", os.path.join(rocm, "include"),
+           "-D__HIP_PLATFORM_AMD__", "-L", HERE, "-lsed_hip", "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-lm",
+           "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", C_EXAMPLE]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("C example failed to build:\n%s\n%s" % (" ".join(cmd), r.stderr))
+    return C_EXAMPLE
 
 
 if __name__ == "__main__":

@@ -1,4 +1,6 @@
 """GPU parity of the individual HIP ops (through the C ABI) against plain PyTorch fp32 on the CPU."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -550,3 +552,15 @@ def test_multihead_attention_forward_backward(ops, B, T, train):
             assert a.grad.abs().max().item() < 1e-4 * leaves[5].grad.abs().max().item() and b.grad.abs().max().item() < 1e-4 * leaves[5].grad.abs().max().item()
             continue
         assert rel(a.grad.cpu(), b.grad) < 3e-5, name
+
+
+def test_plain_c_host_of_the_abi():
+    """examples/capi_conv.c (gcc, HIP C API + include/sed_hip.h only) runs a ConvBlock convolution through the Winograd and
+    the direct kernels and checks them against its own CPU loop: the boundary really is a C ABI."""
+    import subprocess
+    from sound_event_detection_dcase2017_task4_amd import build as b
+    exe = b.C_EXAMPLE
+    assert os.path.exists(exe), "run `python -m sound_event_detection_dcase2017_task4_amd.build` first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "capi_conv ok" in r.stdout
