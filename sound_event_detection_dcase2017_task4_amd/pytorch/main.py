@@ -24,7 +24,7 @@ import torch.utils.data
 from .. import parallel
 from ..optim import FusedAdamAmsgrad
 from ..utils.config import (sample_rate, classes_num, mel_bins, fmin, fmax, window_size, hop_size)
-from ..utils.data_generator import DCASE2017Task4Dataset, TrainSampler, TestSampler, collate_fn
+from ..utils.data_generator import DCASE2017Task4Dataset, PinnedBatchLoader, TrainSampler, TestSampler, collate_fn
 from ..utils.utilities import create_folder, get_filename, create_logging, Mixup, StatisticsContainer
 from .evaluate import Evaluator
 from . import models as _models
@@ -86,10 +86,11 @@ def train(args):
 
     mix = 'mixup' in args.augmentation
     per_rank = args.batch_size * 2 if mix else args.batch_size
-    dataset = DCASE2017Task4Dataset(keep_int16=True)
     train_sampler = TrainSampler(hdf5_path=train_path, batch_size=per_rank, random_seed=1234 + rank)
-    train_loader = torch.utils.data.DataLoader(dataset=dataset, batch_sampler=train_sampler, collate_fn=collate_fn,
-                                               num_workers=0 if args.synthetic else 8, pin_memory=True)
+    # same batch stream as DataLoader(DCASE2017Task4Dataset, batch_sampler, collate_fn) (main.py:126-131 of the reference), but
+    # assembled by threads into page-locked int16 buffers and uploaded one batch ahead on a copy stream: the reference's
+    # 8 worker processes + pickled numpy batches deliver ~300-600 waveforms/s, one MI355X consumes 5300
+    train_loader = PinnedBatchLoader(train_path, train_sampler, device=device)
     mixup_augmenter = Mixup(mixup_alpha=1., random_seed=1234 + rank) if mix else None
     train_bgn_time = time.time()
 
@@ -140,8 +141,8 @@ def train(args):
             logging.info('Model saved to {}'.format(checkpoint_path))
         if mix:
             batch_data_dict['mixup_lambda'] = mixup_augmenter.get_lambda(batch_size=len(batch_data_dict['waveform']))
-        wave = torch.from_numpy(batch_data_dict['waveform']).to(device, non_blocking=True)     # int16 over PCIe
-        target = move_data_to_device(batch_data_dict['target'], device)
+        wave = batch_data_dict['waveform']               # int16 on the device (the log-mel kernel folds the /32767)
+        target = batch_data_dict['target']
         model.train()
         if mix:
             lam = move_data_to_device(batch_data_dict['mixup_lambda'], device)
