@@ -106,8 +106,7 @@ def train(args):
             csv_path = os.path.join(args.dataset_dir, 'metadata', csv)
             if os.path.exists(pack_path) and os.path.exists(csv_path):
                 sampler = TestSampler(hdf5_path=pack_path, batch_size=args.batch_size)
-                loader = torch.utils.data.DataLoader(dataset=DCASE2017Task4Dataset(), batch_sampler=sampler,
-                                                     collate_fn=collate_fn, num_workers=8, pin_memory=True)
+                loader = PinnedBatchLoader(pack_path, sampler, device=device)
                 eval_sets.append((data_type, loader, csv_path))
         if eval_sets:
             create_folder(predictions_dir)
@@ -174,12 +173,10 @@ def inference_prob(args):
     checkpoint = torch.load(os.path.join(checkpoints_dir, '{}_iterations.pth'.format(args.iteration)), map_location='cpu')
     model.load_state_dict(checkpoint['model'])
     model.to(device)
-    dataset = DCASE2017Task4Dataset()
     for data_type, name in (('test', 'testing.h5'), ('evaluate', 'evaluation.h5')):
         path = 'synthetic:{}'.format(args.synthetic) if args.synthetic else os.path.join(args.workspace, 'hdf5s', name)
         sampler = TestSampler(hdf5_path=path, batch_size=args.batch_size)
-        loader = torch.utils.data.DataLoader(dataset=dataset, batch_sampler=sampler, collate_fn=collate_fn,
-                                             num_workers=0 if args.synthetic else 8, pin_memory=True)
+        loader = PinnedBatchLoader(path, sampler, device=device)      # int16 to the device; the log-mel kernel scales
         print('Inferencing {} data ...'.format(data_type))
         output_dict = forward(model, loader, return_target=True)
         prediction_path = os.path.join(predictions_dir, '{}_iterations.prediction.{}.pkl'.format(args.iteration, data_type))

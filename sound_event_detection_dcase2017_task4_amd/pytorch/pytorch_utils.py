@@ -27,8 +27,12 @@ def forward(model, data_loader, return_input=False, return_target=False):
     """Batched eval-mode inference (pytorch_utils.py:25-77) -> dict of numpy arrays."""
     device = next(model.parameters()).device
     output_dict = {}
+    def host(v):                                         # loader tensors may live in recycled buffers: copy out
+        return v.cpu().numpy().copy() if torch.is_tensor(v) else v
+
     for n, batch_data_dict in enumerate(data_loader):
-        batch_waveform = move_data_to_device(batch_data_dict['waveform'], device)
+        w = batch_data_dict['waveform']                  # numpy float (reference loaders) or int16 / float tensor
+        batch_waveform = w.to(device) if torch.is_tensor(w) else move_data_to_device(w, device)
         with torch.no_grad():
             model.eval()
             batch_output = model(batch_waveform)
@@ -37,12 +41,12 @@ def forward(model, data_loader, return_input=False, return_target=False):
         if 'framewise_output' in batch_output.keys():
             append_to_dict(output_dict, 'framewise_output', batch_output['framewise_output'].data.cpu().numpy())
         if return_input:
-            append_to_dict(output_dict, 'waveform', batch_data_dict['waveform'])
+            append_to_dict(output_dict, 'waveform', host(batch_data_dict['waveform']))
         if return_target:
             if 'target' in batch_data_dict.keys():
-                append_to_dict(output_dict, 'target', batch_data_dict['target'])
+                append_to_dict(output_dict, 'target', host(batch_data_dict['target']))
             if 'strong_target' in batch_data_dict.keys():
-                append_to_dict(output_dict, 'strong_target', batch_data_dict['strong_target'])
+                append_to_dict(output_dict, 'strong_target', host(batch_data_dict['strong_target']))
     for key in output_dict.keys():
         output_dict[key] = np.concatenate(output_dict[key], axis=0)
     return output_dict
