@@ -262,7 +262,11 @@ class PinnedBatchLoader(object):
             first = True
             while True:
                 if not first:
-                    free_slots.release()                   # the batch handed out before is no longer needed
+                    # the batch handed out before is no longer needed: mark the point in the consumer's stream after its
+                    # last reader FIRST, then let the producer have the slot (its upload waits for that event)
+                    if prev is not None:
+                        prev['consumed'].record(torch.cuda.current_stream(self.device))
+                    free_slots.release()
                 first = False
                 item = q.get()
                 if item is None:
@@ -271,10 +275,7 @@ class PinnedBatchLoader(object):
                     raise item
                 slot, names = item
                 if self.device is not None:
-                    cur = torch.cuda.current_stream(self.device)
-                    if prev is not None:
-                        prev['consumed'].record(cur)       # everything that read the previous batch is enqueued by now
-                    cur.wait_event(slot['ready'])
+                    torch.cuda.current_stream(self.device).wait_event(slot['ready'])
                     out = {'audio_name': names, 'waveform': slot['dwave'], 'target': slot['dtarget']}
                     prev = slot
                 else:
