@@ -204,3 +204,36 @@ def test_pinned_batch_loader_reproduces_the_dataloader_stream(tmp_path):
     # finite sampler (evaluation order) with a ragged last batch
     got = [b["audio_name"] for b in PinnedBatchLoader(root, TestSampler(root, 8))]
     assert [len(g) for g in got] == [8, 8, 8, 8, 5] and got[0][0] == "c000.wav" and got[-1][-1] == "c036.wav"
+
+
+def test_parameter_initialisation_follows_the_reference_recipes():
+    """SURVEY.md 8a row I1 (reference models.py:15-55): conv / linear / 1x1-conv weights xavier-uniform with zero bias, BN
+    gamma = 1 / beta = 0, GRU per-gate uniform(+-sqrt(3/fan_in)) for W_ih and the r, z blocks of W_hh, an orthogonal n
+    block, zero biases.  Bit equality with the reference is neither possible nor required (it sets no seed): the
+    distributions are checked."""
+    from sound_event_detection_dcase2017_task4_amd.pytorch import models
+    torch.manual_seed(0)
+    m = models.Cnn_9layers_Gru_FrameAtt(32000, 1024, 320, 64, 50, 14000, 17)
+    sd = m.state_dict()
+    for name, cin, cout in (("conv_block1.conv1", 1, 64), ("conv_block2.conv2", 128, 128), ("conv_block4.conv1", 256, 512)):
+        w = sd[name + ".weight"]
+        bound = (6.0 / (9 * cin + 9 * cout)) ** 0.5
+        assert w.abs().max() <= bound * (1 + 1e-6)
+        if w.numel() > 10000:                            # uniform: std = bound / sqrt(3), mean 0
+            assert abs(w.std().item() / (bound / 3 ** 0.5) - 1) < 0.03 and abs(w.mean().item()) < 0.02 * bound
+    for name in ("bn0", "conv_block3.bn2", "att_block.bn_att"):
+        assert torch.all(sd[name + ".weight"] == 1) and torch.all(sd[name + ".bias"] == 0)
+        assert torch.all(sd[name + ".running_mean"] == 0) and torch.all(sd[name + ".running_var"] == 1)
+    for name in ("att_block.att", "att_block.cla"):
+        w = sd[name + ".weight"]
+        assert w.shape == (17, 512, 1) and w.abs().max() <= (6.0 / (512 + 17)) ** 0.5 * (1 + 1e-6)
+        assert torch.all(sd[name + ".bias"] == 0)
+    for sfx in ("", "_reverse"):
+        w_ih, w_hh = sd["gru.weight_ih_l0" + sfx], sd["gru.weight_hh_l0" + sfx]
+        assert w_ih.shape == (768, 512) and w_hh.shape == (768, 256)
+        assert w_ih.abs().max() <= (3.0 / 512) ** 0.5 * (1 + 1e-6) and abs(w_ih.std().item() / (1.0 / 512) ** 0.5 - 1) < 0.03
+        rz = w_hh[:512]
+        assert rz.abs().max() <= (3.0 / 256) ** 0.5 * (1 + 1e-6) and abs(rz.std().item() / (1.0 / 256) ** 0.5 - 1) < 0.03
+        n = w_hh[512:].double()
+        assert (n @ n.T - torch.eye(256, dtype=torch.float64)).abs().max() < 1e-5
+        assert torch.all(sd["gru.bias_ih_l0" + sfx] == 0) and torch.all(sd["gru.bias_hh_l0" + sfx] == 0)
