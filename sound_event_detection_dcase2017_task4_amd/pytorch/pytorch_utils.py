@@ -1,4 +1,6 @@
-"""Tensor utilities on the hot path (reference pytorch/pytorch_utils.py)."""
+"""Tensor utilities on the hot path; same names and behaviour as reference pytorch/pytorch_utils.py."""
+from collections import defaultdict
+
 import numpy as np
 import torch
 
@@ -6,52 +8,50 @@ from .. import ops
 
 
 def move_data_to_device(x, device):
-    """pytorch_utils.py:6-15: float arrays -> float32 tensor, int arrays -> int64 tensor, others unchanged."""
-    if 'float' in str(x.dtype):
-        x = torch.Tensor(x)
-    elif 'int' in str(x.dtype):
-        x = torch.LongTensor(x)
-    else:
-        return x
-    return x.to(device)
+    """numpy array -> tensor on `device`: float* becomes float32, int* becomes int64, anything else (e.g. the array
+    of audio names) is handed back untouched (reference pytorch_utils.py:6-15)."""
+    kind = np.dtype(x.dtype).kind if not torch.is_tensor(x) else None
+    if kind == 'f':
+        return torch.as_tensor(np.asarray(x, dtype=np.float32)).to(device)
+    if kind in 'iu':
+        return torch.as_tensor(np.asarray(x, dtype=np.int64)).to(device)
+    return x
 
 
 def append_to_dict(dict, key, value):
-    if key in dict.keys():
-        dict[key].append(value)
-    else:
-        dict[key] = [value]
+    """dict[key] is a list that grows (reference pytorch_utils.py:18-22)."""
+    dict.setdefault(key, []).append(value)
+
+
+def _to_host(v):
+    # loader tensors may live in recycled (pinned / device) buffers: always copy out
+    return v.cpu().numpy().copy() if torch.is_tensor(v) else v
 
 
 def forward(model, data_loader, return_input=False, return_target=False):
-    """Batched eval-mode inference (pytorch_utils.py:25-77) -> dict of numpy arrays."""
+    """Eval-mode inference over a loader (reference pytorch_utils.py:25-77).  Returns numpy arrays concatenated over the
+    batches: 'audio_name', 'clipwise_output', 'framewise_output' (when the model has one), plus 'waveform' /
+    'target' / 'strong_target' on request.  Batches may carry numpy float waveforms (reference loaders) or int16 /
+    float tensors (PinnedBatchLoader)."""
     device = next(model.parameters()).device
-    output_dict = {}
-    def host(v):                                         # loader tensors may live in recycled buffers: copy out
-        return v.cpu().numpy().copy() if torch.is_tensor(v) else v
-
-    for n, batch_data_dict in enumerate(data_loader):
-        w = batch_data_dict['waveform']                  # numpy float (reference loaders) or int16 / float tensor
-        batch_waveform = w.to(device) if torch.is_tensor(w) else move_data_to_device(w, device)
+    model.eval()
+    collected = defaultdict(list)
+    wanted_from_batch = (['waveform'] if return_input else []) + (['target', 'strong_target'] if return_target else [])
+    for batch in data_loader:
+        wave = batch['waveform']
+        wave_dev = wave.to(device) if torch.is_tensor(wave) else move_data_to_device(wave, device)
         with torch.no_grad():
-            model.eval()
-            batch_output = model(batch_waveform)
-        append_to_dict(output_dict, 'audio_name', batch_data_dict['audio_name'])
-        append_to_dict(output_dict, 'clipwise_output', batch_output['clipwise_output'].data.cpu().numpy())
-        if 'framewise_output' in batch_output.keys():
-            append_to_dict(output_dict, 'framewise_output', batch_output['framewise_output'].data.cpu().numpy())
-        if return_input:
-            append_to_dict(output_dict, 'waveform', host(batch_data_dict['waveform']))
-        if return_target:
-            if 'target' in batch_data_dict.keys():
-                append_to_dict(output_dict, 'target', host(batch_data_dict['target']))
-            if 'strong_target' in batch_data_dict.keys():
-                append_to_dict(output_dict, 'strong_target', host(batch_data_dict['strong_target']))
-    for key in output_dict.keys():
-        output_dict[key] = np.concatenate(output_dict[key], axis=0)
-    return output_dict
+            out = model(wave_dev)
+        collected['audio_name'].append(batch['audio_name'])
+        for key in ('clipwise_output', 'framewise_output'):
+            if key in out:
+                collected[key].append(out[key].detach().cpu().numpy())
+        for key in wanted_from_batch:
+            if key in batch:
+                collected[key].append(_to_host(batch[key]))
+    return {key: np.concatenate(parts, axis=0) for key, parts in collected.items()}
 
 
 def do_mixup(x, mixup_lambda):
-    """pytorch_utils.py:80-93: out[i] = lam[2i]*x[2i] + lam[2i+1]*x[2i+1]   (N, ...) -> (N/2, ...)."""
+    """out[i] = lam[2i] * x[2i] + lam[2i+1] * x[2i+1], (N, ...) -> (N/2, ...) (reference pytorch_utils.py:80-93)."""
     return ops.mixup_rows(x, mixup_lambda)
