@@ -5,12 +5,17 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" = one pass of the hot path over one batch: log-mel -> bn0+SpecAugment+mixup -> 4 ConvBlocks -> head ->
-clip_bce -> backward -> (RCCL all-reduce) -> Adam-amsgrad, with the waveforms already resident in HBM.  Workload at
-N=1 = BASELINE.json configs[1] (B=256 post-mixup clips = 512 waveforms per step, mixup on); weak scaling (B per GPU
-fixed).  Prints ONE JSON line on rank 0 carrying `roofline` (dominant kernel, HIP-event timed inside the timed
-region) and `cpu_baseline` (the CPU oracle timed on this host's cores, config 0).
+clip_bce -> backward (the RCCL all-reduce of the flat gradient runs in buckets beside it) -> Adam-amsgrad, with the
+waveforms already resident in HBM.  Workload at N=1 = BASELINE.json configs[1] (B=256 post-mixup clips = 512 waveforms
+per step, mixup on); weak scaling (B per GPU fixed).  `--gpus N` started WITHOUT a launcher (no WORLD_SIZE in the
+environment) re-executes itself as N ranks under torch.distributed.run and refuses to run if the node has fewer than
+N GPUs.  Prints ONE JSON line on rank 0 carrying `roofline` (dominant kernel, HIP-event timed inside the timed
+region), `cpu_baseline` (the CPU oracle timed on this host's cores, config 0) and, at N=1, `extra_configs`: the other
+BASELINE.json configurations timed for a few steps each in the same process.
 """
 import argparse
+import gc
+import glob
 import json
 import os
 import sys
@@ -31,6 +36,7 @@ from sound_event_detection_dcase2017_task4_amd.utils.utilities import Mixup
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 HBM_PEAK_GBPS = 8000.0
+CTOR = (32000, 1024, 320, 64, 50, 14000, 17)
 
 
 def synth_batch(B2, L, seed, device):
@@ -41,11 +47,11 @@ def synth_batch(B2, L, seed, device):
     return wave, target
 
 
-def cpu_baseline(batch=32, clips=64, seconds=10, threads=0):
+def cpu_baseline(batch=32, clips=128, seconds=10, threads=0):
     """Config 0 on the host cores with the CPU oracle (a "port": the reference's Python cannot travel):
     Cnn_9layers_FrameAvg, B=32, clip_bce, no mixup (SpecAugment on), Adam-amsgrad, `clips`/32 steps; first step =
-    warm-up, the rest timed."""
-    from oracle import frontend as ofe
+    warm-up, the remaining three timed.  (The reference's own code re-measured in the build container:
+    tools/ref_cpu_baseline.py -> profiles/.)"""
     from oracle import model as om
     threads = threads or min(os.cpu_count() or 1, 32)      # torch CPU conv scaling flattens/regresses beyond ~32 threads
     torch.set_num_threads(threads)
@@ -73,25 +79,147 @@ def cpu_baseline(batch=32, clips=64, seconds=10, threads=0):
     timed = times[1:] if len(times) > 1 else times
     return {"value": round(batch * len(timed) / sum(timed), 3), "unit": "clips/s", "cores": threads, "kind": "port",
             "sample": "config 0: %d x %d-clip train steps (10 s clips, no mixup, SpecAugment on, Adam-amsgrad) of the "
-                      "CPU oracle (torch fp32, %d threads); first step warm-up, %d timed" % (len(times), batch, threads, len(timed))}
+                      "CPU oracle (torch fp32, %d threads); first step warm-up, %d timed (%s s)"
+                      % (len(times), batch, threads, len(timed), "/".join("%.1f" % t for t in timed))}
 
 
-def pmc_traffic(family):
+def latest_profile(name):
+    """Newest profiles/rNN/<name> (the PMC digests are produced per round by tools/pmc_digest.py)."""
+    cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9]*", name)))
+    return cands[-1] if cands else None
+
+
+def pmc_traffic(substrings):
     """HBM bytes per launch of a timed kernel family, from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
     gfx950 correction + WRITE_SIZE; tools/pmc_digest.py).  PMC collection needs rocprofv3 around the process, so it cannot
     be sampled live: the figure is valid for the default workload only, otherwise null."""
-    sub = {"conv3x3_wino_mfma(fwd+dgrad)": "conv_wino_kernel", "conv3x3_wino2d_mfma(fwd+dgrad)": "conv_wino2_kernel",
-           "conv3x3_wgrad_wino2d_mfma(+slice reduce)": "wgrad_wino2_", "conv3x3_wgrad_wino_mfma(+slice reduce)": "wgrad_wino_",
-           "conv3x3_igemm_mfma(fwd+dgrad)": "conv_igemm_kernel", "conv3x3_wgrad_mfma(+slice reduce)": "wgrad_kernel"}.get(family)
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_traffic.json")
-    if sub is None or not os.path.exists(path):
+    path = latest_profile("pmc_traffic.json")
+    if not substrings or path is None:
         return None, None
     tot, n = 0.0, 0
     for k, v in json.load(open(path)).items():
-        if sub in k:
+        if any(sub in k for sub in substrings):
             tot += (v["fetch_bytes_x2_per_launch"] + v["write_bytes_per_launch"]) * v["launches"]
             n += v["launches"] if "reduce" not in k else 0
-    return (round(tot / n) if n else None), "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes/launch)"
+    return (round(tot / n) if n else None), "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes/launch)" % os.path.relpath(path, REPO)
+
+
+FAMILY_KERNELS = {"conv3x3_wino_mfma(fwd+dgrad)": ["conv_wino_kernel"], "conv3x3_wino2d_mfma(fwd+dgrad)": ["conv_wino2_kernel"],
+                  "conv3x3_wgrad_wino2d_mfma(+slice reduce)": ["wgrad_wino2_"], "conv3x3_wgrad_wino_mfma(+slice reduce)": ["wgrad_wino_"],
+                  "conv3x3_igemm_mfma(fwd+dgrad)": ["conv_igemm_kernel"], "conv3x3_wgrad_mfma(+slice reduce)": ["wgrad_kernel"]}
+
+
+class Workload(object):
+    """One configuration of the hot path on this rank: model + optimiser + a resident pool of synthetic batches."""
+
+    def __init__(self, model_type, B, mix, rank, world, dev, seconds=10, inference=False, int16=False, h2d=False):
+        self.mt, self.B, self.mix, self.inference, self.h2d = model_type, B, mix, inference, h2d
+        self.rank, self.world, self.dev = rank, world, dev
+        self.B2 = 2 * B if (mix and not inference) else B
+        L = 32000 * seconds
+        torch.manual_seed(1234 + rank)
+        self.model = getattr(models, model_type)(*CTOR).to(dev)
+        self.model.train()
+        self.opt = FusedAdamAmsgrad(self.model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, world_size=world)
+        parallel.broadcast_flat(self.opt.flat)
+        parallel.broadcast_buffers(self.model)
+        self.loss_func = get_loss_func("clip_bce")
+        self.mixup = Mixup(mixup_alpha=1., random_seed=1234 + rank)
+        self.pool = [synth_batch(self.B2, L, 1000 * rank + i, dev) for i in range(2)]
+        if int16 or h2d:
+            self.pool = [((w * 32767.0).round().to(torch.int16), t) for (w, t) in self.pool]
+        if h2d:                       # double-buffered upload on a copy stream, one batch ahead of the compute
+            self.host_pool = [w.cpu().pin_memory() for (w, _) in self.pool]
+            self.copy_stream = torch.cuda.Stream()
+            self.dbuf = [torch.empty_like(self.pool[0][0]) for _ in range(2)]
+            self.dev_ready = [torch.cuda.Event() for _ in range(2)]
+            self.upload(0)
+        if inference:
+            self.model.eval()
+
+    def upload(self, i):
+        self.copy_stream.wait_stream(torch.cuda.current_stream())     # the buffer's previous reader (step i-2) is done
+        with torch.cuda.stream(self.copy_stream):
+            self.dbuf[i % 2].copy_(self.host_pool[i % len(self.host_pool)], non_blocking=True)
+            self.dev_ready[i % 2].record(self.copy_stream)
+
+    def step(self, i):
+        wave, target = self.pool[i % len(self.pool)]
+        if self.h2d:
+            torch.cuda.current_stream().wait_event(self.dev_ready[i % 2])
+            wave = self.dbuf[i % 2]
+            self.upload(i + 1)
+        if self.inference:
+            with torch.no_grad():
+                out = self.model(wave, None)
+            return out["clipwise_output"].sum()
+        if self.mix:
+            lam = torch.from_numpy(self.mixup.get_lambda(self.B2).astype(np.float32)).to(self.dev, non_blocking=True)
+            out = self.model(wave, lam)
+            tgt = do_mixup(target, lam)
+        else:
+            out = self.model(wave, None)
+            tgt = target
+        loss = self.loss_func(out, {"target": tgt})
+        self.opt.zero_grad()
+        loss.backward()                  # gradient buckets go to RCCL as they complete (parallel.GradBuckets)
+        self.opt.step()                  # waits for the buckets, then ONE Adam kernel over the flat buffer (1/world folded in)
+        return loss
+
+    def sync(self):
+        if self.world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def run(self, steps, warmup, timing=False):
+        """W untimed steps, then exactly K timed ones bracketed by barrier + synchronize; MAX over ranks."""
+        for i in range(warmup):
+            self.step(i)
+        self.sync()
+        if timing:
+            ops.TIMING = {}
+        t0 = time.time()
+        for i in range(steps):
+            loss = self.step(warmup + i)
+        self.sync()
+        dt = time.time() - t0
+        tm, ops.TIMING = ops.TIMING, None
+        ops.check_device_errors()
+        if self.world > 1:
+            t = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, float(loss.item()), tm
+
+    def describe(self, seconds=10, int16=False):
+        return "%s, batch_size=%d per GPU%s, %d s @ 32 kHz %s waveforms resident in HBM, %s" % (
+            self.mt, self.B, (" (post-mixup clips), mixup (%d waveforms/step/GPU)" % self.B2) if (self.mix and not self.inference)
+            else ", no mixup", seconds, "int16" if int16 else "fp32",
+            "eval-mode forward only" if self.inference else "SpecAugment on, clip_bce, Adam-amsgrad")
+
+
+def extra_configs(rank, world, dev, steps=5, warmup=2):
+    """The other BASELINE.json configurations, a few steps each (single GPU, same process, after the headline run)."""
+    out = []
+    for tag, mt, B, mix, inf in (
+            ("configs[2] Cnn_9layers_FrameAtt B=256 mixup", "Cnn_9layers_FrameAtt", 256, True, False),
+            ("configs[3] Cnn_9layers_Gru_FrameAtt B=256 mixup", "Cnn_9layers_Gru_FrameAtt", 256, True, False),
+            ("metric batch size: Cnn_9layers_FrameAvg B=32 mixup (reference README)", "Cnn_9layers_FrameAvg", 32, True, False),
+            ("configs[0] shape on the GPU: Cnn_9layers_FrameAvg B=32 no mixup", "Cnn_9layers_FrameAvg", 32, False, False),
+            ("inference (eval-mode forward) Cnn_9layers_FrameAvg 256 clips/step", "Cnn_9layers_FrameAvg", 256, False, True)):
+        try:
+            w = Workload(mt, B, mix, rank, world, dev, inference=inf)
+            k = steps * (4 if B <= 32 else 1)
+            dt, loss, _ = w.run(k, warmup)
+            out.append({"config": tag, "workload": w.describe(), "value": round(B * k / dt, 2), "unit": "clips/s", "steps": k,
+                        "warmup": warmup, "ms_per_step": round(dt / k * 1e3, 3),
+                        "metric": "inference clips/sec" if inf else "training clips/sec", "loss": round(loss, 5)})
+            del w
+        except Exception as e:                 # a side number must never lose the headline line
+            out.append({"config": tag, "value": None, "error": repr(e)})
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -99,11 +227,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--model_type", type=str, default="Cnn_9layers_FrameAvg")
+    ap.add_argument("--model_type", type=str, default="Cnn_9layers_FrameAvg",
+                    help="Cnn_9layers_Gru_FrameAtt = BASELINE.json configs[3] / [4] (with --gpus 8)")
     ap.add_argument("--batch_size", type=int, default=256, help="post-mixup clips per GPU per step")
     ap.add_argument("--no_mixup", action="store_true")
     ap.add_argument("--seconds", type=int, default=10)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_extra", action="store_true", help="skip the extra_configs runs (other BASELINE.json configurations)")
     ap.add_argument("--int16", action="store_true", help="feed int16 waveforms (the HDF5 storage dtype)")
     ap.add_argument("--by_shape", action="store_true", help="print a per-layer MFMA kernel table to stderr")
     ap.add_argument("--cpu_threads", type=int, default=0)
@@ -113,9 +243,12 @@ def main():
                     help="secondary: each step first copies its int16 waveforms from pinned host memory (PCIe-inclusive rate)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become N ranks (one per GPU) or fail loudly -- never a silent 1-rank run
+        parallel.respawn_under_torchrun(args.gpus, os.path.abspath(__file__), sys.argv[1:])
     rank, world, local_rank = parallel.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (HIP kernels only; no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -123,79 +256,13 @@ def main():
 
     B = args.batch_size
     mix = not args.no_mixup
-    B2 = 2 * B if mix else B
-    L = 32000 * args.seconds
-    torch.manual_seed(1234 + rank)
-    model = getattr(models, args.model_type)(32000, 1024, 320, 64, 50, 14000, 17).to(dev)
-    model.train()
-    opt = FusedAdamAmsgrad(model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, world_size=world)
-    parallel.broadcast_flat(opt.flat)
-    parallel.broadcast_buffers(model)
-    loss_func = get_loss_func("clip_bce")
-    mixup = Mixup(mixup_alpha=1., random_seed=1234 + rank)
-    pool = [synth_batch(B2, L, 1000 * rank + i, dev) for i in range(2)]
-    if args.int16 or args.h2d:
-        pool = [((w * 32767.0).round().to(torch.int16), t) for (w, t) in pool]
-    host_pool = [w.cpu().pin_memory() for (w, _) in pool] if args.h2d else None
-    if args.h2d:                       # double-buffered upload on a copy stream, one batch ahead of the compute
-        copy_stream = torch.cuda.Stream()
-        dbuf = [torch.empty_like(pool[0][0]) for _ in range(2)]
-        dev_ready = [torch.cuda.Event() for _ in range(2)]
-
-        def upload(i):
-            copy_stream.wait_stream(torch.cuda.current_stream())     # the buffer's previous reader (step i-2) is done
-            with torch.cuda.stream(copy_stream):
-                dbuf[i % 2].copy_(host_pool[i % len(host_pool)], non_blocking=True)
-                dev_ready[i % 2].record(copy_stream)
-        upload(0)
-    if args.inference:
-        model.eval()
-
-    def step(i):
-        wave, target = pool[i % len(pool)]
-        if args.h2d:
-            torch.cuda.current_stream().wait_event(dev_ready[i % 2])
-            wave = dbuf[i % 2]
-            upload(i + 1)
-        if args.inference:
-            with torch.no_grad():
-                out = model(wave[:B], None)
-            return out["clipwise_output"].sum()
-        if mix:
-            lam = torch.from_numpy(mixup.get_lambda(B2).astype(np.float32)).to(dev, non_blocking=True)
-            out = model(wave, lam)
-            tgt = do_mixup(target, lam)
-        else:
-            out = model(wave, None)
-            tgt = target
-        loss = loss_func(out, {"target": tgt})
-        opt.zero_grad()
-        loss.backward()
-        parallel.allreduce_flat_grad(opt.flat_grad)
-        opt.step()
-        return loss
-
-    def sync():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    sync()
-    ops.TIMING = {}
-    t0 = time.time()
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
-    sync()
-    dt = time.time() - t0
-    timing, ops.TIMING = ops.TIMING, None
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    wl = Workload(args.model_type, B, mix, rank, world, dev, seconds=args.seconds, inference=args.inference, int16=args.int16,
+                  h2d=args.h2d)
+    B2 = wl.B2
+    dt, loss, timing = wl.run(args.steps, args.warmup, timing=True)
     if rank != 0:
         return
+    bucket_ranges = [[lo, hi] for lo, hi in wl.opt.buckets.ranges]
 
     def summarise(groups):
         out = {}
@@ -211,18 +278,17 @@ def main():
     for tag, evs in timing.items():
         fam.setdefault(tag.split("|")[0], []).extend(evs)
     kern = summarise(fam)
+    default_workload = (B == 256 and mix and args.model_type == "Cnn_9layers_FrameAvg" and not args.inference
+                        and not args.h2d and not args.int16 and args.seconds == 10)
     frontend = None
     if fe:
         ms = sum(a.elapsed_time(b) for a, b, _ in fe)
         gbps = sum(nb for _, _, nb in fe) / (ms * 1e-3) / 1e9
+        tr, src = pmc_traffic(["logmel_kernel"]) if default_workload else (None, None)
         frontend = {"kernel": "logmel_kernel (STFT+mel+log, K1)", "bound": "hbm", "achieved": round(gbps, 1),
-                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None,
-                    "avg_launch_ms": round(ms / len(fe), 4),
-                    "bytes_per_waveform": int(fe[0][2] / B2),
-                    # ~34 kflop per frame (FFT 25.6k + unpack/power 6.5k + window/mel 2k), 1001 frames at 10 s: the
-                    # kernel is bound by the fp32 vector unit (22 flop/B), see DESIGN.md section 5
-                    "valu_tflops": round(B2 * len(fe) * (args.seconds * 100 + 1) * 34.1e3 / (ms * 1e-3) / 1e12, 2),
-                    "valu_peak_tflops": 78.6}
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": tr,
+                    "traffic_source": src, "avg_launch_ms": round(ms / len(fe), 4),
+                    "bytes_per_waveform": int(fe[0][2] / B2)}
     if args.by_shape:
         for tag, v in sorted(summarise(timing).items()):
             print("# %-62s %3d launches  %8.3f ms/launch  %6.1f TFLOP/s" % (tag, v["launches"], v["avg_ms"], v["tflops"]),
@@ -244,9 +310,10 @@ def main():
                                 "executes %.4gx fewer" % (what, fewer))
             roofline["executed_tflops"] = round(kern[dom]["tflops"] / fewer, 2)
             roofline["executed_frac"] = round(kern[dom]["tflops"] / fewer / FP32_MFMA_PEAK_TFLOPS, 4)
-        roofline["traffic"], src = pmc_traffic(dom)
-        if src:
-            roofline["traffic_source"] = src
+        if default_workload:
+            roofline["traffic"], src = pmc_traffic(FAMILY_KERNELS.get(dom))
+            if src:
+                roofline["traffic_source"] = src
     conv_ms = sum(v["ms_total"] for v in kern.values())
     clips_per_s = B * world * args.steps / dt
     line = {
@@ -256,20 +323,23 @@ def main():
         "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s, batch_size=%d per GPU (post-mixup clips)%s, %d s @ 32 kHz %s waveforms resident in HBM, "
-                               "SpecAugment on, clip_bce, Adam-amsgrad; BASELINE.json configs[1]%s"
-                               % (args.model_type, B, ", mixup (%d waveforms/step/GPU)" % B2 if mix else ", no mixup",
-                                  args.seconds, "int16" if args.int16 else "fp32",
-                                  "" if (B == 256 and mix and args.model_type == "Cnn_9layers_FrameAvg" and not args.inference
-                                         and not args.h2d) else " (modified by flags)"),
-                   "global_batch": B * world, "waveforms_per_step": B2 * world, "parallelism": "dp%d" % world},
+        "config": {"workload": wl.describe(args.seconds, args.int16) + ("; BASELINE.json configs[1]" if default_workload else
+                                                                         " (modified by flags)"),
+                   "global_batch": B * world, "waveforms_per_step": B2 * world, "parallelism": "dp%d" % world,
+                   "grad_allreduce": "%d buckets of the flat fp32 gradient (elements %s), issued from inside backward"
+                                     % (len(bucket_ranges), bucket_ranges)},
         "waveforms_per_s": round(B2 * world * args.steps / dt, 2),
-        "loss": round(float(loss.item()), 5),
+        "loss": round(loss, 5),
         "roofline": roofline,
         "roofline_frontend": frontend,
         "kernels": kern,
         "mfma_kernels_share_of_step": round(conv_ms / (dt * 1e3), 4),
     }
+    del wl
+    gc.collect()
+    torch.cuda.empty_cache()
+    if world == 1 and default_workload and not args.no_extra:
+        line["extra_configs"] = extra_configs(rank, world, dev)
     if world == 1 and not args.no_cpu_baseline:
         try:
             line["cpu_baseline"] = cpu_baseline(threads=args.cpu_threads)

@@ -235,14 +235,23 @@ int sed_gru_gate_bwd(const float* g_out0, const float* g_out1, long ld_go, const
  * saves [2][T][B][4H] = r,z,n,gh_n, out [B][T][2H] = concat(forward, reverse).  Backward: g_out [B][T][2H];
  * wt_* = W_hh^T [H][3H]; produces dgi [B][T][6H] and dgh [2][T][B][3H] (gate pre-activation gradients on the input /
  * hidden side; weight and bias gradients are plain GEMMs / column sums over them).
- * ws: sed_gru_seq_ws_floats() floats of scratch (counters; zeroed by the call). */
+ * ws: sed_gru_seq_ws_floats() floats of scratch (counters; zeroed by the call).
+ * Run-time failure: the workgroups of a launch wait for each other, so all of them must be resident at once.
+ * sed_gru_seq_supported also asks the CURRENT device (CU count, occupancy of both kernels) and answers 0 when they
+ * cannot be; if a launch still cannot make progress (CU mask, co-tenant kernel), its bounded spin gives up and a
+ * follow-up kernel overwrites `out` / `dgi` with NaN and stores 1 (forward) / 2 (backward) into *err_host, a
+ * DEVICE-VISIBLE HOST int (hipHostMalloc / pinned; may be null) that the host can poll without synchronising.
+ * sed_gru_set_spin_limit (test hook): polls before giving up (default 2^23, about 1 s; <= 0 restores the default).
+ * sed_debug_occupy (test hook): holds `blocks` CUs (one workgroup with lds_bytes of LDS each) for `microseconds`. */
 int sed_gru_seq_supported(int B, int Hd);
 long sed_gru_seq_ws_floats(void);
 int sed_gru_seq_fwd(const float* gi, const float* w_hh_f, const float* w_hh_b, const float* b_hh_f,
                     const float* b_hh_b, int B, int T, int Hd, float* hs, float* saves, float* out, float* ws,
-                    sed_stream_t stream);
+                    int* err_host, sed_stream_t stream);
 int sed_gru_seq_bwd(const float* g_out, const float* wt_f, const float* wt_b, const float* hs, const float* saves,
-                    int B, int T, int Hd, float* dgi, float* dgh, float* ws, sed_stream_t stream);
+                    int B, int T, int Hd, float* dgi, float* dgh, float* ws, int* err_host, sed_stream_t stream);
+int sed_gru_set_spin_limit(long spins);
+int sed_debug_occupy(int blocks, int lds_bytes, long microseconds, sed_stream_t stream);
 
 /* ---- multi-head self-attention of the Transformer heads (models.py:587-665; 8 heads x 64) ----------------------
  * q, k, v, o, g_*: [B*T][512] fp32, head h in columns 64h..64h+63 (the Linear outputs of w_qs / w_ks / w_vs, no

@@ -58,13 +58,13 @@ __device__ __forceinline__ void group_arrive(int* counter) {
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void group_wait(int* counter, int target, int* err) {
+__device__ __forceinline__ void group_wait(int* counter, int target, int* err, long spin_limit) {
     if (threadIdx.x == 0) {
         long spins = 0;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
             if ((++spins & 1023) == 0 &&
-                (spins > (1L << 23) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                (spins > spin_limit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                 __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // give up everywhere, never hang
                 break;
             }
@@ -82,6 +82,7 @@ struct GruSeqFwdP {
     float* out;                // [B][T][2H]
     int* flags;                // [ngroups] arrival counters (zeroed by the launcher) + error word at [GRU_MAX_GROUPS]
     int B, T, ngroups;
+    long spin_limit;
 };
 
 __global__ __launch_bounds__(512) void gru_seq_fwd_kernel(GruSeqFwdP p) {
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_kernel(GruSeqFwdP p) {
         float2 gh[3] = {bias[0], bias[1], bias[2]};
         float2 hp = make_float2(0.f, 0.f);
         if (k > 0) {
-            group_wait(counter, 8 * k, err);
+            group_wait(counter, 8 * k, err, p.spin_limit);
             f4r a[4];
             const float* ap = h_prev + (long)arow * GH + kb;
 #pragma unroll
@@ -206,6 +207,7 @@ struct GruSeqBwdP {
     float* dgh;                // [2][T][B][3H]
     int* flags;
     int B, T, ngroups;
+    long spin_limit;
 };
 
 __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqBwdP p) {
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqBwdP p) {
         if (k > 0) hp = *reinterpret_cast<const float2*>(p.hs + ((long)d * T + (d ? t + 1 : t - 1)) * bh + (long)rowc * GH + j);
         dh.x += dhz.x; dh.y += dhz.y;
         if (done > 0) {
-            group_wait(counter, 8 * done, err);
+            group_wait(counter, 8 * done, err, p.spin_limit);
             const float* dgh_later = p.dgh + ((long)d * T + (d ? t - 1 : t + 1)) * 3 * bh;
             f4r a[12];
             const float* ap = dgh_later + (long)arow * 3 * GH + kb;
@@ -313,34 +315,98 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqBwdP p) {
     }
 }
 
+
+// ---- run-time failure handling --------------------------------------------------------------------------------------
+// The persistent kernels need all their workgroups resident.  If a bounded spin gives up (CU mask, partitioned GPU, a
+// co-tenant kernel holding CUs for longer than the bound) the error word in `flags` is set and the results are garbage.
+// This follow-up kernel, enqueued right behind the recurrence, makes that LOUD without a host synchronisation: it
+// overwrites the pass's output with NaN and raises a flag in host-mapped memory that the host polls at its next call.
+__global__ __launch_bounds__(256) void gru_seq_check_kernel(const int* flags, int* err_host, int code, float* out, long n) {
+    if (__hip_atomic_load(flags + GRU_MAX_GROUPS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+    const float nan = __builtin_nanf("");
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = nan;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && err_host)
+        __hip_atomic_store(err_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// test hook: occupies `blocks` whole CUs (one workgroup with all of the CU's LDS each) for `microseconds`
+__global__ __launch_bounds__(256) void occupy_kernel(long ticks) {
+    extern __shared__ float hog[];
+    hog[threadIdx.x] = 0.f;
+    const long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
+long g_spin_limit = 1L << 23;          // ~1 s of polling
+
+// all workgroups of the persistent kernels fit on the current device at once?  (cached per device)
+bool gru_device_fits(int grid) {
+    static int cached_dev = -1, cached_cap = 0;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return false;
+    if (dev != cached_dev) {
+        int cus = 0, per_f = 0, per_b = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_f, gru_seq_fwd_kernel, 512, 0) != hipSuccess) return false;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_b, gru_seq_bwd_kernel, 512, 0) != hipSuccess) return false;
+        // one workgroup per CU is what the kernels are laid out for; the occupancy API may over-report by one block per CU
+        // (MI355X_MICROARCH.md), so only its ">= 1" answer is used
+        cached_cap = (per_f >= 1 && per_b >= 1) ? cus : 0;
+        cached_dev = dev;
+    }
+    return grid <= cached_cap;
+}
+
 }  // namespace
 
-SED_API int sed_gru_seq_supported(int B, int Hd) { return Hd == GH && B > 0 && 2 * sed_cdiv(B, 32) * (GH / 32) <= 256; }
+SED_API int sed_gru_seq_supported(int B, int Hd) {
+    if (!(Hd == GH && B > 0 && 2 * sed_cdiv(B, 32) * (GH / 32) <= 256)) return 0;
+    return gru_device_fits(2 * sed_cdiv(B, 32) * (GH / 32)) ? 1 : 0;
+}
 SED_API long sed_gru_seq_ws_floats(void) { return GRU_FLAG_INTS; }
+SED_API int sed_gru_set_spin_limit(long spins) {
+    g_spin_limit = spins > 0 ? spins : (1L << 23);
+    return 0;
+}
+SED_API int sed_debug_occupy(int blocks, int lds_bytes, long microseconds, hipStream_t stream) {
+    if (blocks <= 0 || lds_bytes < 1024 || lds_bytes > 160 * 1024 || microseconds < 0 || microseconds > 2000000) return SED_EINVAL;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(256), lds_bytes, stream, microseconds * 100L);   // 100 MHz wall clock
+    SED_LAUNCH_CHECK();
+    return 0;
+}
 
 // Whole forward recurrence in one launch.  Direction 0 walks t = 0..T-1, direction 1 walks t = T-1..0.
 SED_API int sed_gru_seq_fwd(const float* gi, const float* w_hh_f, const float* w_hh_b, const float* b_hh_f,
                             const float* b_hh_b, int B, int T, int Hd, float* hs, float* saves, float* out, float* ws,
-                            hipStream_t stream) {
+                            int* err_host, hipStream_t stream) {
     const int ngroups = 2 * sed_cdiv(B, 32);
     if (B <= 0 || T <= 0 || Hd != GH || ngroups > GRU_MAX_GROUPS || ngroups * (GH / 32) > 256) return SED_EINVAL;
     hipError_t e = hipMemsetAsync(ws, 0, GRU_FLAG_INTS * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
-    GruSeqFwdP p{gi, {w_hh_f, w_hh_b}, {b_hh_f, b_hh_b}, hs, saves, out, reinterpret_cast<int*>(ws), B, T, ngroups};
+    GruSeqFwdP p{gi, {w_hh_f, w_hh_b}, {b_hh_f, b_hh_b}, hs, saves, out, reinterpret_cast<int*>(ws), B, T, ngroups, g_spin_limit};
     hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3(ngroups * (GH / 32)), dim3(512), 0, stream, p);
+    SED_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gru_seq_check_kernel, dim3(256), dim3(256), 0, stream, reinterpret_cast<const int*>(ws), err_host, 1, out,
+                       (long)B * T * 2 * GH);
     SED_LAUNCH_CHECK();
     return 0;
 }
 
 // Whole backward recurrence in one launch (reverse processing order).
 SED_API int sed_gru_seq_bwd(const float* g_out, const float* wt_f, const float* wt_b, const float* hs, const float* saves,
-                            int B, int T, int Hd, float* dgi, float* dgh, float* ws, hipStream_t stream) {
+                            int B, int T, int Hd, float* dgi, float* dgh, float* ws, int* err_host, hipStream_t stream) {
     const int ngroups = 2 * sed_cdiv(B, 32);
     if (B <= 0 || T <= 0 || Hd != GH || ngroups > GRU_MAX_GROUPS || ngroups * (GH / 32) > 256) return SED_EINVAL;
     hipError_t e = hipMemsetAsync(ws, 0, GRU_FLAG_INTS * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
-    GruSeqBwdP p{g_out, {wt_f, wt_b}, hs, saves, dgi, dgh, reinterpret_cast<int*>(ws), B, T, ngroups};
+    GruSeqBwdP p{g_out, {wt_f, wt_b}, hs, saves, dgi, dgh, reinterpret_cast<int*>(ws), B, T, ngroups, g_spin_limit};
     hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(ngroups * (GH / 32)), dim3(512), 0, stream, p);
+    SED_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gru_seq_check_kernel, dim3(256), dim3(256), 0, stream, reinterpret_cast<const int*>(ws), err_host, 2, dgi,
+                       (long)B * T * 6 * GH);
     SED_LAUNCH_CHECK();
     return 0;
 }

@@ -76,6 +76,105 @@ def _call(name, *args):
 
 
 # ------------------------------------------------------------------------------------------------------------
+# asynchronous device-side error flag (fused GRU give-up).  The flag lives in host-mapped pinned memory: kernels
+# raise it with a system-scope store, the host polls it without synchronising.
+
+_ERR_FLAG = None
+
+
+def _err_flag():
+    """One pinned int32[4] per process; its device-visible address is handed to the kernels that can fail at run time."""
+    global _ERR_FLAG
+    if _ERR_FLAG is None:
+        _ERR_FLAG = torch.zeros((4,), dtype=torch.int32).pin_memory()
+    return _ERR_FLAG
+
+
+def check_device_errors(synchronize=False):
+    """Raise if a kernel reported a run-time failure since the last check (no device synchronisation unless asked: the
+    flag is written through host-mapped memory, so a failure surfaces at the next call after the kernel ran)."""
+    if _ERR_FLAG is None:
+        return
+    if synchronize:
+        torch.cuda.synchronize()
+    code = int(_ERR_FLAG[0])
+    if code:
+        _ERR_FLAG.zero_()
+        raise RuntimeError(
+            "sound_event_detection_dcase2017_task4_amd: the fused GRU recurrence (sed_gru_seq_%s) gave up waiting for its "
+            "partner workgroups -- its 128 persistent workgroups were not all resident (CU mask, partitioned GPU or a "
+            "co-tenant kernel).  Its outputs were overwritten with NaN.  Set ops.USE_FUSED_GRU = False to use the "
+            "per-step launches on this device." % ("fwd" if code == 1 else "bwd"))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# gradient sinks (optim.FusedAdamAmsgrad, direct_grads): the backward kernels write weight gradients straight into
+# the flat gradient buffer and autograd gets None for them -- no per-parameter accumulate kernels.
+
+def _sinks(ctx, params, first_index):
+    """Remember, for the parameters passed to a Function.forward at positions first_index.., where their gradients go
+    (None = the ordinary autograd return path) and tell the bucketed all-reduce to expect them."""
+    out = []
+    for k, p in enumerate(params):
+        s = getattr(p, "_sed_sink", None) if p is not None else None
+        if s is not None and not ctx.needs_input_grad[first_index + k]:
+            s = None
+        if s is not None:
+            s.expect()
+        out.append(s)
+    return out
+
+
+def _dst(sink, shape, device):
+    """Tensor a gradient kernel should write into."""
+    if sink is not None:
+        return sink.view.view(shape)
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
+def _ret(sink, t):
+    """What backward() returns for a gradient already written into _dst(sink, ...)."""
+    if sink is not None:
+        sink.done()
+        return None
+    return t
+
+
+def _put(sink, t):
+    """Return path for a gradient that was computed into a temporary (slices of padded / stacked results)."""
+    if sink is not None:
+        sink.view.copy_(t.reshape(sink.view.shape))
+        sink.done()
+        return None
+    return t.contiguous()
+
+
+# weight operands derived from parameters (padded head matrices, stacked GRU input weights): rebuilt only when a
+# source parameter changed.  In-place updates through torch bump `_version`; the fused Adam kernel updates the flat
+# buffer through raw pointers and bumps PARAM_GENERATION instead (so does invalidate_weight_caches()).
+PARAM_GENERATION = 0
+_WCACHE = {}
+
+
+def invalidate_weight_caches():
+    global PARAM_GENERATION
+    PARAM_GENERATION += 1
+
+
+def _cached(kind, srcs, build):
+    key = (kind,) + tuple(t.data_ptr() for t in srcs)
+    stamp = (PARAM_GENERATION,) + tuple(t._version for t in srcs)
+    hit = _WCACHE.get(key)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    val = build()
+    if len(_WCACHE) > 64:
+        _WCACHE.clear()
+    _WCACHE[key] = (stamp, val)
+    return val
+
+
+# ------------------------------------------------------------------------------------------------------------
 # front-end constants (host side, built once per model; numpy float64 -> float32)
 
 MEL_TASK_TAPS = 12
@@ -172,15 +271,15 @@ def bn_eval_affine(bn_w, bn_b, running_mean, running_var):
     return st
 
 
-def bn_bwd_finalize(partials, nparts, N, st, want_coef=True, batch_stats=True):
+def bn_bwd_finalize(partials, nparts, N, st, want_coef=True, batch_stats=True, sinks=(None, None)):
     C = st.mean.numel()
     dev = st.mean.device
-    dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
-    dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
+    dgamma = _dst(sinks[0], (C,), dev)
+    dbeta = _dst(sinks[1], (C,), dev)
     coef = torch.empty((3, C), dtype=torch.float32, device=dev) if want_coef else None
     _call("sed_bn_bwd_finalize", _ptr(partials), nparts, N, C, _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale),
           1 if batch_stats else 0, _ptr(dgamma), _ptr(dbeta), _ptr(coef), _ptr(_ws(C, dev)), _stream())
-    return dgamma, dbeta, coef
+    return _ret(sinks[0], dgamma), _ret(sinks[1], dbeta), coef
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -211,6 +310,7 @@ class Bn0AugMix(torch.autograd.Function):
         _call("sed_bn0_aug_mix_fwd", _ptr(lm), B2, T, _ptr(st.scale), _ptr(st.shift), _ptr(stripes), _ptr(lam), _ptr(out),
               _stream())
         ctx.st, ctx.training = st, training
+        ctx.sinks = _sinks(ctx, (bn_w, bn_b), 1)
         ctx.save_for_backward(lm, stripes, lam)
         return out
 
@@ -225,7 +325,8 @@ class Bn0AugMix(torch.autograd.Function):
         n = ctypes.c_int(0)
         _call("sed_bn0_aug_mix_bwd", _ptr(lm), _ptr(g), B2, T, _ptr(st.mean), _ptr(st.invstd), _ptr(stripes), _ptr(lam),
               _ptr(partials), ctypes.byref(n), _stream())
-        dgamma, dbeta, _ = bn_bwd_finalize(partials, n.value, B2 * T, st, want_coef=False)   # same formula in eval mode
+        dgamma, dbeta, _ = bn_bwd_finalize(partials, n.value, B2 * T, st, want_coef=False,   # same formula in eval mode
+                                           sinks=ctx.sinks)
         return None, dgamma, dbeta, None, None, None, None, None
 
 
@@ -304,50 +405,50 @@ def _wgrad_wino_ok(W, Cin, Cout):
     return W in (8, 16, 32, 64) and Cin % 64 == 0 and Cout % 64 == 0
 
 
-def _wgrad_wino(x, gy, B, H, W, Cin, Cout, in_st=None):
+def _wgrad_wino(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None):
     ns, pps = ctypes.c_int(0), ctypes.c_int(0)
     nfl = _lib.lib().sed_wgrad_wino_partial_floats(B * H * W, Cin, Cout, ctypes.byref(ns), ctypes.byref(pps))
     partial = torch.empty((nfl,), dtype=torch.float32, device=x.device)
-    dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
+    dw = _dst(sink, (Cout, Cin, 3, 3), x.device)
     with _timed("conv3x3_wgrad_wino_mfma(+slice reduce)|%d->%d@%dx%d%s" % (Cin, Cout, H, W, "+inT" if in_st is not None else ""),
                 2.0 * 9 * B * H * W * Cin * Cout):
         _call("sed_conv3x3_wgrad_wino", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
               _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, _stream())
-    return dw
+    return _ret(sink, dw)
 
 
-def _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=None):
+def _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None):
     ns, ups = ctypes.c_int(0), ctypes.c_int(0)
     nfl = _lib.lib().sed_wgrad_wino2_partial_floats(B, H, W, Cin, Cout, ctypes.byref(ns), ctypes.byref(ups))
     if nfl <= 0:
         raise RuntimeError("sed_conv3x3_wgrad_wino2 does not support this shape")
     partial = torch.empty((nfl,), dtype=torch.float32, device=x.device)
-    dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
+    dw = _dst(sink, (Cout, Cin, 3, 3), x.device)
     with _timed("conv3x3_wgrad_wino2d_mfma(+slice reduce)|%d->%d@%dx%d%s" % (Cin, Cout, H, W, "+inT" if in_st is not None else ""),
                 2.0 * 9 * B * H * W * Cin * Cout):
         _call("sed_conv3x3_wgrad_wino2", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
               _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, _stream())
-    return dw
+    return _ret(sink, dw)
 
 
-def _wgrad(x, gy, B, H, W, Cin, Cout, in_st=None):
+def _wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None):
     if USE_WINOGRAD >= 2 and W in (8, 16, 32, 64) and Cin % 32 == 0 and Cout % 64 == 0:
-        return _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=in_st)
+        return _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink)
     if USE_WINOGRAD and _wgrad_wino_ok(W, Cin, Cout):
-        return _wgrad_wino(x, gy, B, H, W, Cin, Cout, in_st=in_st)
-    return _wgrad_direct(x, gy, B, H, W, Cin, Cout, in_st=in_st)
+        return _wgrad_wino(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink)
+    return _wgrad_direct(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink)
 
 
-def _wgrad_direct(x, gy, B, H, W, Cin, Cout, in_st=None):
+def _wgrad_direct(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None):
     ns, pps = ctypes.c_int(0), ctypes.c_int(0)
     nfl = _lib.lib().sed_wgrad_partial_floats(B * H * W, Cin, Cout, 9, ctypes.byref(ns), ctypes.byref(pps))
     partial = torch.empty((nfl,), dtype=torch.float32, device=x.device)
-    dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
+    dw = _dst(sink, (Cout, Cin, 3, 3), x.device)
     with _timed("conv3x3_wgrad_mfma(+slice reduce)|%d->%d@%dx%d%s" % (Cin, Cout, H, W, "+inT" if in_st is not None else ""),
                 2.0 * 9 * B * H * W * Cin * Cout):
         _call("sed_conv3x3_wgrad", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
               _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, _stream())
-    return dw
+    return _ret(sink, dw)
 
 
 
@@ -437,6 +538,7 @@ class ConvBlockFn(torch.autograd.Function):
         else:
             ctx.save_for_backward(x, y1, y2, w1c, w2c)
         ctx.st1, ctx.st2, ctx.pool, ctx.training = st1, st2, (ph, pw), bool(training)
+        ctx.sinks = _sinks(ctx, (w1, g1, b1, None, None, w2, g2, b2), 1)
         return out
 
     @staticmethod
@@ -466,17 +568,18 @@ class ConvBlockFn(torch.autograd.Function):
             part = torch.empty((npmax, 2, Cout), dtype=torch.float32, device=dev)
             _call("sed_bn_relu_pool_bwd_reduce", _ptr(y2), _ptr(g_out), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift),
                   _ptr(st2.mean), _ptr(st2.invstd), _ptr(part), ctypes.byref(n), _stream())
-        dg2, db2, coef2 = bn_bwd_finalize(part, n.value, M, st2, batch_stats=ctx.training)
+        sk = ctx.sinks                                   # (w1, g1, b1, -, -, w2, g2, b2)
+        dg2, db2, coef2 = bn_bwd_finalize(part, n.value, M, st2, batch_stats=ctx.training, sinks=(sk[6], sk[7]))
         gy2 = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
         _call("sed_bn_relu_pool_bwd_apply", _ptr(y2), _ptr(g_out), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift),
               _ptr(coef2), _ptr(gy2), _stream())
         # conv2: wgrad (operand relu(bn1(y1)) on the fly) and dgrad fused with relu-mask + BN1 backward sums
-        dw2 = _wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=st1)
+        dw2 = _wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=st1, sink=sk[5])
         npb, _, nfb = _conv_parts(B, H, W, Cout, Cout)
         partb = torch.empty((nfb,), dtype=torch.float32, device=dev)
         gy1 = _conv_fwd_like(gy2, w2, B, H, W, Cout, Cout, dgrad=True, epi=2, partials=partb, yprev=y1, p_st=st1)
         del gy2
-        dg1, db1, coef1 = bn_bwd_finalize(partb, npb, M, st1, batch_stats=ctx.training)
+        dg1, db1, coef1 = bn_bwd_finalize(partb, npb, M, st1, batch_stats=ctx.training, sinks=(sk[1], sk[2]))
         # conv1
         gx = None
         if Cin != 1:
@@ -484,14 +587,15 @@ class ConvBlockFn(torch.autograd.Function):
         if Cin == 1:                                   # BN1 backward g = a*dz + b*y1 + c is applied on load by the kernel
             nblk = (M + 1023) // 1024
             dwp = torch.empty((nblk, 576), dtype=torch.float32, device=dev)
-            dw1 = torch.empty((Cout, 1, 3, 3), dtype=torch.float32, device=dev)
+            dw1 = _dst(sk[0], (Cout, 1, 3, 3), dev)
             want_gx = ctx.needs_input_grad[0]
             tbuf = torch.empty((M, 9), dtype=torch.float32, device=dev) if want_gx else None
             gx = torch.empty((B, H, W, 1), dtype=torch.float32, device=dev) if want_gx else None
             _call("sed_conv1_bwd", _ptr(x), _ptr(w1), _ptr(gy1), _ptr(y1), _ptr(coef1), B, H, W, _ptr(dw1), _ptr(gx), _ptr(dwp),
                   _ptr(tbuf), _stream())
+            dw1 = _ret(sk[0], dw1)
         else:
-            dw1 = _wgrad(x, gy1, B, H, W, Cin, Cout)
+            dw1 = _wgrad(x, gy1, B, H, W, Cin, Cout, sink=sk[0])
             if ctx.needs_input_grad[0]:
                 gx = _conv_fwd_like(gy1, w1, B, H, W, Cout, Cin, dgrad=True, epi=0)
         return gx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, None, None, None
@@ -509,22 +613,23 @@ def gemm_nt(x, w, bias=None):
     return y
 
 
-def gemm_tn(x, gy):
+def gemm_tn(x, gy, out=None):
     """dw[N][K] = sum_m gy[m][n] x[m][k]."""
     M, K = x.shape
     N = gy.shape[1]
     ns, pps = ctypes.c_int(0), ctypes.c_int(0)
     nfl = _lib.lib().sed_wgrad_partial_floats(M, K, N, 1, ctypes.byref(ns), ctypes.byref(pps))
     partial = torch.empty((nfl,), dtype=torch.float32, device=x.device)
-    dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
+    dw = out if out is not None else torch.empty((N, K), dtype=torch.float32, device=x.device)
     _call("sed_gemm_tn", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), M, N, K, _stream())
     return dw
 
 
-def col_sums(x2d, ncols=None):
+def col_sums(x2d, ncols=None, out=None):
     n, ld = x2d.shape
     K = ld if ncols is None else ncols
-    out = torch.empty((K,), dtype=torch.float32, device=x2d.device)
+    if out is None:
+        out = torch.empty((K,), dtype=torch.float32, device=x2d.device)
     ws = torch.empty((256 * K,), dtype=torch.float32, device=x2d.device) if n > 512 else None
     _call("sed_reduce_rows", _ptr(x2d), n, K, ld, _ptr(out), 0, _ptr(ws), _stream())
     return out
@@ -538,32 +643,52 @@ def transpose_b(x):
     return out
 
 
+class InterpolateFn(torch.autograd.Function):
+    """models.py:58-69.  (B,T,K) -> (B,T*ratio,K), each frame repeated `ratio` times.  The backward (sum over the
+    repeats) only runs for a loss on `framewise_output`, which the reference's training never uses: off the hot path."""
+
+    @staticmethod
+    def forward(ctx, frame, ratio):
+        _chk_dev(frame)
+        frame = _f32c(frame)
+        B, T, K = frame.shape
+        out = torch.empty((B, T * ratio, K), dtype=torch.float32, device=frame.device)
+        _call("sed_interpolate", _ptr(frame), B * T, K, ratio, _ptr(out), _stream())
+        ctx.ratio = ratio
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, TR, K = g.shape
+        return g.reshape(B, TR // ctx.ratio, ctx.ratio, K).sum(dim=2), None
+
+
 def interpolate(frame, ratio):
-    """models.py:58-69.  (B,T,K) -> (B,T*ratio,K)."""
-    B, T, K = frame.shape
-    out = torch.empty((B, T * ratio, K), dtype=torch.float32, device=frame.device)
-    _call("sed_interpolate", _ptr(frame), B * T, K, ratio, _ptr(out), _stream())
-    return out
+    return InterpolateFn.apply(frame, ratio)
 
 
 LDN = 64   # padded logit width of the 17-class heads (MFMA GEMM N granularity)
 
 
 def _pad_rows(ws, device):
-    """Stack weight matrices (each (17, K)) into a zero-padded (64, K) operand (device copy only)."""
-    K = ws[0].numel() // ws[0].shape[0]
-    out = torch.zeros((LDN, K), dtype=torch.float32, device=device)
-    r = 0
-    for w in ws:
-        w2 = w.detach().reshape(w.shape[0], K)
-        out[r:r + w2.shape[0]].copy_(w2)
-        r += w2.shape[0]
-    return out
+    """Stack weight matrices (each (17, K)) into a zero-padded (64, K) operand and its (K, 64) transpose (device copies,
+    cached until a source parameter changes)."""
+    def build():
+        K = ws[0].numel() // ws[0].shape[0]
+        out = torch.zeros((LDN, K), dtype=torch.float32, device=device)
+        r = 0
+        for w in ws:
+            w2 = w.detach().reshape(w.shape[0], K)
+            out[r:r + w2.shape[0]].copy_(w2)
+            r += w2.shape[0]
+        return out, transpose_b(out.view(1, LDN, K)).view(K, LDN)
+    return _cached("pad_rows", ws, build)
 
 
 class FcHeadFn(torch.autograd.Function):
     """FrameAvg (mode 0, models.py:306-312) / FrameMax (mode 1, :221-227) head.
-    feat (B,T,512) -> frame (B,T,17), clip (B,17).  Gradient flows from `clip` only."""
+    feat (B,T,512) -> frame (B,T,17), clip (B,17).  The training loss (clip_bce) feeds `clip`; a gradient arriving
+    through `frame` (a strong-label loss, not used by the reference's main.py) is honoured too, off the hot path."""
 
     @staticmethod
     def forward(ctx, feat, w, b, mode):
@@ -571,36 +696,39 @@ class FcHeadFn(torch.autograd.Function):
         feat = _f32c(feat)
         B, T, C = feat.shape
         ncls = w.shape[0]
-        wp = _pad_rows([w], feat.device)
+        wp, wpt = _pad_rows([w], feat.device)
         logits = gemm_nt(feat.view(B * T, C), wp)
         frame = torch.empty((B, T, ncls), dtype=torch.float32, device=feat.device)
         clip = torch.empty((B, ncls), dtype=torch.float32, device=feat.device)
         amax = torch.empty((B, ncls), dtype=torch.int32, device=feat.device) if mode == 1 else None
         _call("sed_head_pool_fwd", _ptr(logits), B, T, LDN, ncls, _ptr(_f32c(b)), mode, _ptr(frame), _ptr(clip), _ptr(amax),
               _stream())
-        ctx.save_for_backward(feat, wp, frame, amax)
+        ctx.save_for_backward(feat, wpt, frame, amax)
         ctx.mode, ctx.ncls = mode, ncls
-        ctx.mark_non_differentiable(frame)
+        ctx.sinks = _sinks(ctx, (w, b), 1)
+        ctx.set_materialize_grads(False)
         return frame, clip
 
     @staticmethod
     def backward(ctx, g_frame, g_clip):
-        feat, wp, frame, amax = ctx.saved_tensors
+        feat, wpt, frame, amax = ctx.saved_tensors
         B, T, C = feat.shape
         ncls = ctx.ncls
-        g_clip = _f32c(g_clip)
+        g_clip = _f32c(g_clip) if g_clip is not None else torch.zeros((B, ncls), dtype=torch.float32, device=feat.device)
         gl = torch.empty((B * T, LDN), dtype=torch.float32, device=feat.device)
         _call("sed_head_pool_bwd", _ptr(g_clip), _ptr(frame), _ptr(amax), B, T, LDN, ncls, ctx.mode, _ptr(gl), _stream())
-        wpt = transpose_b(wp.view(1, LDN, C)).view(C, LDN)
+        if g_frame is not None:                       # d frame / d logit = frame (1 - frame)
+            gl.view(B, T, LDN)[:, :, :ncls] += g_frame * frame * (1.0 - frame)
         g_feat = gemm_nt(gl, wpt).view(B, T, C)
         dwp = gemm_tn(feat.view(B * T, C), gl)
-        db = col_sums(gl, ncls)
-        return g_feat, dwp[:ncls].contiguous(), db, None
+        db = col_sums(gl, ncls, out=_dst(ctx.sinks[1], (ncls,), feat.device))
+        return g_feat, _put(ctx.sinks[0], dwp[:ncls]), _ret(ctx.sinks[1], db), None
 
 
 class AttHeadFn(torch.autograd.Function):
     """AttBlock(512, 17, 'sigmoid') (models.py:118-149).  feat (B,T,512) -> clip (B,17), cla (B,T,17),
-    norm_att (B,T,17).  Gradient flows from `clip` only (clip_bce)."""
+    norm_att (B,T,17).  The training loss (clip_bce) feeds `clip`; gradients arriving through `cla` / `norm_att`
+    (strong-label losses, not used by the reference's main.py) are honoured too, off the hot path."""
 
     @staticmethod
     def forward(ctx, feat, w_att, b_att, w_cla, b_cla):
@@ -609,7 +737,7 @@ class AttHeadFn(torch.autograd.Function):
         B, T, C = feat.shape
         ncls = w_att.shape[0]
         dev = feat.device
-        wp = _pad_rows([w_att, w_cla], dev)
+        wp, wpt = _pad_rows([w_att, w_cla], dev)
         logits = gemm_nt(feat.view(B * T, C), wp)
         clip = torch.empty((B, ncls), dtype=torch.float32, device=dev)
         cla = torch.empty((B, T, ncls), dtype=torch.float32, device=dev)
@@ -618,26 +746,35 @@ class AttHeadFn(torch.autograd.Function):
         b_att, b_cla = _f32c(b_att), _f32c(b_cla)
         _call("sed_att_pool_fwd", _ptr(logits), B, T, LDN, ncls, _ptr(b_att), _ptr(b_cla), _ptr(clip), _ptr(cla), _ptr(natt),
               _ptr(asum), _stream())
-        ctx.save_for_backward(feat, wp, logits, b_att, clip, cla, natt, asum)
+        ctx.save_for_backward(feat, wpt, logits, b_att, clip, cla, natt, asum)
         ctx.ncls, ctx.wshape = ncls, w_att.shape
-        ctx.mark_non_differentiable(cla, natt)
+        ctx.sinks = _sinks(ctx, (w_att, b_att, w_cla, b_cla), 1)
+        ctx.set_materialize_grads(False)
         return clip, cla, natt
 
     @staticmethod
     def backward(ctx, g_clip, g_cla, g_natt):
-        feat, wp, logits, b_att, clip, cla, natt, asum = ctx.saved_tensors
+        feat, wpt, logits, b_att, clip, cla, natt, asum = ctx.saved_tensors
         B, T, C = feat.shape
         ncls = ctx.ncls
-        g_clip = _f32c(g_clip)
+        g_clip = _f32c(g_clip) if g_clip is not None else torch.zeros((B, ncls), dtype=torch.float32, device=feat.device)
         gl = torch.empty((B * T, LDN), dtype=torch.float32, device=feat.device)
         _call("sed_att_pool_bwd", _ptr(g_clip), _ptr(logits), _ptr(b_att), _ptr(clip), _ptr(cla), _ptr(natt), _ptr(asum), B, T,
               LDN, ncls, _ptr(gl), _stream())
-        wpt = transpose_b(wp.view(1, LDN, C)).view(C, LDN)
+        gl3 = gl.view(B, T, LDN)
+        if g_cla is not None:                         # cla = sigmoid(.)
+            gl3[:, :, ncls:2 * ncls] += g_cla * cla * (1.0 - cla)
+        if g_natt is not None:                        # norm_att = a / sum_t a,  a = exp(clamp(z, -10, 10)) + 1e-6
+            S = asum.view(B, 1, ncls)
+            da = (g_natt - (g_natt * natt).sum(dim=1, keepdim=True)) / S
+            z = logits.view(B, T, LDN)[:, :, :ncls] + b_att.view(1, 1, ncls)
+            gl3[:, :, :ncls] += da * (natt * S - 1e-6) * ((z >= -10.0) & (z <= 10.0)).to(da.dtype)
         g_feat = gemm_nt(gl, wpt).view(B, T, C)
         dwp = gemm_tn(feat.view(B * T, C), gl)
         dbias = col_sums(gl, 2 * ncls)
-        return (g_feat, dwp[:ncls].reshape(ctx.wshape).contiguous(), dbias[:ncls].contiguous(),
-                dwp[ncls:2 * ncls].reshape(ctx.wshape).contiguous(), dbias[ncls:2 * ncls].contiguous())
+        sk = ctx.sinks
+        return (g_feat, _put(sk[0], dwp[:ncls].reshape(ctx.wshape)), _put(sk[1], dbias[:ncls]),
+                _put(sk[2], dwp[ncls:2 * ncls].reshape(ctx.wshape)), _put(sk[3], dbias[ncls:2 * ncls]))
 
 
 class MultiHeadFn(torch.autograd.Function):
@@ -667,6 +804,7 @@ class MultiHeadFn(torch.autograd.Function):
         _call("sed_drop_relu_fwd", _ptr(y), _ptr(kf), float(p_fc), M * C, _ptr(out), _stream())
         ctx.save_for_backward(x2, q, k, v, o, stats, out, wq, wk, wv, wo, ka, kf)
         ctx.dims, ctx.p = (B, T, C), (float(p_attn), float(p_fc))
+        ctx.sinks = _sinks(ctx, (wq, bq, wk, bk, wv, bv, wo, bo), 1)
         return out.view(B, T, C)
 
     @staticmethod
@@ -677,7 +815,9 @@ class MultiHeadFn(torch.autograd.Function):
         g = _f32c(g).view(M, C)
         gy = torch.empty_like(g)
         _call("sed_drop_relu_bwd", _ptr(g), _ptr(out), _ptr(kf), ctx.p[1], M * C, _ptr(gy), _stream())
-        dwo, dbo = gemm_tn(o, gy), col_sums(gy)
+        sk = ctx.sinks                       # (wq, bq, wk, bk, wv, bv, wo, bo)
+        dwo = _ret(sk[6], gemm_tn(o, gy, out=_dst(sk[6], (C, C), g.device)))
+        dbo = _ret(sk[7], col_sums(gy, out=_dst(sk[7], (C,), g.device)))
         go = gemm_nt(gy, transpose_b(_f32c(wo).view(1, C, C)).view(C, C))
         gq, gk, gv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
         _call("sed_mha_bwd", _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(go), _ptr(ka), ctx.p[0], B, T, _ptr(stats), _ptr(gq),
@@ -686,8 +826,11 @@ class MultiHeadFn(torch.autograd.Function):
         for gt, w in ((gk, wk), (gv, wv)):
             t = gemm_nt(gt, transpose_b(_f32c(w).view(1, C, C)).view(C, C))
             _call("sed_axpy", _ptr(gx), _ptr(t), M * C, _stream())
-        return (gx.view(B, T, C), gemm_tn(x2, gq), col_sums(gq), gemm_tn(x2, gk), col_sums(gk), gemm_tn(x2, gv), col_sums(gv),
-                dwo, dbo, None, None, None, None)
+        grads = []
+        for n, gt in enumerate((gq, gk, gv)):
+            grads.append(_ret(sk[2 * n], gemm_tn(x2, gt, out=_dst(sk[2 * n], (C, C), g.device))))
+            grads.append(_ret(sk[2 * n + 1], col_sums(gt, out=_dst(sk[2 * n + 1], (C,), g.device))))
+        return (gx.view(B, T, C),) + tuple(grads) + (dwo, dbo, None, None, None, None)
 
 
 def gemm_nt_pair(x0, x1, w0, w1, b0, b1, y0, y1):
@@ -695,6 +838,14 @@ def gemm_nt_pair(x0, x1, w0, w1, b0, b1, y0, y1):
     M, K = x0.shape
     N = w0.shape[0]
     _call("sed_gemm_nt_pair", _ptr(x0), _ptr(x1), _ptr(w0), _ptr(w1), _ptr(b0), _ptr(b1), _ptr(y0), _ptr(y1), M, N, K, _stream())
+
+
+def _gru_ih_operands(w_ih_f, w_ih_b, b_ih_f, b_ih_b):
+    """(6H, I) stacked input weights of both directions, their (6H,) biases and the (I, 6H) transpose."""
+    w_ih = torch.cat([_f32c(w_ih_f.detach()), _f32c(w_ih_b.detach())], dim=0).contiguous()
+    b_ih = torch.cat([_f32c(b_ih_f.detach()), _f32c(b_ih_b.detach())], dim=0).contiguous()
+    n, i = w_ih.shape
+    return w_ih, b_ih, transpose_b(w_ih.view(1, n, i)).view(i, n)
 
 
 class GruFn(torch.autograd.Function):
@@ -711,19 +862,24 @@ class GruFn(torch.autograd.Function):
         Hd = w_hh_f.shape[1]
         dev = x.device
         out = torch.empty((B, T, 2 * Hd), dtype=torch.float32, device=dev)
-        w_ih = torch.cat([_f32c(w_ih_f), _f32c(w_ih_b)], dim=0).contiguous()          # (6H, I)   device copy
-        b_ih = torch.cat([_f32c(b_ih_f), _f32c(b_ih_b)], dim=0).contiguous()
+        check_device_errors()                                                          # a failure of an earlier launch
+        # stacked / transposed weight operands: device copies, rebuilt only when a parameter changed
+        w_ih, b_ih, w_ih_t = _cached("gru_ih", (w_ih_f, w_ih_b, b_ih_f, b_ih_b), lambda: _gru_ih_operands(
+            w_ih_f, w_ih_b, b_ih_f, b_ih_b))
         gi = gemm_nt(x.view(B * T, I), w_ih, b_ih).view(B, T, 6 * Hd)                  # (B, T, 6H)
         hs = torch.empty((2, T, B, Hd), dtype=torch.float32, device=dev)
         saves = torch.empty((2, T, B, 4 * Hd), dtype=torch.float32, device=dev)
         whh = (_f32c(w_hh_f), _f32c(w_hh_b))
         bhh = (_f32c(b_hh_f), _f32c(b_hh_b))
-        if USE_FUSED_GRU and _lib.lib().sed_gru_seq_supported(B, Hd):
-            # fused recurrence: ONE persistent launch for all T steps of both directions (csrc/gru.hip)
+        ctx.sinks = _sinks(ctx, (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_b, w_hh_b, b_ih_b, b_hh_b), 1)
+        ctx.fused = bool(USE_FUSED_GRU and _lib.lib().sed_gru_seq_supported(B, Hd))
+        if ctx.fused:
+            # fused recurrence: ONE persistent launch for all T steps of both directions (csrc/gru.hip); a launch that
+            # cannot make progress poisons `out` with NaN and raises the host-mapped flag polled by check_device_errors
             ws = torch.empty((_lib.lib().sed_gru_seq_ws_floats(),), dtype=torch.float32, device=dev)
             _call("sed_gru_seq_fwd", _ptr(gi), _ptr(whh[0]), _ptr(whh[1]), _ptr(bhh[0]), _ptr(bhh[1]), B, T, Hd,
-                  _ptr(hs), _ptr(saves), _ptr(out), _ptr(ws), _stream())
-            ctx.save_for_backward(x, w_ih, whh[0], whh[1], hs, saves)
+                  _ptr(hs), _ptr(saves), _ptr(out), _ptr(ws), _ptr(_err_flag()), _stream())
+            ctx.save_for_backward(x, w_ih_t, whh[0], whh[1], hs, saves)
             return out
         gh0 = torch.stack([bhh[0].view(1, -1).expand(B, -1), bhh[1].view(1, -1).expand(B, -1)]).contiguous()  # h0 = 0
         gh = torch.empty((2, B, 3 * Hd), dtype=torch.float32, device=dev)
@@ -739,12 +895,12 @@ class GruFn(torch.autograd.Function):
             _call("sed_gru_gate_fwd", _ptr(gi[:, tf, 0:3 * Hd]), _ptr(gi[:, tb, 3 * Hd:6 * Hd]), T * 6 * Hd, _ptr(g0), _ptr(g1),
                   _ptr(p0), _ptr(p1), B, Hd, _ptr(hs[0, tf]), _ptr(hs[1, tb]), Hd, _ptr(out[:, tf, 0:Hd]),
                   _ptr(out[:, tb, Hd:2 * Hd]), T * 2 * Hd, _ptr(saves[0, tf]), _ptr(saves[1, tb]), s)
-        ctx.save_for_backward(x, w_ih, whh[0], whh[1], hs, saves)
+        ctx.save_for_backward(x, w_ih_t, whh[0], whh[1], hs, saves)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        x, w_ih, w_hh_f, w_hh_b, hs, saves = ctx.saved_tensors
+        x, w_ih_t, w_hh_f, w_hh_b, hs, saves = ctx.saved_tensors
         g_out = _f32c(g_out)
         B, T, I = x.shape
         Hd = w_hh_f.shape[1]
@@ -752,13 +908,13 @@ class GruFn(torch.autograd.Function):
         s = _stream()
         dgi = torch.empty((B, T, 6 * Hd), dtype=torch.float32, device=dev)
         dgh = torch.empty((2, T, B, 3 * Hd), dtype=torch.float32, device=dev)
-        wt = (transpose_b(w_hh_f.view(1, 3 * Hd, Hd)).view(Hd, 3 * Hd),               # (H, 3H): dh = dgh x W_hh
-              transpose_b(w_hh_b.view(1, 3 * Hd, Hd)).view(Hd, 3 * Hd))
-        fused = USE_FUSED_GRU and _lib.lib().sed_gru_seq_supported(B, Hd)
+        wt = _cached("gru_hh_t", (w_hh_f, w_hh_b), lambda: (                          # (H, 3H): dh = dgh x W_hh
+            transpose_b(w_hh_f.view(1, 3 * Hd, Hd)).view(Hd, 3 * Hd), transpose_b(w_hh_b.view(1, 3 * Hd, Hd)).view(Hd, 3 * Hd)))
+        fused = ctx.fused
         if fused:
             ws = torch.empty((_lib.lib().sed_gru_seq_ws_floats(),), dtype=torch.float32, device=dev)
             _call("sed_gru_seq_bwd", _ptr(g_out), _ptr(wt[0]), _ptr(wt[1]), _ptr(hs), _ptr(saves), B, T, Hd,
-                  _ptr(dgi), _ptr(dgh), _ptr(ws), s)
+                  _ptr(dgi), _ptr(dgh), _ptr(ws), _ptr(_err_flag()), s)
         direct = [torch.empty((2, B, Hd), dtype=torch.float32, device=dev) for _ in range(2)]   # ping-pong
         rec = [torch.empty((2, B, Hd), dtype=torch.float32, device=dev) for _ in range(2)]
         have = False
@@ -777,19 +933,22 @@ class GruFn(torch.autograd.Function):
                 gemm_nt_pair(dgh[0, tf], dgh[1, tb], wt[0], wt[1], None, None, rec[cur][0], rec[cur][1])
             have = True
         # weight gradients of the recurrence: dW_hh = sum_t dgh_t^T h_{prev(t)}; h_prev is a shifted view of hs
-        dw_hh_f = gemm_tn(hs[0, 0:T - 1].reshape((T - 1) * B, Hd), dgh[0, 1:T].reshape((T - 1) * B, 3 * Hd)) if T > 1 else \
-            torch.zeros((3 * Hd, Hd), dtype=torch.float32, device=dev)
-        dw_hh_b = gemm_tn(hs[1, 1:T].reshape((T - 1) * B, Hd), dgh[1, 0:T - 1].reshape((T - 1) * B, 3 * Hd)) if T > 1 else \
-            torch.zeros((3 * Hd, Hd), dtype=torch.float32, device=dev)
-        db_hh_f = col_sums(dgh[0].view(T * B, 3 * Hd))
-        db_hh_b = col_sums(dgh[1].view(T * B, 3 * Hd))
+        sk = ctx.sinks                       # (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_b, w_hh_b, b_ih_b, b_hh_b)
+        if T > 1:
+            dw_hh_f = gemm_tn(hs[0, 0:T - 1].reshape((T - 1) * B, Hd), dgh[0, 1:T].reshape((T - 1) * B, 3 * Hd),
+                              out=_dst(sk[1], (3 * Hd, Hd), dev))
+            dw_hh_b = gemm_tn(hs[1, 1:T].reshape((T - 1) * B, Hd), dgh[1, 0:T - 1].reshape((T - 1) * B, 3 * Hd),
+                              out=_dst(sk[5], (3 * Hd, Hd), dev))
+        else:
+            dw_hh_f, dw_hh_b = _dst(sk[1], (3 * Hd, Hd), dev).zero_(), _dst(sk[5], (3 * Hd, Hd), dev).zero_()
+        db_hh_f = col_sums(dgh[0].view(T * B, 3 * Hd), out=_dst(sk[3], (3 * Hd,), dev))
+        db_hh_b = col_sums(dgh[1].view(T * B, 3 * Hd), out=_dst(sk[7], (3 * Hd,), dev))
         dgi2 = dgi.view(B * T, 6 * Hd)
-        w_ih_t = transpose_b(w_ih.view(1, 6 * Hd, I)).view(I, 6 * Hd)
         gx = gemm_nt(dgi2, w_ih_t).view(B, T, I)
         dw_ih = gemm_tn(x.view(B * T, I), dgi2)                                          # (6H, I)
         db_ih = col_sums(dgi2)
-        return (gx, dw_ih[:3 * Hd].contiguous(), dw_hh_f, db_ih[:3 * Hd].contiguous(), db_hh_f,
-                dw_ih[3 * Hd:].contiguous(), dw_hh_b, db_ih[3 * Hd:].contiguous(), db_hh_b)
+        return (gx, _put(sk[0], dw_ih[:3 * Hd]), _ret(sk[1], dw_hh_f), _put(sk[2], db_ih[:3 * Hd]), _ret(sk[3], db_hh_f),
+                _put(sk[4], dw_ih[3 * Hd:]), _ret(sk[5], dw_hh_b), _put(sk[6], db_ih[3 * Hd:]), _ret(sk[7], db_hh_b))
 
 
 class ClipBceFn(torch.autograd.Function):
@@ -825,5 +984,6 @@ def mixup_rows(x, lam):
 
 def adam_amsgrad_(p, g, m, v, vmax, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
     _chk_dev(p, g)
+    invalidate_weight_caches()                     # parameters change through raw pointers: `_version` does not see it
     _call("sed_adam_amsgrad", _ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vmax), p.numel(), step, lr, beta1, beta2, eps,
           grad_scale, _stream())

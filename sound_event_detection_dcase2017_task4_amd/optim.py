@@ -2,27 +2,78 @@
 
 The trainable parameters of the model are re-pointed at slices of a single contiguous fp32 buffer and their
 `.grad`s at slices of a single contiguous gradient buffer, so that (i) the optimiser step is one HIP kernel
-(sed_adam_amsgrad) and (ii) the data-parallel exchange is ONE RCCL all-reduce of that buffer
-(parallel.allreduce_gradients) instead of DataParallel's per-step parameter broadcast + reduce_add.
+(sed_adam_amsgrad), (ii) the data-parallel exchange is a handful of RCCL all-reduces over contiguous ranges of that
+buffer (parallel.GradBuckets) instead of DataParallel's per-step parameter broadcast + reduce_add, and (iii) the
+backward kernels write their weight gradients STRAIGHT into the buffer (`direct_grads`): the autograd Functions of
+ops.py find the destination through the `_sed_sink` attribute this optimiser puts on every parameter, write there and
+hand autograd `None`, so no per-parameter accumulate kernel runs.
 Parameters that never receive a gradient (the reference's unused `att_block.bn_att.*`) keep a zero gradient and
 therefore never move, which equals torch.optim.Adam skipping `grad is None` parameters.
+
+`direct_grads=True` means "this backward pass DEFINES the gradient" (what zero_grad() + backward() gives); accumulating
+several backward passes into one step needs `direct_grads=False` (plain autograd accumulation into the same views).
 """
 import torch
 
-from . import ops
+from . import ops, parallel
+
+
+class GradSink(object):
+    """Where the gradient of one parameter goes: a view into the flat gradient buffer + the readiness callback."""
+    __slots__ = ("opt", "index", "view")
+
+    def __init__(self, opt, index, view):
+        self.opt, self.index, self.view = opt, index, view
+
+    def expect(self):
+        self.opt.buckets.expect(self.index)
+
+    def done(self):
+        self.opt.buckets.ready(self.index)
+
+
+def bucket_cuts(names, offsets, numels, min_bytes=1 << 19):
+    """Cut positions (element offsets) for the gradient buckets: parameters are grouped by top-level module
+    (`conv_block3.conv1.weight` -> `conv_block3`), groups are walked from the END of the buffer (the order backward
+    finishes them) and a cut is placed in front of a group once the running bucket holds >= min_bytes.
+    Cnn_9layers_FrameAvg -> [bn0 + block1 + block2 | block3 | block4 + fc]; Gru_FrameAtt adds [gru + att_block]."""
+    groups = []                                   # (start offset, elements) per top-level module, in buffer order
+    last = None
+    for name, off, k in zip(names, offsets, numels):
+        top = name.split(".")[0] if name else None
+        if top is None or top != last:
+            groups.append([off, 0])
+            last = top
+        groups[-1][1] += k
+    cuts, acc = [], 0
+    for start, k in reversed(groups):
+        acc += 4 * k
+        if acc >= min_bytes and start > 0:
+            cuts.append(start)
+            acc = 0
+    # a small leftover at the very front (bn0 alone) stays with the bucket after it
+    if cuts and 4 * min(cuts) < min_bytes:
+        cuts.remove(min(cuts))
+    return sorted(cuts)
 
 
 class FusedAdamAmsgrad(object):
-    def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, world_size=1):
-        params = [p for p in (model.parameters() if hasattr(model, "parameters") else model) if p.requires_grad]
-        if not params:
+    def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, world_size=1, direct_grads=True, cuts="auto"):
+        if hasattr(model, "named_parameters"):
+            named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        else:
+            named = [("", p) for p in model if p.requires_grad]
+        if not named:
             raise ValueError("no trainable parameters")
+        names = [n for n, _ in named]
+        params = [p for _, p in named]
         dev = params[0].device
         if dev.type != "cuda":
             raise RuntimeError("FusedAdamAmsgrad: move the model to the GPU first (HIP kernel, no CPU path)")
         self.params = params
         self.lr, self.betas, self.eps = lr, betas, eps
         self.world_size = world_size
+        self.direct_grads = bool(direct_grads)
         n = sum(p.numel() for p in params)
         self.flat = torch.empty((n,), dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros((n,), dtype=torch.float32, device=dev)
@@ -39,13 +90,22 @@ class FusedAdamAmsgrad(object):
                 p.grad = self.flat_grad[off:off + k].view(p.shape)
                 self.offsets.append(off)
                 off += k
+        numels = [p.numel() for p in params]
+        if cuts == "auto":
+            cuts = bucket_cuts(names, self.offsets, numels)
+        self.buckets = parallel.GradBuckets(self.flat_grad, self.offsets, numels, cuts)
+        for i, p in enumerate(params):
+            p._sed_sink = GradSink(self, i, p.grad) if self.direct_grads else None
         self.step_count = 0
 
     def zero_grad(self, set_to_none=False):
+        self.buckets.new_gradients()
         self.flat_grad.zero_()
-        for p, off in zip(self.params, self.offsets):          # re-attach if user code detached the views
+        for i, (p, off) in enumerate(zip(self.params, self.offsets)):   # re-attach if user code detached the views
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
                 p.grad = self.flat_grad[off:off + p.numel()].view(p.shape)
+                if self.direct_grads:
+                    p._sed_sink = GradSink(self, i, p.grad)
 
     def _gather(self):
         for p, off in zip(self.params, self.offsets):
@@ -54,12 +114,20 @@ class FusedAdamAmsgrad(object):
             elif p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
                 self.flat_grad[off:off + p.numel()].copy_(p.grad.reshape(-1))
 
+    def reduce_gradients(self):
+        """Finish the data-parallel exchange of this step's gradients (buckets not yet triggered by the backward pass
+        are issued now; the current stream then waits for all of them).  Called by step(); idempotent."""
+        self._gather()
+        self.buckets.finish()
+
     @torch.no_grad()
     def step(self):
-        self._gather()
+        self.reduce_gradients()
+        self.buckets.begin_step()
         self.step_count += 1
         ops.adam_amsgrad_(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq, self.step_count,
                           self.lr, self.betas[0], self.betas[1], self.eps, 1.0 / float(self.world_size))
+        ops.check_device_errors()
 
     def state_dict(self):
         return {"step": self.step_count, "lr": self.lr, "betas": self.betas, "eps": self.eps,

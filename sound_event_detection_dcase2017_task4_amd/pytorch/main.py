@@ -5,9 +5,17 @@ workspace layout (:72-110, :297-324) and checkpoint format (`{'iteration', 'mode
         --holdout_fold 1 --model_type Cnn_9layers_FrameAvg --loss_type clip_bce --augmentation mixup \
         --learning_rate 1e-3 --batch_size 32 --resume_iteration 0 --stop_iteration 50000 --cuda
 
-Differences, all additive: one process per GPU under torchrun (RCCL all-reduce of one flat gradient buffer) instead
-of nn.DataParallel; `--synthetic N` trains on N synthetic clips when no packed data exists; `--print_every` (the
-reference prints, i.e. synchronises, every iteration).  The every-1000-iterations evaluation branch (main.py:188-209)
+Differences, all additive: one process per GPU under torchrun (bucketed RCCL all-reduce of one flat gradient buffer)
+instead of nn.DataParallel; `--synthetic N` trains on N synthetic clips when no packed data exists; `--print_every` (the
+reference prints, i.e. synchronises, every iteration).
+
+Batch semantics under N GPUs = the reference's (main.py:138, :160-166; nn.DataParallel scatters the batch):
+`--batch_size` is the GLOBAL batch.  There is ONE seed-1234 sampler stream, ONE seed-1234 mixup-lambda stream and ONE
+SpecAugment draw per step, computed identically on every rank; rank r consumes rows [r*n/N, (r+1)*n/N) of each (n =
+waveforms per step; the slice length is even, so mixup pairs stay on one rank).  An N-rank run therefore sees exactly
+the samples, lambdas and stripes of the 1-rank run with the same command line and differs from it only by per-replica
+BatchNorm statistics -- which is also how DataParallel behaves.  `--per_gpu_batch` (extension) makes `--batch_size`
+the per-GPU batch instead (global batch = N x batch_size; weak scaling).  The every-1000-iterations evaluation branch (main.py:188-209)
 runs `evaluate.Evaluator` on the test / evaluation packs when they and their strong-label csv files exist (rank 0), with
 the segment-based metrics restated in utils/utilities.py because sed_eval is not installed; otherwise it logs and skips.
 """
@@ -24,7 +32,9 @@ import torch.utils.data
 from .. import parallel
 from ..optim import FusedAdamAmsgrad
 from ..utils.config import (sample_rate, classes_num, mel_bins, fmin, fmax, window_size, hop_size)
-from ..utils.data_generator import DCASE2017Task4Dataset, PinnedBatchLoader, TrainSampler, TestSampler, collate_fn
+from ..utils.augmentation import draw_specaug_stripes
+from ..utils.data_generator import (DCASE2017Task4Dataset, PinnedBatchLoader, ShardedBatchSampler, TrainSampler, TestSampler,
+                                    collate_fn)
 from ..utils.utilities import create_folder, get_filename, create_logging, Mixup, StatisticsContainer
 from .evaluate import Evaluator
 from . import models as _models
@@ -83,15 +93,20 @@ def train(args):
         optimizer.load_state_dict(ck['optimizer'])
     parallel.broadcast_flat(optimizer.flat)
     parallel.broadcast_buffers(model)
+    parallel.broadcast_rng_state()
 
     mix = 'mixup' in args.augmentation
-    per_rank = args.batch_size * 2 if mix else args.batch_size
-    train_sampler = TrainSampler(hdf5_path=train_path, batch_size=per_rank, random_seed=1234 + rank)
-    # same batch stream as DataLoader(DCASE2017Task4Dataset, batch_sampler, collate_fn) (main.py:126-131 of the reference), but
-    # assembled by threads into page-locked int16 buffers and uploaded one batch ahead on a copy stream: the reference's
-    # 8 worker processes + pickled numpy batches deliver ~300-600 waveforms/s, one MI355X consumes 5300
+    global_batch = args.batch_size * (world if args.per_gpu_batch else 1)          # post-mixup clips per step, all ranks
+    rows_global = global_batch * 2 if mix else global_batch                        # waveforms per step, all ranks
+    row_lo, row_hi = parallel.shard_rows(rows_global, rank, world, pair=mix)       # this rank's rows of every global batch
+    # ONE sampler stream (seed 1234, data_generator.py:52-101) for the global batch; every rank walks it and loads only its
+    # own rows.  Same batch stream as DataLoader(DCASE2017Task4Dataset, batch_sampler, collate_fn) (main.py:126-131 of the
+    # reference), but assembled by threads into page-locked int16 buffers and uploaded one batch ahead on a copy stream: the
+    # reference's 8 worker processes + pickled numpy batches deliver ~300-600 waveforms/s, one MI355X consumes 5300
+    train_sampler = ShardedBatchSampler(TrainSampler(hdf5_path=train_path, batch_size=rows_global, random_seed=1234),
+                                        row_lo, row_hi)
     train_loader = PinnedBatchLoader(train_path, train_sampler, device=device)
-    mixup_augmenter = Mixup(mixup_alpha=1., random_seed=1234 + rank) if mix else None
+    mixup_augmenter = Mixup(mixup_alpha=1., random_seed=1234) if mix else None
     train_bgn_time = time.time()
 
     # evaluation sets of the every-1000-iterations branch (main.py:78-89, :150-176): used when present
@@ -114,10 +129,13 @@ def train(args):
                 args.workspace, 'checkpoints')), 'statistics.pickle')
             create_folder(os.path.dirname(statistics_path))
             statistics_container = StatisticsContainer(statistics_path)
+            if args.resume_iteration and os.path.exists(statistics_path):
+                statistics_container.load_state_dict(args.resume_iteration)        # keep the history up to the resume point
             evaluator = Evaluator(model=model)
 
     for batch_data_dict in train_loader:
-        if iteration % 1000 == 0 and iteration > (args.resume_iteration or 0) and rank == 0:
+        evaluate_now = iteration % 1000 == 0 and iteration > (args.resume_iteration or 0)
+        if evaluate_now and rank == 0:
             train_fin_time = time.time()
             for data_type, loader, csv_path in eval_sets:
                 statistics, _ = evaluator.evaluate(loader, csv_path, os.path.join(predictions_dir, '_tmp_submission.csv'))
@@ -133,28 +151,32 @@ def train(args):
                 iteration, train_fin_time - train_bgn_time, time.time() - train_fin_time,
                 '' if eval_sets else '  (no test / evaluation packs with strong-label csv found: evaluation skipped)'))
             train_bgn_time = time.time()
+        if evaluate_now:
+            parallel.barrier()           # the other ranks wait here (not inside an all-reduce) while rank 0 evaluates
         if iteration % 10000 == 0 and rank == 0:
             checkpoint = {'iteration': iteration, 'model': model.state_dict(), 'optimizer': optimizer.state_dict()}
             checkpoint_path = os.path.join(checkpoints_dir, '{}_iterations.pth'.format(iteration))
             torch.save(checkpoint, checkpoint_path)
             logging.info('Model saved to {}'.format(checkpoint_path))
-        if mix:
-            batch_data_dict['mixup_lambda'] = mixup_augmenter.get_lambda(batch_size=len(batch_data_dict['waveform']))
         wave = batch_data_dict['waveform']               # int16 on the device (the log-mel kernel folds the /32767)
         target = batch_data_dict['target']
+        if mix:                                          # global lambda stream, this rank's rows of it
+            batch_data_dict['mixup_lambda'] = mixup_augmenter.get_lambda(batch_size=rows_global)[row_lo:row_hi]
+        # SpecAugment positions of the GLOBAL batch from the global torch generator (all ranks hold the same state), rows
+        # of this rank: the stripes do not depend on the number of ranks
+        stripes = draw_specaug_stripes(rows_global, wave.shape[1] // hop_size + 1, mel_bins)[row_lo:row_hi]
         model.train()
         if mix:
             lam = move_data_to_device(batch_data_dict['mixup_lambda'], device)
-            batch_output_dict = model(wave, lam)
+            batch_output_dict = model(wave, lam, specaug_stripes=stripes)
             batch_target_dict = {'target': do_mixup(target, lam)}
         else:
-            batch_output_dict = model(wave, None)
+            batch_output_dict = model(wave, None, specaug_stripes=stripes)
             batch_target_dict = {'target': target}
         loss = loss_func(batch_output_dict, batch_target_dict)
         optimizer.zero_grad()
-        loss.backward()
-        parallel.allreduce_flat_grad(optimizer.flat_grad)
-        optimizer.step()
+        loss.backward()                                  # gradient buckets are handed to RCCL as they complete
+        optimizer.step()                                 # waits for them; 1/world is folded into the Adam kernel
         if rank == 0 and args.print_every and iteration % args.print_every == 0:
             print(iteration, loss.item())
         if iteration == args.stop_iteration:
@@ -202,6 +224,8 @@ def build_parser():
     p.add_argument('--mini_data', action='store_true', default=False)
     p.add_argument('--synthetic', type=int, default=0, help='(extension) train on N synthetic clips')
     p.add_argument('--print_every', type=int, default=100, help='(extension) loss print cadence; 1 = reference')
+    p.add_argument('--per_gpu_batch', action='store_true', default=False,
+                   help='(extension) --batch_size is per GPU (global batch = ranks x batch_size) instead of the global batch')
     q = subparsers.add_parser('inference_prob')
     q.add_argument('--dataset_dir', type=str, required=True, help='Directory of dataset.')
     q.add_argument('--workspace', type=str, required=True, help='Directory of your workspace.')

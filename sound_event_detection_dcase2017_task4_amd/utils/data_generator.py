@@ -147,6 +147,20 @@ class TestSampler(object):
             pointer += self.batch_size
 
 
+class ShardedBatchSampler(object):
+    """Rows [row_lo, row_hi) of every batch of `sampler`: the slice of ONE global sampler stream that a data-parallel rank
+    consumes (the reference scatters each batch over its GPUs, main.py:138; here every rank walks the same seeded stream and
+    loads only its own rows)."""
+
+    def __init__(self, sampler, row_lo, row_hi):
+        self.sampler, self.row_lo, self.row_hi = sampler, int(row_lo), int(row_hi)
+        self.batch_size = self.row_hi - self.row_lo
+
+    def __iter__(self):
+        for batch_meta in self.sampler:
+            yield batch_meta[self.row_lo:self.row_hi]
+
+
 def collate_fn(list_data_dict):
     """list of per-clip dicts -> dict of stacked numpy arrays."""
     return {key: np.array([d[key] for d in list_data_dict]) for key in list_data_dict[0].keys()}
@@ -210,6 +224,7 @@ class PinnedBatchLoader(object):
         pool = ThreadPoolExecutor(max_workers=self.threads)
 
         def fill(slot, idx):
+            # (rows beyond len(idx) of a slot keep stale data; the consumer only sees the first len(idx) rows)
             wave_np, target_np = slot['wave'].numpy(), slot['target'].numpy()
             strong_np = slot['strong'].numpy() if 'strong' in slot else None
 
@@ -225,13 +240,19 @@ class PinnedBatchLoader(object):
 
         def producer():
             try:
+                if self.device is not None:
+                    # page-locked allocations and the copy stream belong to THIS rank's GPU (a thread starts with device
+                    # 0 current, which would create a context on GPU 0 from every rank)
+                    torch.cuda.set_device(self.device)
                 i = 0
                 for batch_meta in self.sampler:
                     if stop.is_set():
                         return
                     idx = [int(m['index_in_hdf5']) for m in batch_meta]
-                    if self._slots is None or self._slots[0]['wave'].shape[0] != len(idx):
-                        self._slots = self._alloc(len(idx))
+                    # slots are sized once, for the sampler's full batch; a shorter (last) batch uses their first rows
+                    cap = max(len(idx), int(getattr(self.sampler, 'batch_size', 0) or 0))
+                    if self._slots is None or self._slots[0]['wave'].shape[0] < len(idx):
+                        self._slots = self._alloc(cap)
                     while not free_slots.acquire(timeout=0.2):
                         if stop.is_set():
                             return
@@ -241,15 +262,16 @@ class PinnedBatchLoader(object):
                     fill(slot, idx)
                     names = [self.names[j] for j in idx]
                     names = [x.decode() if isinstance(x, bytes) else str(x) for x in names]
+                    n = len(idx)
                     if self.device is not None:
                         with torch.cuda.stream(copy_stream):
                             if slot['in_use']:
                                 copy_stream.wait_event(slot['consumed'])   # its last readers have been enqueued and ran
-                            slot['dwave'].copy_(slot['wave'], non_blocking=True)
-                            slot['dtarget'].copy_(slot['target'], non_blocking=True)
+                            slot['dwave'][:n].copy_(slot['wave'][:n], non_blocking=True)
+                            slot['dtarget'][:n].copy_(slot['target'][:n], non_blocking=True)
                             slot['ready'].record(copy_stream)
                         slot['in_use'] = True
-                    q.put((slot, names))
+                    q.put((slot, names, n))
                     i += 1
                 q.put(None)
             except BaseException as e:                        # surface loader errors in the consumer
@@ -273,15 +295,15 @@ class PinnedBatchLoader(object):
                     return
                 if isinstance(item, BaseException):
                     raise item
-                slot, names = item
+                slot, names, n = item
                 if self.device is not None:
                     torch.cuda.current_stream(self.device).wait_event(slot['ready'])
-                    out = {'audio_name': names, 'waveform': slot['dwave'], 'target': slot['dtarget']}
+                    out = {'audio_name': names, 'waveform': slot['dwave'][:n], 'target': slot['dtarget'][:n]}
                     prev = slot
                 else:
-                    out = {'audio_name': names, 'waveform': slot['wave'], 'target': slot['target']}
+                    out = {'audio_name': names, 'waveform': slot['wave'][:n], 'target': slot['target'][:n]}
                 if 'strong' in slot:
-                    out['strong_target'] = slot['strong']
+                    out['strong_target'] = slot['strong'][:n]
                 yield out
         finally:
             stop.set()

@@ -1,91 +1,106 @@
 """Host-side helpers on the training path (reference utils/utilities.py): folders, logging, int16<->float,
 the Mixup lambda generator, and the post-processing / scoring helpers of the evaluation branch (events from framewise
 probabilities, submission files, segment-based metrics restated from sed_eval, which is not installed)."""
+import datetime
 import logging
 import os
 import pickle
+import re
 
 import numpy as np
 
 
 def create_folder(fd):
-    if not os.path.exists(fd):
-        os.makedirs(fd)
+    os.makedirs(fd, exist_ok=True)
 
 
 def get_filename(path):
-    path = os.path.realpath(path)
-    na_ext = path.split('/')[-1]
-    return os.path.splitext(na_ext)[0]
+    """'/a/b/main.py' -> 'main' (symlinks resolved; names the workspace sub-folders, main.py:72)."""
+    return os.path.splitext(os.path.basename(os.path.realpath(path)))[0]
 
 
 def create_logging(log_dir, filemode):
-    """utilities.py:29-51: <log_dir>/NNNN.log + console."""
+    """Log DEBUG+ to the next free <log_dir>/NNNN.log and INFO+ to the console (what utilities.py:29-51 sets up).
+    Handlers are attached to the root logger explicitly, so a second call (tests, several runs in one process) opens
+    a new file instead of being ignored the way a repeated logging.basicConfig() is."""
     create_folder(log_dir)
-    i1 = 0
-    while os.path.isfile(os.path.join(log_dir, '{:04d}.log'.format(i1))):
-        i1 += 1
-    log_path = os.path.join(log_dir, '{:04d}.log'.format(i1))
-    logging.basicConfig(level=logging.DEBUG,
-                        format='%(asctime)s %(filename)s[line:%(lineno)d] %(levelname)s %(message)s',
-                        datefmt='%a, %d %b %Y %H:%M:%S', filename=log_path, filemode=filemode)
-    console = logging.StreamHandler()
-    console.setLevel(logging.INFO)
-    console.setFormatter(logging.Formatter('%(name)-12s: %(levelname)-8s %(message)s'))
-    logging.getLogger('').addHandler(console)
+    taken = [int(m.group(1)) for m in (re.match(r"^(\d{4})\.log$", f) for f in os.listdir(log_dir)) if m]
+    index = 0
+    while index in taken:                          # first gap, like the reference's isfile() probe
+        index += 1
+    root = logging.getLogger('')
+    for h in [h for h in root.handlers if getattr(h, '_sed_handler', False)]:
+        root.removeHandler(h)
+        h.close()
+    root.setLevel(logging.DEBUG)
+    to_file = logging.FileHandler(os.path.join(log_dir, '{:04d}.log'.format(index)), mode=filemode)
+    to_file.setLevel(logging.DEBUG)
+    to_file.setFormatter(logging.Formatter('%(asctime)s %(filename)s[line:%(lineno)d] %(levelname)s %(message)s',
+                                           datefmt='%a, %d %b %Y %H:%M:%S'))
+    to_console = logging.StreamHandler()
+    to_console.setLevel(logging.INFO)
+    to_console.setFormatter(logging.Formatter('%(name)-12s: %(levelname)-8s %(message)s'))
+    for h in (to_file, to_console):
+        h._sed_handler = True
+        root.addHandler(h)
     return logging
 
 
 def float32_to_int16(x):
-    if np.max(np.abs(x)) > 1.:
-        x = x / np.max(np.abs(x))
-    return (x * 32767.).astype(np.int16)
+    """[-1, 1] float waveform -> int16 storage (peak-normalised first when it overshoots; utilities.py:61-64)."""
+    x = np.asarray(x)
+    peak = float(np.abs(x).max()) if x.size else 0.0
+    return ((x / peak if peak > 1.0 else x) * 32767.0).astype(np.int16)
 
 
 def int16_to_float32(x):
-    return (x / 32767.).astype(np.float32)
+    """utilities.py:66-67.  (On the GPU path the division is folded into the log-mel kernel's load instead.)"""
+    return (np.asarray(x) / 32767.0).astype(np.float32)
 
 
 class Mixup(object):
+    """Mixup coefficient stream (utilities.py:220-242): one Beta(alpha, alpha) draw per PAIR of batch rows from a
+    RandomState(seed), emitted as [lam0, 1-lam0, lam1, 1-lam1, ...].  The legacy RandomState fills an array draw by
+    draw, so one `beta(size=pairs)` call consumes the stream exactly like the reference's per-pair scalar draws
+    (tests/test_capi_and_host.py pins this bit for bit)."""
+
     def __init__(self, mixup_alpha, random_seed=1234):
-        """Mixup coefficient generator (utilities.py:220-242)."""
         self.mixup_alpha = mixup_alpha
         self.random_state = np.random.RandomState(random_seed)
 
     def get_lambda(self, batch_size):
-        """-> (batch_size,) float64: [lam0, 1-lam0, lam1, 1-lam1, ...]."""
-        lams = np.empty(batch_size, dtype=np.float64)
-        for n in range(0, batch_size, 2):
-            lam = self.random_state.beta(self.mixup_alpha, self.mixup_alpha, 1)[0]
-            lams[n] = lam
-            if n + 1 < batch_size:
-                lams[n + 1] = 1. - lam
-        return lams
+        pairs = (batch_size + 1) // 2
+        lam = self.random_state.beta(self.mixup_alpha, self.mixup_alpha, size=pairs)
+        return np.stack([lam, 1.0 - lam], axis=1).reshape(-1)[:2 * pairs].astype(np.float64)
 
 
 class StatisticsContainer(object):
-    """utilities.py:188-217 (pickle of per-iteration evaluation statistics)."""
+    """Evaluation statistics of a run, appended every 1000 iterations and pickled (utilities.py:188-217): a dict
+    {'train': [...], 'test': [...], 'evaluate': [...]} of per-iteration dicts, written to `statistics_path` and to a
+    time-stamped backup next to it.  load_state_dict(resume_iteration) keeps the entries up to that iteration."""
+    DATA_TYPES = ('train', 'test', 'evaluate')
 
     def __init__(self, statistics_path):
         self.statistics_path = statistics_path
-        self.statistics_dict = {'test': [], 'evaluate': []}
+        stem = os.path.splitext(statistics_path)[0]
+        self.backup_statistics_path = '{}_{}.pkl'.format(stem, datetime.datetime.now().strftime('%Y-%m-%d_%H-%M-%S'))
+        self.statistics_dict = {k: [] for k in self.DATA_TYPES}
 
     def append(self, data_type, iteration, statistics):
         statistics['iteration'] = iteration
         self.statistics_dict[data_type].append(statistics)
 
     def dump(self):
-        pickle.dump(self.statistics_dict, open(self.statistics_path, 'wb'))
-        logging.info('    Dump statistics to {}'.format(self.statistics_path))
+        for path in (self.statistics_path, self.backup_statistics_path):
+            with open(path, 'wb') as f:
+                pickle.dump(self.statistics_dict, f)
+            logging.info('    Dump statistics to {}'.format(path))
 
     def load_state_dict(self, resume_iteration):
-        self.statistics_dict = pickle.load(open(self.statistics_path, 'rb'))
-        out = {'test': [], 'evaluate': []}
-        for key in self.statistics_dict.keys():
-            for statistics in self.statistics_dict[key]:
-                if statistics['iteration'] <= resume_iteration:
-                    out[key].append(statistics)
-        self.statistics_dict = out
+        with open(self.statistics_path, 'rb') as f:
+            stored = pickle.load(f)
+        self.statistics_dict = {k: [st for st in stored.get(k, []) if st['iteration'] <= resume_iteration]
+                                for k in set(self.DATA_TYPES) | set(stored)}
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -190,6 +190,96 @@ def model_fixture(model_type, seed, long_case=False):
     return out
 
 
+BIG_ROWS, BIG_L = 32, 64000            # the low-noise training fixture: 32 waveforms -> 16 clips of 2 s (T = 201)
+LONG_MODELS = ("Cnn_9layers_FrameAvg", "Cnn_9layers_FrameAtt", "Cnn_9layers_Gru_FrameAtt")     # BASELINE.json configs[1..3]
+
+
+def sample_index(numel, cap=2048):
+    """Deterministic subsample of a flattened tensor: everything up to `cap` entries, else every ceil(numel/cap)-th."""
+    return np.arange(0, numel, max(1, -(-numel // cap)))
+
+
+def big_fixture(model_type, seed):
+    """(1) eval + train forward of FULL-LENGTH clips (L = 320000, T' = 125) for the models of configs[1..3];
+    (2) a training fixture big enough that ReLU-flip noise sits well below the 1e-3 gradient gate (32 x 2 s waveforms):
+    three optimisation steps of the reference in FLOAT64 (the yardstick) and step 0 of the reference in float32 (to
+    record how far the reference's own fp32 arithmetic is from it).  Large tensors are stored as deterministic
+    subsamples (`sample_index`) plus their norms."""
+    out = {}
+    if model_type in LONG_MODELS:
+        m = build(model_type, seed)
+        xl = torch.from_numpy(waves(200 + seed, 2, 320000))
+        m.eval()
+        with torch.no_grad():
+            o = m(xl)
+        assert o["framewise_output"].shape == (2, 1000, 17)
+        out["eval10_clip"], out["eval10_frame"] = o["clipwise_output"].numpy(), o["framewise_output"].numpy()[:, ::8]
+        xt = torch.from_numpy(waves(250 + seed, 4, 320000))
+        lam = ofe.mixup_lambdas(4, np.random.RandomState(4321)).astype(np.float32)
+        torch.manual_seed(600 + seed)
+        out["train10_stripes"] = ofe.draw_specaug_stripes(4, 1001, 64)
+        m = build(model_type, seed)
+        m.train()
+        torch.manual_seed(600 + seed)
+        with torch.no_grad():
+            o = m(xt, torch.from_numpy(lam))
+        out["train10_lambda"] = lam
+        out["train10_clip"], out["train10_frame"] = o["clipwise_output"].numpy(), o["framewise_output"].numpy()[:, ::8]
+        out["train10_b4bn2_running_mean"] = m.state_dict()["conv_block4.bn2.running_mean"].numpy()
+    T = BIG_L // 320 + 1
+    Tq = ((T // 2) // 2) // 2
+    loss_func = ref_losses.get_loss_func('clip_bce')
+    runs = {}
+    for tag, dtype, steps in (("f64", torch.float64, 3), ("f32", torch.float32, 1)):
+        m = build(model_type, seed)
+        if dtype == torch.float64:
+            m = m.double()
+        opt = optim.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-08, weight_decay=0., amsgrad=True)
+        rs = np.random.RandomState(1234)
+        losses, stripes_all, grads0 = [], [], None
+        for it in range(steps):
+            xw = torch.from_numpy(waves(1700 + 10 * seed + it, BIG_ROWS, BIG_L)).to(dtype)
+            tg = torch.from_numpy(targets(1800 + 10 * seed + it, BIG_ROWS)).to(dtype)
+            lam_t = torch.from_numpy(ofe.mixup_lambdas(BIG_ROWS, rs).astype(np.float32)).to(dtype)
+            torch.manual_seed(1900 + 10 * seed + it)
+            stripes_all.append(ofe.draw_specaug_stripes(BIG_ROWS, T, 64))
+            torch.manual_seed(1900 + 10 * seed + it)
+            m.train()
+            set_dropout(m, 6000 + 10 * seed + it, BIG_ROWS // 2, Tq)
+            o = m(xw, lam_t)
+            # (float32 lambda pairs do not sum to exactly 1 in float64: the mixed target may exceed 1 by 1e-8, which
+            # F.binary_cross_entropy rejects -> clamp; the effect on the loss is below 1e-6 relative)
+            loss = loss_func(o, {'target': ref_utils.do_mixup(tg, lam_t).clamp(max=1.0)})
+            opt.zero_grad()
+            loss.backward()
+            if it == 0:
+                grads0 = {k: p.grad.detach().double().numpy().copy() for k, p in m.named_parameters() if p.grad is not None}
+            opt.step()
+            losses.append(loss.item())
+        runs[tag] = (losses, stripes_all, grads0, {k: v.detach().double().numpy().copy() for k, v in m.state_dict().items()})
+    losses64, stripes_all, g64, after64 = runs["f64"]
+    losses32, _, g32, _ = runs["f32"]
+    out["big_losses64"], out["big_loss32"] = np.array(losses64), np.array(losses32[0])
+    out["big_stripes"] = np.stack(stripes_all)
+    out["big_dropout_seeds"] = np.array([6000 + 10 * seed + it for it in range(3)])
+    worst = (0.0, None)
+    for k, g in g64.items():
+        idx = sample_index(g.size)
+        out["big_g64/" + k] = g.reshape(-1)[idx].astype(np.float32)
+        out["big_g64n/" + k] = np.array([np.sqrt((g ** 2).sum()), g.sum(), np.abs(g).sum(), np.abs(g).max()])
+        den = max(np.sqrt((g ** 2).sum()), 1e-300)
+        e32 = float(np.sqrt(((g32[k] - g) ** 2).sum()) / den)
+        out["big_ref32err/" + k] = np.array([e32, float(np.abs(g32[k] - g).max() / max(np.abs(g).max(), 1e-300))])
+        if e32 > worst[0]:
+            worst = (e32, k)
+    for k, v in after64.items():
+        if k not in om.FROZEN_KEYS and not k.endswith("num_batches_tracked"):
+            out["big_after3/" + k] = v.reshape(-1)[sample_index(v.size)].astype(np.float32)
+    print(model_type, "big fixture: losses64", losses64, "loss32", losses32[0],
+          "| reference fp32 vs fp64 gradient, worst relative L2: %.2e (%s)" % worst)
+    return out
+
+
 def misc_fixture():
     out = {"mixup_lambda64": ofe.mixup_lambdas(64, np.random.RandomState(1234))}
     torch.manual_seed(7)
@@ -207,6 +297,13 @@ def misc_fixture():
 
 if __name__ == "__main__":
     only = sys.argv[1:]                     # optional: model types to (re)generate; default everything
+    if only and only[0] == "--big":         # only the <model>__big.npz files (full-length clips + low-noise training fixture)
+        for i, mt in enumerate(om.MODEL_TYPES):
+            if len(only) > 1 and mt not in only[1:]:
+                continue
+            np.savez_compressed(os.path.join(HERE, mt + "__big.npz"), **big_fixture(mt, seed=i + 1))
+            print(mt + "__big.npz", os.path.getsize(os.path.join(HERE, mt + "__big.npz")))
+        sys.exit(0)
     if not only:
         np.savez_compressed(os.path.join(HERE, "frontend.npz"), **frontend_fixture())
         np.savez_compressed(os.path.join(HERE, "misc.npz"), **misc_fixture())

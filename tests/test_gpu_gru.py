@@ -1,0 +1,138 @@
+"""Fused BiGRU recurrence (csrc/gru.hip) at the production shape of BASELINE.json configs[3]/[4] -- B = 256 clips,
+T = 125 frames, nn.GRU(512, 256, bidirectional) (reference models.py:529-530, :565-567) -- and its run-time failure
+handling: a launch whose persistent workgroups cannot all make progress must never hand back garbage silently."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse",
+         "bias_ih_l0_reverse", "bias_hh_l0_reverse"]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from sound_event_detection_dcase2017_task4_amd import ops as o
+    return o
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+def make(B, T, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    gru = torch.nn.GRU(512, 256, num_layers=1, bias=True, batch_first=True, bidirectional=True)
+    for p in gru.parameters():
+        p.data = torch.randn(p.shape, generator=g) * 0.05
+    x = torch.randn(B, T, 512, generator=g)
+    gy = torch.randn(B, T, 512, generator=g)
+    return gru, x, gy
+
+
+def run(ops, gru, x, gy, fused):
+    old = ops.USE_FUSED_GRU
+    ops.USE_FUSED_GRU = fused
+    try:
+        ps = [getattr(gru, n).detach().clone().cuda().requires_grad_(True) for n in NAMES]
+        xd = x.detach().clone().cuda().requires_grad_(True)
+        y = ops.GruFn.apply(xd, *ps)
+        y.backward(gy.cuda())
+        return [y.detach(), xd.grad] + [p.grad for p in ps]
+    finally:
+        ops.USE_FUSED_GRU = old
+
+
+def test_production_shape_fused_vs_per_step_vs_torch(ops):
+    """B=256, T=125: 128 co-resident workgroups spinning on each other for 125 steps.  Fused == per-step launches
+    (<= 1e-6 relative) == torch.nn.GRU on the CPU (forward 3e-6 abs, gradients 1e-4 relative), and 20 repeats of the
+    fused pass are BIT-identical (the cross-workgroup hand-off is the only source of nondeterminism it could have)."""
+    B, T = 256, 125
+    gru, x, gy = make(B, T)
+    assert ops._lib.lib().sed_gru_seq_supported(B, 256) == 1
+    xr = x.clone().requires_grad_(True)
+    y, _ = gru(xr)
+    y.backward(gy)
+    ref = [y.detach(), xr.grad] + [getattr(gru, n).grad for n in NAMES]
+    step = run(ops, gru, x, gy, fused=False)
+    first = run(ops, gru, x, gy, fused=True)
+    ops.check_device_errors(synchronize=True)
+    assert (first[0].cpu() - ref[0]).abs().max().item() < 3e-6
+    for a, b, c, n in zip(first, step, ref, ["y", "dx"] + NAMES):
+        assert rel(a, b) < 1e-6, ("fused vs per-step", n, rel(a, b))
+        assert rel(a.cpu(), c) < 1e-4, ("fused vs torch", n, rel(a.cpu(), c))
+    for it in range(20):
+        cur = run(ops, gru, x, gy, fused=True)
+        for a, b, n in zip(cur, first, ["y", "dx"] + NAMES):
+            assert torch.equal(a, b), ("repeat %d differs" % it, n, (a - b).abs().max().item())
+    ops.check_device_errors(synchronize=True)
+
+
+def test_fused_gru_beside_a_co_tenant_kernel(ops):
+    """A second stream holds 64 whole CUs (one 160 KB-LDS workgroup each) while the fused recurrence is launched: the 128
+    persistent workgroups still find CUs, and the results equal the undisturbed run bit for bit -- or, if the device
+    cannot host them, the failure is reported (never silent garbage)."""
+    B, T = 256, 125
+    gru, x, gy = make(B, T, seed=1)
+    want = run(ops, gru, x, gy, fused=True)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    L = ops._lib.lib()
+    for hog_cus in (64, 120):
+        with torch.cuda.stream(side):
+            rc = L.sed_debug_occupy(hog_cus, 160 * 1024, 30000, ctypes.c_void_p(side.cuda_stream))      # 30 ms
+            assert rc == 0
+        got = run(ops, gru, x, gy, fused=True)
+        torch.cuda.synchronize()
+        try:
+            ops.check_device_errors()
+        except RuntimeError:
+            assert torch.isnan(got[0]).all()
+            continue
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+
+
+def test_give_up_is_loud(ops):
+    """Failure path end to end: with the spin bound cut to one poll and 224 of the 256 CUs held by another stream, the
+    resident recurrence workgroups give up waiting for the ones still queued.  The pass must then (i) overwrite its output
+    with NaN on the device and (ii) raise RuntimeError at the next host-side check -- and the NEXT launch, with the
+    default bound restored, is correct again."""
+    B, T = 256, 16
+    gru, x, gy = make(B, T, seed=2)
+    want = run(ops, gru, x, gy, fused=True)
+    torch.cuda.synchronize()
+    ops.check_device_errors()
+    L = ops._lib.lib()
+    side = torch.cuda.Stream()
+    L.sed_gru_set_spin_limit(1)
+    try:
+        with torch.cuda.stream(side):
+            assert L.sed_debug_occupy(224, 160 * 1024, 50000, ctypes.c_void_p(side.cuda_stream)) == 0     # 50 ms
+        ps = [getattr(gru, n).detach().clone().cuda() for n in NAMES]
+        y = ops.GruFn.apply(x.cuda(), *ps)
+        torch.cuda.synchronize()
+    finally:
+        L.sed_gru_set_spin_limit(0)
+    failed = bool(torch.isnan(y).any().item())
+    if failed:
+        assert torch.isnan(y).all()                      # poisoned, not partially plausible
+        with pytest.raises(RuntimeError, match="fused GRU"):
+            ops.check_device_errors()
+    else:
+        # the dispatcher happened to place all 128 workgroups at once (possible: placement is not ours to control)
+        assert torch.equal(y, want[0])
+        ops.check_device_errors()
+    again = run(ops, gru, x, gy, fused=True)
+    ops.check_device_errors(synchronize=True)
+    for a, b in zip(again, want):
+        assert torch.equal(a, b)
+
+
+def test_supported_asks_the_device(ops):
+    L = ops._lib.lib()
+    assert L.sed_gru_seq_supported(256, 256) == 1 and L.sed_gru_seq_supported(512, 256) == 1
+    assert L.sed_gru_seq_supported(513, 256) == 0          # 34 row blocks x 8 = 272 workgroups > 256 CUs
+    assert L.sed_gru_seq_supported(256, 128) == 0          # kernels are built for hidden size 256

@@ -1,0 +1,147 @@
+"""Data-parallel training of the REAL models on more than one rank (reference main.py:138, :245-257: nn.DataParallel).
+
+`test_two_ranks_*`: two processes run one optimisation step of the real model (FusedAdamAmsgrad with direct gradient
+sinks + the bucketed all-reduce issued from inside backward) on their halves of a batch; the parent replays the same
+step in ONE process -- each half through its own BatchNorm statistics (= per-replica BN, DataParallel's semantics),
+gradients summed, 1/world folded into Adam -- and the post-step flat parameters must agree.
+  * over gloo with both ranks on cuda:0: runs on the 1-GPU box the driver uses;
+  * over nccl (= RCCL) with one GPU per rank: runs wherever >= 2 GPUs are visible, skipped otherwise.
+`test_bench_gpus_2_*`: `python bench.py --gpus 2` without a launcher either becomes 2 RCCL ranks or fails loudly."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CTOR = (32000, 1024, 320, 64, 50, 14000, 17)
+
+
+def _inputs(mt, rows, L=32000):
+    from oracle import frontend as ofe
+    rs = np.random.RandomState(4242)
+    x = (rs.randn(rows, L) * 0.1).astype(np.float32)
+    y = (rs.rand(rows, 17) < 0.2).astype(np.float32)
+    lam = ofe.mixup_lambdas(rows, np.random.RandomState(1234)).astype(np.float32)
+    torch.manual_seed(99)
+    stripes = ofe.draw_specaug_stripes(rows, L // 320 + 1, 64)
+    return x, y, lam, stripes
+
+
+def _one_step(mt, dev, x, y, lam, stripes, world, seed=3):
+    """Build the model from the seeded recipe, run forward / loss / backward on the given rows.  Returns (model, opt)
+    BEFORE the optimiser step."""
+    from oracle import model as om
+    from sound_event_detection_dcase2017_task4_amd.optim import FusedAdamAmsgrad
+    from sound_event_detection_dcase2017_task4_amd.pytorch import models
+    from sound_event_detection_dcase2017_task4_amd.pytorch.losses import clip_bce
+    from sound_event_detection_dcase2017_task4_amd.pytorch.pytorch_utils import do_mixup
+    m = getattr(models, mt)(*CTOR)
+    m.load_state_dict(om.recipe_state(mt, seed))
+    m = m.to(dev).train()
+    opt = FusedAdamAmsgrad(m, lr=1e-3, world_size=world)
+    lam_d = torch.from_numpy(lam).to(dev)
+    out = m(torch.from_numpy(x).to(dev), lam_d, specaug_stripes=stripes)
+    loss = clip_bce(out, {"target": do_mixup(torch.from_numpy(y).to(dev), lam_d)})
+    opt.zero_grad()
+    loss.backward()
+    return m, opt
+
+
+def _worker(rank, world, port, backend, mt, outdir):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank if backend == "nccl" else 0),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from sound_event_detection_dcase2017_task4_amd import parallel
+    parallel.init_from_env(backend=backend)
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    rows = 16
+    x, y, lam, stripes = _inputs(mt, rows)
+    lo, hi = parallel.shard_rows(rows, rank, world, pair=True)
+    m, opt = _one_step(mt, dev, x[lo:hi], y[lo:hi], lam[lo:hi], stripes[lo:hi], world)
+    order = list(opt.buckets.issue_order)            # buckets handed to the backend from inside backward
+    opt.step()
+    torch.cuda.synchronize()
+    torch.save({"flat": opt.flat.cpu(), "grad": opt.flat_grad.cpu(), "order": order, "ranges": opt.buckets.ranges,
+                "bn0_mean": m.bn0.running_mean.cpu()}, os.path.join(outdir, "rank%d.pt" % rank))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def _reference(mt, world=2):
+    """The same step in ONE process: per-replica BatchNorm = each half separately, gradients summed over the halves,
+    1/world folded into the Adam kernel."""
+    from sound_event_detection_dcase2017_task4_amd import ops, parallel
+    dev = torch.device("cuda", 0)
+    rows = 16
+    x, y, lam, stripes = _inputs(mt, rows)
+    gsum, bn0 = None, []
+    for r in range(world):
+        lo, hi = r * rows // world, (r + 1) * rows // world
+        m, opt = _one_step(mt, dev, x[lo:hi], y[lo:hi], lam[lo:hi], stripes[lo:hi], 1)
+        gsum = opt.flat_grad.clone() if gsum is None else gsum + opt.flat_grad
+        bn0.append(m.bn0.running_mean.cpu())
+    opt.flat_grad.copy_(gsum)
+    opt.world_size = world
+    opt.buckets.begin_step()
+    opt.step_count += 1
+    ops.adam_amsgrad_(opt.flat, opt.flat_grad, opt.exp_avg, opt.exp_avg_sq, opt.max_exp_avg_sq, 1, opt.lr, 0.9, 0.999, 1e-8,
+                      1.0 / world)
+    torch.cuda.synchronize()
+    return opt.flat.cpu(), gsum.cpu(), bn0
+
+
+def _run_two_ranks(tmp_path, backend, mt):
+    from sound_event_detection_dcase2017_task4_amd import parallel
+    port = parallel.free_port()
+    mp.spawn(_worker, args=(2, port, backend, mt, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(str(tmp_path), "rank0.pt"))
+    r1 = torch.load(os.path.join(str(tmp_path), "rank1.pt"))
+    flat, gsum, bn0 = _reference(mt)
+    assert torch.equal(r0["flat"], r1["flat"]), "ranks diverged"
+    assert torch.equal(r0["grad"], r1["grad"])
+    # summed gradient and post-Adam parameters: the all-reduce adds two fp32 numbers per entry, exactly like the reference
+    gerr = (r0["grad"] - gsum).abs().max().item() / gsum.abs().max().item()
+    perr = (r0["flat"] - flat).abs().max().item()
+    assert gerr < 1e-6, gerr
+    assert perr < 1e-6, perr
+    # BatchNorm statistics stay rank-local (DataParallel: per-replica statistics)
+    assert torch.allclose(r0["bn0_mean"], bn0[0], atol=1e-6) and torch.allclose(r1["bn0_mean"], bn0[1], atol=1e-6)
+    assert not torch.allclose(r0["bn0_mean"], r1["bn0_mean"], atol=1e-4)
+    # the buckets were issued from INSIDE backward, from the end of the buffer (head / block 4) towards block 1
+    nb = len(r0["ranges"])
+    assert nb >= 3 and r0["order"] == list(range(nb - 1, -1, -1)), (r0["order"], r0["ranges"])
+    return gerr, perr
+
+
+@pytest.mark.parametrize("mt", ["Cnn_9layers_Gru_FrameAtt", "Cnn_9layers_FrameAvg"])
+def test_two_ranks_one_gpu_gloo(tmp_path, mt):
+    _run_two_ranks(tmp_path, "gloo", mt)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL refuses two ranks on one device)")
+def test_two_ranks_rccl(tmp_path):
+    _run_two_ranks(tmp_path, "nccl", "Cnn_9layers_Gru_FrameAtt")
+
+
+def test_bench_gpus_2_spawns_ranks_or_fails_loudly():
+    """`python bench.py --gpus 2` with no launcher in the environment: on a >= 2-GPU node it must report n_gpus = 2 (it
+    re-executes itself under torch.distributed.run); on a 1-GPU box it must exit non-zero saying so -- never a 1-rank line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch_size", "16", "--no_cpu_baseline", "--no_extra"], capture_output=True, text=True, env=env,
+                       timeout=900)
+    if torch.cuda.device_count() >= 2:
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 32 and line["value"] > 0
+    else:
+        assert r.returncode != 0
+        assert "needs 2 GPUs" in (r.stderr + r.stdout) and '"n_gpus"' not in r.stdout

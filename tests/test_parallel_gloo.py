@@ -80,3 +80,116 @@ def test_single_process_is_a_noop():
     g = torch.ones(10)
     assert parallel.allreduce_flat_grad(g) == [] and torch.all(g == 1)
     assert parallel.world_size() == 1 and parallel.shard_range(10, 0, 1) == (0, 10)
+
+
+def _bucket_worker(rank, world, port, out):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from sound_event_detection_dcase2017_task4_amd import parallel
+    parallel.init_from_env(backend="gloo")
+    # 6 "parameters" in one flat buffer, cut into 3 buckets; parameter 3 never takes part (like att_block.bn_att)
+    numels = [4, 6, 10, 2, 20, 8]
+    offsets = list(np.cumsum([0] + numels[:-1]))
+    flat = torch.zeros(sum(numels))
+    gb = parallel.GradBuckets(flat, offsets, numels, cuts=[offsets[2], offsets[4]])
+    assert gb.ranges == [(0, 10), (10, 22), (22, 50)] and gb.bucket_of == [0, 0, 1, 1, 2, 2]
+    for step in range(2):
+        for i in (0, 1, 2, 4, 5):
+            gb.expect(i)                                          # forward pass
+        gb.new_gradients()                                        # zero_grad (after the forward, as in main.py)
+        flat.zero_()
+        for i in (5, 4, 2, 1, 0):                                 # backward: from the end of the buffer
+            flat[offsets[i]:offsets[i] + numels[i]] = float((rank + 1) * (i + 1) * (step + 1))
+            fired_before = list(gb.issue_order)
+            gb.ready(i)
+            if i == 4:
+                assert gb.issue_order == [2] and fired_before == []       # the tail bucket left as soon as it was complete
+            if i == 2:
+                assert gb.issue_order == [2, 1]                           # parameter 3 is not expected: does not block
+        gb.finish()
+        assert gb.issue_order == [2, 1, 0]
+        want = torch.zeros_like(flat)
+        for i in (0, 1, 2, 4, 5):
+            want[offsets[i]:offsets[i] + numels[i]] = 3.0 * (i + 1) * (step + 1)  # (1 + 2) * ...
+        assert torch.equal(flat, want), (flat, want)
+        gb.begin_step()
+    # a gradient that arrives without having been announced is still reduced (at finish)
+    flat.fill_(float(rank + 1))
+    gb.finish()
+    assert torch.all(flat == 3.0)
+    gb.begin_step()
+    # two backward passes in one cycle overwrite gradients: refused loudly
+    gb.expect(5); gb.ready(5); gb.expect(5); gb.ready(5)
+    try:
+        gb.finish()
+        raise AssertionError("second backward was not detected")
+    except RuntimeError as e:
+        assert "direct_grads=False" in str(e)
+    # one global batch, one RNG state: rows of rank r
+    assert parallel.shard_rows(64, rank, world) == (32 * rank, 32 * rank + 32)
+    torch.manual_seed(100 + rank)
+    parallel.broadcast_rng_state()
+    v = torch.rand(3)
+    vs = [torch.zeros(3) for _ in range(world)]
+    dist.all_gather(vs, v)
+    assert torch.equal(vs[0], vs[1])
+    dist.barrier()
+    if rank == 0:
+        open(out, "w").write("ok")
+    dist.destroy_process_group()
+
+
+def test_grad_buckets_world_size_2_gloo(tmp_path):
+    out = str(tmp_path / "ok.txt")
+    mp.spawn(_bucket_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read() == "ok"
+
+
+def test_shard_rows_keeps_mixup_pairs_together():
+    sys.path.insert(0, REPO)
+    from sound_event_detection_dcase2017_task4_amd import parallel
+    assert [parallel.shard_rows(64, r, 8) for r in (0, 7)] == [(0, 8), (56, 64)]
+    with pytest.raises(ValueError):
+        parallel.shard_rows(64, 0, 3)                 # does not split evenly
+    with pytest.raises(ValueError):
+        parallel.shard_rows(12, 0, 4)                 # 3 waveforms per rank: a mixup pair would straddle ranks
+    assert parallel.shard_rows(12, 1, 4, pair=False) == (3, 6)
+
+
+def test_bucket_cuts_of_the_real_models():
+    """[bn0 + block1 + block2 | block3 | block4 (+ fc)] and an extra [gru + att_block] bucket for configs[3]/[4]."""
+    sys.path.insert(0, REPO)
+    from sound_event_detection_dcase2017_task4_amd.optim import bucket_cuts
+    from sound_event_detection_dcase2017_task4_amd.pytorch import models
+    for mt, want in (("Cnn_9layers_FrameAvg", ["conv_block3.conv1.weight", "conv_block4.conv1.weight"]),
+                     ("Cnn_9layers_Gru_FrameAtt", ["conv_block3.conv1.weight", "conv_block4.conv1.weight", "gru.weight_ih_l0"])):
+        m = getattr(models, mt)(32000, 1024, 320, 64, 50, 14000, 17)
+        named = [(n, p) for n, p in m.named_parameters() if p.requires_grad]
+        numels = [p.numel() for _, p in named]
+        offsets = [int(v) for v in np.cumsum([0] + numels[:-1])]
+        cuts = bucket_cuts([n for n, _ in named], offsets, numels)
+        assert [named[offsets.index(c)][0] for c in cuts] == want, (mt, cuts)
+
+
+def test_sharded_sampler_is_a_slice_of_one_stream():
+    """N ranks walking ONE seed-1234 sampler stream and taking their rows reproduce the single-process batches
+    (reference data_generator.py:52-101 feeds one batch to DataParallel, which scatters it)."""
+    sys.path.insert(0, REPO)
+    from sound_event_detection_dcase2017_task4_amd.utils.data_generator import ShardedBatchSampler, TrainSampler
+    path = "synthetic:50:3200"
+    whole = iter(TrainSampler(path, 16, random_seed=1234))
+    parts = [iter(ShardedBatchSampler(TrainSampler(path, 16, random_seed=1234), 4 * r, 4 * r + 4)) for r in range(4)]
+    for _ in range(9):                                            # crosses the reshuffle at the wrap-around
+        full = [m["index_in_hdf5"] for m in next(whole)]
+        got = sum(([m["index_in_hdf5"] for m in next(p)] for p in parts), [])
+        assert got == full
+
+
+def test_bench_gpus_n_never_degrades_to_one_rank():
+    """`python bench.py --gpus 8` with no launcher and fewer than 8 GPUs (none here) must fail loudly, not print n_gpus 1."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8"], capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert r.returncode != 0 and "needs 8 GPUs" in r.stderr and '"n_gpus"' not in r.stdout
