@@ -6,6 +6,7 @@ CPU tensors raises.
 """
 import ctypes
 import math
+import weakref
 
 import numpy as np
 import torch
@@ -162,15 +163,18 @@ def invalidate_weight_caches():
 
 
 def _cached(kind, srcs, build):
-    key = (kind,) + tuple(t.data_ptr() for t in srcs)
-    stamp = (PARAM_GENERATION,) + tuple(t._version for t in srcs)
+    """The entry belongs to these very tensor OBJECTS (weak references: the allocator recycles addresses and Python
+    recycles ids, so neither identifies a parameter) in this very state (storage address, torch version counter,
+    PARAM_GENERATION)."""
+    key = (kind,) + tuple(id(t) for t in srcs)
+    stamp = (PARAM_GENERATION,) + tuple((t.data_ptr(), t._version) for t in srcs)
     hit = _WCACHE.get(key)
-    if hit is not None and hit[0] == stamp:
+    if hit is not None and hit[0] == stamp and all(r() is t for r, t in zip(hit[2], srcs)):
         return hit[1]
     val = build()
     if len(_WCACHE) > 64:
         _WCACHE.clear()
-    _WCACHE[key] = (stamp, val)
+    _WCACHE[key] = (stamp, val, [weakref.ref(t) for t in srcs])
     return val
 
 

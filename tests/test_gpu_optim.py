@@ -158,5 +158,43 @@ def test_framewise_output_and_embedding_are_differentiable(mt):
         ofe._CACHE.clear()
     assert abs(loss.item() - lo.item()) < 1e-3 * max(1.0, abs(lo.item()))
     for k, g, w in zip(keys, got, want):
+        if w.norm().item() < 1e-6:                     # structurally zero (att.bias: the attention is shift invariant)
+            assert g.abs().max().item() < 1e-5, (k, g.abs().max().item())
+            continue
         err = (g.double().cpu() - w).norm().item() / max(w.norm().item(), 1e-12)
         assert err < 2e-3, (k, err)
+
+
+def test_att_head_gradients_through_all_three_outputs():
+    """AttHeadFn (models.py:118-149) with gradients arriving through clip, cla AND norm_att (the clamp active on part of
+    the logits) against the same arithmetic written with torch ops on the CPU in float64."""
+    from sound_event_detection_dcase2017_task4_amd import ops
+    g = torch.Generator().manual_seed(21)
+    B, T, C, K = 5, 23, 512, 17
+    feat = torch.randn(B, T, C, generator=g)
+    w_att = torch.randn(K, C, 1, generator=g) * 0.35            # |logit| reaches > 10 on a few percent of the entries
+    w_cla = torch.randn(K, C, 1, generator=g) * 0.05
+    b_att, b_cla = torch.randn(K, generator=g) * 0.1, torch.randn(K, generator=g) * 0.1
+    wc, wl, wn = torch.randn(B, K, generator=g), torch.randn(B, T, K, generator=g), torch.randn(B, T, K, generator=g)
+
+    def ref(feat, w_att, b_att, w_cla, b_cla):
+        z = torch.einsum("btc,kc->btk", feat, w_att[:, :, 0]) + b_att
+        att = torch.exp(torch.clamp(z, -10, 10)) + 1e-6
+        natt = att / att.sum(dim=1, keepdim=True)
+        cla = torch.sigmoid(torch.einsum("btc,kc->btk", feat, w_cla[:, :, 0]) + b_cla)
+        return (natt * cla).sum(dim=1), cla, natt, z
+
+    leaves = [t.double().requires_grad_(True) for t in (feat, w_att, b_att, w_cla, b_cla)]
+    clip, cla, natt, z = ref(*leaves)
+    assert ((z.abs() > 10).float().mean().item() > 0.005) and ((z.abs() < 10).float().mean().item() > 0.5)
+    loss = (clip * wc.double()).sum() + (cla * wl.double()).sum() + (natt * wn.double()).sum() * 3.0
+    want = torch.autograd.grad(loss, leaves)
+    dl = [t.cuda().requires_grad_(True) for t in (feat, w_att, b_att, w_cla, b_cla)]
+    c2, l2, n2 = ops.AttHeadFn.apply(*dl)
+    assert (c2.detach().cpu() - clip.detach()).abs().max().item() < 1e-5
+    assert (n2.detach().cpu() - natt.detach()).abs().max().item() < 1e-5
+    loss2 = (c2 * wc.cuda()).sum() + (l2 * wl.cuda()).sum() + (n2 * wn.cuda()).sum() * 3.0
+    got = torch.autograd.grad(loss2, dl)
+    for name, a, b in zip(("feat", "w_att", "b_att", "w_cla", "b_cla"), got, want):
+        err = (a.double().cpu() - b).norm().item() / b.norm().item()
+        assert err < 2e-4, (name, err)
