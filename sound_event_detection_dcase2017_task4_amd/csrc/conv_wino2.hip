@@ -222,9 +222,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2P p) {
     }
 #define w2lstore(BUF) { SED_W2A_STORE(BUF, 0) SED_W2A_STORE(BUF, 1) SED_W2A_STORE(BUF, 2) }
 
-    // halo entries and rows outside the image are never stored: zero both A stages once
-    for (int i = tid; i < 2 * W2_ASTAGE / 4; i += 256) reinterpret_cast<float4*>(As)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();                                   // zero fill visible before the first stores
+    // The K loop never stores the halo entries (plane 0 position 0 = column -1, plane 1 position TW = column W of every
+    // block row) nor the pixels of rows outside the image: zero exactly those, once, in both stages (~2 LDS stores per
+    // thread instead of a 25-store fill of both stages + a barrier; the barrier behind the first tile store publishes them)
+    for (int i = tid; i < nrows * 8; i += 256) {       // (34 block rows at W = 8: 272 entries)
+        const int r = i >> 3, e = (i >> 2) & 1;
+        const int row = (r * 2 + e) * S + (e ? TW : 0);
+        *reinterpret_cast<float4*>(&As[(i & 1) * W2_ASTAGE + sw_off(row, (i >> 1) & 1)]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#define SED_W2ZERO(i)                                                                                           \
+    if (!sok##i && (((tid + 256 * i) >> 1) >> logW) < nrows) {                                                  \
+        *reinterpret_cast<float4*>(&As[lso##i]) = make_float4(0.f, 0.f, 0.f, 0.f);                              \
+        *reinterpret_cast<float4*>(&As[W2_ASTAGE + lso##i]) = make_float4(0.f, 0.f, 0.f, 0.f);                  \
+    }
+    SED_W2ZERO(0) SED_W2ZERO(1) SED_W2ZERO(2)
+#undef SED_W2ZERO
     w2gload(0, 0);
     w2lstore(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
