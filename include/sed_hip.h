@@ -32,18 +32,19 @@ const char* sed_version(void);
  * Replaces torchlibrosa Spectrogram + LogmelFilterBank as constructed at pytorch/models.py:251-258 and called
  * at :284-285 (reflect pad 512, Hann-windowed 1024-point DFT, hop 320, power, 513x64 Slaney mel matrix,
  * 10*log10(clamp(., amin))).  wave [B2][L] -> out [B2][T = L/320 + 1][64].
- * window[1024] = conv_real.weight[0,0,:] (the Hann window); tw1024t [16][64] float2 = exp(-2*pi*i*lane*k1/1024)
- * laid out [k1][lane]; tw64t [16][4] float2 = exp(-2*pi*i*(4*i'+g)*s/64) laid out [i'*4+s][g];
+ * window[1024] = conv_real.weight[0,0,:] (the Hann window).  The 1024-point FFT of a frame PAIR (z = a + i b) is factored
+ * 16 x 16 x 4 (n = 64 n1 + 4 n2 + n3): tw1024t [16][64] float2 = exp(-2*pi*i*m*k1/1024) laid out [k1][m], m = 4 n2 + n3;
+ * tw64t [16][4] float2 = exp(-2*pi*i*n3*k2/64) laid out [k2][n3].
  * mel_tasks [n_tasks][4] int32 = {first bin, taps (<= 12), offset into mel_w, band}: the non-zero run of each melW
- * column cut into <= 12-tap tasks, sorted by band; mel_bands [64][2] int32 = {first task, #tasks} per band; mel_w =
- * the concatenated non-zero runs (mel_nnz <= 1024 floats).  The i16 variant folds utils/utilities.py:66-67
- * (int16 / 32767) into the load. */
+ * column cut into <= 12-tap tasks, sorted by band (n_tasks <= 128); mel_bands [64][2] int32 = {first task, #tasks} per
+ * band, max_band_tasks = the largest #tasks; mel_w = the concatenated non-zero runs (mel_nnz <= 1024 floats).
+ * The i16 variant folds utils/utilities.py:66-67 (int16 / 32767) into the window. */
 int sed_logmel_f32(const float* wave, int B2, int L, const float* window, const float* tw1024t, const float* tw64t,
-                   const int* mel_tasks, int n_tasks, const int* mel_bands, const float* mel_w, int mel_nnz,
-                   float amin, float* out, sed_stream_t stream);
+                   const int* mel_tasks, int n_tasks, const int* mel_bands, int max_band_tasks, const float* mel_w,
+                   int mel_nnz, float amin, float* out, sed_stream_t stream);
 int sed_logmel_i16(const short* wave, int B2, int L, const float* window, const float* tw1024t, const float* tw64t,
-                   const int* mel_tasks, int n_tasks, const int* mel_bands, const float* mel_w, int mel_nnz,
-                   float amin, float* out, sed_stream_t stream);
+                   const int* mel_tasks, int n_tasks, const int* mel_bands, int max_band_tasks, const float* mel_w,
+                   int mel_nnz, float amin, float* out, sed_stream_t stream);
 
 /* ---- BatchNorm statistics (nn.BatchNorm2d, models.py:87-88, :264; eps 1e-5, momentum 0.1) -------------------
  * sed_chan_stats: per-channel (sum, M2) partials of x [N][C] in tiles of sed_stats_rows_per_part() rows;

@@ -1,11 +1,25 @@
 // K1  log-mel front-end: reflect-pad STFT (Hann, n_fft 1024, hop 320) -> power -> 64-band mel -> 10*log10.
 //
 // Replaces the reference's `Spectrogram` + `LogmelFilterBank` calls (reference pytorch/models.py:284-285;
-// torchlibrosa 0.0.4 semantics) WITHOUT materialising the (B2,1,T,513) power
-// spectrogram: each wave packs two real frames into one 1024-point complex FFT (16 x 4 x 16 factorisation: two in-register
-// radix-16 passes, one LDS transpose, one 4-lane shuffle transpose), unpacks the two spectra, and lane m
-// accumulates mel band m from the compact (non-zero only) filter table.  HBM traffic = waveform once +
-// (T,64) out: 1,536,256 B per 10 s clip (fp32 in) -- the roofline denominator of SURVEY.md §8d.
+// torchlibrosa 0.0.4 semantics) WITHOUT materialising the (B2,1,T,513) power spectrogram.
+// HBM traffic = waveform once + (T,64) out: 1,536,256 B per 10 s clip (fp32 in) -- the roofline denominator of
+// SURVEY.md §8d.  The kernel is bound by the vector ALU, not by HBM (22 flop/B), so it is written for instruction count:
+//
+//  * one wave = one 1024-point COMPLEX FFT = two real frames (z = a + i b), 16 complex values per lane held as
+//    (re, im) register pairs so that every butterfly add / twiddle product is ONE packed-fp32 instruction
+//    (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32; the multiplications by +-i and the complex products use the
+//    op_sel / neg operand modifiers instead of extra instructions);
+//  * factorisation 16 x 16 x 4 (n = 64 n1 + 4 n2 + n3, k = k1 + 16 k2 + 256 k3): radix-16 in registers over n1, twiddle
+//    W1024^((4 n2 + n3) k1) from 15 per-lane register pairs, transposition T1 through padded LDS, radix-16 over n2, twiddle
+//    W64^(n3 k2), transposition T2, radix-4 over n3; the spectrum goes to LDS in natural order once;
+//  * unpack of the two real spectra + |.|^2 from the pairs (Z[k], Z[1024-k]) on packed pairs (the 1/4 of the unpack is
+//    folded into the mel weights); the powers of both frames are stored as ONE (Pa, Pb) pair per bin, so the mel stage is
+//    one ds_read_b64 + one v_pk_fma_f32 per filter tap for both frames;
+//  * mel: the 866 non-zero taps of the 513x64 filter bank are cut into <= 12-tap tasks (105 of them); a lane owns the same
+//    two tasks for every frame, its 24 weights live in registers; a wave walks 32 consecutive frames (16 FFTs) so that the
+//    ~100 table loads that fill those registers are paid once per 16 FFTs, and the samples of the next pair are requested
+//    before the current pair's arithmetic starts;
+//  * 10 log10(x) = 3.0103 log2(x) on the hardware v_log_f32 (1 ulp: < 1e-5 dB), the clamp mapped to exactly -100 dB.
 #include "common.h"
 #include "sed_hip.h"
 #include <math.h>
@@ -14,239 +28,300 @@ namespace {
 
 constexpr int NFFT = 1024;
 constexpr int HOP = 320;
-constexpr int TROW = 68;                         // transpose row stride in float2 (64 + 4 pad: conflict-free)
+constexpr int TROW = 68;                         // transposition row stride in float2 (64 + 4 pad: conflict-free)
 constexpr int NBINS = 513;
-constexpr int PSTR = 516;
 constexpr int MELW_MAX = 1024;
+constexpr int FPW = 32;                          // frames per wave (16 FFT pairs), 128 frames per workgroup
+constexpr int TASK_TAPS = 12;
+constexpr int MAX_TASKS = 128;
+constexpr int WBUF = 16 * TROW;
+#ifndef SED_LM_ABLATE
+#define SED_LM_ABLATE 0       // timing experiments only (results become wrong): 1 no transposes, 2 no mel, 4 no sample loads, 8 no FFT math
+#endif
+// Two waves per SIMD: the per-lane constants (window 16, twiddles 30 + 30, mel weights 24) and the prefetched samples of the
+// next frame pair (32) stay in registers, ~216 VGPRs.  Measured alternatives: 3 waves/SIMD (168 VGPRs) spills and runs
+// 0.83 ms against 0.64; streaming the second twiddle set and the mel weights from L1-resident tables to reach 3 / 4
+// waves per SIMD runs 1.3 / 1.7 ms (64 x 4-byte gathers per instruction are slow).
+#define SED_LM_OCC 2                  // float2 per wave: T1 / T2 / spectrum / powers / mel partials, aliased
 
-struct cpx { float re, im; };
+typedef float f2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void fft4(float& r0, float& i0, float& r1, float& i1, float& r2, float& i2,
-                                     float& r3, float& i3) {
-    float t0r = r0 + r2, t0i = i0 + i2, t1r = r0 - r2, t1i = i0 - i2;
-    float t2r = r1 + r3, t2i = i1 + i3;
-    float t3r = i1 - i3, t3i = -(r1 - r3);       // (a1 - a3) * (-i)
-    r0 = t0r + t2r; i0 = t0i + t2i;
-    r1 = t1r + t3r; i1 = t1i + t3i;
-    r2 = t0r - t2r; i2 = t0i - t2i;
-    r3 = t1r - t3r; i3 = t1i - t3i;
+// ---- complex arithmetic on (re, im) register pairs: one packed instruction each ----------------------------------
+// a + (-i) b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ f2 c_add_mi(f2 a, f2 b) {
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + (+i) b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ f2 c_add_pi(f2 a, f2 b) {
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a * w, w = (wr, wi) in a VGPR pair: t = a * wr;  r = (t.x - a.y wi, t.y + a.x wi)
+__device__ __forceinline__ f2 c_mul(f2 a, f2 w) {
+    f2 t, r;
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"
+        : "=&v"(t), "=v"(r) : "v"(a), "v"(w));
+    return r;
+}
+// the same with a wave-uniform twiddle in an SGPR pair
+__device__ __forceinline__ f2 c_mul_s(f2 a, f2 w) {
+    f2 t, r;
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"
+        : "=&v"(t), "=v"(r) : "v"(a), "s"(w));
+    return r;
+}
+// a + conj(b) and a - conj(b)
+__device__ __forceinline__ f2 c_add_conj(f2 a, f2 b) {
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f2 c_sub_conj(f2 a, f2 b) {
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
-__device__ __forceinline__ void cmul(float& r, float& i, float wr, float wi) {
-    float nr = r * wr - i * wi;
-    float ni = r * wi + i * wr;
-    r = nr; i = ni;
+// acc + p * w.x (HI = false) or acc + p * w.y (HI = true): the weight pair feeds two consecutive filter taps
+template <bool HI>
+__device__ __forceinline__ f2 pk_fma_tap(f2 p, f2 w, f2 acc) {
+    f2 r;
+    if (HI) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(p), "v"(w), "v"(acc));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(p), "v"(w), "v"(acc));
+    return r;
 }
 
-// In-register 16-point forward DFT, natural order in and out (4x4 Cooley-Tukey, n = 4a+b, k = c+4d).
-__device__ __forceinline__ void fft16(float (&re)[16], float (&im)[16]) {
+// 4-point DFT, in place; a2 may carry a pending factor -i (MI2) that is absorbed into the first butterfly.
+template <bool MI2>
+__device__ __forceinline__ void fft4(f2& a0, f2& a1, f2& a2, f2& a3) {
+    const f2 t0 = MI2 ? c_add_mi(a0, a2) : a0 + a2;
+    const f2 t1 = MI2 ? c_add_pi(a0, a2) : a0 - a2;
+    const f2 t2 = a1 + a3;
+    const f2 d = a1 - a3;
+    a0 = t0 + t2;
+    a2 = t0 - t2;
+    a1 = c_add_mi(t1, d);                        // t1 + (a1 - a3)(-i)
+    a3 = c_add_pi(t1, d);
+}
+
+// In-register 16-point forward DFT, natural order in and out (4x4 Cooley-Tukey, n = 4a+b, k = c+4d): 81 packed instructions.
+__device__ __forceinline__ void fft16(f2 (&x)[16]) {
     constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R = 0.70710678118654752f;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) fft4(re[b], im[b], re[4 + b], im[4 + b], re[8 + b], im[8 + b], re[12 + b], im[12 + b]);
-    // now element (c,b) sits at index 4c+b.  twiddle W16^(b*c)
-    cmul(re[5], im[5], C1, -S1);  cmul(re[6], im[6], R, -R);    cmul(re[7], im[7], S1, -C1);
-    cmul(re[9], im[9], R, -R);    { float t = re[10]; re[10] = im[10]; im[10] = -t; }   cmul(re[11], im[11], -R, -R);
-    cmul(re[13], im[13], S1, -C1); cmul(re[14], im[14], -R, -R); cmul(re[15], im[15], -C1, S1);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) fft4(re[4 * c], im[4 * c], re[4 * c + 1], im[4 * c + 1], re[4 * c + 2], im[4 * c + 2],
-                                     re[4 * c + 3], im[4 * c + 3]);
-    // index 4c+d now holds X[c+4d]: transpose to natural order
-#define SWP(a, b) { float t = re[a]; re[a] = re[b]; re[b] = t; t = im[a]; im[a] = im[b]; im[b] = t; }
+    for (int b = 0; b < 4; ++b) fft4<false>(x[b], x[4 + b], x[8 + b], x[12 + b]);
+    // element (c, b) sits at index 4c+b: twiddle W16^(b c); W16^4 = -i of index 10 is absorbed by the next butterfly
+    const f2 W1 = {C1, -S1}, W2 = {R, -R}, W3 = {S1, -C1}, W6 = {-R, -R}, W9 = {-C1, S1};
+    x[5] = c_mul_s(x[5], W1);   x[6] = c_mul_s(x[6], W2);   x[7] = c_mul_s(x[7], W3);
+    x[9] = c_mul_s(x[9], W2);                               x[11] = c_mul_s(x[11], W6);
+    x[13] = c_mul_s(x[13], W3); x[14] = c_mul_s(x[14], W6); x[15] = c_mul_s(x[15], W9);
+    fft4<false>(x[0], x[1], x[2], x[3]);
+    fft4<false>(x[4], x[5], x[6], x[7]);
+    fft4<true>(x[8], x[9], x[10], x[11]);
+    fft4<false>(x[12], x[13], x[14], x[15]);
+    // index 4c+d now holds X[c+4d]: transpose to natural order (register renaming)
+#define SWP(a, b) { const f2 t = x[a]; x[a] = x[b]; x[b] = t; }
     SWP(1, 4) SWP(2, 8) SWP(3, 12) SWP(6, 9) SWP(7, 13) SWP(11, 14)
 #undef SWP
 }
 
 template <typename T> __device__ __forceinline__ float load_sample(const T* p, long i);
 template <> __device__ __forceinline__ float load_sample<float>(const float* p, long i) { return p[i]; }
-// utils/utilities.py:66-67  int16_to_float32: x / 32767.
-template <> __device__ __forceinline__ float load_sample<short>(const short* p, long i) { return (float)p[i] / 32767.0f; }
+// utils/utilities.py:66-67  int16_to_float32: x / 32767.  (the 1/32767 is folded into the window registers)
+template <> __device__ __forceinline__ float load_sample<short>(const short* p, long i) { return (float)p[i]; }
 
-// v2 structure (occupancy first): no LDS sample staging (frames are read straight from global memory: 256-B
-// coalesced segments, the 3.2x overlap is served by L2), twiddles streamed from L1-resident tables instead of living in
-// 64 VGPRs, spectra / powers / mel partials aliased onto ONE 8.7 KB per-wave LDS buffer  =>  <= 128 VGPRs and 38.9 KB
-// per workgroup  =>  4 workgroups (16 waves) per CU instead of 2 (8 waves).  The mel stage is balanced: the 866
-// non-zero filter taps are cut into <= 12-tap tasks (105 of them) spread over the lanes in two rounds (24 iterations
-// instead of 47 x 2), partial sums combined per band through LDS.
-constexpr int FPW = 8;                            // frames per wave (4 FFT pairs), 32 frames per workgroup
-constexpr int TASK_TAPS = 12;
-constexpr int MAX_TASKS = 128;
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
 template <typename T>
-__global__ __launch_bounds__(256, 3) void logmel_kernel(const T* __restrict__ wave, int L, int T_frames,
+__global__ __launch_bounds__(256, SED_LM_OCC) void logmel_kernel(const T* __restrict__ wave, int L, int T_frames,
                                                         const float* __restrict__ window,      // [16][64] = natural order
-                                                        const float2* __restrict__ tw1024t,    // [16 k1][64 lane] W1024^(lane*k1)
-                                                        const float2* __restrict__ tw64t,      // [16 e = i'*4+s][4 g] W64^((4i'+g)*s)
+                                                        const float2* __restrict__ tw1024t,    // [16 k1][64 m] W1024^(m*k1)
+                                                        const float2* __restrict__ tw64t,      // [16 k2][4 n3] W64^(n3*k2)
                                                         const int4* __restrict__ tasks,        // [ntasks] {lo, cnt, off, band}
                                                         int ntasks, const int2* __restrict__ bands,   // [64] {first task, #tasks}
-                                                        const float* __restrict__ mel_w, int mel_nnz, float amin,
+                                                        int max_band_tasks, const float* __restrict__ mel_w, float amin,
                                                         float floor_db, float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* melw_s = reinterpret_cast<float*>(smem_raw);                       // [MELW_MAX]
-    float2* tbuf_all = reinterpret_cast<float2*>(melw_s + MELW_MAX);          // 4 x [16*TROW]
+    __shared__ __attribute__((aligned(16))) f2 lds[4 * WBUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = blockIdx.y;
     const int frame0 = blockIdx.x * (4 * FPW) + wv * FPW;
+    if (frame0 >= T_frames) return;                    // whole wave idle (no workgroup-wide barrier below)
     const T* x = wave + (long)b * L;
-    for (int j = tid; j < mel_nnz; j += 256) melw_s[j] = mel_w[j];
+    f2* const tb = lds + wv * WBUF;
+
+    // ---- per-lane constants, resident for the wave's 4 FFTs -------------------------------------------------------
+    constexpr float in_scale = sizeof(T) == 2 ? (float)(1.0 / 32767.0) : 1.0f;
     float win[16];
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) win[n1] = window[64 * n1 + lane];
-    const int k1 = lane >> 2, g = lane & 3;
-    __syncthreads();
+    for (int n1 = 0; n1 < 16; ++n1) win[n1] = window[64 * n1 + lane] * in_scale;
+    f2 twa[16];                                        // W1024^(lane * k1)
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { const float2 w = tw1024t[k * 64 + lane]; twa[k] = f2{w.x, w.y}; }
+    const int k1r = lane >> 2, g = lane & 3;           // after T1: lane = (k1, n3)
+    f2 twb[16];                                        // W64^(g * k2)
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { const float2 w = tw64t[k * 4 + g]; twb[k] = f2{w.x, w.y}; }
+    // mel tasks of this lane (lane and lane + 64); weights carry the 1/4 of the real-spectrum unpack
+    int tlo[2];
+    f2 tw_[2][TASK_TAPS / 2];                          // weight pairs (tap 2i, tap 2i+1)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int t = lane + 64 * r;
+        int4 tk = make_int4(0, 0, 0, 0);
+        if (t < ntasks) tk = tasks[t];
+        tlo[r] = tk.x;
+#pragma unroll
+        for (int i = 0; i < TASK_TAPS / 2; ++i)
+            tw_[r][i] = f2{2 * i < tk.y ? 0.25f * mel_w[tk.z + 2 * i] : 0.f, 2 * i + 1 < tk.y ? 0.25f * mel_w[tk.z + 2 * i + 1] : 0.f};
+    }
+    const int2 bd = bands[lane];
+    f2* const mp = tb + 544;                           // mel partials [MAX_TASKS] behind the 513 (+ read-ahead) power pairs
 
-    float2* tb = tbuf_all + wv * 16 * TROW;
-    float* pa = reinterpret_cast<float*>(tb);          // powers alias the (dead) spectrum buffer
-    float* pb = pa + PSTR;
-    float2* mp = reinterpret_cast<float2*>(pb + PSTR); // mel partials [MAX_TASKS]
-
+    // raw samples of one frame pair: lane takes n = 64 n1 + lane of frames ta (x) and ta + 1 (y).  Interior pairs are two
+    // runs of coalesced loads; the first / last pairs of a clip apply F.pad(mode='reflect') indexing (frames past the end = 0)
+    f2 raw[16];
+#define SED_LM_LOAD(TA)                                                                                         \
+    {                                                                                                           \
+        const int ta_ = (TA);                                                                                   \
+        const int base_ = ta_ * HOP - NFFT / 2;           /* signal index of n = 0 of frame a (frame b: + HOP) */ \
+        if (base_ >= 0 && base_ + HOP + NFFT <= L && ta_ + 1 < T_frames) {                                      \
+            /* (raw buffer loads with immediate offsets save the 64-bit address arithmetic but measured 10 % slower) */ \
+            const T* xa = x + base_ + lane;                                                                     \
+            _Pragma("unroll") for (int n1 = 0; n1 < 16; ++n1)                                                   \
+                raw[n1] = f2{load_sample<T>(xa, 64 * n1), load_sample<T>(xa, HOP + 64 * n1)};                   \
+        } else {                                                                                                \
+            _Pragma("unroll") for (int n1 = 0; n1 < 16; ++n1) {                                                 \
+                int ia = base_ + 64 * n1 + lane, ib = ia + HOP;                                                 \
+                ia = ia < 0 ? -ia : ia; ia = ia >= L ? 2 * (L - 1) - ia : ia;                                   \
+                ib = ib < 0 ? -ib : ib; ib = ib >= L ? 2 * (L - 1) - ib : ib;                                   \
+                const float va = (ia >= 0 && ia < L) ? load_sample<T>(x, ia) : 0.f;                             \
+                const float vb = (ib >= 0 && ib < L && ta_ + 1 < T_frames) ? load_sample<T>(x, ib) : 0.f;       \
+                raw[n1] = f2{va, vb};                                                                           \
+            }                                                                                                   \
+        }                                                                                                       \
+    }
+    SED_LM_LOAD(frame0)
     for (int pr = 0; pr < FPW / 2; ++pr) {
         const int ta = frame0 + 2 * pr;
         if (ta >= T_frames) break;                     // wave-uniform
-        const long base_a = (long)ta * HOP - NFFT / 2; // signal index of n = 0 of frame a (frame b: + HOP)
-        const bool fast = base_a >= 0 && base_a + HOP + NFFT <= (long)L && ta + 1 < T_frames;
-        float re[16], im[16];
-        if (fast) {
+        f2 z[16];
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) {
-                re[n1] = load_sample<T>(x, base_a + 64 * n1 + lane) * win[n1];
-                im[n1] = load_sample<T>(x, base_a + HOP + 64 * n1 + lane) * win[n1];
-            }
-        } else {                                       // clip edges: F.pad(mode='reflect') indexing, frames past the end = 0
+        for (int n1 = 0; n1 < 16; ++n1) z[n1] = raw[n1] * f2{win[n1], win[n1]};
+        // the next pair's samples are requested now and arrive behind this pair's arithmetic
+        if (!(SED_LM_ABLATE & 4) && pr + 1 < FPW / 2 && ta + 2 < T_frames) SED_LM_LOAD(ta + 2)
+        // ---- pass A: 16-point DFT over n1, twiddle W1024^(m k1), m = lane = 4 n2 + n3
+        if (!(SED_LM_ABLATE & 8)) fft16(z);
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) {
-                long ia = base_a + 64 * n1 + lane, ib = ia + HOP;
-                if (ia < 0) ia = -ia;
-                if (ia >= L) ia = 2L * (L - 1) - ia;
-                if (ib < 0) ib = -ib;
-                if (ib >= L) ib = 2L * (L - 1) - ib;
-                float va = (ia >= 0 && ia < L) ? load_sample<T>(x, ia) : 0.f;
-                float vb = (ib >= 0 && ib < L && ta + 1 < T_frames) ? load_sample<T>(x, ib) : 0.f;
-                re[n1] = va * win[n1];
-                im[n1] = vb * win[n1];
-            }
+        for (int k = 1; k < 16; ++k) z[k] = c_mul(z[k], twa[k]);
+        wave_lds_fence();                              // previous pair's readers of this buffer are done
+        if (!(SED_LM_ABLATE & 1))
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tb[k * TROW + lane] = z[k];
+        wave_lds_fence();
+        // ---- T1: lane (k1r, g) takes n2 = 0..15 of its k1 and n3
+        if (!(SED_LM_ABLATE & 1))
+#pragma unroll
+        for (int i = 0; i < 16; ++i) z[i] = tb[k1r * TROW + 4 * i + g];
+        // ---- pass B: 16-point DFT over n2, twiddle W64^(n3 k2)
+        if (!(SED_LM_ABLATE & 8)) fft16(z);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) z[k] = c_mul(z[k], twb[k]);
+        wave_lds_fence();
+        if (!(SED_LM_ABLATE & 1))
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tb[k1r * TROW + 4 * k + g] = z[k];        // element (k1, k2, n3)
+        wave_lds_fence();
+        // ---- T2 + pass C: lane takes (k1 + 16 k2) = lane + 64 j, j = 0..3, all four n3 (32 contiguous bytes each)
+        if (!(SED_LM_ABLATE & 1))
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kk = lane + 64 * j;              // k1 = kk & 15, k2 = kk >> 4
+            const float4* src = reinterpret_cast<const float4*>(tb + (kk & 15) * TROW + 4 * (kk >> 4));
+            const float4 v01 = src[0], v23 = src[1];
+            z[4 * j + 0] = f2{v01.x, v01.y}; z[4 * j + 1] = f2{v01.z, v01.w};
+            z[4 * j + 2] = f2{v23.x, v23.y}; z[4 * j + 3] = f2{v23.z, v23.w};
         }
-        // pass A: 16-point DFT over n1, twiddle W1024^(lane*k1)
-        fft16(re, im);
 #pragma unroll
-        for (int k = 1; k < 16; ++k) { float2 w = tw1024t[k * 64 + lane]; cmul(re[k], im[k], w.x, w.y); }
-        __builtin_amdgcn_wave_barrier();
+        for (int j = 0; j < 4; ++j) fft4<false>(z[4 * j], z[4 * j + 1], z[4 * j + 2], z[4 * j + 3]);
+        // z[4j + k3] = Z[lane + 64 j + 256 k3]: the spectrum in natural order
+        wave_lds_fence();
 #pragma unroll
-        for (int k = 0; k < 16; ++k) tb[k * TROW + lane] = make_float2(re[k], im[k]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { float2 v = tb[k1 * TROW + 4 * i + g]; re[i] = v.x; im[i] = v.y; }
-        // pass B1: 4-point DFT over p for each i', twiddle W64^(q*s), q = 4i'+g
+            for (int k3 = 0; k3 < 4; ++k3) tb[lane + 64 * j + 256 * k3] = z[4 * j + k3];
+        wave_lds_fence();
+        // ---- unpack the two real spectra: A[k] = (Z[k] + conj Z[N-k]) / 2, B[k] = (Z[k] - conj Z[N-k]) / 2i; powers of
+        // bins k = lane + 64 i (i = 0..7) and of bin 512 (lane 0).  The 1/4 lives in the mel weights.
+        f2 pw[9];
 #pragma unroll
-        for (int ip = 0; ip < 4; ++ip) {
-            fft4(re[ip], im[ip], re[4 + ip], im[4 + ip], re[8 + ip], im[8 + ip], re[12 + ip], im[12 + ip]);
-#pragma unroll
-            for (int s = 1; s < 4; ++s) { float2 w = tw64t[(ip * 4 + s) * 4 + g]; cmul(re[4 * s + ip], im[4 * s + ip], w.x, w.y); }
+        for (int i = 0; i < 8; ++i) {
+            const int k = lane + 64 * i;
+            const f2 zk = tb[k], zn = tb[(NFFT - k) & (NFFT - 1)];
+            const f2 s = c_add_conj(zk, zn), d = c_sub_conj(zk, zn);
+            const f2 s2 = s * s, d2 = d * d;
+            pw[i] = f2{s2.x + s2.y, d2.x + d2.y};
         }
-        // 4x4 transpose across the quad's lanes: lane s must own all q = 4i'+g
-        float vr[16], vi[16];
-#pragma unroll
-        for (int ip = 0; ip < 4; ++ip) {
-            float ar[4], ai[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) { ar[s] = re[4 * s + ip]; ai[s] = im[4 * s + ip]; }
-            {
-                bool odd = g & 1;
-                float s0r = odd ? ar[0] : ar[1], s0i = odd ? ai[0] : ai[1];
-                float s1r = odd ? ar[2] : ar[3], s1i = odd ? ai[2] : ai[3];
-                float r0r = __shfl_xor(s0r, 1, 64), r0i = __shfl_xor(s0i, 1, 64);
-                float r1r = __shfl_xor(s1r, 1, 64), r1i = __shfl_xor(s1i, 1, 64);
-                if (odd) { ar[0] = r0r; ai[0] = r0i; ar[2] = r1r; ai[2] = r1i; }
-                else     { ar[1] = r0r; ai[1] = r0i; ar[3] = r1r; ai[3] = r1i; }
-            }
-            {
-                bool hi = g & 2;
-                float s0r = hi ? ar[0] : ar[2], s0i = hi ? ai[0] : ai[2];
-                float s1r = hi ? ar[1] : ar[3], s1i = hi ? ai[1] : ai[3];
-                float r0r = __shfl_xor(s0r, 2, 64), r0i = __shfl_xor(s0i, 2, 64);
-                float r1r = __shfl_xor(s1r, 2, 64), r1i = __shfl_xor(s1i, 2, 64);
-                if (hi) { ar[0] = r0r; ai[0] = r0i; ar[1] = r1r; ai[1] = r1i; }
-                else    { ar[2] = r0r; ai[2] = r0i; ar[3] = r1r; ai[3] = r1i; }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { vr[4 * ip + j] = ar[j]; vi[4 * ip + j] = ai[j]; }
-        }
-        // pass B2: 16-point DFT over q; lane (k1, s=g) output u -> bin k1 + 16*(s + 4u)
-        fft16(vr, vi);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int u = 0; u < 16; ++u) tb[k1 + 16 * g + 64 * u] = make_float2(vr[u], vi[u]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // unpack the two real spectra and take |.|^2 into registers, then overwrite the spectrum buffer with them
-        float ppa[9], ppb[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            int k = lane + 64 * i;
-            ppa[i] = 0.f; ppb[i] = 0.f;
-            if (k < NBINS) {
-                float2 zk = tb[k], zn = tb[(NFFT - k) & (NFFT - 1)];
-                float ar_ = zk.x + zn.x, ai_ = zk.y - zn.y;
-                float br_ = zk.x - zn.x, bi_ = zk.y + zn.y;
-                ppa[i] = 0.25f * (ar_ * ar_ + ai_ * ai_);
-                ppb[i] = 0.25f * (br_ * br_ + bi_ * bi_);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            int k = lane + 64 * i;
-            if (k < NBINS) { pa[k] = ppa[i]; pb[k] = ppb[i]; }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // mel: <= 12-tap tasks over the lanes (two rounds), then one lane per band combines its tasks
-#pragma unroll
-        for (int r = 0; r < MAX_TASKS / 64; ++r) {
-            int t = lane + 64 * r;
-            if (t < ntasks) {
-                int4 tk = tasks[t];
-                float sa = 0.f, sb = 0.f;
-#pragma unroll
-                for (int i = 0; i < TASK_TAPS; ++i)
-                    if (i < tk.y) {
-                        float w = melw_s[tk.z + i];
-                        sa = fmaf(w, pa[tk.x + i], sa);
-                        sb = fmaf(w, pb[tk.x + i], sb);
-                    }
-                mp[t] = make_float2(sa, sb);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
         {
-            int2 bd = bands[lane];
-            float ma = 0.f, mb = 0.f;
-            for (int j = 0; j < bd.y; ++j) { float2 v = mp[bd.x + j]; ma += v.x; mb += v.y; }
-            float* o = out + ((long)b * T_frames + ta) * 64 + lane;
-            // fp32 log10 (2 ulp) everywhere except AT the clamp, where the reference yields exactly 10*log10(amin)
-            o[0] = ma > amin ? 10.0f * log10f(ma) : floor_db;
-            if (ta + 1 < T_frames) o[64] = mb > amin ? 10.0f * log10f(mb) : floor_db;
+            const f2 zk = tb[512];
+            pw[8] = f2{4.f * zk.x * zk.x, 4.f * zk.y * zk.y};
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_fence();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tb[lane + 64 * i] = pw[i];
+        if (lane == 0) tb[512] = pw[8];
+        if (lane < 16) tb[513 + lane] = f2{0.f, 0.f};  // read-ahead of the fixed 12-tap tasks stays finite
+        wave_lds_fence();
+        // ---- mel: <= 12-tap tasks, one (Pa, Pb) read + one packed FMA per tap; then one lane per band sums its tasks
+        if (!(SED_LM_ABLATE & 2))
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            f2 acc = {0.f, 0.f};
+            const f2* pp = tb + tlo[r];
+#pragma unroll
+            for (int i = 0; i < TASK_TAPS / 2; ++i) {
+                acc = pk_fma_tap<false>(pp[2 * i], tw_[r][i], acc);
+                acc = pk_fma_tap<true>(pp[2 * i + 1], tw_[r][i], acc);
+            }
+            mp[lane + 64 * r] = acc;
+        }
+        wave_lds_fence();
+        {
+            f2 m = {0.f, 0.f};
+            for (int j = 0; j < max_band_tasks; ++j) {
+                const f2 v = mp[bd.x + (j < bd.y ? j : 0)];
+                if (j < bd.y) m += v;
+            }
+            float* o = out + ((long)b * T_frames + ta) * 64 + lane;
+            // 10 log10(x) = 10 log10(2) log2(x) on v_log_f32 everywhere except AT the clamp, where the reference yields
+            // exactly 10*log10(amin)
+            o[0] = m.x > amin ? 3.0102999566398120f * __log2f(m.x) : floor_db;
+            if (ta + 1 < T_frames) o[64] = m.y > amin ? 3.0102999566398120f * __log2f(m.y) : floor_db;
+        }
     }
-}
+#undef SED_LM_LOAD
 
-constexpr size_t LOGMEL_SMEM = (size_t)MELW_MAX * 4 + 4 * 16 * TROW * 8;
+}
 
 template <typename T>
 int launch_logmel(const T* wave, int B2, int L, const float* window, const float* tw1024t, const float* tw64t,
-                  const int* tasks, int ntasks, const int* bands, const float* mel_w, int mel_nnz, float amin, float* out,
-                  hipStream_t stream) {
-    if (B2 <= 0 || L <= NFFT / 2 || mel_nnz <= 0 || mel_nnz > MELW_MAX || ntasks <= 0 || ntasks > MAX_TASKS) return SED_EINVAL;
+                  const int* tasks, int ntasks, const int* bands, int max_band_tasks, const float* mel_w, int mel_nnz, float amin,
+                  float* out, hipStream_t stream) {
+    if (B2 <= 0 || L <= NFFT / 2 || (long)L + 2 * NFFT >= (1L << 31) || mel_nnz <= 0 || mel_nnz > MELW_MAX || ntasks <= 0 || ntasks > MAX_TASKS ||
+        max_band_tasks <= 0 || max_band_tasks > MAX_TASKS)
+        return SED_EINVAL;
     int T_frames = L / HOP + 1;
     dim3 grid(sed_cdiv(T_frames, 4 * FPW), B2);
-    hipLaunchKernelGGL(logmel_kernel<T>, grid, dim3(256), LOGMEL_SMEM, stream, wave, L, T_frames, window,
+    hipLaunchKernelGGL(logmel_kernel<T>, grid, dim3(256), 0, stream, wave, L, T_frames, window,
                        reinterpret_cast<const float2*>(tw1024t), reinterpret_cast<const float2*>(tw64t),
-                       reinterpret_cast<const int4*>(tasks), ntasks, reinterpret_cast<const int2*>(bands), mel_w, mel_nnz,
+                       reinterpret_cast<const int4*>(tasks), ntasks, reinterpret_cast<const int2*>(bands), max_band_tasks, mel_w,
                        amin, (float)(10.0 * log10((double)amin)), out);
     SED_LAUNCH_CHECK();
     return 0;
@@ -255,13 +330,15 @@ int launch_logmel(const T* wave, int B2, int L, const float* window, const float
 }  // namespace
 
 SED_API int sed_logmel_f32(const float* wave, int B2, int L, const float* window, const float* tw1024t,
-                           const float* tw64t, const int* mel_tasks, int n_tasks, const int* mel_bands,
+                           const float* tw64t, const int* mel_tasks, int n_tasks, const int* mel_bands, int max_band_tasks,
                            const float* mel_w, int mel_nnz, float amin, float* out, hipStream_t stream) {
-    return launch_logmel<float>(wave, B2, L, window, tw1024t, tw64t, mel_tasks, n_tasks, mel_bands, mel_w, mel_nnz, amin, out, stream);
+    return launch_logmel<float>(wave, B2, L, window, tw1024t, tw64t, mel_tasks, n_tasks, mel_bands, max_band_tasks, mel_w, mel_nnz,
+                                amin, out, stream);
 }
 
 SED_API int sed_logmel_i16(const short* wave, int B2, int L, const float* window, const float* tw1024t,
-                           const float* tw64t, const int* mel_tasks, int n_tasks, const int* mel_bands,
+                           const float* tw64t, const int* mel_tasks, int n_tasks, const int* mel_bands, int max_band_tasks,
                            const float* mel_w, int mel_nnz, float amin, float* out, hipStream_t stream) {
-    return launch_logmel<short>(wave, B2, L, window, tw1024t, tw64t, mel_tasks, n_tasks, mel_bands, mel_w, mel_nnz, amin, out, stream);
+    return launch_logmel<short>(wave, B2, L, window, tw1024t, tw64t, mel_tasks, n_tasks, mel_bands, max_band_tasks, mel_w, mel_nnz,
+                                amin, out, stream);
 }

@@ -191,10 +191,7 @@ def frontend_tables(window, melW, device):
     k1 = np.arange(16)[:, None]
     tw = np.exp(-2j * np.pi * (lane * k1) / 1024.0)                              # [16 k1][64 lane]
     tw1024t = np.stack([tw.real, tw.imag], axis=-1).astype(np.float32)
-    e = np.arange(16)[:, None]
-    g = np.arange(4)[None, :]
-    ip, s = e // 4, e % 4
-    t64 = np.exp(-2j * np.pi * ((4 * ip + g) * s) / 64.0)                        # [16 e=i'*4+s][4 g]
+    t64 = np.exp(-2j * np.pi * (np.arange(16)[:, None] * np.arange(4)[None, :]) / 64.0)   # [16 k2][4 n3]
     tw64t = np.stack([t64.real, t64.imag], axis=-1).astype(np.float32)
     W = melW.detach().cpu().numpy().astype(np.float32)                           # (513, 64)
     tasks, bands, vals = [], [], []
@@ -218,6 +215,7 @@ def frontend_tables(window, melW, device):
         "mel_tasks": torch.tensor(tasks, dtype=torch.int32, device=dev).contiguous(),
         "n_tasks": len(tasks),
         "mel_bands": torch.tensor(bands, dtype=torch.int32, device=dev).contiguous(),
+        "max_band_tasks": max(1, max(nb for _, nb in bands)),
         "mel_w": torch.tensor(vals, dtype=torch.float32, device=dev),
         "mel_nnz": len(vals),
     }
@@ -238,8 +236,8 @@ def logmel(wave, tables, amin=1e-10):
     in_bytes = 2 if wave.dtype == torch.int16 else 4
     with _timed("logmel_frontend", float(B2) * (L * in_bytes + T * 64 * 4)):      # "flops" slot carries ALGORITHMIC BYTES
         _call(name, _ptr(wave), B2, L, _ptr(tables["window"]), _ptr(tables["tw1024t"]), _ptr(tables["tw64t"]),
-              _ptr(tables["mel_tasks"]), tables["n_tasks"], _ptr(tables["mel_bands"]), _ptr(tables["mel_w"]),
-              tables["mel_nnz"], amin, _ptr(out), _stream())
+              _ptr(tables["mel_tasks"]), tables["n_tasks"], _ptr(tables["mel_bands"]), tables["max_band_tasks"],
+              _ptr(tables["mel_w"]), tables["mel_nnz"], amin, _ptr(out), _stream())
     return out
 
 
