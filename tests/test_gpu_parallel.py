@@ -75,7 +75,7 @@ def _worker(rank, world, port, backend, mt, outdir):
     torch.distributed.destroy_process_group()
 
 
-def _reference(mt, world=2):
+def _reference(mt, world):
     """The same step in ONE process: per-replica BatchNorm = each half separately, gradients summed over the halves,
     1/world folded into the Adam kernel."""
     from sound_event_detection_dcase2017_task4_amd import ops, parallel
@@ -98,22 +98,25 @@ def _reference(mt, world=2):
     return opt.flat.cpu(), gsum.cpu(), bn0
 
 
-def _run_two_ranks(tmp_path, backend, mt):
+def _run_two_ranks(tmp_path, backend, mt, world=2):
     from sound_event_detection_dcase2017_task4_amd import parallel
     port = parallel.free_port()
-    mp.spawn(_worker, args=(2, port, backend, mt, str(tmp_path)), nprocs=2, join=True)
-    r0 = torch.load(os.path.join(str(tmp_path), "rank0.pt"))
-    r1 = torch.load(os.path.join(str(tmp_path), "rank1.pt"))
-    flat, gsum, bn0 = _reference(mt)
-    assert torch.equal(r0["flat"], r1["flat"]), "ranks diverged"
-    assert torch.equal(r0["grad"], r1["grad"])
-    # summed gradient and post-Adam parameters: the all-reduce adds two fp32 numbers per entry, exactly like the reference
+    mp.spawn(_worker, args=(world, port, backend, mt, str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
+    r0, r1 = rs[0], rs[1]
+    flat, gsum, bn0 = _reference(mt, world)
+    for r in rs[1:]:
+        assert torch.equal(r0["flat"], r["flat"]), "ranks diverged"
+        assert torch.equal(r0["grad"], r["grad"])
+    # summed gradient and post-Adam parameters (the collective's summation order may differ from the reference's by a
+    # rounding for more than two ranks)
     gerr = (r0["grad"] - gsum).abs().max().item() / gsum.abs().max().item()
     perr = (r0["flat"] - flat).abs().max().item()
     assert gerr < 1e-6, gerr
-    assert perr < 1e-6, perr
+    assert perr < (1e-6 if world == 2 else 2.1e-3), perr          # Adam's first step is +-lr: a rounding may flip a ~0 entry
     # BatchNorm statistics stay rank-local (DataParallel: per-replica statistics)
-    assert torch.allclose(r0["bn0_mean"], bn0[0], atol=1e-6) and torch.allclose(r1["bn0_mean"], bn0[1], atol=1e-6)
+    for r in range(world):
+        assert torch.allclose(rs[r]["bn0_mean"], bn0[r], atol=1e-6)
     assert not torch.allclose(r0["bn0_mean"], r1["bn0_mean"], atol=1e-4)
     # the buckets were issued from INSIDE backward, from the end of the buffer (head / block 4) towards block 1
     nb = len(r0["ranges"])
@@ -124,6 +127,11 @@ def _run_two_ranks(tmp_path, backend, mt):
 @pytest.mark.parametrize("mt", ["Cnn_9layers_Gru_FrameAtt", "Cnn_9layers_FrameAvg"])
 def test_two_ranks_one_gpu_gloo(tmp_path, mt):
     _run_two_ranks(tmp_path, "gloo", mt)
+
+
+def test_four_ranks_one_gpu_gloo(tmp_path):
+    """world_size 4 (4 waveforms = 2 mixup pairs per rank): same contract."""
+    _run_two_ranks(tmp_path, "gloo", "Cnn_9layers_FrameAvg", world=4)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL refuses two ranks on one device)")
@@ -145,3 +153,24 @@ def test_bench_gpus_2_spawns_ranks_or_fails_loudly():
     else:
         assert r.returncode != 0
         assert "needs 2 GPUs" in (r.stderr + r.stdout) and '"n_gpus"' not in r.stdout
+
+
+def test_bench_two_ranks_code_path_on_one_gpu():
+    """The exact launch line the driver uses for N = 2 (torch.distributed.run, one process per rank), with the two ranks
+    sharing GPU 0 over gloo (SED_BENCH_SHARE_GPU=1, a test-only switch): barrier + synchronize around the timed region,
+    MAX over ranks, ONE JSON line from rank 0 with n_gpus = 2 and the whole-job value."""
+    from sound_event_detection_dcase2017_task4_amd import parallel
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SED_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(parallel.free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2",
+                        "--steps", "3", "--warmup", "1", "--batch_size", "16", "--seconds", "2"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["config"]["global_batch"] == 32
+    assert line["scaling"] == "weak" and line["cpu_baseline"] is None and "extra_configs" not in line
+    assert abs(line["value"] - 32 * 3 / (line["ms_per_step"] * 3e-3)) < 0.02 * line["value"]
+    assert line["roofline"]["kernel"].startswith("conv3x3")
