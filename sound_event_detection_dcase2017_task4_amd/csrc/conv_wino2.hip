@@ -22,6 +22,15 @@
 #include "common.h"
 #include "sed_hip.h"
 
+#ifndef SED_ABL
+#define SED_ABL 0       // timing experiments only (tools/ablate.sh; results become wrong): 1 no output stores, 2 no yprev loads,
+#endif                  // 4 no eta exchange through LDS, 8 no statistics, 16 one K-step only
+// Round-2 measurements with these switches (64->64 @ 1001x64, B = 128): prologue + ONE K-step + epilogue
+// = 0.94 ms of the 2.69 ms the 8-step kernel takes, i.e. the per-workgroup fixed cost equals 2.8 K-steps and is NOT hidden
+// by the co-resident workgroup; of it the output stores are 0.17 ms, the eta exchange 0.03 ms, the statistics 0, the
+// previous-activation loads of the dgrad epilogue 0.33 ms.  Delaying half of the first generation of workgroups by 7-14 us
+// (so that the two workgroups of a CU stay out of phase) changes nothing: the fixed cost is memory-system time (first-touch
+// loads of 32-byte pieces out of 128-byte lines + 4-byte-per-lane stores), not idle issue slots.
 namespace {
 
 constexpr int W2_AROWS = 400;                 // >= (2*RP+2) * 2 * S for every supported W (max 396 at W = 64)
@@ -304,6 +313,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2P p) {
         // (no 128 v_mov per wave, which matters for the 8-step 64-channel layers)
         W2_STEP(0, KT > 1 ? 1 : 0)
         int it = 1;
+        if (SED_ABL & 16) it = KT;
         for (; it + 1 < KT; it += 2) {
             W2_STEP(1, it + 1)
             W2_STEP(0, it + 2 < KT ? it + 2 : it + 1)
@@ -329,8 +339,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2P p) {
     f2 mine[16];                                       // [row pair rp][q]: accumulator rows 2rp, 2rp+1
 #define SED_AP(a) f2{acc[a][2 * rp], acc[a][2 * rp + 1]}
 #define SED_GIVE(G0, G1)                                                                                        \
+    if (!(SED_ABL & 4)) {                                                                                       \
     xch[(wvu * 32 + 4 * rp + 0) * 64 + lane] = G0.x; xch[(wvu * 32 + 4 * rp + 1) * 64 + lane] = G1.x;           \
-    xch[(wvu * 32 + 4 * rp + 2) * 64 + lane] = G0.y; xch[(wvu * 32 + 4 * rp + 3) * 64 + lane] = G1.y;
+    xch[(wvu * 32 + 4 * rp + 2) * 64 + lane] = G0.y; xch[(wvu * 32 + 4 * rp + 3) * 64 + lane] = G1.y; }
     if (eh) {
 #pragma unroll
         for (int rp = 0; rp < 8; ++rp) {
@@ -372,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2P p) {
     float e_sc = 0.f, e_sh = 0.f, e_mu = 0.f, e_is = 0.f;
     // everything below works on pairs over the accumulator rows (2rp, 2rp+1), separately for q = 0 and q = 1
     f2 yp0[EPI == 2 ? 8 : 1], yp1[EPI == 2 ? 8 : 1];   // previous-layer activations
-    if (EPI == 2) {                                    // ... their loads overlap the LDS exchange
+    if (EPI == 2 && !(SED_ABL & 2)) {                  // ... their loads overlap the LDS exchange
         e_sc = p.p_scale[col]; e_sh = p.p_shift[col]; e_mu = p.p_mean[col]; e_is = p.p_invstd[col];
 #pragma unroll
         for (int rp = 0; rp < 8; ++rp) {
@@ -387,8 +398,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2P p) {
     f2 yq0[8], yq1[8];                                 // outputs
 #pragma unroll
     for (int rp = 0; rp < 8; ++rp) {
-        f2 y0 = mine[2 * rp] + f2{rx[(4 * rp + 0) * 64], rx[(4 * rp + 2) * 64]};      // q = 0 of rows 2rp, 2rp+1
-        f2 y1 = mine[2 * rp + 1] + f2{rx[(4 * rp + 1) * 64], rx[(4 * rp + 3) * 64]};  // q = 1
+        f2 y0 = mine[2 * rp], y1 = mine[2 * rp + 1];
+        if (!(SED_ABL & 4)) {
+            y0 += f2{rx[(4 * rp + 0) * 64], rx[(4 * rp + 2) * 64]};      // q = 0 of rows 2rp, 2rp+1
+            y1 += f2{rx[(4 * rp + 1) * 64], rx[(4 * rp + 3) * 64]};      // q = 1
+        }
         if (EPI == 1 || EPI == 2) {
             const bool oka = yoff[2 * rp] < y_img_bytes, okb = yoff[2 * rp + 1] < y_img_bytes;
             if (EPI == 2) {
@@ -405,10 +419,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2P p) {
             s1p += y0 + y1;
         }
         yq0[rp] = y0; yq1[rp] = y1;
+        if (!(SED_ABL & 1) || rp == 7) {
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y0.x), yrs, (int)yoff[2 * rp], 0, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y1.x), yrs, (int)yoff[2 * rp], n4, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y0.y), yrs, (int)yoff[2 * rp + 1], 0, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y1.y), yrs, (int)yoff[2 * rp + 1], n4, 0);
+        }
     }
     float cnt = 0.f;
     if (EPI == 1) {
@@ -437,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2P p) {
         s1 = s1p.x + s1p.y; s2 = s2p.x + s2p.y;
         s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
     }
-    if ((EPI == 1 || EPI == 2) && half == 0) {
+    if ((EPI == 1 || EPI == 2) && half == 0 && !(SED_ABL & 8)) {
         const long part = (long)tblk * 4 + wvu;
         p.partials[(part * 2 + 0) * p.N + col] = s1;
         p.partials[(part * 2 + 1) * p.N + col] = s2;
