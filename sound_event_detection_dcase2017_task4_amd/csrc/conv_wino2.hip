@@ -336,6 +336,42 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2P p) {
     float* xch = smem;                                 // [4 waves][32][64 lanes]
     const int half = lane >> 5;
     const int col = n0 + (lane & 31);
+    // byte offset (within the image) of output pixel (2*th+eh, 2*tw) of block tile tl, channel col:
+    //   pixel = (2*th0+eh)*W + 2*(tl + (tl & ~(TW-1)));  rows past the image land beyond num_records
+    const unsigned y_img_bytes = (unsigned)p.H * W * p.N * 4u;
+    const __amdgpu_buffer_rsrc_t yrs =
+        __builtin_amdgcn_make_buffer_rsrc(p.y + (long)b * p.H * W * p.N, 0, (int)y_img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(EPI == 2 ? p.yprev + (long)b * p.H * W * p.N : p.x), 0, (int)y_img_bytes, 0x00020000);
+    const int n4 = p.N * 4;
+    const unsigned n8 = (unsigned)p.N * 8u;
+    const int t0 = tb * 32 + 4 * half;
+    const unsigned lane_off = (unsigned)(((2 * th0 + eh) * W * p.N + col) * 4);
+    unsigned yoff[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned tl = (unsigned)(t0 + (r & 3) + 8 * (r >> 2));
+        yoff[r] = __umul24(tl + (tl & ~(unsigned)(TW - 1)), n8) + lane_off;
+    }
+    float s1 = 0.f, s2 = 0.f;
+    f2 s1p = {0.f, 0.f}, s2p = {0.f, 0.f};
+    float e_sc = 0.f, e_sh = 0.f, e_mu = 0.f, e_is = 0.f;
+    // everything below works on pairs over the accumulator rows (2rp, 2rp+1), separately for q = 0 and q = 1
+    f2 yp0[EPI == 2 ? 8 : 1], yp1[EPI == 2 ? 8 : 1];   // previous-layer activations
+#define SED_YPREV_LOADS \
+    if (EPI == 2 && !(SED_ABL & 2)) { \
+        e_sc = p.p_scale[col]; e_sh = p.p_shift[col]; e_mu = p.p_mean[col]; e_is = p.p_invstd[col]; \
+_Pragma("unroll") \
+        for (int rp = 0; rp < 8; ++rp) { \
+            yp0[EPI == 2 ? rp : 0] = f2{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, (int)yoff[2 * rp], 0, 0)), \
+                                        __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, (int)yoff[2 * rp + 1], 0, 0))}; \
+            yp1[EPI == 2 ? rp : 0] = f2{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, (int)yoff[2 * rp], n4, 0)), \
+                                        __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, (int)yoff[2 * rp + 1], n4, 0))}; \
+        } \
+    }
+    SED_YPREV_LOADS         // requested first, needed behind the output transform + the eta exchange (placing them
+                            // after the exchange writes instead measures the same: the compiler hoists them anyway)
+#undef SED_YPREV_LOADS
     f2 mine[16];                                       // [row pair rp][q]: accumulator rows 2rp, 2rp+1
 #define SED_AP(a) f2{acc[a][2 * rp], acc[a][2 * rp + 1]}
 #define SED_GIVE(G0, G1)                                                                                        \
@@ -361,38 +397,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2P p) {
     }
 #undef SED_AP
 #undef SED_GIVE
-    // byte offset (within the image) of output pixel (2*th+eh, 2*tw) of block tile tl, channel col:
-    //   pixel = (2*th0+eh)*W + 2*(tl + (tl & ~(TW-1)));  rows past the image land beyond num_records
-    const unsigned y_img_bytes = (unsigned)p.H * W * p.N * 4u;
-    const __amdgpu_buffer_rsrc_t yrs =
-        __builtin_amdgcn_make_buffer_rsrc(p.y + (long)b * p.H * W * p.N, 0, (int)y_img_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(EPI == 2 ? p.yprev + (long)b * p.H * W * p.N : p.x), 0, (int)y_img_bytes, 0x00020000);
-    const int n4 = p.N * 4;
-    const unsigned n8 = (unsigned)p.N * 8u;
-    const int t0 = tb * 32 + 4 * half;
-    const unsigned lane_off = (unsigned)(((2 * th0 + eh) * W * p.N + col) * 4);
-    unsigned yoff[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const unsigned tl = (unsigned)(t0 + (r & 3) + 8 * (r >> 2));
-        yoff[r] = __umul24(tl + (tl & ~(unsigned)(TW - 1)), n8) + lane_off;
-    }
-    float s1 = 0.f, s2 = 0.f;
-    f2 s1p = {0.f, 0.f}, s2p = {0.f, 0.f};
-    float e_sc = 0.f, e_sh = 0.f, e_mu = 0.f, e_is = 0.f;
-    // everything below works on pairs over the accumulator rows (2rp, 2rp+1), separately for q = 0 and q = 1
-    f2 yp0[EPI == 2 ? 8 : 1], yp1[EPI == 2 ? 8 : 1];   // previous-layer activations
-    if (EPI == 2 && !(SED_ABL & 2)) {                  // ... their loads overlap the LDS exchange
-        e_sc = p.p_scale[col]; e_sh = p.p_shift[col]; e_mu = p.p_mean[col]; e_is = p.p_invstd[col];
-#pragma unroll
-        for (int rp = 0; rp < 8; ++rp) {
-            yp0[EPI == 2 ? rp : 0] = f2{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, (int)yoff[2 * rp], 0, 0)),
-                                        __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, (int)yoff[2 * rp + 1], 0, 0))};
-            yp1[EPI == 2 ? rp : 0] = f2{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, (int)yoff[2 * rp], n4, 0)),
-                                        __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, (int)yoff[2 * rp + 1], n4, 0))};
-        }
-    }
     __syncthreads();
     const float* rx = xch + ((wvu ^ 1) * 32) * 64 + lane;
     f2 yq0[8], yq1[8];                                 // outputs
