@@ -108,10 +108,15 @@ def test_evaluator_end_to_end_through_the_hip_model(tmp_path):
     assert np.abs(out["clipwise_output"] - rc).max() < 1e-4 and np.abs(out["framewise_output"] - rf).max() < 1e-4
     tgt = strong.any(axis=1).astype(np.float32)
     seen = tgt.sum(0) > 0                                           # AP is undefined for classes without positives
-    np.testing.assert_allclose(stats["clipwise_ap"][seen], metrics.average_precision_score(tgt, rc, average=None)[seen], atol=1e-6)
+    # the scores are functions of the model outputs (equal to the oracle's within 1e-4, checked above): rank-based metrics on
+    # 5 clips flip with the 7th digit of a probability, so they are recomputed here from the outputs the Evaluator saw
+    hc, hf = out["clipwise_output"], out["framewise_output"]
+    np.testing.assert_allclose(stats["clipwise_ap"][seen], metrics.average_precision_score(tgt, hc, average=None)[seen], atol=1e-9)
+    np.testing.assert_allclose(stats["framewise_ap"][seen], sed_average_precision(strong[:, :1000].astype(np.float32), hf, None)[seen],
+                               atol=1e-9)
     np.testing.assert_allclose(stats["framewise_ap"][seen], sed_average_precision(strong[:, :1000].astype(np.float32), rf, None)[seen],
-                               atol=1e-3)
-    ev_ref = U.frame_prediction_to_event_prediction({"audio_name": out["audio_name"], "clipwise_output": rc, "framewise_output": rf},
+                               atol=5e-2)
+    ev_ref = U.frame_prediction_to_event_prediction({"audio_name": out["audio_name"], "clipwise_output": hc, "framewise_output": hf},
                                                     Evaluator(model=m).sed_params_dict)
     assert len(ev_ref) > 0
     want = U.segment_based_metrics(U.load_event_list(str(csv)),
