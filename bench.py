@@ -246,12 +246,10 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become N ranks (one per GPU) or fail loudly -- never a silent 1-rank run
         parallel.respawn_under_torchrun(args.gpus, os.path.abspath(__file__), sys.argv[1:])
-    # SED_BENCH_SHARE_GPU=1 (tests only): all ranks share GPU 0 and talk over gloo, so that the N-rank code path of this
-    # script can be exercised on a 1-GPU box (RCCL refuses two ranks on one device).  Never set by the driver.
-    share_gpu = os.environ.get("SED_BENCH_SHARE_GPU") == "1"
-    rank, world, local_rank = parallel.init_from_env(backend="gloo" if share_gpu else None)
-    if share_gpu:
-        local_rank = 0
+    # SED_SHARE_GPU=1 (tests only, parallel.init_from_env): all ranks share GPU 0 and talk over gloo, so that the N-rank
+    # code path of this script can be exercised on a 1-GPU box (RCCL refuses two ranks on one device).  Never set by the driver.
+    share_gpu = os.environ.get("SED_SHARE_GPU") == "1"
+    rank, world, local_rank = parallel.init_from_env()
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():

@@ -26,6 +26,10 @@ def init_from_env(backend=None, timeout_minutes=60):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SED_SHARE_GPU") == "1":
+        # test / debug switch: all ranks use GPU 0 and talk over gloo, so that the N-rank code paths (CLI, bench) can run on
+        # a 1-GPU box -- RCCL refuses two ranks on one device.  Never set in production.
+        local_rank, backend = 0, "gloo"
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

@@ -157,11 +157,11 @@ def test_bench_gpus_2_spawns_ranks_or_fails_loudly():
 
 def test_bench_two_ranks_code_path_on_one_gpu():
     """The exact launch line the driver uses for N = 2 (torch.distributed.run, one process per rank), with the two ranks
-    sharing GPU 0 over gloo (SED_BENCH_SHARE_GPU=1, a test-only switch): barrier + synchronize around the timed region,
+    sharing GPU 0 over gloo (SED_SHARE_GPU=1, a test-only switch): barrier + synchronize around the timed region,
     MAX over ranks, ONE JSON line from rank 0 with n_gpus = 2 and the whole-job value."""
     from sound_event_detection_dcase2017_task4_amd import parallel
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env["SED_BENCH_SHARE_GPU"] = "1"
+    env["SED_SHARE_GPU"] = "1"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", str(parallel.free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2",
                         "--steps", "3", "--warmup", "1", "--batch_size", "16", "--seconds", "2"],
@@ -174,3 +174,41 @@ def test_bench_two_ranks_code_path_on_one_gpu():
     assert line["scaling"] == "weak" and line["cpu_baseline"] is None and "extra_configs" not in line
     assert abs(line["value"] - 32 * 3 / (line["ms_per_step"] * 3e-3)) < 0.02 * line["value"]
     assert line["roofline"]["kernel"].startswith("conv3x3")
+
+
+def test_train_cli_two_ranks_global_batch(tmp_path):
+    """The train CLI under torch.distributed.run with 2 ranks (sharing GPU 0 over gloo): `--batch_size 8` is the GLOBAL batch
+    (reference main.py:138: DataParallel scatters it), each rank trains on its 4 clips = 8 waveforms of every step, the
+    gradient buckets are exchanged, rank 0 writes the checkpoint, and every rank ends with the same parameters."""
+    from sound_event_detection_dcase2017_task4_amd import parallel
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SED_SHARE_GPU"] = "1"
+    env["PYTHONPATH"] = REPO + os.pathsep + env.get("PYTHONPATH", "")
+    ws = str(tmp_path)
+    probe = os.path.join(ws, "probe.py")
+    with open(probe, "w") as f:                      # same entry point, plus a dump of every rank's final parameters
+        f.write("import os, sys, torch\n"
+                "from sound_event_detection_dcase2017_task4_amd.pytorch import main as cli\n"
+                "from sound_event_detection_dcase2017_task4_amd import optim\n"
+                "keep = []\n"
+                "orig = optim.FusedAdamAmsgrad.__init__\n"
+                "def init(self, *a, **k):\n"
+                "    orig(self, *a, **k); keep.append(self)\n"
+                "optim.FusedAdamAmsgrad.__init__ = init\n"
+                "cli.FusedAdamAmsgrad = optim.FusedAdamAmsgrad\n"
+                "cli.main(sys.argv[1:])\n"
+                "torch.save(keep[0].flat.cpu(), os.path.join(sys.argv[sys.argv.index('--workspace') + 1], 'flat_rank%s.pt' % os.environ['RANK']))\n")
+    args = ["train", "--dataset_dir", ws, "--workspace", ws, "--holdout_fold", "1", "--model_type", "Cnn_9layers_Gru_FrameAtt",
+            "--loss_type", "clip_bce", "--augmentation", "mixup", "--learning_rate", "1e-3", "--batch_size", "8",
+            "--resume_iteration", "0", "--stop_iteration", "2", "--cuda", "--synthetic", "24", "--print_every", "1"]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(parallel.free_port()), probe] + args,
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    losses = [float(l.split()[1]) for l in r.stdout.splitlines() if len(l.split()) == 2 and l.split()[0] in ("0", "1", "2")]
+    assert len(losses) == 3 and all(np.isfinite(losses)), r.stdout[-1000:]
+    a, b = torch.load(os.path.join(ws, "flat_rank0.pt")), torch.load(os.path.join(ws, "flat_rank1.pt"))
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+    ck = os.path.join(ws, "checkpoints", "main", "holdout_fold=1", "model_type=Cnn_9layers_Gru_FrameAtt", "loss_type=clip_bce",
+                      "augmentation=mixup", "batch_size=8", "0_iterations.pth")
+    assert os.path.exists(ck)
