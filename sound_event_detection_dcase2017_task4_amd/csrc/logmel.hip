@@ -42,7 +42,16 @@ constexpr int WBUF = 16 * TROW;
 // next frame pair (32) stay in registers, ~216 VGPRs.  Measured alternatives: 3 waves/SIMD (168 VGPRs) spills and runs
 // 0.83 ms against 0.64; streaming the second twiddle set and the mel weights from L1-resident tables to reach 3 / 4
 // waves per SIMD runs 1.3 / 1.7 ms (64 x 4-byte gathers per instruction are slow).
-#define SED_LM_OCC 2                  // float2 per wave: T1 / T2 / spectrum / powers / mel partials, aliased
+#define SED_LM_OCC 2
+#ifndef SED_LM_PAIRS
+#define SED_LM_PAIRS 1        // frame pairs (FFTs) in flight per wave; 2 (independent instruction streams, 216 VGPRs, 70 KB of
+#endif                        // LDS per workgroup) measures the same 0.59 ms, as does prefetching the next pair's samples:
+// the kernel is NOT latency-bound but throughput-bound on the vector ALU plus the LDS.  tools/valu_ubench.hip on this part:
+// v_add/v_fma_f32 3.3, v_pk_add/v_pk_fma_f32 5.2, ds_read_b64 10, ds_write_b64 26 cycles per wave-instruction per SIMD with
+// every SIMD of the CU busy (80 B/clk/CU of LDS store bandwidth).  Per frame pair: 357 packed (1860 cycles) + ~100 plain
+// VALU (330) + 29 KB of LDS stores (two transpositions, the natural-order spectrum, the power pairs: 1530) + LDS loads
+// (1280, of which 600 are the 2.5-way bank-conflicted mel taps and 160 the 2-way conflicted T2 gathers) + ~500 VMEM / SALU
+// = 5500 cycles, which is what the kernel measures (0.59 ms x 2.4 GHz x 1024 SIMDs / 262 144 pairs = 5530).                  // float2 per wave: T1 / T2 / spectrum / powers / mel partials, aliased
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -139,7 +148,7 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <typename T>
+template <typename T, int U>
 __global__ __launch_bounds__(256, SED_LM_OCC) void logmel_kernel(const T* __restrict__ wave, int L, int T_frames,
                                                         const float* __restrict__ window,      // [16][64] = natural order
                                                         const float2* __restrict__ tw1024t,    // [16 k1][64 m] W1024^(m*k1)
@@ -148,16 +157,16 @@ __global__ __launch_bounds__(256, SED_LM_OCC) void logmel_kernel(const T* __rest
                                                         int ntasks, const int2* __restrict__ bands,   // [64] {first task, #tasks}
                                                         int max_band_tasks, const float* __restrict__ mel_w, float amin,
                                                         float floor_db, float* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) f2 lds[4 * WBUF];
+    __shared__ __attribute__((aligned(16))) f2 lds[4 * U * WBUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = blockIdx.y;
     const int frame0 = blockIdx.x * (4 * FPW) + wv * FPW;
     if (frame0 >= T_frames) return;                    // whole wave idle (no workgroup-wide barrier below)
     const T* x = wave + (long)b * L;
-    f2* const tb = lds + wv * WBUF;
+    f2* const tbw = lds + wv * U * WBUF;               // U private buffers of this wave
 
-    // ---- per-lane constants, resident for the wave's 4 FFTs -------------------------------------------------------
+    // ---- per-lane constants, resident for all the wave's FFTs ------------------------------------------------------
     constexpr float in_scale = sizeof(T) == 2 ? (float)(1.0 / 32767.0) : 1.0f;
     float win[16];
 #pragma unroll
@@ -183,12 +192,10 @@ __global__ __launch_bounds__(256, SED_LM_OCC) void logmel_kernel(const T* __rest
             tw_[r][i] = f2{2 * i < tk.y ? 0.25f * mel_w[tk.z + 2 * i] : 0.f, 2 * i + 1 < tk.y ? 0.25f * mel_w[tk.z + 2 * i + 1] : 0.f};
     }
     const int2 bd = bands[lane];
-    f2* const mp = tb + 544;                           // mel partials [MAX_TASKS] behind the 513 (+ read-ahead) power pairs
 
     // raw samples of one frame pair: lane takes n = 64 n1 + lane of frames ta (x) and ta + 1 (y).  Interior pairs are two
     // runs of coalesced loads; the first / last pairs of a clip apply F.pad(mode='reflect') indexing (frames past the end = 0)
-    f2 raw[16];
-#define SED_LM_LOAD(TA)                                                                                         \
+#define SED_LM_LOAD(RAW, TA)                                                                                    \
     {                                                                                                           \
         const int ta_ = (TA);                                                                                   \
         const int base_ = ta_ * HOP - NFFT / 2;           /* signal index of n = 0 of frame a (frame b: + HOP) */ \
@@ -196,104 +203,133 @@ __global__ __launch_bounds__(256, SED_LM_OCC) void logmel_kernel(const T* __rest
             /* (raw buffer loads with immediate offsets save the 64-bit address arithmetic but measured 10 % slower) */ \
             const T* xa = x + base_ + lane;                                                                     \
             _Pragma("unroll") for (int n1 = 0; n1 < 16; ++n1)                                                   \
-                raw[n1] = f2{load_sample<T>(xa, 64 * n1), load_sample<T>(xa, HOP + 64 * n1)};                   \
+                RAW[n1] = f2{load_sample<T>(xa, 64 * n1), load_sample<T>(xa, HOP + 64 * n1)};                   \
         } else {                                                                                                \
             _Pragma("unroll") for (int n1 = 0; n1 < 16; ++n1) {                                                 \
                 int ia = base_ + 64 * n1 + lane, ib = ia + HOP;                                                 \
                 ia = ia < 0 ? -ia : ia; ia = ia >= L ? 2 * (L - 1) - ia : ia;                                   \
                 ib = ib < 0 ? -ib : ib; ib = ib >= L ? 2 * (L - 1) - ib : ib;                                   \
-                const float va = (ia >= 0 && ia < L) ? load_sample<T>(x, ia) : 0.f;                             \
+                const float va = (ta_ < T_frames && ia >= 0 && ia < L) ? load_sample<T>(x, ia) : 0.f;           \
                 const float vb = (ib >= 0 && ib < L && ta_ + 1 < T_frames) ? load_sample<T>(x, ib) : 0.f;       \
-                raw[n1] = f2{va, vb};                                                                           \
+                RAW[n1] = f2{va, vb};                                                                           \
             }                                                                                                   \
         }                                                                                                       \
     }
-    SED_LM_LOAD(frame0)
-    for (int pr = 0; pr < FPW / 2; ++pr) {
-        const int ta = frame0 + 2 * pr;
-        if (ta >= T_frames) break;                     // wave-uniform
-        f2 z[16];
+    // U independent frame pairs per wave and iteration (see SED_LM_PAIRS above)
+    for (int it = 0; it < FPW / (2 * U); ++it) {
+        const int ta0 = frame0 + 2 * U * it;
+        if (ta0 >= T_frames) break;                    // wave-uniform
+        f2 z[U][16];
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) z[n1] = raw[n1] * f2{win[n1], win[n1]};
-        // the next pair's samples are requested now and arrive behind this pair's arithmetic
-        if (!(SED_LM_ABLATE & 4) && pr + 1 < FPW / 2 && ta + 2 < T_frames) SED_LM_LOAD(ta + 2)
-        // ---- pass A: 16-point DFT over n1, twiddle W1024^(m k1), m = lane = 4 n2 + n3
-        if (!(SED_LM_ABLATE & 8)) fft16(z);
-#pragma unroll
-        for (int k = 1; k < 16; ++k) z[k] = c_mul(z[k], twa[k]);
-        wave_lds_fence();                              // previous pair's readers of this buffer are done
-        if (!(SED_LM_ABLATE & 1))
-#pragma unroll
-        for (int k = 0; k < 16; ++k) tb[k * TROW + lane] = z[k];
-        wave_lds_fence();
-        // ---- T1: lane (k1r, g) takes n2 = 0..15 of its k1 and n3
-        if (!(SED_LM_ABLATE & 1))
-#pragma unroll
-        for (int i = 0; i < 16; ++i) z[i] = tb[k1r * TROW + 4 * i + g];
-        // ---- pass B: 16-point DFT over n2, twiddle W64^(n3 k2)
-        if (!(SED_LM_ABLATE & 8)) fft16(z);
-#pragma unroll
-        for (int k = 1; k < 16; ++k) z[k] = c_mul(z[k], twb[k]);
-        wave_lds_fence();
-        if (!(SED_LM_ABLATE & 1))
-#pragma unroll
-        for (int k = 0; k < 16; ++k) tb[k1r * TROW + 4 * k + g] = z[k];        // element (k1, k2, n3)
-        wave_lds_fence();
-        // ---- T2 + pass C: lane takes (k1 + 16 k2) = lane + 64 j, j = 0..3, all four n3 (32 contiguous bytes each)
-        if (!(SED_LM_ABLATE & 1))
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int kk = lane + 64 * j;              // k1 = kk & 15, k2 = kk >> 4
-            const float4* src = reinterpret_cast<const float4*>(tb + (kk & 15) * TROW + 4 * (kk >> 4));
-            const float4 v01 = src[0], v23 = src[1];
-            z[4 * j + 0] = f2{v01.x, v01.y}; z[4 * j + 1] = f2{v01.z, v01.w};
-            z[4 * j + 2] = f2{v23.x, v23.y}; z[4 * j + 3] = f2{v23.z, v23.w};
+        for (int u = 0; u < U; ++u) {
+            SED_LM_LOAD(z[u], ta0 + 2 * u)
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fft4<false>(z[4 * j], z[4 * j + 1], z[4 * j + 2], z[4 * j + 3]);
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) z[u][n1] = z[u][n1] * f2{win[n1], win[n1]};
+        // ---- pass A: 16-point DFT over n1, twiddle W1024^(m k1), m = lane = 4 n2 + n3
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!(SED_LM_ABLATE & 8)) fft16(z[u]);
+#pragma unroll
+            for (int k = 1; k < 16; ++k) z[u][k] = c_mul(z[u][k], twa[k]);
+        }
+        wave_lds_fence();                              // previous iteration's readers of these buffers are done
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tbw[u * WBUF + k * TROW + lane] = z[u][k];
+        wave_lds_fence();
+        // ---- T1: lane (k1r, g) takes n2 = 0..15 of its k1 and n3
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) z[u][i] = tbw[u * WBUF + k1r * TROW + 4 * i + g];
+        // ---- pass B: 16-point DFT over n2, twiddle W64^(n3 k2)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!(SED_LM_ABLATE & 8)) fft16(z[u]);
+#pragma unroll
+            for (int k = 1; k < 16; ++k) z[u][k] = c_mul(z[u][k], twb[k]);
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tbw[u * WBUF + k1r * TROW + 4 * k + g] = z[u][k];   // element (k1, k2, n3)
+        wave_lds_fence();
+        // ---- T2 + pass C: lane takes (k1 + 16 k2) = lane + 64 j, j = 0..3, all four n3 (32 contiguous bytes each)
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kk = lane + 64 * j;          // k1 = kk & 15, k2 = kk >> 4
+                const float4* src = reinterpret_cast<const float4*>(tbw + u * WBUF + (kk & 15) * TROW + 4 * (kk >> 4));
+                const float4 v01 = src[0], v23 = src[1];
+                z[u][4 * j + 0] = f2{v01.x, v01.y}; z[u][4 * j + 1] = f2{v01.z, v01.w};
+                z[u][4 * j + 2] = f2{v23.x, v23.y}; z[u][4 * j + 3] = f2{v23.z, v23.w};
+            }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fft4<false>(z[u][4 * j], z[u][4 * j + 1], z[u][4 * j + 2], z[u][4 * j + 3]);
         // z[4j + k3] = Z[lane + 64 j + 256 k3]: the spectrum in natural order
         wave_lds_fence();
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int k3 = 0; k3 < 4; ++k3) tb[lane + 64 * j + 256 * k3] = z[4 * j + k3];
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k3 = 0; k3 < 4; ++k3) tbw[u * WBUF + lane + 64 * j + 256 * k3] = z[u][4 * j + k3];
         wave_lds_fence();
         // ---- unpack the two real spectra: A[k] = (Z[k] + conj Z[N-k]) / 2, B[k] = (Z[k] - conj Z[N-k]) / 2i; powers of
         // bins k = lane + 64 i (i = 0..7) and of bin 512 (lane 0).  The 1/4 lives in the mel weights.
-        f2 pw[9];
+        f2 pw[U][9];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k = lane + 64 * i;
-            const f2 zk = tb[k], zn = tb[(NFFT - k) & (NFFT - 1)];
-            const f2 s = c_add_conj(zk, zn), d = c_sub_conj(zk, zn);
-            const f2 s2 = s * s, d2 = d * d;
-            pw[i] = f2{s2.x + s2.y, d2.x + d2.y};
-        }
-        {
+        for (int u = 0; u < U; ++u) {
+            const f2* tb = tbw + u * WBUF;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = lane + 64 * i;
+                const f2 zk = tb[k], zn = tb[(NFFT - k) & (NFFT - 1)];
+                const f2 s = c_add_conj(zk, zn), d = c_sub_conj(zk, zn);
+                const f2 s2 = s * s, d2 = d * d;
+                pw[u][i] = f2{s2.x + s2.y, d2.x + d2.y};
+            }
             const f2 zk = tb[512];
-            pw[8] = f2{4.f * zk.x * zk.x, 4.f * zk.y * zk.y};
+            pw[u][8] = f2{4.f * zk.x * zk.x, 4.f * zk.y * zk.y};
         }
         wave_lds_fence();
 #pragma unroll
-        for (int i = 0; i < 8; ++i) tb[lane + 64 * i] = pw[i];
-        if (lane == 0) tb[512] = pw[8];
-        if (lane < 16) tb[513 + lane] = f2{0.f, 0.f};  // read-ahead of the fixed 12-tap tasks stays finite
+        for (int u = 0; u < U; ++u) {
+            f2* tb = tbw + u * WBUF;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) tb[lane + 64 * i] = pw[u][i];
+            if (lane == 0) tb[512] = pw[u][8];
+            if (lane < 16) tb[513 + lane] = f2{0.f, 0.f};  // read-ahead of the fixed 12-tap tasks stays finite
+        }
         wave_lds_fence();
         // ---- mel: <= 12-tap tasks, one (Pa, Pb) read + one packed FMA per tap; then one lane per band sums its tasks
         if (!(SED_LM_ABLATE & 2))
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            f2 acc = {0.f, 0.f};
-            const f2* pp = tb + tlo[r];
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int i = 0; i < TASK_TAPS / 2; ++i) {
-                acc = pk_fma_tap<false>(pp[2 * i], tw_[r][i], acc);
-                acc = pk_fma_tap<true>(pp[2 * i + 1], tw_[r][i], acc);
+            for (int r = 0; r < 2; ++r) {
+                f2 acc = {0.f, 0.f};
+                const f2* pp = tbw + u * WBUF + tlo[r];
+#pragma unroll
+                for (int i = 0; i < TASK_TAPS / 2; ++i) {
+                    acc = pk_fma_tap<false>(pp[2 * i], tw_[r][i], acc);
+                    acc = pk_fma_tap<true>(pp[2 * i + 1], tw_[r][i], acc);
+                }
+                tbw[u * WBUF + 544 + lane + 64 * r] = acc;      // mel partials [MAX_TASKS] behind the 513 (+ read-ahead) power pairs
             }
-            mp[lane + 64 * r] = acc;
-        }
         wave_lds_fence();
-        {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ta = ta0 + 2 * u;
+            const f2* mp = tbw + u * WBUF + 544;
             f2 m = {0.f, 0.f};
             for (int j = 0; j < max_band_tasks; ++j) {
                 const f2 v = mp[bd.x + (j < bd.y ? j : 0)];
@@ -302,12 +338,11 @@ __global__ __launch_bounds__(256, SED_LM_OCC) void logmel_kernel(const T* __rest
             float* o = out + ((long)b * T_frames + ta) * 64 + lane;
             // 10 log10(x) = 10 log10(2) log2(x) on v_log_f32 everywhere except AT the clamp, where the reference yields
             // exactly 10*log10(amin)
-            o[0] = m.x > amin ? 3.0102999566398120f * __log2f(m.x) : floor_db;
+            if (ta < T_frames) o[0] = m.x > amin ? 3.0102999566398120f * __log2f(m.x) : floor_db;
             if (ta + 1 < T_frames) o[64] = m.y > amin ? 3.0102999566398120f * __log2f(m.y) : floor_db;
         }
     }
 #undef SED_LM_LOAD
-
 }
 
 template <typename T>
@@ -319,7 +354,7 @@ int launch_logmel(const T* wave, int B2, int L, const float* window, const float
         return SED_EINVAL;
     int T_frames = L / HOP + 1;
     dim3 grid(sed_cdiv(T_frames, 4 * FPW), B2);
-    hipLaunchKernelGGL(logmel_kernel<T>, grid, dim3(256), 0, stream, wave, L, T_frames, window,
+    hipLaunchKernelGGL((logmel_kernel<T, SED_LM_PAIRS>), grid, dim3(256), 0, stream, wave, L, T_frames, window,
                        reinterpret_cast<const float2*>(tw1024t), reinterpret_cast<const float2*>(tw64t),
                        reinterpret_cast<const int4*>(tasks), ntasks, reinterpret_cast<const int2*>(bands), max_band_tasks, mel_w,
                        amin, (float)(10.0 * log10((double)amin)), out);
