@@ -30,7 +30,7 @@ constexpr int NFFT = 1024;
 constexpr int HOP = 320;
 constexpr int TROW = 68;                         // transposition row stride in float2 (64 + 4 pad: conflict-free)
 constexpr int NBINS = 513;
-constexpr int MELW_MAX = 1024;
+constexpr int MELW_MAX = 2048;
 constexpr int FPW = 32;                          // frames per wave (16 FFT pairs), 128 frames per workgroup
 constexpr int TASK_TAPS = 12;
 constexpr int MAX_TASKS = 128;
@@ -43,6 +43,9 @@ constexpr int WBUF = 16 * TROW;
 // 0.83 ms against 0.64; streaming the second twiddle set and the mel weights from L1-resident tables to reach 3 / 4
 // waves per SIMD runs 1.3 / 1.7 ms (64 x 4-byte gathers per instruction are slow).
 #define SED_LM_OCC 2
+#ifndef SED_LM_VARIANT
+#define SED_LM_VARIANT 32     // FFT factorisation: 32 = 32 x 32 with one LDS transposition (logmel32_kernel), 16 = 16 x 16 x 4
+#endif
 #ifndef SED_LM_PAIRS
 #define SED_LM_PAIRS 1        // frame pairs (FFTs) in flight per wave; 2 (independent instruction streams, 216 VGPRs, 70 KB of
 #endif                        // LDS per workgroup) measures the same 0.59 ms, as does prefetching the next pair's samples:
@@ -138,10 +141,77 @@ __device__ __forceinline__ void fft16(f2 (&x)[16]) {
 #undef SWP
 }
 
+// 8-point DFT over e[0..7] (stride-agnostic references), natural order in and out: two 4-point DFTs + radix-2 (28 packed ops)
+__device__ __forceinline__ void fft8(f2& e0, f2& e1, f2& e2, f2& e3, f2& e4, f2& e5, f2& e6, f2& e7) {
+    constexpr float R = 0.70710678118654752f;
+    fft4<false>(e0, e2, e4, e6);                 // E[0..3] in e0, e2, e4, e6
+    fft4<false>(e1, e3, e5, e7);                 // O[0..3] in e1, e3, e5, e7
+    const f2 rp = {R, R}, rn = {-R, -R};
+    f2 t1 = c_add_mi(e3, e3);                    // O1 (1 - i)
+    asm("v_pk_mul_f32 %0, %0, %1" : "+v"(t1) : "s"(rp));
+    f2 t3 = c_add_pi(e7, e7);                    // O3 (1 + i)
+    asm("v_pk_mul_f32 %0, %0, %1" : "+v"(t3) : "s"(rn));     // O3 W8^3 = -R (1 + i) O3
+    const f2 E0 = e0, E1 = e2, E2 = e4, E3 = e6, O0 = e1, O2 = e5;
+    e0 = E0 + O0;             e4 = E0 - O0;
+    e1 = E1 + t1;             e5 = E1 - t1;
+    e2 = c_add_mi(E2, O2);    e6 = c_add_pi(E2, O2);         // W8^2 = -i
+    e3 = E3 + t3;             e7 = E3 - t3;
+}
+
+// In-register 32-point forward DFT, natural order in and out: n = 4 na + nb, k = ka + 8 kb: four 8-point DFTs over na,
+// twiddle W32^(nb ka), eight 4-point DFTs over nb (218 packed instructions).
+__device__ __forceinline__ void fft32(f2 (&x)[32]) {
+    static constexpr float W32[22][2] = {
+        {1.f, -0.f},
+        {0.98078525066375732f, -0.19509032368659973f}, {0.92387950420379639f, -0.38268342614173889f},
+        {0.83146959543228149f, -0.55557024478912354f}, {0.70710676908493042f, -0.70710676908493042f},
+        {0.55557024478912354f, -0.83146959543228149f}, {0.38268342614173889f, -0.92387950420379639f},
+        {0.19509032368659973f, -0.98078525066375732f}, {0.f, -1.f},
+        {-0.19509032368659973f, -0.98078525066375732f}, {-0.38268342614173889f, -0.92387950420379639f},
+        {-0.55557024478912354f, -0.83146959543228149f}, {-0.70710676908493042f, -0.70710676908493042f},
+        {-0.83146959543228149f, -0.55557024478912354f}, {-0.92387950420379639f, -0.38268342614173889f},
+        {-0.98078525066375732f, -0.19509032368659973f}, {-1.f, -0.f},
+        {-0.98078525066375732f, 0.19509032368659973f}, {-0.92387950420379639f, 0.38268342614173889f},
+        {-0.83146959543228149f, 0.55557024478912354f}, {-0.70710676908493042f, 0.70710676908493042f},
+        {-0.55557024478912354f, 0.83146959543228149f}};
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+        fft8(x[nb], x[4 + nb], x[8 + nb], x[12 + nb], x[16 + nb], x[20 + nb], x[24 + nb], x[28 + nb]);
+    // index 4 ka + nb now holds the ka-th output of column nb
+#pragma unroll
+    for (int ka = 1; ka < 8; ++ka)
+#pragma unroll
+        for (int nb = 1; nb < 4; ++nb) {
+            const f2 w = {W32[nb * ka][0], W32[nb * ka][1]};
+            x[4 * ka + nb] = c_mul_s(x[4 * ka + nb], w);
+        }
+#pragma unroll
+    for (int ka = 0; ka < 8; ++ka) fft4<false>(x[4 * ka], x[4 * ka + 1], x[4 * ka + 2], x[4 * ka + 3]);
+    // index 4 ka + kb holds X[ka + 8 kb]: to natural order (register renaming)
+    f2 y[32];
+#pragma unroll
+    for (int ka = 0; ka < 8; ++ka)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) y[ka + 8 * kb] = x[4 * ka + kb];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) x[i] = y[i];
+}
+
 template <typename T> __device__ __forceinline__ float load_sample(const T* p, long i);
 template <> __device__ __forceinline__ float load_sample<float>(const float* p, long i) { return p[i]; }
 // utils/utilities.py:66-67  int16_to_float32: x / 32767.  (the 1/32767 is folded into the window registers)
 template <> __device__ __forceinline__ float load_sample<short>(const short* p, long i) { return (float)p[i]; }
+
+// sum of the (<= 4) task partials of this lane's band
+__device__ __forceinline__ void band_sum(const f2* mp, int4 bd, int max_band_tasks, f2& m) {
+    const int slot[4] = {bd.x, bd.y, bd.z, bd.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (j < max_band_tasks) {
+            const f2 v = mp[slot[j] < 0 ? 0 : slot[j]];
+            if (slot[j] >= 0) m += v;
+        }
+}
 
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -154,7 +224,7 @@ __global__ __launch_bounds__(256, SED_LM_OCC) void logmel_kernel(const T* __rest
                                                         const float2* __restrict__ tw1024t,    // [16 k1][64 m] W1024^(m*k1)
                                                         const float2* __restrict__ tw64t,      // [16 k2][4 n3] W64^(n3*k2)
                                                         const int4* __restrict__ tasks,        // [ntasks] {lo, cnt, off, band}
-                                                        int ntasks, const int2* __restrict__ bands,   // [64] {first task, #tasks}
+                                                        int ntasks, const int4* __restrict__ bands,   // [64] task slots of the band (-1 = none)
                                                         int max_band_tasks, const float* __restrict__ mel_w, float amin,
                                                         float floor_db, float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) f2 lds[4 * U * WBUF];
@@ -191,7 +261,7 @@ __global__ __launch_bounds__(256, SED_LM_OCC) void logmel_kernel(const T* __rest
         for (int i = 0; i < TASK_TAPS / 2; ++i)
             tw_[r][i] = f2{2 * i < tk.y ? 0.25f * mel_w[tk.z + 2 * i] : 0.f, 2 * i + 1 < tk.y ? 0.25f * mel_w[tk.z + 2 * i + 1] : 0.f};
     }
-    const int2 bd = bands[lane];
+    const int4 bd = bands[lane];
 
     // raw samples of one frame pair: lane takes n = 64 n1 + lane of frames ta (x) and ta + 1 (y).  Interior pairs are two
     // runs of coalesced loads; the first / last pairs of a clip apply F.pad(mode='reflect') indexing (frames past the end = 0)
@@ -331,10 +401,7 @@ __global__ __launch_bounds__(256, SED_LM_OCC) void logmel_kernel(const T* __rest
             const int ta = ta0 + 2 * u;
             const f2* mp = tbw + u * WBUF + 544;
             f2 m = {0.f, 0.f};
-            for (int j = 0; j < max_band_tasks; ++j) {
-                const f2 v = mp[bd.x + (j < bd.y ? j : 0)];
-                if (j < bd.y) m += v;
-            }
+            band_sum(mp, bd, max_band_tasks, m);
             float* o = out + ((long)b * T_frames + ta) * 64 + lane;
             // 10 log10(x) = 10 log10(2) log2(x) on v_log_f32 everywhere except AT the clamp, where the reference yields
             // exactly 10*log10(amin)
@@ -345,19 +412,167 @@ __global__ __launch_bounds__(256, SED_LM_OCC) void logmel_kernel(const T* __rest
 #undef SED_LM_LOAD
 }
 
+// ---- variant 32: 1024 = 32 x 32, ONE transposition --------------------------------------------------------------------
+// A half-wave (32 lanes) owns one complex FFT = one frame pair, 32 complex values per lane: radix-32 in registers over n1
+// (n = 32 n1 + n2, lane = n2), twiddle W1024^(n2 k1), ONE padded-LDS transposition, radix-32 over n2 (lane = row k1, output
+// X[k1 + 32 k2] in register k2).  Rows k1 and 32 - k1 sit on ADJACENT lanes, so the mirror bin Z[1024 - k] of the real-spectrum
+// unpack is the neighbour's register 31 - k2 (DPP quad_perm, no LDS); rows 0 and 16 mirror onto themselves and are patched by
+// selects.  LDS stores per pair: 8 KB (transposition) + 4 KB (power pairs) instead of 29 KB for the 16 x 16 x 4 variant.
+constexpr int T32 = 33;                          // transposition row stride in float2 (32 + 1 pad)
+constexpr int WBUF32 = 32 * T32;                 // 1056 float2 per half-wave: transposition / powers / mel partials, aliased
+
+__device__ __forceinline__ float dpp_swap1(float v) {      // value of lane ^ 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void logmel32_kernel(const T* __restrict__ wave, int L, int T_frames,
+                                                          const float* __restrict__ window,      // [32 n1][32 n2] = natural order
+                                                          const float2* __restrict__ tw1024t,    // [32 k1][32 n2] W1024^(n2*k1)
+                                                          const int4* __restrict__ tasks, int ntasks,
+                                                          const int4* __restrict__ bands, int max_band_tasks,
+                                                          const float* __restrict__ mel_w, float amin, float floor_db,
+                                                          float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) f2 lds[4 * 2 * WBUF32];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int frame0 = blockIdx.x * (4 * FPW) + wv * FPW;
+    if (frame0 >= T_frames) return;
+    const T* x = wave + (long)b * L;
+    f2* const tbw = lds + wv * 2 * WBUF32;             // two private buffers of this wave (one per half-wave / frame pair)
+    f2* const tbh = tbw + h * WBUF32;
+    // row of the transposed matrix this lane owns: lanes (2p, 2p+1) hold rows (p, 32 - p); lanes 0, 1 rows 0 and 16
+    const int row = j == 0 ? 0 : (j == 1 ? 16 : ((j & 1) ? 32 - (j >> 1) : (j >> 1)));
+
+    constexpr float in_scale = sizeof(T) == 2 ? (float)(1.0 / 32767.0) : 1.0f;
+    float win[32];
+#pragma unroll
+    for (int n1 = 0; n1 < 32; ++n1) win[n1] = window[32 * n1 + j] * in_scale;
+    f2 twa[32];                                        // W1024^(n2 * k1), n2 = j
+#pragma unroll
+    for (int k = 1; k < 32; ++k) { const float2 w = tw1024t[k * 32 + j]; twa[k] = f2{w.x, w.y}; }
+    int tlo[2];
+    f2 tw_[2][TASK_TAPS / 2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int t = lane + 64 * r;
+        int4 tk = make_int4(0, 0, 0, 0);
+        if (t < ntasks) tk = tasks[t];
+        tlo[r] = tk.x;
+#pragma unroll
+        for (int i = 0; i < TASK_TAPS / 2; ++i)
+            tw_[r][i] = f2{2 * i < tk.y ? 0.25f * mel_w[tk.z + 2 * i] : 0.f, 2 * i + 1 < tk.y ? 0.25f * mel_w[tk.z + 2 * i + 1] : 0.f};
+    }
+    const int4 bd = bands[lane];
+    const bool is0 = j == 0, is1 = j == 1;
+
+    for (int it = 0; it < FPW / 4; ++it) {
+        const int ta0 = frame0 + 4 * it;               // this iteration: pairs (ta0, ta0+1) on lanes 0-31, (ta0+2, ta0+3) on 32-63
+        if (ta0 >= T_frames) break;                    // wave-uniform
+        const int ta = ta0 + 2 * h;
+        const int base = ta * HOP - NFFT / 2;
+        f2 z[32];
+        const int base0 = ta0 * HOP - NFFT / 2;
+        if (base0 >= 0 && base0 + 3 * HOP + NFFT <= L && ta0 + 3 < T_frames) {        // all four frames interior
+            const T* xa = x + base + j;
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) z[n1] = f2{load_sample<T>(xa, 32 * n1), load_sample<T>(xa, HOP + 32 * n1)};
+        } else {                                       // clip edges: F.pad(mode='reflect') indexing, frames past the end = 0
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) {
+                int ia = base + 32 * n1 + j, ib = ia + HOP;
+                ia = ia < 0 ? -ia : ia; ia = ia >= L ? 2 * (L - 1) - ia : ia;
+                ib = ib < 0 ? -ib : ib; ib = ib >= L ? 2 * (L - 1) - ib : ib;
+                const float va = (ta < T_frames && ia >= 0 && ia < L) ? load_sample<T>(x, ia) : 0.f;
+                const float vb = (ta + 1 < T_frames && ib >= 0 && ib < L) ? load_sample<T>(x, ib) : 0.f;
+                z[n1] = f2{va, vb};
+            }
+        }
+#pragma unroll
+        for (int n1 = 0; n1 < 32; ++n1) z[n1] = z[n1] * f2{win[n1], win[n1]};
+        // ---- pass A: 32-point DFT over n1, twiddle W1024^(n2 k1)
+        fft32(z);
+#pragma unroll
+        for (int k = 1; k < 32; ++k) z[k] = c_mul(z[k], twa[k]);
+        wave_lds_fence();                              // previous iteration's readers of this buffer are done
+#pragma unroll
+        for (int k = 0; k < 32; ++k) tbh[k * T32 + j] = z[k];
+        wave_lds_fence();
+#pragma unroll
+        for (int n2 = 0; n2 < 32; ++n2) z[n2] = tbh[row * T32 + n2];
+        // ---- pass B: 32-point DFT over n2: z[k2] = Z[row + 32 k2]
+        fft32(z);
+        // ---- real-spectrum unpack in registers.  Mirror of bin row + 32 k2 is (32 - row) + 32 (31 - k2): the neighbour lane's
+        // register 31 - k2.  Row 16 mirrors onto its own register 31 - k2, row 0 onto its own register (32 - k2) & 31.
+        f2 pw[16];
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+            const int r = 31 - k2;
+            f2 q = f2{dpp_swap1(z[r].x), dpp_swap1(z[r].y)};
+            const f2 own0 = z[(r + 1) & 31];           // row 0
+            q.x = is1 ? z[r].x : (is0 ? own0.x : q.x);
+            q.y = is1 ? z[r].y : (is0 ? own0.y : q.y);
+            const f2 s = c_add_conj(z[k2], q), d = c_sub_conj(z[k2], q);
+            const f2 s2 = s * s, d2 = d * d;
+            pw[k2] = f2{s2.x + s2.y, d2.x + d2.y};
+        }
+        const f2 p512 = f2{4.f * z[16].x * z[16].x, 4.f * z[16].y * z[16].y};    // bin 512 = row 0, k2 = 16 (real and imaginary parts)
+        wave_lds_fence();                              // the transposition reads are done: the buffer becomes the power pairs
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) tbh[row + 32 * k2] = pw[k2];
+        if (is0) tbh[512] = p512;
+        if (j < 16) tbh[513 + j] = f2{0.f, 0.f};       // read-ahead of the fixed 12-tap tasks stays finite
+        wave_lds_fence();
+        // ---- mel + log + store, one frame pair after the other on all 64 lanes
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const f2* pb = tbw + u * WBUF32;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                f2 acc = {0.f, 0.f};
+                const f2* pp = pb + tlo[r];
+#pragma unroll
+                for (int i = 0; i < TASK_TAPS / 2; ++i) {
+                    acc = pk_fma_tap<false>(pp[2 * i], tw_[r][i], acc);
+                    acc = pk_fma_tap<true>(pp[2 * i + 1], tw_[r][i], acc);
+                }
+                tbw[u * WBUF32 + 544 + lane + 64 * r] = acc;
+            }
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int tu = ta0 + 2 * u;
+            const f2* mp = tbw + u * WBUF32 + 544;
+            f2 m = {0.f, 0.f};
+            band_sum(mp, bd, max_band_tasks, m);
+            float* o = out + ((long)b * T_frames + tu) * 64 + lane;
+            if (tu < T_frames) o[0] = m.x > amin ? 3.0102999566398120f * __log2f(m.x) : floor_db;
+            if (tu + 1 < T_frames) o[64] = m.y > amin ? 3.0102999566398120f * __log2f(m.y) : floor_db;
+        }
+    }
+}
+
 template <typename T>
 int launch_logmel(const T* wave, int B2, int L, const float* window, const float* tw1024t, const float* tw64t,
                   const int* tasks, int ntasks, const int* bands, int max_band_tasks, const float* mel_w, int mel_nnz, float amin,
                   float* out, hipStream_t stream) {
     if (B2 <= 0 || L <= NFFT / 2 || (long)L + 2 * NFFT >= (1L << 31) || mel_nnz <= 0 || mel_nnz > MELW_MAX || ntasks <= 0 || ntasks > MAX_TASKS ||
-        max_band_tasks <= 0 || max_band_tasks > MAX_TASKS)
+        max_band_tasks <= 0 || max_band_tasks > 4)
         return SED_EINVAL;
     int T_frames = L / HOP + 1;
     dim3 grid(sed_cdiv(T_frames, 4 * FPW), B2);
+#if SED_LM_VARIANT == 32
+    hipLaunchKernelGGL(logmel32_kernel<T>, grid, dim3(256), 0, stream, wave, L, T_frames, window,
+                       reinterpret_cast<const float2*>(tw1024t), reinterpret_cast<const int4*>(tasks), ntasks,
+                       reinterpret_cast<const int4*>(bands), max_band_tasks, mel_w, amin, (float)(10.0 * log10((double)amin)), out);
+#else
     hipLaunchKernelGGL((logmel_kernel<T, SED_LM_PAIRS>), grid, dim3(256), 0, stream, wave, L, T_frames, window,
                        reinterpret_cast<const float2*>(tw1024t), reinterpret_cast<const float2*>(tw64t),
-                       reinterpret_cast<const int4*>(tasks), ntasks, reinterpret_cast<const int2*>(bands), max_band_tasks, mel_w,
+                       reinterpret_cast<const int4*>(tasks), ntasks, reinterpret_cast<const int4*>(bands), max_band_tasks, mel_w,
                        amin, (float)(10.0 * log10((double)amin)), out);
+#endif
     SED_LAUNCH_CHECK();
     return 0;
 }
@@ -377,3 +592,7 @@ SED_API int sed_logmel_i16(const short* wave, int B2, int L, const float* window
     return launch_logmel<short>(wave, B2, L, window, tw1024t, tw64t, mel_tasks, n_tasks, mel_bands, max_band_tasks, mel_w, mel_nnz,
                                 amin, out, stream);
 }
+
+// FFT factorisation the library was built with: 32 -> tw1024t is [32 k1][32 n2] = exp(-2 pi i n2 k1 / 1024) and tw64t is unused;
+// 16 -> the [16][64] / [16][4] tables described in sed_hip.h.
+SED_API int sed_logmel_variant(void) { return SED_LM_VARIANT; }

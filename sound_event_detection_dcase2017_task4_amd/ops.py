@@ -187,38 +187,89 @@ MEL_TASK_TAPS = 12
 def frontend_tables(window, melW, device):
     """window: (1024,) tensor = conv_real.weight[0,0,:]; melW (513,64) tensor.  Returns the device tables the
     log-mel kernel needs (FFT twiddles + the mel filter bank cut into <= 12-tap tasks)."""
-    lane = np.arange(64)[None, :]
-    k1 = np.arange(16)[:, None]
-    tw = np.exp(-2j * np.pi * (lane * k1) / 1024.0)                              # [16 k1][64 lane]
+    if _lib.lib().sed_logmel_variant() == 32:                                     # 1024 = 32 x 32
+        tw = np.exp(-2j * np.pi * (np.arange(32)[None, :] * np.arange(32)[:, None]) / 1024.0)   # [32 k1][32 n2]
+    else:                                                                         # 1024 = 16 x 16 x 4
+        tw = np.exp(-2j * np.pi * (np.arange(64)[None, :] * np.arange(16)[:, None]) / 1024.0)   # [16 k1][64 m]
     tw1024t = np.stack([tw.real, tw.imag], axis=-1).astype(np.float32)
     t64 = np.exp(-2j * np.pi * (np.arange(16)[:, None] * np.arange(4)[None, :]) / 64.0)   # [16 k2][4 n3]
     tw64t = np.stack([t64.real, t64.imag], axis=-1).astype(np.float32)
     W = melW.detach().cpu().numpy().astype(np.float32)                           # (513, 64)
-    tasks, bands, vals = [], [], []
-    for m in range(W.shape[1]):
-        nz = np.nonzero(W[:, m])[0]
-        first = len(tasks)
-        if len(nz):
-            a, b = int(nz[0]), int(nz[-1]) + 1
-            off = len(vals)
-            vals.extend(W[a:b, m].tolist())
-            for c in range(0, b - a, MEL_TASK_TAPS):
-                tasks.append([a + c, min(MEL_TASK_TAPS, b - a - c), off + c, m])
-        bands.append([first, len(tasks) - first])
-    if len(vals) > 1024 or len(tasks) > 128 or W.shape[1] != 64:
-        raise RuntimeError("mel filter bank does not fit the kernel tables (%d non-zeros, %d tasks)" % (len(vals), len(tasks)))
+    tasks, bands, vals = mel_task_tables(W)
     dev = torch.device(device)
     return {
         "window": window.detach().to(dev, torch.float32).contiguous(),
         "tw1024t": torch.from_numpy(tw1024t).to(dev).contiguous(),
         "tw64t": torch.from_numpy(tw64t).to(dev).contiguous(),
-        "mel_tasks": torch.tensor(tasks, dtype=torch.int32, device=dev).contiguous(),
-        "n_tasks": len(tasks),
-        "mel_bands": torch.tensor(bands, dtype=torch.int32, device=dev).contiguous(),
-        "max_band_tasks": max(1, max(nb for _, nb in bands)),
-        "mel_w": torch.tensor(vals, dtype=torch.float32, device=dev),
-        "mel_nnz": len(vals),
+        "mel_tasks": torch.from_numpy(tasks).to(dev).contiguous(),
+        "n_tasks": int(tasks.shape[0]),
+        "mel_bands": torch.from_numpy(bands).to(dev).contiguous(),
+        "max_band_tasks": int((bands >= 0).sum(axis=1).max()),
+        "mel_w": torch.from_numpy(vals).to(dev).contiguous(),
+        "mel_nnz": int(vals.size),
     }
+
+
+def mel_task_tables(W, slots=128):
+    """melW (513, 64) -> the mel-stage tables of the log-mel kernel (include/sed_hip.h):
+
+    tasks (slots, 4) int32 {window start bin, taps, offset into weights, band}, bands (64, 4) int32 task slots per band (-1 = none),
+    weights (slots * 12,) float32.  The non-zero run of every band is cut into <= 12-bin chunks; each chunk becomes a task that
+    reads a 12-bin window CONTAINING it (zero weights outside the chunk).  Where the window starts is free within 12 - len
+    positions, and that freedom is used to make the reads of the kernel bank-conflict free: task slot s is handled by lane
+    s % 64 in round s // 64, a ds_read_b64 is conflict-free when the 32 lanes of a half-wave read (Pa, Pb) pairs at bins that
+    differ mod 32, so the tasks are matched (Kuhn's augmenting paths) to cells (group s // 32, start mod 32), one task per cell."""
+    nbins, nbands = W.shape
+    if nbands != 64:
+        raise RuntimeError("the log-mel kernel is built for 64 mel bands")
+    chunks = []                                                   # (band, first bin, last bin + 1)
+    for m in range(nbands):
+        nz = np.nonzero(W[:, m])[0]
+        if len(nz):
+            a, b = int(nz[0]), int(nz[-1]) + 1
+            for c in range(a, b, MEL_TASK_TAPS):
+                chunks.append((m, c, min(c + MEL_TASK_TAPS, b)))
+    groups = slots // 32
+    if len(chunks) > slots or max(sum(1 for ch in chunks if ch[0] == m) for m in range(nbands)) > 4:
+        raise RuntimeError("mel filter bank does not fit the kernel tables (%d tasks)" % len(chunks))
+    allowed = [list(range(max(0, e - MEL_TASK_TAPS), c + 1)) for (_, c, e) in chunks]      # window starts that cover the chunk
+    cell_of, task_of = {}, {}                                      # task -> (group, residue, start);  (group, residue) -> task
+
+    def try_place(t, seen):
+        for st in allowed[t]:
+            for g in range(groups):
+                cell = (g, st % 32)
+                if cell in seen:
+                    continue
+                seen.add(cell)
+                if cell not in task_of or try_place(task_of[cell], seen):
+                    task_of[cell] = t
+                    cell_of[t] = (g, st % 32, st)
+                    return True
+        return False
+
+    order = sorted(range(len(chunks)), key=lambda t: len(allowed[t]))          # most constrained first
+    placed_all = all(try_place(t, set()) for t in order)
+    tasks = np.zeros((slots, 4), dtype=np.int32)
+    bands = -np.ones((nbands, 4), dtype=np.int32)
+    vals = np.zeros((slots * MEL_TASK_TAPS,), dtype=np.float32)
+    next_lane = [0] * groups
+    for t, (m, c, e) in enumerate(chunks):
+        if placed_all:
+            g, _, st = cell_of[t]
+        else:                                                      # (never for the reference's filter bank) fall back: any slot
+            g, st = min(range(groups), key=lambda q: next_lane[q]), allowed[t][-1]
+        slot = g * 32 + next_lane[g]
+        next_lane[g] += 1
+        tasks[slot] = [st, MEL_TASK_TAPS, slot * MEL_TASK_TAPS, m]
+        vals[slot * MEL_TASK_TAPS + (c - st):slot * MEL_TASK_TAPS + (e - st)] = W[c:e, m]
+        bands[m, int((bands[m] >= 0).sum())] = slot
+    for g in range(groups):                                        # idle slots read too (zero weights): keep them off the used banks
+        used = {int(tasks[s][0]) % 32 for s in range(g * 32, g * 32 + next_lane[g])}
+        free = [r for r in range(32) if r not in used]
+        for i, slot in enumerate(range(g * 32 + next_lane[g], g * 32 + 32)):
+            tasks[slot] = [free[i % len(free)] if free else 0, 0, slot * MEL_TASK_TAPS, 0]
+    return tasks, bands, vals
 
 
 def logmel(wave, tables, amin=1e-10):
