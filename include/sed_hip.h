@@ -33,23 +33,19 @@ const char* sed_version(void);
  * at :284-285 (reflect pad 512, Hann-windowed 1024-point DFT, hop 320, power, 513x64 Slaney mel matrix,
  * 10*log10(clamp(., amin))).  wave [B2][L] -> out [B2][T = L/320 + 1][64].
  * window[1024] = conv_real.weight[0,0,:] (the Hann window).  The 1024-point FFT of a frame PAIR (z = a + i b) is factored
- * 16 x 16 x 4 (n = 64 n1 + 4 n2 + n3): tw1024t [16][64] float2 = exp(-2*pi*i*m*k1/1024) laid out [k1][m], m = 4 n2 + n3;
- * tw64t [16][4] float2 = exp(-2*pi*i*n3*k2/64) laid out [k2][n3].
+ * 32 x 32 (n = 32 n1 + n2, k = k1 + 32 k2): tw1024t [32][32] float2 = exp(-2*pi*i*n2*k1/1024) laid out [k1][n2].
  * mel_tasks [n_tasks][4] int32 = {first bin of a 12-bin window, taps (<= 12), offset into mel_w, band}: the non-zero run of
  * each melW column is cut into <= 12-bin chunks; task slot s (s = lane + 64 r of the kernel) reads the (Pa, Pb) pairs of
  * its window and the host places the tasks so that the 32 slots of every group s/32 start at bins that differ mod 32 (bank
  * conflict-free LDS reads); empty slots have taps = 0 (n_tasks <= 128).  mel_bands [64][4] int32 = the task slots of each band
  * (-1 = none), max_band_tasks <= 4 = the largest count; mel_w = the task weights (mel_nnz <= 2048 floats).
  * The i16 variant folds utils/utilities.py:66-67 (int16 / 32767) into the window. */
-int sed_logmel_f32(const float* wave, int B2, int L, const float* window, const float* tw1024t, const float* tw64t,
-                   const int* mel_tasks, int n_tasks, const int* mel_bands, int max_band_tasks, const float* mel_w,
-                   int mel_nnz, float amin, float* out, sed_stream_t stream);
-int sed_logmel_i16(const short* wave, int B2, int L, const float* window, const float* tw1024t, const float* tw64t,
-                   const int* mel_tasks, int n_tasks, const int* mel_bands, int max_band_tasks, const float* mel_w,
-                   int mel_nnz, float amin, float* out, sed_stream_t stream);
-/* FFT factorisation the library was built with.  32: 1024 = 32 x 32 (one LDS transposition), tw1024t is [32 k1][32 n2]
- * float2 = exp(-2*pi*i*n2*k1/1024) and tw64t is ignored.  16: the 16 x 16 x 4 tables described above. */
-int sed_logmel_variant(void);
+int sed_logmel_f32(const float* wave, int B2, int L, const float* window, const float* tw1024t, const int* mel_tasks,
+                   int n_tasks, const int* mel_bands, int max_band_tasks, const float* mel_w, int mel_nnz, float amin,
+                   float* out, sed_stream_t stream);
+int sed_logmel_i16(const short* wave, int B2, int L, const float* window, const float* tw1024t, const int* mel_tasks,
+                   int n_tasks, const int* mel_bands, int max_band_tasks, const float* mel_w, int mel_nnz, float amin,
+                   float* out, sed_stream_t stream);
 
 /* ---- BatchNorm statistics (nn.BatchNorm2d, models.py:87-88, :264; eps 1e-5, momentum 0.1) -------------------
  * sed_chan_stats: per-channel (sum, M2) partials of x [N][C] in tiles of sed_stats_rows_per_part() rows;

@@ -3,23 +3,33 @@
 // Replaces the reference's `Spectrogram` + `LogmelFilterBank` calls (reference pytorch/models.py:284-285;
 // torchlibrosa 0.0.4 semantics) WITHOUT materialising the (B2,1,T,513) power spectrogram.
 // HBM traffic = waveform once + (T,64) out: 1,536,256 B per 10 s clip (fp32 in) -- the roofline denominator of
-// SURVEY.md §8d.  The kernel is bound by the vector ALU, not by HBM (22 flop/B), so it is written for instruction count:
+// SURVEY.md §8d.  The kernel is bound by the vector ALU and the LDS, not by HBM (22 flop/B), so it is written for
+// instruction count and LDS bytes:
 //
-//  * one wave = one 1024-point COMPLEX FFT = two real frames (z = a + i b), 16 complex values per lane held as
-//    (re, im) register pairs so that every butterfly add / twiddle product is ONE packed-fp32 instruction
-//    (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32; the multiplications by +-i and the complex products use the
-//    op_sel / neg operand modifiers instead of extra instructions);
-//  * factorisation 16 x 16 x 4 (n = 64 n1 + 4 n2 + n3, k = k1 + 16 k2 + 256 k3): radix-16 in registers over n1, twiddle
-//    W1024^((4 n2 + n3) k1) from 15 per-lane register pairs, transposition T1 through padded LDS, radix-16 over n2, twiddle
-//    W64^(n3 k2), transposition T2, radix-4 over n3; the spectrum goes to LDS in natural order once;
-//  * unpack of the two real spectra + |.|^2 from the pairs (Z[k], Z[1024-k]) on packed pairs (the 1/4 of the unpack is
-//    folded into the mel weights); the powers of both frames are stored as ONE (Pa, Pb) pair per bin, so the mel stage is
-//    one ds_read_b64 + one v_pk_fma_f32 per filter tap for both frames;
-//  * mel: the 866 non-zero taps of the 513x64 filter bank are cut into <= 12-tap tasks (105 of them); a lane owns the same
-//    two tasks for every frame, its 24 weights live in registers; a wave walks 32 consecutive frames (16 FFTs) so that the
-//    ~100 table loads that fill those registers are paid once per 16 FFTs, and the samples of the next pair are requested
-//    before the current pair's arithmetic starts;
+//  * two real frames = one 1024-point COMPLEX FFT (z = a + i b) on (re, im) register pairs: every butterfly add and every half
+//    of a twiddle product is ONE packed-fp32 instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32; the +-i rotations and the
+//    complex products use the op_sel / neg operand modifiers instead of extra instructions);
+//  * factorisation 1024 = 32 x 32 (n = 32 n1 + n2, k = k1 + 32 k2): a half-wave (32 lanes) owns one FFT, 32 complex values per
+//    lane; radix-32 in registers over n1 (lane = n2), twiddle W1024^(n2 k1) from 31 per-lane register pairs, ONE transposition
+//    through padded LDS, radix-32 over n2 (lane = row k1, register = k2);
+//  * rows k1 and 32 - k1 sit on ADJACENT lanes, so the mirror bin Z[1024 - k] of the real-spectrum unpack is the neighbour's
+//    register 31 - k2 (one DPP move, no LDS); the two self-mirrored rows 0 and 16 are patched by selects; |.|^2 of both frames
+//    is stored as ONE (Pa, Pb) pair per bin (the 1/4 of the unpack is folded into the mel weights);
+//  * mel: the 866 non-zero taps of the 513x64 filter bank are cut into <= 12-bin tasks (105 of them), one ds_read_b64 + one
+//    v_pk_fma_f32 per tap for both frames; a lane owns the same two tasks for every frame, its 24 weights live in registers, and
+//    the host places the task windows so that the reads are bank-conflict free (ops.mel_task_tables);
+//  * a wave walks 32 consecutive frames (8 iterations of 2 FFTs), so the ~150 table loads that fill the constant registers are
+//    paid once per 16 FFTs;
 //  * 10 log10(x) = 3.0103 log2(x) on the hardware v_log_f32 (1 ulp: < 1e-5 dB), the clamp mapped to exactly -100 dB.
+//
+// Cost model (tools/valu_ubench.hip on this part, every SIMD of the CU busy: v_add/v_fma_f32 3.3, v_pk_add/v_pk_fma_f32 5.2,
+// ds_read_b64 10, ds_write_b64 26 cycles per wave-instruction per SIMD = 80 B/clk/CU of LDS stores).  Per frame pair: ~350
+// packed (1820 cycles) + ~150 plain VALU (500) + 13 KB of LDS stores (670) + LDS loads (430) + VMEM / SALU (400) = 3800; the
+// kernel measures 4450 (0.48 ms per 512 x 10 s waveforms).  The 16 x 16 x 4 factorisation of the first packed version (two
+// transpositions + a natural-order spectrum round trip = 29 KB of LDS stores per pair, conflicted mel reads) measured the
+// 5500 cycles its instruction count predicts (0.59 ms); neither two independent frame pairs in flight per wave nor prefetching
+// the next pair's samples changed that, i.e. the kernel is throughput-bound, not latency-bound.  2 waves/SIMD (248 VGPRs):
+// 3 waves/SIMD spills (0.83 ms), streaming twiddles / mel weights from L1-resident tables to reach 3-4 waves runs 1.3-1.7 ms.
 #include "common.h"
 #include "sed_hip.h"
 #include <math.h>
@@ -28,33 +38,10 @@ namespace {
 
 constexpr int NFFT = 1024;
 constexpr int HOP = 320;
-constexpr int TROW = 68;                         // transposition row stride in float2 (64 + 4 pad: conflict-free)
-constexpr int NBINS = 513;
 constexpr int MELW_MAX = 2048;
-constexpr int FPW = 32;                          // frames per wave (16 FFT pairs), 128 frames per workgroup
+constexpr int FPW = 32;                          // frames per wave (8 iterations x 2 FFT pairs), 128 frames per workgroup
 constexpr int TASK_TAPS = 12;
 constexpr int MAX_TASKS = 128;
-constexpr int WBUF = 16 * TROW;
-#ifndef SED_LM_ABLATE
-#define SED_LM_ABLATE 0       // timing experiments only (results become wrong): 1 no transposes, 2 no mel, 4 no sample loads, 8 no FFT math
-#endif
-// Two waves per SIMD: the per-lane constants (window 16, twiddles 30 + 30, mel weights 24) and the prefetched samples of the
-// next frame pair (32) stay in registers, ~216 VGPRs.  Measured alternatives: 3 waves/SIMD (168 VGPRs) spills and runs
-// 0.83 ms against 0.64; streaming the second twiddle set and the mel weights from L1-resident tables to reach 3 / 4
-// waves per SIMD runs 1.3 / 1.7 ms (64 x 4-byte gathers per instruction are slow).
-#define SED_LM_OCC 2
-#ifndef SED_LM_VARIANT
-#define SED_LM_VARIANT 32     // FFT factorisation: 32 = 32 x 32 with one LDS transposition (logmel32_kernel), 16 = 16 x 16 x 4
-#endif
-#ifndef SED_LM_PAIRS
-#define SED_LM_PAIRS 1        // frame pairs (FFTs) in flight per wave; 2 (independent instruction streams, 216 VGPRs, 70 KB of
-#endif                        // LDS per workgroup) measures the same 0.59 ms, as does prefetching the next pair's samples:
-// the kernel is NOT latency-bound but throughput-bound on the vector ALU plus the LDS.  tools/valu_ubench.hip on this part:
-// v_add/v_fma_f32 3.3, v_pk_add/v_pk_fma_f32 5.2, ds_read_b64 10, ds_write_b64 26 cycles per wave-instruction per SIMD with
-// every SIMD of the CU busy (80 B/clk/CU of LDS store bandwidth).  Per frame pair: 357 packed (1860 cycles) + ~100 plain
-// VALU (330) + 29 KB of LDS stores (two transpositions, the natural-order spectrum, the power pairs: 1530) + LDS loads
-// (1280, of which 600 are the 2.5-way bank-conflicted mel taps and 160 the 2-way conflicted T2 gathers) + ~500 VMEM / SALU
-// = 5500 cycles, which is what the kernel measures (0.59 ms x 2.4 GHz x 1024 SIMDs / 262 144 pairs = 5530).                  // float2 per wave: T1 / T2 / spectrum / powers / mel partials, aliased
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -119,26 +106,6 @@ __device__ __forceinline__ void fft4(f2& a0, f2& a1, f2& a2, f2& a3) {
     a2 = t0 - t2;
     a1 = c_add_mi(t1, d);                        // t1 + (a1 - a3)(-i)
     a3 = c_add_pi(t1, d);
-}
-
-// In-register 16-point forward DFT, natural order in and out (4x4 Cooley-Tukey, n = 4a+b, k = c+4d): 81 packed instructions.
-__device__ __forceinline__ void fft16(f2 (&x)[16]) {
-    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R = 0.70710678118654752f;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) fft4<false>(x[b], x[4 + b], x[8 + b], x[12 + b]);
-    // element (c, b) sits at index 4c+b: twiddle W16^(b c); W16^4 = -i of index 10 is absorbed by the next butterfly
-    const f2 W1 = {C1, -S1}, W2 = {R, -R}, W3 = {S1, -C1}, W6 = {-R, -R}, W9 = {-C1, S1};
-    x[5] = c_mul_s(x[5], W1);   x[6] = c_mul_s(x[6], W2);   x[7] = c_mul_s(x[7], W3);
-    x[9] = c_mul_s(x[9], W2);                               x[11] = c_mul_s(x[11], W6);
-    x[13] = c_mul_s(x[13], W3); x[14] = c_mul_s(x[14], W6); x[15] = c_mul_s(x[15], W9);
-    fft4<false>(x[0], x[1], x[2], x[3]);
-    fft4<false>(x[4], x[5], x[6], x[7]);
-    fft4<true>(x[8], x[9], x[10], x[11]);
-    fft4<false>(x[12], x[13], x[14], x[15]);
-    // index 4c+d now holds X[c+4d]: transpose to natural order (register renaming)
-#define SWP(a, b) { const f2 t = x[a]; x[a] = x[b]; x[b] = t; }
-    SWP(1, 4) SWP(2, 8) SWP(3, 12) SWP(6, 9) SWP(7, 13) SWP(11, 14)
-#undef SWP
 }
 
 // 8-point DFT over e[0..7] (stride-agnostic references), natural order in and out: two 4-point DFTs + radix-2 (28 packed ops)
@@ -218,206 +185,6 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <typename T, int U>
-__global__ __launch_bounds__(256, SED_LM_OCC) void logmel_kernel(const T* __restrict__ wave, int L, int T_frames,
-                                                        const float* __restrict__ window,      // [16][64] = natural order
-                                                        const float2* __restrict__ tw1024t,    // [16 k1][64 m] W1024^(m*k1)
-                                                        const float2* __restrict__ tw64t,      // [16 k2][4 n3] W64^(n3*k2)
-                                                        const int4* __restrict__ tasks,        // [ntasks] {lo, cnt, off, band}
-                                                        int ntasks, const int4* __restrict__ bands,   // [64] task slots of the band (-1 = none)
-                                                        int max_band_tasks, const float* __restrict__ mel_w, float amin,
-                                                        float floor_db, float* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) f2 lds[4 * U * WBUF];
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int b = blockIdx.y;
-    const int frame0 = blockIdx.x * (4 * FPW) + wv * FPW;
-    if (frame0 >= T_frames) return;                    // whole wave idle (no workgroup-wide barrier below)
-    const T* x = wave + (long)b * L;
-    f2* const tbw = lds + wv * U * WBUF;               // U private buffers of this wave
-
-    // ---- per-lane constants, resident for all the wave's FFTs ------------------------------------------------------
-    constexpr float in_scale = sizeof(T) == 2 ? (float)(1.0 / 32767.0) : 1.0f;
-    float win[16];
-#pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) win[n1] = window[64 * n1 + lane] * in_scale;
-    f2 twa[16];                                        // W1024^(lane * k1)
-#pragma unroll
-    for (int k = 1; k < 16; ++k) { const float2 w = tw1024t[k * 64 + lane]; twa[k] = f2{w.x, w.y}; }
-    const int k1r = lane >> 2, g = lane & 3;           // after T1: lane = (k1, n3)
-    f2 twb[16];                                        // W64^(g * k2)
-#pragma unroll
-    for (int k = 1; k < 16; ++k) { const float2 w = tw64t[k * 4 + g]; twb[k] = f2{w.x, w.y}; }
-    // mel tasks of this lane (lane and lane + 64); weights carry the 1/4 of the real-spectrum unpack
-    int tlo[2];
-    f2 tw_[2][TASK_TAPS / 2];                          // weight pairs (tap 2i, tap 2i+1)
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int t = lane + 64 * r;
-        int4 tk = make_int4(0, 0, 0, 0);
-        if (t < ntasks) tk = tasks[t];
-        tlo[r] = tk.x;
-#pragma unroll
-        for (int i = 0; i < TASK_TAPS / 2; ++i)
-            tw_[r][i] = f2{2 * i < tk.y ? 0.25f * mel_w[tk.z + 2 * i] : 0.f, 2 * i + 1 < tk.y ? 0.25f * mel_w[tk.z + 2 * i + 1] : 0.f};
-    }
-    const int4 bd = bands[lane];
-
-    // raw samples of one frame pair: lane takes n = 64 n1 + lane of frames ta (x) and ta + 1 (y).  Interior pairs are two
-    // runs of coalesced loads; the first / last pairs of a clip apply F.pad(mode='reflect') indexing (frames past the end = 0)
-#define SED_LM_LOAD(RAW, TA)                                                                                    \
-    {                                                                                                           \
-        const int ta_ = (TA);                                                                                   \
-        const int base_ = ta_ * HOP - NFFT / 2;           /* signal index of n = 0 of frame a (frame b: + HOP) */ \
-        if (base_ >= 0 && base_ + HOP + NFFT <= L && ta_ + 1 < T_frames) {                                      \
-            /* (raw buffer loads with immediate offsets save the 64-bit address arithmetic but measured 10 % slower) */ \
-            const T* xa = x + base_ + lane;                                                                     \
-            _Pragma("unroll") for (int n1 = 0; n1 < 16; ++n1)                                                   \
-                RAW[n1] = f2{load_sample<T>(xa, 64 * n1), load_sample<T>(xa, HOP + 64 * n1)};                   \
-        } else {                                                                                                \
-            _Pragma("unroll") for (int n1 = 0; n1 < 16; ++n1) {                                                 \
-                int ia = base_ + 64 * n1 + lane, ib = ia + HOP;                                                 \
-                ia = ia < 0 ? -ia : ia; ia = ia >= L ? 2 * (L - 1) - ia : ia;                                   \
-                ib = ib < 0 ? -ib : ib; ib = ib >= L ? 2 * (L - 1) - ib : ib;                                   \
-                const float va = (ta_ < T_frames && ia >= 0 && ia < L) ? load_sample<T>(x, ia) : 0.f;           \
-                const float vb = (ib >= 0 && ib < L && ta_ + 1 < T_frames) ? load_sample<T>(x, ib) : 0.f;       \
-                RAW[n1] = f2{va, vb};                                                                           \
-            }                                                                                                   \
-        }                                                                                                       \
-    }
-    // U independent frame pairs per wave and iteration (see SED_LM_PAIRS above)
-    for (int it = 0; it < FPW / (2 * U); ++it) {
-        const int ta0 = frame0 + 2 * U * it;
-        if (ta0 >= T_frames) break;                    // wave-uniform
-        f2 z[U][16];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            SED_LM_LOAD(z[u], ta0 + 2 * u)
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) z[u][n1] = z[u][n1] * f2{win[n1], win[n1]};
-        // ---- pass A: 16-point DFT over n1, twiddle W1024^(m k1), m = lane = 4 n2 + n3
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!(SED_LM_ABLATE & 8)) fft16(z[u]);
-#pragma unroll
-            for (int k = 1; k < 16; ++k) z[u][k] = c_mul(z[u][k], twa[k]);
-        }
-        wave_lds_fence();                              // previous iteration's readers of these buffers are done
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) tbw[u * WBUF + k * TROW + lane] = z[u][k];
-        wave_lds_fence();
-        // ---- T1: lane (k1r, g) takes n2 = 0..15 of its k1 and n3
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) z[u][i] = tbw[u * WBUF + k1r * TROW + 4 * i + g];
-        // ---- pass B: 16-point DFT over n2, twiddle W64^(n3 k2)
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!(SED_LM_ABLATE & 8)) fft16(z[u]);
-#pragma unroll
-            for (int k = 1; k < 16; ++k) z[u][k] = c_mul(z[u][k], twb[k]);
-        }
-        wave_lds_fence();
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) tbw[u * WBUF + k1r * TROW + 4 * k + g] = z[u][k];   // element (k1, k2, n3)
-        wave_lds_fence();
-        // ---- T2 + pass C: lane takes (k1 + 16 k2) = lane + 64 j, j = 0..3, all four n3 (32 contiguous bytes each)
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int kk = lane + 64 * j;          // k1 = kk & 15, k2 = kk >> 4
-                const float4* src = reinterpret_cast<const float4*>(tbw + u * WBUF + (kk & 15) * TROW + 4 * (kk >> 4));
-                const float4 v01 = src[0], v23 = src[1];
-                z[u][4 * j + 0] = f2{v01.x, v01.y}; z[u][4 * j + 1] = f2{v01.z, v01.w};
-                z[u][4 * j + 2] = f2{v23.x, v23.y}; z[u][4 * j + 3] = f2{v23.z, v23.w};
-            }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fft4<false>(z[u][4 * j], z[u][4 * j + 1], z[u][4 * j + 2], z[u][4 * j + 3]);
-        // z[4j + k3] = Z[lane + 64 j + 256 k3]: the spectrum in natural order
-        wave_lds_fence();
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int k3 = 0; k3 < 4; ++k3) tbw[u * WBUF + lane + 64 * j + 256 * k3] = z[u][4 * j + k3];
-        wave_lds_fence();
-        // ---- unpack the two real spectra: A[k] = (Z[k] + conj Z[N-k]) / 2, B[k] = (Z[k] - conj Z[N-k]) / 2i; powers of
-        // bins k = lane + 64 i (i = 0..7) and of bin 512 (lane 0).  The 1/4 lives in the mel weights.
-        f2 pw[U][9];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const f2* tb = tbw + u * WBUF;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int k = lane + 64 * i;
-                const f2 zk = tb[k], zn = tb[(NFFT - k) & (NFFT - 1)];
-                const f2 s = c_add_conj(zk, zn), d = c_sub_conj(zk, zn);
-                const f2 s2 = s * s, d2 = d * d;
-                pw[u][i] = f2{s2.x + s2.y, d2.x + d2.y};
-            }
-            const f2 zk = tb[512];
-            pw[u][8] = f2{4.f * zk.x * zk.x, 4.f * zk.y * zk.y};
-        }
-        wave_lds_fence();
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            f2* tb = tbw + u * WBUF;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) tb[lane + 64 * i] = pw[u][i];
-            if (lane == 0) tb[512] = pw[u][8];
-            if (lane < 16) tb[513 + lane] = f2{0.f, 0.f};  // read-ahead of the fixed 12-tap tasks stays finite
-        }
-        wave_lds_fence();
-        // ---- mel: <= 12-tap tasks, one (Pa, Pb) read + one packed FMA per tap; then one lane per band sums its tasks
-        if (!(SED_LM_ABLATE & 2))
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                f2 acc = {0.f, 0.f};
-                const f2* pp = tbw + u * WBUF + tlo[r];
-#pragma unroll
-                for (int i = 0; i < TASK_TAPS / 2; ++i) {
-                    acc = pk_fma_tap<false>(pp[2 * i], tw_[r][i], acc);
-                    acc = pk_fma_tap<true>(pp[2 * i + 1], tw_[r][i], acc);
-                }
-                tbw[u * WBUF + 544 + lane + 64 * r] = acc;      // mel partials [MAX_TASKS] behind the 513 (+ read-ahead) power pairs
-            }
-        wave_lds_fence();
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int ta = ta0 + 2 * u;
-            const f2* mp = tbw + u * WBUF + 544;
-            f2 m = {0.f, 0.f};
-            band_sum(mp, bd, max_band_tasks, m);
-            float* o = out + ((long)b * T_frames + ta) * 64 + lane;
-            // 10 log10(x) = 10 log10(2) log2(x) on v_log_f32 everywhere except AT the clamp, where the reference yields
-            // exactly 10*log10(amin)
-            if (ta < T_frames) o[0] = m.x > amin ? 3.0102999566398120f * __log2f(m.x) : floor_db;
-            if (ta + 1 < T_frames) o[64] = m.y > amin ? 3.0102999566398120f * __log2f(m.y) : floor_db;
-        }
-    }
-#undef SED_LM_LOAD
-}
-
-// ---- variant 32: 1024 = 32 x 32, ONE transposition --------------------------------------------------------------------
-// A half-wave (32 lanes) owns one complex FFT = one frame pair, 32 complex values per lane: radix-32 in registers over n1
-// (n = 32 n1 + n2, lane = n2), twiddle W1024^(n2 k1), ONE padded-LDS transposition, radix-32 over n2 (lane = row k1, output
-// X[k1 + 32 k2] in register k2).  Rows k1 and 32 - k1 sit on ADJACENT lanes, so the mirror bin Z[1024 - k] of the real-spectrum
-// unpack is the neighbour's register 31 - k2 (DPP quad_perm, no LDS); rows 0 and 16 mirror onto themselves and are patched by
-// selects.  LDS stores per pair: 8 KB (transposition) + 4 KB (power pairs) instead of 29 KB for the 16 x 16 x 4 variant.
 constexpr int T32 = 33;                          // transposition row stride in float2 (32 + 1 pad)
 constexpr int WBUF32 = 32 * T32;                 // 1056 float2 per half-wave: transposition / powers / mel partials, aliased
 
@@ -555,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void logmel32_kernel(const T* __restrict__ 
 }
 
 template <typename T>
-int launch_logmel(const T* wave, int B2, int L, const float* window, const float* tw1024t, const float* tw64t,
+int launch_logmel(const T* wave, int B2, int L, const float* window, const float* tw1024t,
                   const int* tasks, int ntasks, const int* bands, int max_band_tasks, const float* mel_w, int mel_nnz, float amin,
                   float* out, hipStream_t stream) {
     if (B2 <= 0 || L <= NFFT / 2 || (long)L + 2 * NFFT >= (1L << 31) || mel_nnz <= 0 || mel_nnz > MELW_MAX || ntasks <= 0 || ntasks > MAX_TASKS ||
@@ -563,16 +330,9 @@ int launch_logmel(const T* wave, int B2, int L, const float* window, const float
         return SED_EINVAL;
     int T_frames = L / HOP + 1;
     dim3 grid(sed_cdiv(T_frames, 4 * FPW), B2);
-#if SED_LM_VARIANT == 32
     hipLaunchKernelGGL(logmel32_kernel<T>, grid, dim3(256), 0, stream, wave, L, T_frames, window,
                        reinterpret_cast<const float2*>(tw1024t), reinterpret_cast<const int4*>(tasks), ntasks,
                        reinterpret_cast<const int4*>(bands), max_band_tasks, mel_w, amin, (float)(10.0 * log10((double)amin)), out);
-#else
-    hipLaunchKernelGGL((logmel_kernel<T, SED_LM_PAIRS>), grid, dim3(256), 0, stream, wave, L, T_frames, window,
-                       reinterpret_cast<const float2*>(tw1024t), reinterpret_cast<const float2*>(tw64t),
-                       reinterpret_cast<const int4*>(tasks), ntasks, reinterpret_cast<const int4*>(bands), max_band_tasks, mel_w,
-                       amin, (float)(10.0 * log10((double)amin)), out);
-#endif
     SED_LAUNCH_CHECK();
     return 0;
 }
@@ -580,19 +340,15 @@ int launch_logmel(const T* wave, int B2, int L, const float* window, const float
 }  // namespace
 
 SED_API int sed_logmel_f32(const float* wave, int B2, int L, const float* window, const float* tw1024t,
-                           const float* tw64t, const int* mel_tasks, int n_tasks, const int* mel_bands, int max_band_tasks,
+                           const int* mel_tasks, int n_tasks, const int* mel_bands, int max_band_tasks,
                            const float* mel_w, int mel_nnz, float amin, float* out, hipStream_t stream) {
-    return launch_logmel<float>(wave, B2, L, window, tw1024t, tw64t, mel_tasks, n_tasks, mel_bands, max_band_tasks, mel_w, mel_nnz,
+    return launch_logmel<float>(wave, B2, L, window, tw1024t, mel_tasks, n_tasks, mel_bands, max_band_tasks, mel_w, mel_nnz,
                                 amin, out, stream);
 }
 
 SED_API int sed_logmel_i16(const short* wave, int B2, int L, const float* window, const float* tw1024t,
-                           const float* tw64t, const int* mel_tasks, int n_tasks, const int* mel_bands, int max_band_tasks,
+                           const int* mel_tasks, int n_tasks, const int* mel_bands, int max_band_tasks,
                            const float* mel_w, int mel_nnz, float amin, float* out, hipStream_t stream) {
-    return launch_logmel<short>(wave, B2, L, window, tw1024t, tw64t, mel_tasks, n_tasks, mel_bands, max_band_tasks, mel_w, mel_nnz,
+    return launch_logmel<short>(wave, B2, L, window, tw1024t, mel_tasks, n_tasks, mel_bands, max_band_tasks, mel_w, mel_nnz,
                                 amin, out, stream);
 }
-
-// FFT factorisation the library was built with: 32 -> tw1024t is [32 k1][32 n2] = exp(-2 pi i n2 k1 / 1024) and tw64t is unused;
-// 16 -> the [16][64] / [16][4] tables described in sed_hip.h.
-SED_API int sed_logmel_variant(void) { return SED_LM_VARIANT; }

@@ -187,20 +187,14 @@ MEL_TASK_TAPS = 12
 def frontend_tables(window, melW, device):
     """window: (1024,) tensor = conv_real.weight[0,0,:]; melW (513,64) tensor.  Returns the device tables the
     log-mel kernel needs (FFT twiddles + the mel filter bank cut into <= 12-tap tasks)."""
-    if _lib.lib().sed_logmel_variant() == 32:                                     # 1024 = 32 x 32
-        tw = np.exp(-2j * np.pi * (np.arange(32)[None, :] * np.arange(32)[:, None]) / 1024.0)   # [32 k1][32 n2]
-    else:                                                                         # 1024 = 16 x 16 x 4
-        tw = np.exp(-2j * np.pi * (np.arange(64)[None, :] * np.arange(16)[:, None]) / 1024.0)   # [16 k1][64 m]
+    tw = np.exp(-2j * np.pi * (np.arange(32)[None, :] * np.arange(32)[:, None]) / 1024.0)   # [32 k1][32 n2]
     tw1024t = np.stack([tw.real, tw.imag], axis=-1).astype(np.float32)
-    t64 = np.exp(-2j * np.pi * (np.arange(16)[:, None] * np.arange(4)[None, :]) / 64.0)   # [16 k2][4 n3]
-    tw64t = np.stack([t64.real, t64.imag], axis=-1).astype(np.float32)
     W = melW.detach().cpu().numpy().astype(np.float32)                           # (513, 64)
     tasks, bands, vals = mel_task_tables(W)
     dev = torch.device(device)
     return {
         "window": window.detach().to(dev, torch.float32).contiguous(),
         "tw1024t": torch.from_numpy(tw1024t).to(dev).contiguous(),
-        "tw64t": torch.from_numpy(tw64t).to(dev).contiguous(),
         "mel_tasks": torch.from_numpy(tasks).to(dev).contiguous(),
         "n_tasks": int(tasks.shape[0]),
         "mel_bands": torch.from_numpy(bands).to(dev).contiguous(),
@@ -286,7 +280,7 @@ def logmel(wave, tables, amin=1e-10):
         wave = wave.float()
     in_bytes = 2 if wave.dtype == torch.int16 else 4
     with _timed("logmel_frontend", float(B2) * (L * in_bytes + T * 64 * 4)):      # "flops" slot carries ALGORITHMIC BYTES
-        _call(name, _ptr(wave), B2, L, _ptr(tables["window"]), _ptr(tables["tw1024t"]), _ptr(tables["tw64t"]),
+        _call(name, _ptr(wave), B2, L, _ptr(tables["window"]), _ptr(tables["tw1024t"]),
               _ptr(tables["mel_tasks"]), tables["n_tasks"], _ptr(tables["mel_bands"]), tables["max_band_tasks"],
               _ptr(tables["mel_w"]), tables["mel_nnz"], amin, _ptr(out), _stream())
     return out
