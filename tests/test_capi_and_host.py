@@ -238,3 +238,35 @@ def test_parameter_initialisation_follows_the_reference_recipes():
         n = w_hh[512:].double()
         assert (n @ n.T - torch.eye(256, dtype=torch.float64)).abs().max() < 1e-5
         assert torch.all(sd["gru.bias_ih_l0" + sfx] == 0) and torch.all(sd["gru.bias_hh_l0" + sfx] == 0)
+
+
+def test_mel_task_tables_reproduce_the_filter_bank_and_are_bank_conflict_free():
+    """ops.mel_task_tables (host side of the log-mel kernel's mel stage): the <= 12-bin task windows with their zero-padded
+    weights add up to exactly the 513x64 matrix, every band lists its task slots, and within each group of 32 slots the
+    window starts differ mod 32 (the kernel's ds_read_b64 of the (Pa, Pb) pairs is then conflict-free).  Also for filter banks
+    other than the reference's (fmin / fmax changed), where the conflict-free matching may fail and any placement is allowed."""
+    from sound_event_detection_dcase2017_task4_amd import ops
+    from sound_event_detection_dcase2017_task4_amd.pytorch.models import _slaney_mel
+    with pytest.raises(RuntimeError, match="does not fit"):          # a band wider than 4 x 12 bins: refused loudly
+        ops.mel_task_tables(np.ascontiguousarray(_slaney_mel(32000, 1024, 64, 0, 16000).T.astype(np.float32)))
+    for fmin, fmax, strict in ((50, 14000, True), (300, 8000, False), (20, 12000, False)):
+        W = np.ascontiguousarray(_slaney_mel(32000, 1024, 64, fmin, fmax).T.astype(np.float32))     # (513, 64)
+        tasks, bands, vals = ops.mel_task_tables(W)
+        assert tasks.shape == (128, 4) and bands.shape == (64, 4) and vals.shape == (128 * 12,)
+        R = np.zeros_like(W)
+        for s in range(128):
+            lo, cnt, off, band = tasks[s]
+            assert 0 <= lo and lo + 12 <= 513 + 16 and off == 12 * s
+            for i in range(12):
+                if vals[off + i] != 0:
+                    assert cnt == 12 and lo + i < 513
+                    R[lo + i, band] += vals[off + i]
+        assert np.array_equal(R, W)
+        for m in range(64):
+            slots = [int(s) for s in bands[m] if s >= 0]
+            assert all(tasks[s][3] == m and tasks[s][1] == 12 for s in slots)
+            assert len(slots) == len({s for s in range(128) if tasks[s][1] > 0 and tasks[s][3] == m})
+        if strict:
+            for g in range(4):
+                starts = [int(tasks[s][0]) % 32 for s in range(32 * g, 32 * g + 32)]
+                assert len(set(starts)) == 32, (g, starts)
