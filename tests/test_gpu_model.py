@@ -451,3 +451,77 @@ def test_low_noise_training_fixture_vs_float64_reference(mt, golden_dir):
             assert (d > 0.1 * travel).mean() <= 0.10, (k, float((d > 0.1 * travel).mean()))
         assert d.mean() <= (0.05 if d.size >= 1024 else 0.10) * travel, (k, float(d.mean()))
     print("after three steps, worst over tensors (gates: 1e-2, 0.05, 0.10, 0.10):", worst)
+
+
+@pytest.mark.parametrize("mt", ["Cnn_9layers_FrameAvg", "Cnn_9layers_Gru_FrameAtt"])
+def test_twenty_step_loss_trajectory_vs_oracle(mt):
+    """Training dynamics, not just one step: 20 optimiser steps on one fixed batch of 8 waveforms (fresh mixup lambdas and
+    SpecAugment stripes every step) on the HIP path and on the CPU oracle (main.py:281-319 loop body, Adam amsgrad).
+    Adam's first updates are +-lr * sign(gradient) on EVERY entry, so entries whose gradient is rounding noise walk
+    differently in any two fp32 evaluations, and on this tiny batch the curves separate after a few steps.  Yardstick,
+    measured with the oracle alone on this recipe (FrameAvg): fp32 with 8 threads vs fp32 with 1 thread differ by up to
+    9.9e-3 in loss, fp32 vs float64 by 1.7e-2 .. 2.7e-2.  Gate: the first three steps within 1e-4 (measured 3e-5), the
+    first six within 1e-3, every step within 3e-2 (measured 1.2e-2) and the mean difference within 1e-2; both runs must have
+    learnt the batch; the BatchNorm running statistics are compared against the oracle's own spread (below)."""
+    from sound_event_detection_dcase2017_task4_amd.pytorch.losses import get_loss_func
+    from sound_event_detection_dcase2017_task4_amd.pytorch.pytorch_utils import do_mixup
+    from sound_event_detection_dcase2017_task4_amd.optim import FusedAdamAmsgrad
+    seed, rows, L, steps = SEEDS[mt], 8, 32000, 20
+    T = L // 320 + 1
+    xw = waves(2700 + seed, rows, L)
+    tg = targets(2800 + seed, rows)
+    rs = np.random.RandomState(4321)
+    lams = [ofe.mixup_lambdas(rows, rs).astype(np.float32) for _ in range(steps)]
+    torch.manual_seed(77 + seed)
+    stripes = [ofe.draw_specaug_stripes(rows, T) for _ in range(steps)]
+
+    m = build(mt)
+    opt = FusedAdamAmsgrad(m, lr=1e-3, betas=(0.9, 0.999), eps=1e-08)
+    loss_func = get_loss_func("clip_bce")
+    xg, tgg = torch.from_numpy(xw).cuda(), torch.from_numpy(tg).cuda()
+    ours = []
+    m.train()
+    for it in range(steps):
+        lam = torch.from_numpy(lams[it]).cuda()
+        o = m(xg, lam, specaug_stripes=stripes[it])
+        loss = loss_func(o, {"target": do_mixup(tgg, lam)})
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        ours.append(loss.item())
+
+    st = om.recipe_state(mt, seed)
+    unused = set(om.unused_keys(mt))
+    keys = [k for k in om.trainable_keys(mt) if k not in unused]
+    for k in keys:
+        st[k].requires_grad_(True)
+    state = {k: [torch.zeros_like(st[k]) for _ in range(3)] for k in keys}
+    xc, tc = torch.from_numpy(xw), torch.from_numpy(tg)
+    want = []
+    for it in range(steps):
+        lam = torch.from_numpy(lams[it])
+        o = om.forward(mt, st, xc, training=True, mixup_lambda=lam, stripes=stripes[it])
+        loss = om.clip_bce(o, {"target": om.do_mixup(tc, lam).clamp(max=1.0)})
+        grads = torch.autograd.grad(loss, [st[k] for k in keys])
+        with torch.no_grad():
+            for k, g in zip(keys, grads):
+                mm, v, vmax = state[k]
+                om.adam_amsgrad_step(st[k], g, mm, v, vmax, it + 1, 1e-3)
+        want.append(loss.item())
+
+    diff = np.abs(np.array(ours) - np.array(want))
+    print("loss curve ours  :", np.round(ours, 4).tolist())
+    print("loss curve oracle:", np.round(want, 4).tolist())
+    print("max |difference| %.2e at step %d" % (diff.max(), int(diff.argmax())))
+    assert diff[0] < 2e-5 and diff[:3].max() < 1e-4 and diff[:6].max() < 1e-3, diff
+    assert diff.max() < 3e-2 and diff.mean() < 1e-2, diff
+    assert ours[-1] < 0.8 * ours[0] and want[-1] < 0.8 * want[0]
+    # The BatchNorm running statistics integrate the whole trajectory.  The oracle's own spread on this recipe (8 threads
+    # vs 1 thread vs float64): bn0.running_mean 4e-7, conv_block1.bn1.running_var 6e-4, conv_block4.bn2.running_var
+    # 7e-2 .. 8e-2 (lr = 1e-3 is 4 % of a block-4 weight's scale PER STEP, so sign walks of noise-level entries show there).
+    sd = m.state_dict()
+    for k, gate in (("bn0.running_mean", 1e-5), ("conv_block1.bn1.running_var", 5e-3), ("conv_block4.bn2.running_var", 0.25)):
+        a, b = sd[k].double().cpu().numpy(), st[k].double().numpy()
+        err = np.sqrt(((a - b) ** 2).sum() / (b ** 2).sum())
+        print("%s relative L2 %.2e (gate %.0e)" % (k, err, gate))
+        assert err < gate, (k, err)
