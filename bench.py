@@ -263,6 +263,8 @@ def main():
                   h2d=args.h2d)
     B2 = wl.B2
     dt, loss, timing = wl.run(args.steps, args.warmup, timing=True)
+    bucket_order = list(wl.opt.buckets.last_issue_order)
+    parallel.shutdown()               # all ranks: barrier + destroy the process group; rank 0 then reports alone
     if rank != 0:
         return
     bucket_ranges = [[lo, hi] for lo, hi in wl.opt.buckets.ranges]
@@ -330,8 +332,8 @@ def main():
                                                                          " (modified by flags)"),
                    "global_batch": B * world, "waveforms_per_step": B2 * world,
                    "parallelism": "dp%d" % world + (" (TEST MODE: ranks share one GPU over gloo)" if share_gpu else ""),
-                   "grad_allreduce": "%d buckets of the flat fp32 gradient (elements %s), issued from inside backward"
-                                     % (len(bucket_ranges), bucket_ranges)},
+                   "grad_allreduce": "%d buckets of the flat fp32 gradient (elements %s), issued from inside backward in the "
+                                     "order %s" % (len(bucket_ranges), bucket_ranges, bucket_order)},
         "waveforms_per_s": round(B2 * world * args.steps / dt, 2),
         "loss": round(loss, 5),
         "roofline": roofline,

@@ -73,6 +73,17 @@ def respawn_under_torchrun(n_gpus, script, argv):
     os.execvpe(sys.executable, cmd, env)
 
 
+def shutdown():
+    """Orderly end of a multi-rank job: every rank arrives, then the process group (its RCCL communicators and streams)
+    is torn down before the interpreter exits, so that no rank is left inside a collective or prints a leaked-group
+    warning.  No-op for a single process."""
+    if dist.is_initialized():
+        try:
+            dist.barrier()
+        finally:
+            dist.destroy_process_group()
+
+
 def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 

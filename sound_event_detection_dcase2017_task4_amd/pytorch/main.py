@@ -29,7 +29,7 @@ import numpy as np
 import torch
 import torch.utils.data
 
-from .. import parallel
+from .. import ops, parallel
 from ..optim import FusedAdamAmsgrad
 from ..utils.config import (sample_rate, classes_num, mel_bins, fmin, fmax, window_size, hop_size)
 from ..utils.augmentation import draw_specaug_stripes
@@ -182,6 +182,8 @@ def train(args):
         if iteration == args.stop_iteration:
             break
         iteration += 1
+    ops.check_device_errors(synchronize=True)
+    parallel.shutdown()
 
 
 def inference_prob(args):
