@@ -352,6 +352,13 @@ class Bn0AugMix(torch.autograd.Function):
         else:
             st = bn_eval_affine(bn_w, bn_b, running_mean, running_var)
             stripes, lam = None, None
+        # the C ABI takes plain pointers: sizes are checked here (a short lambda / stripe table would be read out of bounds)
+        if lam is not None and (lam.numel() != B2 or B2 % 2):
+            raise ValueError("mixup_lambda must hold one weight per waveform of an EVEN batch (pytorch_utils.py:80-93): "
+                             "got %d for a batch of %d" % (lam.numel(), B2))
+        if stripes is not None and (tuple(stripes.shape) != (B2, 8) or stripes.dtype != torch.int32):
+            raise ValueError("specaug_stripes must be int32 (batch, 8) = [tb0, td0, tb1, td1, fb0, fd0, fb1, fd1] per "
+                             "waveform: got %s %s for a batch of %d" % (stripes.dtype, tuple(stripes.shape), B2))
         Bout = B2 // 2 if lam is not None else B2
         out = torch.empty((Bout, T, 64), dtype=torch.float32, device=dev)
         _call("sed_bn0_aug_mix_fwd", _ptr(lm), B2, T, _ptr(st.scale), _ptr(st.shift), _ptr(stripes), _ptr(lam), _ptr(out),
@@ -1023,6 +1030,9 @@ def mixup_rows(x, lam):
     x = _f32c(x)
     lam = _f32c(lam)
     B2 = x.shape[0]
+    if B2 == 0 or B2 % 2 or lam.numel() != B2:
+        raise ValueError("do_mixup needs an even, non-empty batch and one lambda per row (pytorch_utils.py:80-93): "
+                         "got %d rows and %d lambdas" % (B2, lam.numel()))
     D = x.numel() // B2
     out = torch.empty((B2 // 2,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
     _call("sed_mixup_rows", _ptr(x), _ptr(lam), B2, D, _ptr(out), _stream())
