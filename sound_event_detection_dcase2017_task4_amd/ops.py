@@ -5,6 +5,7 @@ bookkeeping; every computation is a hand-written HIP kernel in libsed_hip.so.  T
 CPU tensors raises.
 """
 import ctypes
+import os
 import math
 import weakref
 
@@ -25,6 +26,64 @@ USE_WINOGRAD = 2          # 2: 2-D F(2x2,3x3) where supported, else 1-D F(2,3), 
 POOL_BWD_WINDOWED = True
 POOL_BWD_GAMMA_MIN = 1e-2
 USE_FUSED_GRU = True        # False: per-step GEMM + gate launches (any hidden size; the fused step kernels are built for 256)
+
+# Weight-gradient kernels (MFMA-bound, off the critical path of backward: nothing downstream reads dW) are issued on a SIDE
+# HIP stream beside the HBM-bound BatchNorm / pool backward passes of the main stream (fork/join, never beside another
+# MFMA kernel -- two MFMA kernels sharing the CUs measured 2-4 % slower than back to back, an MFMA kernel + an elementwise
+# pass 0-8 % faster: tools/stream_overlap_probe.py).  The MFMA kernel owns every VGPR of the CUs it runs on, so the short
+# kernels only get the slots its workgroups free as they retire: the step gains 1.0-1.6 % (A/B on one box), not the 5 % a
+# perfect overlap would give.  SED_WGRAD_SIDE_STREAM=0 turns it off (A/B runs).
+WGRAD_SIDE_STREAM = os.environ.get("SED_WGRAD_SIDE_STREAM", "1") != "0"
+_SIDE = {}
+_PENDING = []            # [(event recorded on the side stream, sink or None)] of weight gradients not yet joined
+
+
+def _side_stream(device):
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    st = _SIDE.get(key)
+    if st is None:
+        # default priority: the device offers (0, -1) only, i.e. nothing BELOW the main stream, and a high-priority side
+        # stream starves the main one (measured 265 instead of 95 ms/step)
+        st = _SIDE[key] = torch.cuda.Stream(device=key)
+    return st
+
+
+def join_side_stream():
+    """Main stream waits for every weight gradient issued on the side stream; their sinks report ready (the bucketed
+    all-reduce may fire here).  Called at the join points of ConvBlockFn.backward and once when the backward pass ends."""
+    if not _PENDING:
+        return
+    main = torch.cuda.current_stream()
+    pend = list(_PENDING)
+    del _PENDING[:]
+    for ev, sink in pend:
+        main.wait_event(ev)
+    for ev, sink in pend:
+        if sink is not None:
+            sink.done()
+
+
+def _fork_wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None):
+    """_wgrad on the side stream behind everything enqueued on the main stream so far.  With a sink the gradient lands in
+    the flat buffer and is joined later (join_side_stream); without one the tensor is returned after an immediate join."""
+    main = torch.cuda.current_stream()
+    side = _side_stream(x.device)
+    side.wait_stream(main)
+    for t in (x, gy) + ((in_st.scale, in_st.shift) if in_st is not None else ()):
+        t.record_stream(side)                    # main may free them before the side stream has read them
+    with torch.cuda.stream(side):
+        dw = _wgrad(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=False)
+        ev = torch.cuda.Event()
+        ev.record(side)
+    if not _PENDING:
+        torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)    # end of this backward pass
+    _PENDING.append((ev, sink))
+    if sink is None:
+        join_side_stream()
+        dw.record_stream(main)
+        return dw
+    return None
+
 
 # bench.py sets this to a dict to HIP-event-time the MFMA kernels inside its timed region:
 # {tag: [(start_event, end_event, algorithmic_flops), ...]}.  None = no instrumentation.
@@ -459,7 +518,7 @@ def _wgrad_wino_ok(W, Cin, Cout):
     return W in (8, 16, 32, 64) and Cin % 64 == 0 and Cout % 64 == 0
 
 
-def _wgrad_wino(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None):
+def _wgrad_wino(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True):
     ns, pps = ctypes.c_int(0), ctypes.c_int(0)
     nfl = _lib.lib().sed_wgrad_wino_partial_floats(B * H * W, Cin, Cout, ctypes.byref(ns), ctypes.byref(pps))
     partial = torch.empty((nfl,), dtype=torch.float32, device=x.device)
@@ -468,10 +527,10 @@ def _wgrad_wino(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None):
                 2.0 * 9 * B * H * W * Cin * Cout):
         _call("sed_conv3x3_wgrad_wino", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
               _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, _stream())
-    return _ret(sink, dw)
+    return _ret(sink, dw) if signal else (None if sink is not None else dw)
 
 
-def _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None):
+def _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True):
     ns, ups = ctypes.c_int(0), ctypes.c_int(0)
     nfl = _lib.lib().sed_wgrad_wino2_partial_floats(B, H, W, Cin, Cout, ctypes.byref(ns), ctypes.byref(ups))
     if nfl <= 0:
@@ -482,18 +541,18 @@ def _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None):
                 2.0 * 9 * B * H * W * Cin * Cout):
         _call("sed_conv3x3_wgrad_wino2", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
               _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, _stream())
-    return _ret(sink, dw)
+    return _ret(sink, dw) if signal else (None if sink is not None else dw)
 
 
-def _wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None):
+def _wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True):
     if USE_WINOGRAD >= 2 and W in (8, 16, 32, 64) and Cin % 32 == 0 and Cout % 64 == 0:
-        return _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink)
+        return _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=signal)
     if USE_WINOGRAD and _wgrad_wino_ok(W, Cin, Cout):
-        return _wgrad_wino(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink)
-    return _wgrad_direct(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink)
+        return _wgrad_wino(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=signal)
+    return _wgrad_direct(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=signal)
 
 
-def _wgrad_direct(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None):
+def _wgrad_direct(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True):
     ns, pps = ctypes.c_int(0), ctypes.c_int(0)
     nfl = _lib.lib().sed_wgrad_partial_floats(B * H * W, Cin, Cout, 9, ctypes.byref(ns), ctypes.byref(pps))
     partial = torch.empty((nfl,), dtype=torch.float32, device=x.device)
@@ -502,7 +561,7 @@ def _wgrad_direct(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None):
                 2.0 * 9 * B * H * W * Cin * Cout):
         _call("sed_conv3x3_wgrad", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
               _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, _stream())
-    return _ret(sink, dw)
+    return _ret(sink, dw) if signal else (None if sink is not None else dw)
 
 
 
@@ -627,11 +686,18 @@ class ConvBlockFn(torch.autograd.Function):
         gy2 = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
         _call("sed_bn_relu_pool_bwd_apply", _ptr(y2), _ptr(g_out), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift),
               _ptr(coef2), _ptr(gy2), _stream())
-        # conv2: wgrad (operand relu(bn1(y1)) on the fly) and dgrad fused with relu-mask + BN1 backward sums
-        dw2 = _wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=st1, sink=sk[5])
+        # conv2: dgrad fused with relu-mask + BN1 backward sums, then the weight gradient (operand relu(bn1(y1)) on the
+        # fly).  With gradient sinks the weight gradients run on the side stream: conv2's beside BN1's backward passes
+        # below, conv1's beside the NEXT block's pool backward (joined there, right here, before its first MFMA kernel).
+        join_side_stream()
+        fork = WGRAD_SIDE_STREAM
         npb, _, nfb = _conv_parts(B, H, W, Cout, Cout)
         partb = torch.empty((nfb,), dtype=torch.float32, device=dev)
         gy1 = _conv_fwd_like(gy2, w2, B, H, W, Cout, Cout, dgrad=True, epi=2, partials=partb, yprev=y1, p_st=st1)
+        if fork and sk[5] is not None:
+            dw2 = _fork_wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=st1, sink=sk[5])
+        else:
+            dw2 = _wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=st1, sink=sk[5])
         del gy2
         dg1, db1, coef1 = bn_bwd_finalize(partb, npb, M, st1, batch_stats=ctx.training, sinks=(sk[1], sk[2]))
         # conv1
@@ -648,10 +714,15 @@ class ConvBlockFn(torch.autograd.Function):
             _call("sed_conv1_bwd", _ptr(x), _ptr(w1), _ptr(gy1), _ptr(y1), _ptr(coef1), B, H, W, _ptr(dw1), _ptr(gx), _ptr(dwp),
                   _ptr(tbuf), _stream())
             dw1 = _ret(sk[0], dw1)
+            join_side_stream()
         else:
-            dw1 = _wgrad(x, gy1, B, H, W, Cin, Cout, sink=sk[0])
+            join_side_stream()                         # conv2's weight gradient is done before the next MFMA kernel starts
             if ctx.needs_input_grad[0]:
                 gx = _conv_fwd_like(gy1, w1, B, H, W, Cout, Cin, dgrad=True, epi=0)
+            if fork and sk[0] is not None:
+                dw1 = _fork_wgrad(x, gy1, B, H, W, Cin, Cout, sink=sk[0])
+            else:
+                dw1 = _wgrad(x, gy1, B, H, W, Cin, Cout, sink=sk[0])
         return gx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, None, None, None
 
 
