@@ -289,8 +289,8 @@ def main():
     if fe:
         ms = sum(a.elapsed_time(b) for a, b, _ in fe)
         gbps = sum(nb for _, _, nb in fe) / (ms * 1e-3) / 1e9
-        tr, src = pmc_traffic(["logmel_kernel"]) if default_workload else (None, None)
-        frontend = {"kernel": "logmel_kernel (STFT+mel+log, K1)", "bound": "hbm", "achieved": round(gbps, 1),
+        tr, src = pmc_traffic(["logmel32_kernel"]) if default_workload else (None, None)
+        frontend = {"kernel": "logmel32_kernel (STFT+mel+log, K1)", "bound": "hbm", "achieved": round(gbps, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": tr,
                     "traffic_source": src, "avg_launch_ms": round(ms / len(fe), 4),
                     "bytes_per_waveform": int(fe[0][2] / B2)}

@@ -193,3 +193,23 @@ def test_bench_gpus_n_never_degrades_to_one_rank():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8"], capture_output=True, text=True, env=env,
                        timeout=600)
     assert r.returncode != 0 and "needs 8 GPUs" in r.stderr and '"n_gpus"' not in r.stdout
+
+
+def test_bench_roofline_traffic_lookup_matches_the_kernels_that_exist():
+    """bench.py fills roofline.traffic / roofline_frontend.traffic from the committed PMC digest by kernel-name substring:
+    the substrings must name kernels that exist in csrc/ AND in the newest profiles/rNN/pmc_traffic.json."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    csrc = os.path.join(REPO, "sound_event_detection_dcase2017_task4_amd", "csrc")
+    source = "".join(open(os.path.join(csrc, f)).read() for f in os.listdir(csrc) if f.endswith(".hip"))
+    text = open(os.path.join(REPO, "bench.py")).read()
+    import re
+    front = re.search(r'pmc_traffic\(\["([a-z0-9_]+)"\]\)', text).group(1)
+    for sub in [front] + [s for subs in bench.FAMILY_KERNELS.values() for s in subs]:
+        assert sub in source, sub
+    tr, src = bench.pmc_traffic([front])
+    assert tr and tr > 786e6 and src.startswith("profiles/r"), (tr, src)       # >= the algorithmic 786.6 MB per launch
+    tr, _ = bench.pmc_traffic(bench.FAMILY_KERNELS["conv3x3_wino2d_mfma(fwd+dgrad)"])
+    assert tr and tr > 1e9

@@ -11,11 +11,23 @@ OUT=$R/gpurun_out/prof_$ROUND
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 B="python $R/bench.py --no_cpu_baseline --no_extra"
+# Pass 1: the default command (weight gradients on the side stream).  Two kernels then run at once and each one's duration
+# includes the time it waited for CU slots, so kernel-time sums no longer add up to the step; the conv_wino2 kernels (the
+# roofline's dominant family) never run beside another kernel and are unaffected.
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $B --steps 5 --warmup 2 > $OUT/bench_line_under_rocprofv3.json 2> $OUT/stats.err
+# Pass 2 and the counters: weight gradients on the MAIN stream (SED_WGRAD_SIDE_STREAM=0) -- clean per-kernel durations.
+export SED_WGRAD_SIDE_STREAM=0
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_serial -o bench -- $B --steps 5 --warmup 2 > $OUT/bench_line_under_rocprofv3_main_stream_only.json 2> $OUT/stats_serial.err
 $B --steps 10 --warmup 3 --by_shape > $OUT/bench_line_steps10_warmup3.json 2> $OUT/by_shape.txt
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sqA SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_WAVES" "sqB SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" \
             "sqC SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES" "sqD MfmaUtil"; do
   set -- $pass; name=$1; shift
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_$name -o p -- $B --steps 1 --warmup 1 > /dev/null 2> $OUT/pmc_$name.err
 done
+unset SED_WGRAD_SIDE_STREAM
+$B --steps 20 --warmup 3 > $OUT/bench_line_default_schedule.json 2> /dev/null
+SED_WGRAD_SIDE_STREAM=0 $B --steps 20 --warmup 3 > $OUT/bench_line_main_stream_only.json 2> /dev/null
+rocprofv3 --kernel-trace --output-format csv -d $OUT/timeline -o t -- $B --steps 2 --warmup 1 > /dev/null 2> $OUT/timeline.err
+python $R/tools/timeline_overlap.py $OUT/timeline/t_kernel_trace.csv > $OUT/timeline_overlap_default_schedule.txt 2>&1
+rm -rf $OUT/timeline
 ls $OUT
