@@ -30,7 +30,9 @@
 // by the co-resident workgroup; of it the output stores are 0.17 ms, the eta exchange 0.03 ms, the statistics 0, the
 // previous-activation loads of the dgrad epilogue 0.33 ms.  Delaying half of the first generation of workgroups by 7-14 us
 // (so that the two workgroups of a CU stay out of phase) changes nothing: the fixed cost is memory-system time (first-touch
-// loads of 32-byte pieces out of 128-byte lines + 4-byte-per-lane stores), not idle issue slots.
+// loads of 32-byte pieces out of 128-byte lines + 4-byte-per-lane stores), not idle issue slots.  Touching the dgrad
+// epilogue's previous-activation lines at kernel start (one 4-byte load per thread, so that they wait in L2) makes the
+// kernel 1-4 % SLOWER: the extra cold requests queue in front of the first A tile.
 namespace {
 
 constexpr int W2_AROWS = 400;                 // >= (2*RP+2) * 2 * S for every supported W (max 396 at W = 64)
