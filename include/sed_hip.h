@@ -166,6 +166,17 @@ int sed_conv3x3_wino2(const float* x, const float* w_wino2, float* y, int B, int
 long sed_wgrad_wino2_partial_floats(int B, int H, int W, int Cin, int Cout, int* nslices_out, int* units_per_slice_out);
 int sed_conv3x3_wgrad_wino2(const float* x, const float* gy, float* dw_oihw, float* partial, int B, int H, int W, int Cin,
                             int Cout, const float* in_scale, const float* in_shift, sed_stream_t stream);
+/* EXPERIMENTAL (round 2; not used by the models): 3x3 convolution on the f16 MFMA pipe with split operands
+ * (x = (hi + lo)/s, three f16 MFMAs per product slab; fp32-level error, csrc/conv_sf16.hip).  Forward-like contract of
+ * sed_conv3x3_wino2 without epilogues: y = conv(relu(in_scale*x + in_shift) or x, w).  wp: sed_conv_sf16_pack_halfs(...)
+ * f16 values written by sed_pack_conv_weights_sf16 (dgrad = 1: operand of the transposed convolution); sa / sw: powers of
+ * two that bring activations / weights into f16 range (|sa*x|, |sw*w| < 65504).  Needs W in {8,16,32,64},
+ * Cin % 16 == 0, Cout % 128 == 0. */
+int sed_conv3x3_sf16_supported(int H, int W, int Cin, int Cout);
+long sed_conv_sf16_pack_halfs(int Cin, int Cout);
+int sed_pack_conv_weights_sf16(const float* w_oihw, int Cout, int Cin, int dgrad, float sw, void* wp, sed_stream_t stream);
+int sed_conv3x3_sf16(const float* x, const void* wp, float* y, int B, int H, int W, int Cin, int Cout,
+                     const float* in_scale, const float* in_shift, float sa, float sw, sed_stream_t stream);
 /* Winograd-domain weight gradient (12 instead of 18 MACs per output pair); same contract as sed_conv3x3_wgrad.
  * Needs W a power of two <= 64 and Cin, Cout % 64 == 0; partial: sed_wgrad_wino_partial_floats(...) floats. */
 long sed_wgrad_wino_partial_floats(long M, int Cin, int Cout, int* nslices_out, int* pix_per_slice_out);

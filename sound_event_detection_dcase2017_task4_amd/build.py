@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsed_hip.so")
-SOURCES = ["logmel.hip", "bn.hip", "conv.hip", "conv_wino.hip", "conv_wino2.hip", "heads.hip", "attention.hip", "gru.hip"]
+SOURCES = ["logmel.hip", "bn.hip", "conv.hip", "conv_wino.hip", "conv_wino2.hip", "conv_sf16.hip", "heads.hip", "attention.hip", "gru.hip"]
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-I", INCLUDE]
 

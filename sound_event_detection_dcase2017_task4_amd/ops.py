@@ -565,6 +565,27 @@ def _wgrad_direct(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True)
 
 
 
+# ---- EXPERIMENTAL split-f16 convolution (csrc/conv_sf16.hip; not used by the models yet)
+
+def pack_sf16(w_oihw, dgrad=False, sw=4096.0):
+    """OIHW fp32 weights -> the split-f16 operand (hi, lo planes, scaled by the power of two sw)."""
+    Cout, Cin = w_oihw.shape[0], w_oihw.shape[1]
+    wp = torch.empty((_lib.lib().sed_conv_sf16_pack_halfs(Cin, Cout),), dtype=torch.float16, device=w_oihw.device)
+    _call("sed_pack_conv_weights_sf16", _ptr(_f32c(w_oihw)), Cout, Cin, 1 if dgrad else 0, float(sw), _ptr(wp), _stream())
+    return wp
+
+
+def conv3x3_sf16(x, wp, B, H, W, Cin, Cout, in_st=None, sa=16.0, sw=4096.0):
+    """y = conv3x3(relu(scale*x + shift) or x) on the f16 MFMA pipe with split operands; x NHWC fp32 -> y NHWC fp32."""
+    y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+    with _timed("conv3x3_sf16_mfma|%d->%d@%dx%d%s" % (Cin, Cout, H, W, "+inT" if in_st is not None else ""),
+                2.0 * 9 * B * H * W * Cin * Cout):
+        _call("sed_conv3x3_sf16", _ptr(x), _ptr(wp), _ptr(y), B, H, W, Cin, Cout,
+              _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None,
+              float(sa), float(sw), _stream())
+    return y
+
+
 def _conv_algo(H, W, Cin, Cout):
     """2 = fused 2-D Winograd F(2x2,3x3), 1 = fused 1-D Winograd F(2,3), 0 = direct implicit GEMM."""
     L = _lib.lib()

@@ -70,6 +70,10 @@ def main():
             runs += [("wino2 fwd epi1+inT", lambda: ops._conv_wino2(x, uf2, B, H, W, ci, co, in_st=st, epi=1, partials=pw2)),
                      ("wino2 fwd epi0    ", lambda: ops._conv_wino2(x, uf2, B, H, W, ci, co)),
                      ("wino2 dgrad epi2  ", lambda: ops._conv_wino2(gy, ud2, B, H, W, co, ci, epi=2, partials=pwb2, yprev=x, p_st=sto))]
+        if args.only in ("", "wino2", "sf16") and L.sed_conv3x3_sf16_supported(H, W, ci, co):
+            wps = ops.pack_sf16(w)
+            runs += [("sf16  fwd epi0    ", lambda: ops.conv3x3_sf16(x, wps, B, H, W, ci, co)),
+                     ("sf16  fwd epi0+inT", lambda: ops.conv3x3_sf16(x, wps, B, H, W, ci, co, in_st=st))]
         if args.only in ("", "wgrad"):
             runs += [("wgrad +inT        ", lambda: ops._wgrad_direct(x, gy, B, H, W, ci, co, in_st=st)),
                      ("wgrad             ", lambda: ops._wgrad_direct(x, gy, B, H, W, ci, co)),
