@@ -69,8 +69,10 @@ int sed_bn_eval_affine(int C, const float* gamma, const float* beta, const float
 int sed_bn_bwd_finalize(const float* partials, int nparts, long N, int C, const float* mean, const float* invstd,
                         const float* scale, int batch_stats, float* dgamma, float* dbeta, float* coef, double* ws,
                         sed_stream_t stream);
-/* g_y = a*dy + b*y + c in place on dy [nrows][C]. */
-int sed_bn_bwd_apply(float* dy_inout, const float* y, long nrows, int C, const float* coef, sed_stream_t stream);
+/* g_y = a*dy + b*y + c in place on dy [nrows][C].  amax_out (nullable, device): receives max |g_y| (the split-f16
+ * convolution that consumes the tensor takes its scale from it; zeroed and accumulated in stream order). */
+int sed_bn_bwd_apply(float* dy_inout, const float* y, long nrows, int C, const float* coef, float* amax_out,
+                     sed_stream_t stream);
 
 /* ---- bn0 + SpecAugmentation + mixup (models.py:287-296; do_mixup pytorch_utils.py:80-93) ----------------------
  * logmel [B2][T][64] -> out [B2 or B2/2][T][64].  stripes [B2][8] = {t_bgn0,t_len0,t_bgn1,t_len1,f_bgn0,f_len0,
@@ -113,7 +115,7 @@ int sed_bn_relu_pool_bwd_reduce(const float* y, const float* g_out, int B, int H
                                 float* partials, int* nparts_out, sed_stream_t stream);
 int sed_bn_relu_pool_bwd_apply(const float* y, const float* g_out, int B, int H, int W, int C, int ph, int pw,
                                const float* scale, const float* shift, const float* coef, float* gy,
-                               sed_stream_t stream);
+                               float* amax_out /* nullable: max |gy|, as in sed_bn_bwd_apply */, sed_stream_t stream);
 
 /* ---- 3x3 convolution, stride 1, pad 1, no bias (nn.Conv2d at models.py:77-85) on fp32 MFMA ---------------------
  * sed_pack_conv_weights: OIHW -> wf [9][Cout][Cin] (forward operand) and wd [9][Cin][Cout], taps flipped (dgrad
@@ -166,17 +168,24 @@ int sed_conv3x3_wino2(const float* x, const float* w_wino2, float* y, int B, int
 long sed_wgrad_wino2_partial_floats(int B, int H, int W, int Cin, int Cout, int* nslices_out, int* units_per_slice_out);
 int sed_conv3x3_wgrad_wino2(const float* x, const float* gy, float* dw_oihw, float* partial, int B, int H, int W, int Cin,
                             int Cout, const float* in_scale, const float* in_shift, sed_stream_t stream);
-/* EXPERIMENTAL (round 2; not used by the models): 3x3 convolution on the f16 MFMA pipe with split operands
- * (x = (hi + lo)/s, three f16 MFMAs per product slab; fp32-level error, csrc/conv_sf16.hip).  Forward-like contract of
- * sed_conv3x3_wino2 without epilogues: y = conv(relu(in_scale*x + in_shift) or x, w).  wp: sed_conv_sf16_pack_halfs(...)
- * f16 values written by sed_pack_conv_weights_sf16 (dgrad = 1: operand of the transposed convolution); sa / sw: powers of
- * two that bring activations / weights into f16 range (|sa*x|, |sw*w| < 65504).  Needs W in {8,16,32,64},
- * Cin % 16 == 0, Cout % 128 == 0. */
+/* 3x3 convolution (forward / dgrad) on the f16 MFMA pipe with SPLIT operands: x = (hi + lo)/s with hi, lo f16 and s a
+ * power of two per tensor, three f16 MFMAs (hi*hi + hi*lo + lo*hi, exact products, fp32 accumulation) per product slab --
+ * the error of a direct fp32 convolution at 3/16 of its MFMA issue time (csrc/conv_sf16.hip).  Same contract as
+ * sed_conv3x3_wino2 (in_scale/in_shift operand transform, epi 0/1/2, partials = sed_conv_sf16_num_parts(...) parts with the
+ * pixel counts appended for epi 1).  wp: sed_conv_sf16_pack_halfs(...) f16 values and wscale[2] (amax, scale) written by
+ * sed_pack_conv_weights_sf16 (dgrad = 1: operand of the transposed convolution).  Activation scale: x_amax (device
+ * pointer to the amax of x, e.g. from sed_amax or a producer kernel) or, when null, the fixed power of two `sa`
+ * (|sa*x| must stay below 65504).  Needs W in {8,16,32,64}, Cin % 16 == 0, Cout % 64 == 0. */
 int sed_conv3x3_sf16_supported(int H, int W, int Cin, int Cout);
 long sed_conv_sf16_pack_halfs(int Cin, int Cout);
-int sed_pack_conv_weights_sf16(const float* w_oihw, int Cout, int Cin, int dgrad, float sw, void* wp, sed_stream_t stream);
-int sed_conv3x3_sf16(const float* x, const void* wp, float* y, int B, int H, int W, int Cin, int Cout,
-                     const float* in_scale, const float* in_shift, float sa, float sw, sed_stream_t stream);
+long sed_conv_sf16_num_parts(int B, int H, int W, int Cout);
+int sed_amax(const float* x, long n, float* amax_out, sed_stream_t stream);
+int sed_pack_conv_weights_sf16(const float* w_oihw, int Cout, int Cin, int dgrad, float* wscale, void* wp,
+                               sed_stream_t stream);
+int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale, float* y, int B, int H, int W, int Cin,
+                     int Cout, const float* in_scale, const float* in_shift, int epi, float* partials,
+                     const float* yprev, const float* p_scale, const float* p_shift, const float* p_mean,
+                     const float* p_invstd, const float* x_amax, float sa, sed_stream_t stream);
 /* Winograd-domain weight gradient (12 instead of 18 MACs per output pair); same contract as sed_conv3x3_wgrad.
  * Needs W a power of two <= 64 and Cin, Cout % 64 == 0; partial: sed_wgrad_wino_partial_floats(...) floats. */
 long sed_wgrad_wino_partial_floats(long M, int Cin, int Cout, int* nslices_out, int* pix_per_slice_out);

@@ -308,8 +308,10 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const float* __re
                                                                const float* __restrict__ invstd,
                                                                const float* __restrict__ coef, int rows_per_block,
                                                                float* __restrict__ partials, float* __restrict__ gy,
-                                                               const float* __restrict__ gamma, float gmin) {
+                                                               const float* __restrict__ gamma, float gmin,
+                                                               float* __restrict__ amax_out) {
     __shared__ float4 red_a[256], red_b[256];
+    float amax = 0.f;
     // PASS 1 with a gamma pointer is the exact fallback of the windowed pass: it runs only when that one declines
     if (PASS == 1 && gamma && !any_small_gamma(gamma, C, gmin)) return;
     const int Ho = H / ph, Wo = W / pw, c4n = C >> 2;
@@ -351,7 +353,12 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const float* __re
             o.x = fmaf(ca.x, dy.x, fmaf(cb.x, v.x, cc.x)); o.y = fmaf(ca.y, dy.y, fmaf(cb.y, v.y, cc.y));
             o.z = fmaf(ca.z, dy.z, fmaf(cb.z, v.z, cc.z)); o.w = fmaf(ca.w, dy.w, fmaf(cb.w, v.w, cc.w));
             reinterpret_cast<float4*>(gy)[r * c4n + c4] = o;
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
+    }
+    if (PASS == 2 && amax_out) {        // amax of the tensor just written, for the split-f16 consumers (conv_sf16.hip)
+        amax = wave_max(amax);
+        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(amax_out), __float_as_uint(amax));
     }
     if (PASS == 1) {
         red_a[threadIdx.x] = sa; red_b[threadIdx.x] = sb;
@@ -418,9 +425,11 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_win_kernel(const float* _
 
 // g_y = a*dy + b*y + c, in place on dy (the conv1-side BN backward, dy produced by the dgrad epilogue)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ dy, const float* __restrict__ y,
-                                                           long nrows, int C, const float* __restrict__ coef) {
+                                                           long nrows, int C, const float* __restrict__ coef,
+                                                           float* __restrict__ amax_out) {
     const int c4n = C >> 2;
     const long total = nrows * c4n;
+    float amax = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         int c4 = (int)(i % c4n);
         float4 ca = reinterpret_cast<const float4*>(coef)[c4], cb = reinterpret_cast<const float4*>(coef)[c4n + c4],
@@ -430,6 +439,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ d
         o.x = fmaf(ca.x, d.x, fmaf(cb.x, v.x, cc.x)); o.y = fmaf(ca.y, d.y, fmaf(cb.y, v.y, cc.y));
         o.z = fmaf(ca.z, d.z, fmaf(cb.z, v.z, cc.z)); o.w = fmaf(ca.w, d.w, fmaf(cb.w, v.w, cc.w));
         reinterpret_cast<float4*>(dy)[i] = o;
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+    }
+    if (amax_out) {
+        amax = wave_max(amax);
+        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(amax_out), __float_as_uint(amax));
     }
 }
 
@@ -582,7 +596,7 @@ SED_API int sed_bn_relu_pool_bwd_reduce_auto(const float* y, const float* g_out,
                        reinterpret_cast<const unsigned*>(cnt), Mp, C, 1.0f / (float)(ph * pw), gamma, beta, rpbw, partials,
                        gamma_min);
     hipLaunchKernelGGL(bn_relu_pool_bwd_kernel<1>, dim3(sed_cdiv(M, rpb)), dim3(256), 0, stream, y, g_out, B, H, W, C, ph, pw,
-                       scale, shift, mean, invstd, (const float*)nullptr, rpb, partials, (float*)nullptr, gamma, gamma_min);
+                       scale, shift, mean, invstd, (const float*)nullptr, rpb, partials, (float*)nullptr, gamma, gamma_min, (float*)nullptr);
     if (nparts_out) *nparts_out = (int)nparts;
     SED_LAUNCH_CHECK();
     return 0;
@@ -604,7 +618,7 @@ SED_API int sed_bn_relu_pool_bwd_reduce(const float* y, const float* g_out, int 
     const int rpb = sed_pool_bwd_rows_per_block((long)B * H * W);
     int nblk = sed_cdiv((long)B * H * W, rpb);
     hipLaunchKernelGGL(bn_relu_pool_bwd_kernel<1>, dim3(nblk), dim3(256), 0, stream, y, g_out, B, H, W, C, ph, pw, scale, shift,
-                       mean, invstd, (const float*)nullptr, rpb, partials, (float*)nullptr, (const float*)nullptr, 0.f);
+                       mean, invstd, (const float*)nullptr, rpb, partials, (float*)nullptr, (const float*)nullptr, 0.f, (float*)nullptr);
     if (nparts_out) *nparts_out = nblk;
     SED_LAUNCH_CHECK();
     return 0;
@@ -613,20 +627,29 @@ SED_API int sed_bn_relu_pool_bwd_reduce(const float* y, const float* g_out, int 
 // pass 2: gy [B][H][W][C]
 SED_API int sed_bn_relu_pool_bwd_apply(const float* y, const float* g_out, int B, int H, int W, int C, int ph, int pw,
                                        const float* scale, const float* shift, const float* coef, float* gy,
-                                       hipStream_t stream) {
+                                       float* amax_out, hipStream_t stream) {
     if (B <= 0 || C < 64 || C > 512 || (256 % (C / 4)) != 0) return SED_EINVAL;
+    if (amax_out) {
+        hipError_t e = hipMemsetAsync(amax_out, 0, sizeof(float), stream);
+        if (e != hipSuccess) return (int)e;
+    }
     const int rpb = sed_pool_bwd_rows_per_block((long)B * H * W);
     int nblk = sed_cdiv((long)B * H * W, rpb);
     hipLaunchKernelGGL(bn_relu_pool_bwd_kernel<2>, dim3(nblk), dim3(256), 0, stream, y, g_out, B, H, W, C, ph, pw, scale, shift,
-                       (const float*)nullptr, (const float*)nullptr, coef, rpb, (float*)nullptr, gy, (const float*)nullptr, 0.f);
+                       (const float*)nullptr, (const float*)nullptr, coef, rpb, (float*)nullptr, gy, (const float*)nullptr, 0.f, amax_out);
     SED_LAUNCH_CHECK();
     return 0;
 }
 
-SED_API int sed_bn_bwd_apply(float* dy_inout, const float* y, long nrows, int C, const float* coef, hipStream_t stream) {
+SED_API int sed_bn_bwd_apply(float* dy_inout, const float* y, long nrows, int C, const float* coef, float* amax_out,
+                             hipStream_t stream) {
     if (nrows <= 0 || (C & 3)) return SED_EINVAL;
+    if (amax_out) {
+        hipError_t e = hipMemsetAsync(amax_out, 0, sizeof(float), stream);
+        if (e != hipSuccess) return (int)e;
+    }
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(nrows * (C / 4))), dim3(256), 0, stream, dy_inout, y, nrows, C,
-                       coef);
+                       coef, amax_out);
     SED_LAUNCH_CHECK();
     return 0;
 }

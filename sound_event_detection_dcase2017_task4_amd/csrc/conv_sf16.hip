@@ -1,20 +1,26 @@
-// 3x3 convolution on the f16 MFMA pipe with SPLIT operands (EXPERIMENTAL, round 2: forward-like use only, not wired
-// into the models; tools/split_f16_study.py is the numerical study, tests/test_gpu_sf16.py the parity test).
+// 3x3 convolution (forward and dgrad) on the f16 MFMA pipe with SPLIT operands.
 //
 //     x = (hi + lo) / s,  hi = f16(s*x),  lo = f16(s*x - hi)            (s = a power of two per tensor)
 //     a*b ~= hi_a*hi_b + hi_a*lo_b + lo_a*hi_b                          (f16 x f16 is exact in the fp32 accumulator)
 //
 // Three v_mfma_f32_32x32x16_f16 replace one K = 16 slab of fp32 MACs: 3/16 of the fp32 MFMA issue time for the same
-// direct-convolution MAC count, 0.42x of the fused Winograd F(2x2,3x3) kernels' MFMA time, at fp32-level error (1.5e-7
-// relative L2 on this model's layer statistics, the same as a direct fp32 convolution; the dropped lo*lo term is 2^-22).
+// direct-convolution MAC count, 0.42x of the fused Winograd F(2x2,3x3) kernels' MFMA time, at the error of a direct fp32
+// convolution (tools/split_f16_study.py: 1.5e-7 relative L2 on this model's layer statistics; the dropped lo*lo term is
+// 2^-22; tests/test_gpu_sf16.py checks the kernel against float64).  Scales: the weights' from their amax (pack kernels,
+// kept on the device), the activations' either fixed (BatchNorm-ed / pooled activations are O(1); 2^4 leaves room up to
+// |x| < 4094 and a NaN shows in the statistics otherwise) or from an amax the producer kernel of a gradient tensor left
+// on the device -- no host synchronisation either way.
 //
-// Dataflow.  A workgroup owns 128 output pixels (TR = 128/W rows x W columns of one image) x 128 output channels; the
-// four waves are 2 pixel halves x 2 channel halves, each a 64 x 64 register tile (4 accumulators).  K-step = 16 input
-// channels: the (TR+2) x (W+2) input patch is converted ONCE to (hi, lo) f16 pairs when it is staged (32-byte LDS row per
-// pixel and plane; the nine taps read shifted windows of it, so the conversion cost is amortised 9 x 128 times), the
-// pre-split weights stream through LDS by LDS-DMA, three taps (one kernel row) per stage, double-buffered.
-// 16-byte chunk index XOR ((row >> 3) & 1) keeps every ds_read_b128 conflict-free (consecutive pixels = consecutive
-// rows, any tap shift).
+// Dataflow.  A workgroup owns 64*MW output pixels (TR rows x W columns of one image) x 64*NW output channels, MW x NW = 4
+// waves, each a 64 x 64 register tile (4 accumulators): MW = 2 for Cout % 128 == 0, MW = 4 (256 pixels x 64 channels) for
+// the 64-channel layers.  K-step = 16 input channels: the (TR+2) x (W+2) input patch is converted ONCE to (hi, lo) f16
+// planes when it is staged (32-byte LDS row per pixel and plane; the nine taps read shifted windows of it, so the
+// conversion is amortised over 9 taps x all output channels), the pre-split weights stream through LDS by LDS-DMA, three
+// taps (one kernel row) per stage, double-buffered.  16-byte chunk index XOR ((row >> 3) & 1) keeps every ds_read_b128
+// conflict-free (consecutive pixels = consecutive rows, for any tap shift).
+//
+// Fusions as in conv_wino2.hip: input relu(scale*x+shift); epilogue 1 = BN statistics (sum, M2) per wave (64 pixels) +
+// the per-part pixel count; epilogue 2 = ReLU mask of the previous activation + BN-backward sums.
 #include "common.h"
 #include "sed_hip.h"
 
@@ -23,21 +29,23 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
-constexpr int SF_AROWS = 264;                  // >= (TR+2) * (W+2): 4*66 at W = 64
-constexpr int SF_APLANE = SF_AROWS * 32;       // bytes per plane (hi / lo)
-constexpr int SF_BN = 128;                     // output channels per workgroup
-constexpr int SF_BPLANE = 3 * SF_BN * 32;      // bytes: 3 taps x 128 co x 16 ci f16
-constexpr int SF_BSTAGE = 2 * SF_BPLANE;
-
 struct Sf16P {
     const float* x;            // [B][H][W][K]
     const _Float16* wp;        // [K/16][3 dy][2 planes][3 dx][N][16]
+    const float* wscale;       // [2]: weights' amax, scale sw (written by the pack kernels)
+    const float* x_amax;       // nullable: amax of x (device), else the fixed scale sa
     float* y;                  // [B][H][W][N]
     const float* in_scale;
     const float* in_shift;
+    float* partials;           // EPI 1: [nparts][2][N] + [nparts] counts; EPI 2: [nparts][2][N]; nparts = B*ntile*MW
+    const float* yprev;
+    const float* p_scale;
+    const float* p_shift;
+    const float* p_mean;
+    const float* p_invstd;
     int B, H, W, K, N;
     int logW, TR, ntile;
-    float sa, inv;             // activation scale (power of two), 1 / (sa * sw)
+    float sa;
 };
 
 __device__ __forceinline__ int sf_sw(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 3) & 1)) << 4); }
@@ -48,23 +56,42 @@ __device__ __forceinline__ int xcd_remap_sf(int bid, int nblk) {
     return base + (bid >> 3);
 }
 
-template <bool INT>
+// power of two that brings a tensor of this amax to [2^13, 2^14)
+__device__ __forceinline__ float sf_scale_of(float amax) {
+    if (!(amax > 0.f)) return 1.f;
+    int e;
+    frexpf(amax, &e);
+    e = 14 - e;
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    return ldexpf(1.f, e);
+}
+
+template <int MW, bool INT, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_sf16_kernel(Sf16P p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * SF_APLANE + 2 * SF_BSTAGE];
+    constexpr int NW = 4 / MW, BN = 64 * NW, RB = BN / 32;
+    constexpr int AROWS = MW == 2 ? 264 : 396;         // >= (TR+2) * (W+2)
+    constexpr int APLANE = AROWS * 32;
+    constexpr int BPLANE = 3 * BN * 32, BSTAGE = 2 * BPLANE;
+    constexpr int NI = MW == 2 ? 4 : 6;                // staging items per thread
+    constexpr int NDMA = 6 * RB / 4;                   // LDS-DMA instructions per wave and stage
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * APLANE + 2 * BSTAGE];
     unsigned char* const As = smem;
-    unsigned char* const Bs = smem + 2 * SF_APLANE;
+    unsigned char* const Bs = smem + 2 * APLANE;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wvu & 1, wn = wvu >> 1;
-    const int nb = p.N / SF_BN;
+    const int wm = wvu % MW, wn = wvu / MW;
+    const int nb = p.N / BN;
     const int logical = xcd_remap_sf(blockIdx.x, gridDim.x);
-    const int n0 = (logical % nb) * SF_BN;
+    const int n0 = (logical % nb) * BN;
     const int t = logical / nb;
     const int b = t / p.ntile, tile = t % p.ntile;
     const int W = p.W, logW = p.logW, TR = p.TR, WP = W + 2;
     const int h0 = tile * TR;
     const int KT = p.K >> 4;
+
+    const float sa = p.x_amax ? sf_scale_of(*p.x_amax) : p.sa;
+    const float inv = 1.0f / (sa * p.wscale[1]);
 
     // ---- A staging: item e = tid + 256*i -> patch pixel e >> 2 (row rr, column c), channel quad e & 3
     constexpr int OOB = (int)0x80000000;
@@ -76,10 +103,10 @@ __global__ __launch_bounds__(256, 2) void conv_sf16_kernel(Sf16P p) {
         const_cast<float*>(INT ? p.in_shift : p.x), 0, p.K * 4, 0x00020000);
     const int q4 = tid & 3;
 #define SF_META(i)                                                                                              \
-    bool val##i, sok##i;                                                                                        \
-    int lso##i, aoff##i;                                                                                        \
+    bool val##i = false, sok##i = false;                                                                        \
+    int lso##i = 0, aoff##i = OOB;                                                                              \
     float4 areg##i = make_float4(0.f, 0.f, 0.f, 0.f);                                                           \
-    {                                                                                                           \
+    if (i < NI) {                                                                                               \
         const int pe = (tid + 256 * i) >> 2;                                                                    \
         const int rr = pe >> logW, c = pe & (W - 1);                                                            \
         const int h = h0 - 1 + rr;                                                                              \
@@ -89,11 +116,11 @@ __global__ __launch_bounds__(256, 2) void conv_sf16_kernel(Sf16P p) {
         lso##i = sf_sw(ridx, q4 >> 1) + (q4 & 1) * 8;                                                           \
         aoff##i = sok##i ? ((h * W + c) * p.K + q4 * 4) * 4 : OOB;                                              \
     }
-    SF_META(0) SF_META(1) SF_META(2) SF_META(3)
+    SF_META(0) SF_META(1) SF_META(2) SF_META(3) SF_META(4) SF_META(5)
 #undef SF_META
     float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-#define SF_ALOAD(i) areg##i = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, aoff##i, k_off, 0));
+#define SF_ALOAD(i) if (i < NI) areg##i = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, aoff##i, k_off, 0));
 #define sf_aload(KS)                                                                                            \
     {                                                                                                           \
         const int k_off = (KS) * 64;                                                                            \
@@ -101,27 +128,27 @@ __global__ __launch_bounds__(256, 2) void conv_sf16_kernel(Sf16P p) {
             sc4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(srs, q4 * 16, k_off, 0));    \
             sh4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(hrs, q4 * 16, k_off, 0));    \
         }                                                                                                       \
-        SF_ALOAD(0) SF_ALOAD(1) SF_ALOAD(2) SF_ALOAD(3)                                                         \
+        SF_ALOAD(0) SF_ALOAD(1) SF_ALOAD(2) SF_ALOAD(3) SF_ALOAD(4) SF_ALOAD(5)                                 \
     }
 #define SF_ASTORE(i)                                                                                            \
-    if (val##i) {                                                                                               \
+    if (i < NI && val##i) {                                                                                     \
         float4 v = areg##i;                                                                                     \
         if (INT) {                                                                                              \
-            v.x = sok##i ? fmaxf(fmaf(v.x, sc4.x, sh4.x), 0.f) : 0.f;                                           \
-            v.y = sok##i ? fmaxf(fmaf(v.y, sc4.y, sh4.y), 0.f) : 0.f;                                           \
-            v.z = sok##i ? fmaxf(fmaf(v.z, sc4.z, sh4.z), 0.f) : 0.f;                                           \
-            v.w = sok##i ? fmaxf(fmaf(v.w, sc4.w, sh4.w), 0.f) : 0.f;                                           \
+            v.x = sok##i ? bn_relu(v.x, sc4.x, sh4.x) : 0.f;                                                    \
+            v.y = sok##i ? bn_relu(v.y, sc4.y, sh4.y) : 0.f;                                                    \
+            v.z = sok##i ? bn_relu(v.z, sc4.z, sh4.z) : 0.f;                                                    \
+            v.w = sok##i ? bn_relu(v.w, sc4.w, sh4.w) : 0.f;                                                    \
         }                                                                                                       \
-        v.x *= p.sa; v.y *= p.sa; v.z *= p.sa; v.w *= p.sa;                                                     \
+        v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa;                                                             \
         const half4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};                          \
         const half4 lo = {(_Float16)(v.x - (float)hi.x), (_Float16)(v.y - (float)hi.y),                         \
                           (_Float16)(v.z - (float)hi.z), (_Float16)(v.w - (float)hi.w)};                        \
         *reinterpret_cast<half4*>(As + lso##i) = hi;                                                            \
-        *reinterpret_cast<half4*>(As + SF_APLANE + lso##i) = lo;                                                \
+        *reinterpret_cast<half4*>(As + APLANE + lso##i) = lo;                                                   \
     }
-#define sf_astore() { SF_ASTORE(0) SF_ASTORE(1) SF_ASTORE(2) SF_ASTORE(3) }
+#define sf_astore() { SF_ASTORE(0) SF_ASTORE(1) SF_ASTORE(2) SF_ASTORE(3) SF_ASTORE(4) SF_ASTORE(5) }
 
-    // ---- B DMA: 24 instructions of 64 lanes x 16 B per stage (2 planes x 3 taps x 4 blocks of 32 rows), 6 per wave
+    // ---- B DMA: 6*RB instructions of 64 lanes x 16 B per stage (2 planes x 3 taps x RB blocks of 32 rows)
     const int brow_in = lane >> 1;
     const int boff = ((n0 + brow_in) * 32 + (((lane & 1) ^ ((brow_in >> 3) & 1)) << 4));     // bytes, thread-constant
     const unsigned bs_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)Bs);
@@ -129,15 +156,15 @@ __global__ __launch_bounds__(256, 2) void conv_sf16_kernel(Sf16P p) {
     const long b_plane_stride = 3L * p.N * 32;          // next plane
     const long b_step_stride = 6L * p.N * 32;           // next (ks, dy)
 #define SF_BDMA(STEP, ST, j)                                                                                    \
-    {                                                                                                           \
-        const int qi = wvu * 6 + (j);                                                                           \
-        const int pl = qi / 12, dxx = (qi >> 2) % 3, rb = qi & 3;                                               \
+    if ((j) < NDMA) {                                                                                           \
+        const int qi = wvu * NDMA + (j);                                                                        \
+        const int pl = qi / (3 * RB), dxx = (qi / RB) % 3, rb = qi % RB;                                        \
         const unsigned char* src = reinterpret_cast<const unsigned char*>(p.wp) + (long)(STEP) * b_step_stride + \
                                    pl * b_plane_stride + dxx * b_dx_stride + rb * 32 * 32;                      \
         unsigned keep_;                                                                                         \
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0" \
                      : "=&s"(keep_)                                                                             \
-                     : "v"(boff), "s"(bs_base + (unsigned)((ST) * SF_BSTAGE + pl * SF_BPLANE + (dxx * SF_BN + rb * 32) * 32)), \
+                     : "v"(boff), "s"(bs_base + (unsigned)((ST) * BSTAGE + pl * BPLANE + (dxx * BN + rb * 32) * 32)), \
                        "s"(src)                                                                                 \
                      : "memory");                                                                               \
     }
@@ -147,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void conv_sf16_kernel(Sf16P p) {
     for (int i = tid; i < (TR + 2) * 8; i += 256) {
         const int rr = i >> 3, side = (i >> 2) & 1, pl = (i >> 1) & 1, ch = i & 1;
         const int ridx = rr * WP + (side ? W + 1 : 0);
-        *reinterpret_cast<float4*>(As + pl * SF_APLANE + sf_sw(ridx, ch)) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(As + pl * APLANE + sf_sw(ridx, ch)) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     sf_aload(0);
     sf_bdma(0, 0);
@@ -169,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv_sf16_kernel(Sf16P p) {
     for (int nk = 0; nk < 2; ++nk) {
         const int row = 64 * wn + 32 * nk + (lane & 31);
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) boffs[nk][dx] = sf_sw(dx * SF_BN + row, kh);
+        for (int dx = 0; dx < 3; ++dx) boffs[nk][dx] = sf_sw(dx * BN + row, kh);
     }
 
     floatx16 acc[2][2];
@@ -192,19 +219,19 @@ __global__ __launch_bounds__(256, 2) void conv_sf16_kernel(Sf16P p) {
             if (dy == 0 && ks + 1 < KT) sf_aload(ks + 1);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
-            const unsigned char* const Bst = Bs + st * SF_BSTAGE;
+            const unsigned char* const Bst = Bs + st * BSTAGE;
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 half8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) {
                     ah[mb] = *reinterpret_cast<const half8*>(As + aoffs[mb][dy * 3 + dx]);
-                    al[mb] = *reinterpret_cast<const half8*>(As + SF_APLANE + aoffs[mb][dy * 3 + dx]);
+                    al[mb] = *reinterpret_cast<const half8*>(As + APLANE + aoffs[mb][dy * 3 + dx]);
                 }
 #pragma unroll
                 for (int nk = 0; nk < 2; ++nk) {
                     bh[nk] = *reinterpret_cast<const half8*>(Bst + boffs[nk][dx]);
-                    bl[nk] = *reinterpret_cast<const half8*>(Bst + SF_BPLANE + boffs[nk][dx]);
+                    bl[nk] = *reinterpret_cast<const half8*>(Bst + BPLANE + boffs[nk][dx]);
                 }
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
@@ -232,27 +259,99 @@ __global__ __launch_bounds__(256, 2) void conv_sf16_kernel(Sf16P p) {
 #undef SF_BDMA
 #undef sf_bdma
 
-    // ---- epilogue: unscale, store (rows past the image fall outside the descriptor and are dropped)
+    // ---- epilogue: unscale, (mask,) statistics, store (rows past the image fall outside the descriptor and are dropped)
     const unsigned y_img_bytes = (unsigned)p.H * W * p.N * 4u;
     const __amdgpu_buffer_rsrc_t yrs =
         __builtin_amdgcn_make_buffer_rsrc(p.y + (long)b * p.H * W * p.N, 0, (int)y_img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(EPI == 2 ? p.yprev + (long)b * p.H * W * p.N : p.x), 0, (int)y_img_bytes, 0x00020000);
+    const int colb = n0 + 64 * wn + (lane & 31);       // + 32*nk
+    const long part = ((long)b * p.ntile + tile) * MW + wm;
+    int yoff[2][16];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int pix = 64 * wm + 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            const int h = h0 + (pix >> logW), c = pix & (W - 1);
-            const int off = ((h * W + c) * p.N + n0 + 64 * wn + (lane & 31)) * 4;
-#pragma unroll
-            for (int nk = 0; nk < 2; ++nk)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mb][nk][r] * p.inv), yrs, off, nk * 128, 0);
+            yoff[mb][r] = (((h0 + (pix >> logW)) * W + (pix & (W - 1))) * p.N + colb) * 4;
         }
+#pragma unroll
+    for (int nk = 0; nk < 2; ++nk) {
+        const int col = colb + 32 * nk;
+        float s1 = 0.f, s2 = 0.f;
+        float e_sc = 0.f, e_sh = 0.f, e_mu = 0.f, e_is = 0.f;
+        if (EPI == 2) { e_sc = p.p_scale[col]; e_sh = p.p_shift[col]; e_mu = p.p_mean[col]; e_is = p.p_invstd[col]; }
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            float yp[16];
+            if (EPI == 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    yp[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, yoff[mb][r], nk * 128, 0));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[mb][nk][r] * inv;
+                const bool ok = (unsigned)yoff[mb][r] < y_img_bytes;
+                if (EPI == 2) {
+                    v = (ok && bn_relu_active(yp[r], e_sc, e_sh)) ? v : 0.f;
+                    s2 = fmaf(v, (yp[r] - e_mu) * e_is, s2);
+                    s1 += v;
+                } else if (EPI == 1) {
+                    v = ok ? v : 0.f;
+                    s1 += v;
+                }
+                acc[mb][nk][r] = v;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, yoff[mb][r], nk * 128, 0);
+            }
+        }
+        if (EPI == 1) {
+            // valid pixels of this wave's 64 (scalar): whole rows of W <= 64 pixels
+            const int rows_w = 64 >> logW;
+            int nv = p.H - (h0 + ((64 * wm) >> logW));
+            nv = nv < 0 ? 0 : (nv > rows_w ? rows_w : nv);
+            const float cnt = (float)(nv * W);
+            s1 += __shfl_xor(s1, 32, 64);
+            const float mean = cnt > 0.f ? s1 / cnt : 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = (unsigned)yoff[mb][r] < y_img_bytes;
+                    const float d = ok ? acc[mb][nk][r] - mean : 0.f;
+                    s2 = fmaf(d, d, s2);
+                }
+            s2 += __shfl_xor(s2, 32, 64);
+            if (kh == 0) {
+                p.partials[(part * 2 + 0) * p.N + col] = s1;
+                p.partials[(part * 2 + 1) * p.N + col] = s2;
+            }
+            if (nk == 0 && wn == 0 && n0 == 0 && lane == 0) p.partials[(long)p.B * p.ntile * MW * 2 * p.N + part] = cnt;
+        }
+        if (EPI == 2) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (kh == 0) {
+                p.partials[(part * 2 + 0) * p.N + col] = s1;
+                p.partials[(part * 2 + 1) * p.N + col] = s2;
+            }
+        }
+    }
 }
 
-// OIHW fp32 -> [K/16][3 dy][2 planes (hi, lo)][3 dx][N][16] f16, values scaled by sw.  dgrad = 1: the operand of the
-// transposed convolution (roles of the channel axes swapped, taps flipped).
-__global__ __launch_bounds__(256) void pack_sf16_kernel(const float* __restrict__ w, int Cout, int Cin, int dgrad, float sw,
-                                                        _Float16* __restrict__ wp) {
+// ---- weights: amax -> power-of-two scale (device resident), then OIHW fp32 -> [K/16][3 dy][2 planes (hi, lo)][3 dx][N][16]
+// f16.  dgrad = 1: the operand of the transposed convolution (roles of the channel axes swapped, taps flipped).
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+    float m = 0.f;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[e]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+}
+
+__global__ __launch_bounds__(256) void pack_sf16_kernel(const float* __restrict__ w, int Cout, int Cin, int dgrad,
+                                                        float* __restrict__ wscale, _Float16* __restrict__ wp) {
+    const float sw = sf_scale_of(wscale[0]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) wscale[1] = sw;
     const int No = dgrad ? Cin : Cout, Ki = dgrad ? Cout : Cin;
     const long total = 9L * No * Ki;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
@@ -273,42 +372,83 @@ __global__ __launch_bounds__(256) void pack_sf16_kernel(const float* __restrict_
     }
 }
 
+static int sf_log2w(int W) { return W == 64 ? 6 : W == 32 ? 5 : W == 16 ? 4 : 3; }
+static int sf_mw(int Cout) { return Cout % 128 == 0 ? 2 : 4; }
+
 }  // namespace
 
 SED_API int sed_conv3x3_sf16_supported(int H, int W, int Cin, int Cout) {
-    return (W == 8 || W == 16 || W == 32 || W == 64) && H >= 1 && Cin % 16 == 0 && Cout % SF_BN == 0;
+    return (W == 8 || W == 16 || W == 32 || W == 64) && H >= 1 && Cin >= 16 && Cin % 16 == 0 && Cout >= 64 && Cout % 64 == 0;
 }
 
 SED_API long sed_conv_sf16_pack_halfs(int Cin, int Cout) { return 18L * Cin * Cout; }
 
-SED_API int sed_pack_conv_weights_sf16(const float* w_oihw, int Cout, int Cin, int dgrad, float sw, void* wp,
-                                       sed_stream_t stream) {
-    if (!w_oihw || !wp || Cout <= 0 || Cin <= 0 || (dgrad ? Cout : Cin) % 16) return SED_EINVAL;
-    const long total = 9L * Cout * Cin;
-    hipLaunchKernelGGL(pack_sf16_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, w_oihw, Cout, Cin, dgrad, sw, (_Float16*)wp);
+SED_API long sed_conv_sf16_num_parts(int B, int H, int W, int Cout) {
+    if (!(W == 8 || W == 16 || W == 32 || W == 64) || Cout % 64) return 0;
+    const int mw = sf_mw(Cout), tr = (64 * mw) >> sf_log2w(W);
+    return (long)B * ((H + tr - 1) / tr) * mw;
+}
+
+SED_API int sed_amax(const float* x, long n, float* amax_out, sed_stream_t stream) {
+    if (!x || !amax_out || n <= 0) return SED_EINVAL;
+    hipError_t e = hipMemsetAsync(amax_out, 0, sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    const long nb = (n + 255) / 256;
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)(nb > 1024 ? 1024 : nb)), dim3(256), 0, (hipStream_t)stream, x, n, amax_out);
     SED_LAUNCH_CHECK();
     return 0;
 }
 
-SED_API int sed_conv3x3_sf16(const float* x, const void* wp, float* y, int B, int H, int W, int Cin, int Cout,
-                             const float* in_scale, const float* in_shift, float sa, float sw, sed_stream_t stream) {
-    if (!x || !wp || !y || B <= 0 || !sed_conv3x3_sf16_supported(H, W, Cin, Cout) || !(sa > 0.f) || !(sw > 0.f))
+SED_API int sed_pack_conv_weights_sf16(const float* w_oihw, int Cout, int Cin, int dgrad, float* wscale, void* wp,
+                                       sed_stream_t stream) {
+    if (!w_oihw || !wp || !wscale || Cout <= 0 || Cin <= 0 || (dgrad ? Cout : Cin) % 16) return SED_EINVAL;
+    const long total = 9L * Cout * Cin;
+    int rc = sed_amax(w_oihw, total, wscale, stream);
+    if (rc) return rc;
+    const long nb = (total + 255) / 256;
+    hipLaunchKernelGGL(pack_sf16_kernel, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                       Cout, Cin, dgrad, wscale, (_Float16*)wp);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale, float* y, int B, int H, int W, int Cin,
+                             int Cout, const float* in_scale, const float* in_shift, int epi, float* partials,
+                             const float* yprev, const float* p_scale, const float* p_shift, const float* p_mean,
+                             const float* p_invstd, const float* x_amax, float sa, sed_stream_t stream) {
+    if (!x || !wp || !wscale || !y || B <= 0 || !sed_conv3x3_sf16_supported(H, W, Cin, Cout) || epi < 0 || epi > 2)
         return SED_EINVAL;
     if ((in_scale == nullptr) != (in_shift == nullptr)) return SED_EINVAL;
+    if (epi >= 1 && !partials) return SED_EINVAL;
+    if (epi == 2 && (!yprev || !p_scale || !p_shift || !p_mean || !p_invstd)) return SED_EINVAL;
+    if (epi == 2 && in_scale) return SED_EINVAL;        // not instantiated (never needed by the models)
+    if (!x_amax && !(sa > 0.f)) return SED_EINVAL;
     Sf16P p;
-    p.x = x; p.wp = (const _Float16*)wp; p.y = y; p.in_scale = in_scale; p.in_shift = in_shift;
+    p.x = x; p.wp = (const _Float16*)wp; p.wscale = wscale; p.x_amax = x_amax; p.y = y;
+    p.in_scale = in_scale; p.in_shift = in_shift; p.partials = partials; p.yprev = yprev;
+    p.p_scale = p_scale; p.p_shift = p_shift; p.p_mean = p_mean; p.p_invstd = p_invstd;
     p.B = B; p.H = H; p.W = W; p.K = Cin; p.N = Cout;
-    p.logW = W == 64 ? 6 : W == 32 ? 5 : W == 16 ? 4 : 3;
-    p.TR = 128 >> p.logW;
+    p.logW = sf_log2w(W);
+    const int mw = sf_mw(Cout);
+    p.TR = (64 * mw) >> p.logW;
     p.ntile = (H + p.TR - 1) / p.TR;
-    p.sa = sa; p.inv = 1.0f / (sa * sw);
-    const long nblk = (long)B * p.ntile * (Cout / SF_BN);
+    p.sa = sa;
+    const long nblk = (long)B * p.ntile * (Cout / (mw == 2 ? 128 : 64));
     if (nblk > 0x7fffffffL) return SED_EINVAL;
-    if (in_scale)
-        hipLaunchKernelGGL(conv_sf16_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL(conv_sf16_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
+    const dim3 g((unsigned)nblk), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+#define SF_LAUNCH(MWV, INTV, EPIV) hipLaunchKernelGGL((conv_sf16_kernel<MWV, INTV, EPIV>), g, blk, 0, s, p)
+    const bool it = in_scale != nullptr;
+    if (mw == 2) {
+        if (epi == 0) { if (it) SF_LAUNCH(2, true, 0); else SF_LAUNCH(2, false, 0); }
+        else if (epi == 1) { if (it) SF_LAUNCH(2, true, 1); else SF_LAUNCH(2, false, 1); }
+        else SF_LAUNCH(2, false, 2);
+    } else {
+        if (epi == 0) { if (it) SF_LAUNCH(4, true, 0); else SF_LAUNCH(4, false, 0); }
+        else if (epi == 1) { if (it) SF_LAUNCH(4, true, 1); else SF_LAUNCH(4, false, 1); }
+        else SF_LAUNCH(4, false, 2);
+    }
+#undef SF_LAUNCH
     SED_LAUNCH_CHECK();
     return 0;
 }

@@ -19,6 +19,7 @@ BN_MOMENTUM = 0.1
 
 # The fused 1-D Winograd F(2,3) kernels (csrc/conv_wino.hip) do the same convolutions with 1.5x fewer MFMA flops; they are
 # used for forward, dgrad and wgrad whenever the layer shape allows.  False = direct implicit GEMM everywhere.
+USE_SF16 = os.environ.get("SED_USE_SF16", "1") != "0"   # split-f16 MFMA convolution (forward / dgrad) where supported; 0: fp32 Winograd kernels
 USE_WINOGRAD = 2          # 2: 2-D F(2x2,3x3) where supported, else 1-D F(2,3), else direct; 1: 1-D; 0: direct only
 # ConvBlock backward: BN2's (sum dy, sum dy*xhat) from the pooled output + per-window ReLU counts instead of a pass over
 # the full-resolution conv output.  The identity divides by gamma, so the kernels themselves fall back to the exact pass
@@ -565,30 +566,46 @@ def _wgrad_direct(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True)
 
 
 
-# ---- EXPERIMENTAL split-f16 convolution (csrc/conv_sf16.hip; not used by the models yet)
+# ---- split-f16 convolution (csrc/conv_sf16.hip)
 
-def pack_sf16(w_oihw, dgrad=False, sw=4096.0):
-    """OIHW fp32 weights -> the split-f16 operand (hi, lo planes, scaled by the power of two sw)."""
+SF16_ACT_SCALE = 16.0        # fixed power of two for BatchNorm-ed / pooled activations (|x| < 4094)
+
+
+def pack_sf16(w_oihw, dgrad=False):
+    """OIHW fp32 weights -> (split-f16 operand [hi, lo planes], wscale[2] = (amax, power-of-two scale) on the device)."""
     Cout, Cin = w_oihw.shape[0], w_oihw.shape[1]
     wp = torch.empty((_lib.lib().sed_conv_sf16_pack_halfs(Cin, Cout),), dtype=torch.float16, device=w_oihw.device)
-    _call("sed_pack_conv_weights_sf16", _ptr(_f32c(w_oihw)), Cout, Cin, 1 if dgrad else 0, float(sw), _ptr(wp), _stream())
-    return wp
+    wscale = torch.empty((2,), dtype=torch.float32, device=w_oihw.device)
+    _call("sed_pack_conv_weights_sf16", _ptr(_f32c(w_oihw)), Cout, Cin, 1 if dgrad else 0, _ptr(wscale), _ptr(wp), _stream())
+    return wp, wscale
 
 
-def conv3x3_sf16(x, wp, B, H, W, Cin, Cout, in_st=None, sa=16.0, sw=4096.0):
-    """y = conv3x3(relu(scale*x + shift) or x) on the f16 MFMA pipe with split operands; x NHWC fp32 -> y NHWC fp32."""
+def amax_of(x):
+    out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    _call("sed_amax", _ptr(x), x.numel(), _ptr(out), _stream())
+    return out
+
+
+def conv3x3_sf16(x, pack, B, H, W, Cin, Cout, in_st=None, epi=0, partials=None, yprev=None, p_st=None, x_amax=None):
+    """y = conv3x3(relu(scale*x + shift) or x) on the f16 MFMA pipe with split operands; x NHWC fp32 -> y NHWC fp32.
+    x_amax: device scalar with the amax of x (gradients); None = the fixed activation scale."""
+    wp, wscale = pack
     y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
-    with _timed("conv3x3_sf16_mfma|%d->%d@%dx%d%s" % (Cin, Cout, H, W, "+inT" if in_st is not None else ""),
+    with _timed("conv3x3_sf16_mfma(fwd+dgrad)|%d->%d@%dx%d epi%d%s" % (Cin, Cout, H, W, epi, "+inT" if in_st is not None else ""),
                 2.0 * 9 * B * H * W * Cin * Cout):
-        _call("sed_conv3x3_sf16", _ptr(x), _ptr(wp), _ptr(y), B, H, W, Cin, Cout,
-              _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None,
-              float(sa), float(sw), _stream())
+        _call("sed_conv3x3_sf16", _ptr(x), _ptr(wp), _ptr(wscale), _ptr(y), B, H, W, Cin, Cout,
+              _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, epi,
+              _ptr(partials), _ptr(yprev), _ptr(p_st.scale) if p_st is not None else None,
+              _ptr(p_st.shift) if p_st is not None else None, _ptr(p_st.mean) if p_st is not None else None,
+              _ptr(p_st.invstd) if p_st is not None else None, _ptr(x_amax), SF16_ACT_SCALE, _stream())
     return y
 
 
 def _conv_algo(H, W, Cin, Cout):
     """2 = fused 2-D Winograd F(2x2,3x3), 1 = fused 1-D Winograd F(2,3), 0 = direct implicit GEMM."""
     L = _lib.lib()
+    if USE_SF16 and L.sed_conv3x3_sf16_supported(H, W, Cin, Cout):
+        return 3
     if USE_WINOGRAD >= 2 and L.sed_conv3x3_wino2_supported(H, W, Cin, Cout):
         return 2
     if USE_WINOGRAD >= 1 and L.sed_conv3x3_wino_supported(H, W, Cin, Cout):
@@ -600,6 +617,11 @@ def _conv_fwd_like(x, w_oihw, B, H, W, Cin, Cout, dgrad=False, **kw):
     """3x3 conv of x with the OIHW weights (dgrad=True: the transposed/flipped conv that maps g_y -> g_x; Cin/Cout are
     then the channel counts of the INPUT/OUTPUT of this call)."""
     algo = _conv_algo(H, W, Cin, Cout)
+    x_amax = kw.pop("x_amax", None)
+    if algo == 3:
+        if dgrad and x_amax is None:
+            x_amax = amax_of(x)                      # gradients have no fixed magnitude: scale from their amax
+        return conv3x3_sf16(x, pack_sf16(w_oihw, dgrad=dgrad), B, H, W, Cin, Cout, x_amax=x_amax, **kw)
     if algo == 2:
         uf, ud = _pack_wino2(w_oihw, want_f=not dgrad, want_d=dgrad)
         return _conv_wino2(x, ud if dgrad else uf, B, H, W, Cin, Cout, **kw)
@@ -616,6 +638,9 @@ def _conv_parts(B, H, W, Cin, Cout):
     L = _lib.lib()
     M = B * H * W
     algo = _conv_algo(H, W, Cin, Cout)
+    if algo == 3:
+        P = int(L.sed_conv_sf16_num_parts(B, H, W, Cout))
+        return P, -1, P * 2 * Cout + P
     if algo == 2:
         P = int(L.sed_conv_wino2_num_parts(B, H, W))
         return P, -1, P * 2 * Cout + P
@@ -705,8 +730,10 @@ class ConvBlockFn(torch.autograd.Function):
         sk = ctx.sinks                                   # (w1, g1, b1, -, -, w2, g2, b2)
         dg2, db2, coef2 = bn_bwd_finalize(part, n.value, M, st2, batch_stats=ctx.training, sinks=(sk[6], sk[7]))
         gy2 = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
+        sf2 = _conv_algo(H, W, Cout, Cout) == 3         # the split-f16 dgrad takes its scale from the tensor's amax
+        amax2 = torch.empty((1,), dtype=torch.float32, device=dev) if sf2 else None
         _call("sed_bn_relu_pool_bwd_apply", _ptr(y2), _ptr(g_out), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift),
-              _ptr(coef2), _ptr(gy2), _stream())
+              _ptr(coef2), _ptr(gy2), _ptr(amax2), _stream())
         # conv2: dgrad fused with relu-mask + BN1 backward sums, then the weight gradient (operand relu(bn1(y1)) on the
         # fly).  With gradient sinks the weight gradients run on the side stream: conv2's beside BN1's backward passes
         # below, conv1's beside the NEXT block's pool backward (joined there, right here, before its first MFMA kernel).
@@ -714,7 +741,7 @@ class ConvBlockFn(torch.autograd.Function):
         fork = WGRAD_SIDE_STREAM
         npb, _, nfb = _conv_parts(B, H, W, Cout, Cout)
         partb = torch.empty((nfb,), dtype=torch.float32, device=dev)
-        gy1 = _conv_fwd_like(gy2, w2, B, H, W, Cout, Cout, dgrad=True, epi=2, partials=partb, yprev=y1, p_st=st1)
+        gy1 = _conv_fwd_like(gy2, w2, B, H, W, Cout, Cout, dgrad=True, epi=2, partials=partb, yprev=y1, p_st=st1, x_amax=amax2)
         if fork and sk[5] is not None:
             dw2 = _fork_wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=st1, sink=sk[5])
         else:
@@ -723,8 +750,11 @@ class ConvBlockFn(torch.autograd.Function):
         dg1, db1, coef1 = bn_bwd_finalize(partb, npb, M, st1, batch_stats=ctx.training, sinks=(sk[1], sk[2]))
         # conv1
         gx = None
+        amax1 = None
         if Cin != 1:
-            _call("sed_bn_bwd_apply", _ptr(gy1), _ptr(y1), M, Cout, _ptr(coef1), _stream())
+            if ctx.needs_input_grad[0] and _conv_algo(H, W, Cout, Cin) == 3:
+                amax1 = torch.empty((1,), dtype=torch.float32, device=dev)
+            _call("sed_bn_bwd_apply", _ptr(gy1), _ptr(y1), M, Cout, _ptr(coef1), _ptr(amax1), _stream())
         if Cin == 1:                                   # BN1 backward g = a*dz + b*y1 + c is applied on load by the kernel
             nblk = (M + 1023) // 1024
             dwp = torch.empty((nblk, 576), dtype=torch.float32, device=dev)
@@ -739,7 +769,7 @@ class ConvBlockFn(torch.autograd.Function):
         else:
             join_side_stream()                         # conv2's weight gradient is done before the next MFMA kernel starts
             if ctx.needs_input_grad[0]:
-                gx = _conv_fwd_like(gy1, w1, B, H, W, Cout, Cin, dgrad=True, epi=0)
+                gx = _conv_fwd_like(gy1, w1, B, H, W, Cout, Cin, dgrad=True, epi=0, x_amax=amax1)
             if fork and sk[0] is not None:
                 dw1 = _fork_wgrad(x, gy1, B, H, W, Cin, Cout, sink=sk[0])
             else:

@@ -161,6 +161,53 @@ def test_conv_block_vs_oracle(ops, Cin, Cout, H, W, ph, pw, training):
             assert rel(dev[n].cpu(), st[n]) < 1e-5, n
 
 
+@pytest.mark.parametrize("Cin,Cout,H,W,ph,pw", [(64, 128, 22, 32, 2, 2), (128, 256, 20, 16, 2, 2), (256, 512, 12, 8, 1, 8),
+                                               (64, 64, 9, 64, 2, 2)])
+def test_conv_block_arithmetic_precision_without_relu_flips(ops, Cin, Cout, H, W, ph, pw):
+    """Precision of the ConvBlock arithmetic alone, against FLOAT64.  With BatchNorm biases of +8 every pre-activation is
+    far from zero, so no ReLU mask can differ between fp32 and fp64 (the mechanism behind the 1e-3-level model-gradient
+    differences of tests/test_gpu_model.py); what remains is rounding, including the cancellation inside the BatchNorm
+    backward.  Gate: forward 2e-6 and every gradient 2e-5, max error relative to the tensor max."""
+    B = 4
+    g = torch.Generator().manual_seed(Cin + H)
+    x = torch.relu(torch.randn(B, Cin, H, W, generator=g)) * 0.7
+    st = {}
+    for i, (ci, co) in enumerate(((Cin, Cout), (Cout, Cout)), start=1):
+        st["cb.conv%d.weight" % i] = torch.randn(co, ci, 3, 3, generator=g) * (1.5 / np.sqrt(9 * ci))
+        st["cb.bn%d.weight" % i] = 1 + 0.2 * torch.randn(co, generator=g)
+        st["cb.bn%d.bias" % i] = 8.0 + 0.2 * torch.randn(co, generator=g)
+        st["cb.bn%d.running_mean" % i] = torch.zeros(co)
+        st["cb.bn%d.running_var" % i] = torch.ones(co)
+        st["cb.bn%d.num_batches_tracked" % i] = torch.tensor(0)
+    names = ["cb.conv1.weight", "cb.bn1.weight", "cb.bn1.bias", "cb.conv2.weight", "cb.bn2.weight", "cb.bn2.bias"]
+    s64 = {k: (v.double().clone() if v.is_floating_point() else v.clone()) for k, v in st.items()}
+    for n in names:
+        s64[n].requires_grad_(True)
+    x64 = x.double().requires_grad_(True)
+    if (ph, pw) == (1, 8):
+        ref = om.conv_block(x64, s64, "cb", (1, 1), True, True).mean(dim=3, keepdim=True)
+    else:
+        ref = om.conv_block(x64, s64, "cb", (ph, pw), True, True)
+    gout = torch.randn(ref.shape, generator=g)
+    ref.backward(gout.double())
+    dev = {k: v.detach().clone().cuda() for k, v in st.items()}
+    xg = nhwc(x).cuda().requires_grad_(True)
+    params = [dev["cb.conv1.weight"], dev["cb.bn1.weight"], dev["cb.bn1.bias"], dev["cb.bn1.running_mean"],
+              dev["cb.bn1.running_var"], dev["cb.conv2.weight"], dev["cb.bn2.weight"], dev["cb.bn2.bias"],
+              dev["cb.bn2.running_mean"], dev["cb.bn2.running_var"]]
+    for i in (0, 1, 2, 5, 6, 7):
+        params[i].requires_grad_(True)
+    out = ops.ConvBlockFn.apply(xg, *params, True, ph, pw)
+    assert rel(nchw(out.detach()).cpu(), ref.detach()) < 2e-6
+    out.backward(nhwc(gout).cuda())
+    report = {"dx": rel(nchw(xg.grad).cpu(), x64.grad)}
+    for p, n in zip(params, ["cb.conv1.weight", "cb.bn1.weight", "cb.bn1.bias", None, None, "cb.conv2.weight", "cb.bn2.weight", "cb.bn2.bias"]):
+        if n is not None:
+            report[n] = rel(p.grad.cpu(), s64[n].grad)
+    print("no-flip ConvBlock %s: %s" % ((Cin, Cout, H, W), {k: "%.1e" % v for k, v in report.items()}))
+    assert max(report.values()) < 1e-5, report          # measured <= 3.6e-6 with the split-f16 and with the Winograd kernels
+
+
 def test_bn0_aug_mix_vs_oracle(ops):
     B2, T = 6, 101
     g = torch.Generator().manual_seed(9)

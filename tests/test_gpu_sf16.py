@@ -1,5 +1,6 @@
-"""EXPERIMENTAL split-f16 3x3 convolution (csrc/conv_sf16.hip) against a float64 convolution: the three-term split
-must be as accurate as the fp32 kernels (tools/split_f16_study.py: 1.5e-7 relative L2)."""
+"""Split-f16 3x3 convolution (csrc/conv_sf16.hip) against a float64 convolution and against the fused epilogues of the
+fp32 direct kernel: the three-term split must be as accurate as a direct fp32 convolution
+(tools/split_f16_study.py: 1.5e-7 relative L2 per 1152-term sum)."""
 import numpy as np
 import pytest
 import torch
@@ -16,40 +17,92 @@ def _ref(x_nhwc, w, scale=None, shift=None):
     return y.permute(0, 2, 3, 1).contiguous()
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout,inT", [(2, 37, 64, 64, 128, False), (3, 21, 32, 128, 128, True),
-                                               (2, 250, 16, 128, 256, False), (3, 13, 8, 256, 512, True),
-                                               (1, 1, 8, 16, 128, False), (2, 5, 64, 32, 256, True)])
+def _err(y, want):
+    d = y.double().cpu() - want
+    return float(d.pow(2).mean().sqrt() / want.pow(2).mean().sqrt()), float(d.abs().max() / want.abs().max())
+
+
+SHAPES = [(2, 37, 64, 64, 128, False), (3, 21, 32, 128, 128, True), (2, 250, 16, 128, 256, False),
+          (3, 13, 8, 256, 512, True), (1, 1, 8, 16, 128, False), (2, 5, 64, 32, 256, True),
+          (2, 9, 64, 64, 64, True), (2, 33, 32, 128, 64, False), (1, 7, 8, 64, 192, True), (2, 3, 16, 48, 64, False)]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,inT", SHAPES)
 def test_sf16_conv_matches_float64(B, H, W, Cin, Cout, inT):
     from sound_event_detection_dcase2017_task4_amd import ops
     g = torch.Generator().manual_seed(B * 1000 + H)
     x = torch.randn((B, H, W, Cin), generator=g) * 1.5
     w = (torch.rand((Cout, Cin, 3, 3), generator=g) * 2 - 1) * float(np.sqrt(6.0 / (9 * Cin + 9 * Cout)))
-    st = None
-    scale = shift = None
+    st = scale = shift = None
     if inT:
         scale = torch.rand(Cin, generator=g) + 0.5
         shift = torch.randn(Cin, generator=g) * 0.3
         st = ops.BnStats(Cin, "cuda")
         st.scale.copy_(scale); st.shift.copy_(shift)
     want = _ref(x, w, scale, shift)
-    wp = ops.pack_sf16(w.cuda())
-    y = ops.conv3x3_sf16(x.cuda(), wp, B, H, W, Cin, Cout, in_st=st)
+    y = ops.conv3x3_sf16(x.cuda(), ops.pack_sf16(w.cuda()), B, H, W, Cin, Cout, in_st=st)
     torch.cuda.synchronize()
-    d = y.double().cpu() - want
-    rel = float(d.pow(2).mean().sqrt() / want.pow(2).mean().sqrt())
-    mx = float(d.abs().max() / want.abs().max())
+    rel, mx = _err(y, want)
     print("sf16 %s: relative L2 %.2e, max %.2e of the output max" % ((B, H, W, Cin, Cout, inT), rel, mx))
     assert rel < 1e-6 and mx < 1e-5      # fp32 accumulation over K = 9*Cin terms: same as a direct fp32 convolution
 
 
-def test_sf16_dgrad_operand_matches_conv_transpose():
-    from sound_event_detection_dcase2017_task4_amd import ops
-    g = torch.Generator().manual_seed(5)
-    B, H, W, Cin, Cout = 2, 19, 32, 128, 64            # w: (Cout=64, Cin=128); dgrad maps 64 -> 128 channels
-    gy = torch.randn((B, H, W, Cout), generator=g)
-    w = (torch.rand((Cout, Cin, 3, 3), generator=g) * 2 - 1) * 0.03
-    want = F.conv_transpose2d(gy.double().permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1)
-    wp = ops.pack_sf16(w.cuda(), dgrad=True)
-    gx = ops.conv3x3_sf16(gy.cuda(), wp, B, H, W, Cout, Cin)
-    d = gx.double().cpu() - want
-    assert float(d.pow(2).mean().sqrt() / want.pow(2).mean().sqrt()) < 1e-6
+@pytest.mark.parametrize("B,H,W,Cin,Cout,inT", [(2, 37, 64, 64, 128, True), (3, 11, 32, 128, 64, False), (2, 1001, 64, 64, 64, True),
+                                               (2, 125, 8, 256, 512, False)])
+def test_sf16_statistics_epilogue(B, H, W, Cin, Cout, inT):
+    """Epilogue 1: the per-part (sum, M2, count) partials merge (sed_bn_finalize) to the batch statistics of the output."""
+    from sound_event_detection_dcase2017_task4_amd import ops, _lib
+    g = torch.Generator().manual_seed(77 + H)
+    x = torch.randn((B, H, W, Cin), generator=g)
+    w = (torch.rand((Cout, Cin, 3, 3), generator=g) * 2 - 1) * 0.05
+    st = None
+    if inT:
+        st = ops.BnStats(Cin, "cuda")
+        st.scale.copy_(torch.rand(Cin, generator=g) + 0.5); st.shift.copy_(torch.randn(Cin, generator=g) * 0.3)
+    P = int(_lib.lib().sed_conv_sf16_num_parts(B, H, W, Cout))
+    part = torch.full((P * 2 * Cout + P,), float("nan"), device="cuda")
+    y = ops.conv3x3_sf16(x.cuda(), ops.pack_sf16(w.cuda()), B, H, W, Cin, Cout, in_st=st, epi=1, partials=part)
+    gam, bet = torch.ones(Cout, device="cuda"), torch.zeros(Cout, device="cuda")
+    rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+    bst = ops.bn_finalize(part, P, -1, B * H * W, gam, bet, rm, rv)
+    torch.cuda.synchronize()
+    assert float(part[P * 2 * Cout:].sum()) == B * H * W
+    y2 = y.double().reshape(-1, Cout)
+    mean, var = y2.mean(0), y2.var(0, unbiased=False)
+    assert (bst.mean.double() - mean).abs().max() < 1e-5 * max(1.0, float(mean.abs().max()))
+    assert ((bst.invstd.double() - 1.0 / torch.sqrt(var + 1e-5)).abs() / (1.0 / torch.sqrt(var + 1e-5))).max() < 1e-5
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 37, 64, 128, 64), (3, 21, 32, 128, 128), (2, 1001, 64, 64, 64), (2, 13, 8, 512, 512)])
+def test_sf16_dgrad_epilogue_and_dynamic_scale(B, H, W, Cin, Cout):
+    """dgrad with epilogue 2 (ReLU mask of the previous activation + BatchNorm-backward sums) on gradients of magnitude 1e-6,
+    scaled by the amax a producer left on the device: against float64."""
+    from sound_event_detection_dcase2017_task4_amd import ops, _lib
+    g = torch.Generator().manual_seed(91 + H)
+    # w: (Cout, Cin): forward maps Cin -> Cout; this dgrad maps gy (Cout channels) -> gx (Cin channels)
+    gy = torch.randn((B, H, W, Cout), generator=g) * 1e-6 * torch.exp(torch.randn((B, H, W, 1), generator=g))
+    w = (torch.rand((Cout, Cin, 3, 3), generator=g) * 2 - 1) * 0.04
+    yprev = torch.randn((B, H, W, Cin), generator=g)
+    pst = ops.BnStats(Cin, "cuda")
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    mu, istd = torch.randn(Cin, generator=g) * 0.1, torch.rand(Cin, generator=g) + 0.5
+    pst.scale.copy_(sc); pst.shift.copy_(sh); pst.mean.copy_(mu); pst.invstd.copy_(istd)
+    full = F.conv_transpose2d(gy.double().permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1)
+    mask = (torch.addcmul(sh, yprev, sc) > 0)            # fp32 fma, like bn_relu_active
+    want = full * mask
+    P = int(_lib.lib().sed_conv_sf16_num_parts(B, H, W, Cin))
+    part = torch.full((P * 2 * Cin,), float("nan"), device="cuda")
+    gyc = gy.cuda()
+    gx = ops.conv3x3_sf16(gyc, ops.pack_sf16(w.cuda(), dgrad=True), B, H, W, Cout, Cin, epi=2, partials=part,
+                          yprev=yprev.cuda(), p_st=pst, x_amax=ops.amax_of(gyc))
+    torch.cuda.synchronize()
+    rel, mx = _err(gx, want)
+    print("sf16 dgrad %s: relative L2 %.2e, max %.2e" % ((B, H, W, Cin, Cout), rel, mx))
+    flips = int(((gx.cpu() != 0) != (want != 0)).sum())
+    assert flips <= 2, flips                               # addcmul vs fma may differ in the last bit at t == 0
+    assert rel < 1e-6 and mx < 2e-5
+    p = part.view(P, 2, Cin).double().sum(0).cpu()
+    s1 = want.reshape(-1, Cin).sum(0)
+    s2 = (want * ((yprev.double() - mu.double()) * istd.double())).reshape(-1, Cin).sum(0)
+    assert (p[0] - s1).abs().max() <= 2e-5 * want.abs().reshape(-1, Cin).sum(0).max()
+    assert (p[1] - s2).abs().max() <= 2e-5 * (want.abs() * ((yprev.double() - mu.double()) * istd.double()).abs()).reshape(-1, Cin).sum(0).max()

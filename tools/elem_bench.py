@@ -46,9 +46,9 @@ def main():
         S = M * C * 4 / 1e9
         Sp = B * Ho * Wo * C * 4 / 1e9
         runs = [
-            ("bn_bwd_apply     ", 3 * S, lambda: ops._call("sed_bn_bwd_apply", ops._ptr(d), ops._ptr(y), M, C, ops._ptr(coef), s)),
+            ("bn_bwd_apply     ", 3 * S, lambda: ops._call("sed_bn_bwd_apply", ops._ptr(d), ops._ptr(y), M, C, ops._ptr(coef), None, s)),
             ("pool_bwd_apply   ", 2 * S + Sp, lambda: ops._call("sed_bn_relu_pool_bwd_apply", ops._ptr(y), ops._ptr(gp), B, H, W, C, ph, pw,
-                                                                 ops._ptr(sc), ops._ptr(sh), ops._ptr(coef), ops._ptr(gy), s)),
+                                                                 ops._ptr(sc), ops._ptr(sh), ops._ptr(coef), ops._ptr(gy), None, s)),
             ("pool_fwd_cnt     ", S + 1.25 * Sp, lambda: ops._call("sed_bn_relu_pool_fwd_cnt", ops._ptr(y), B, H, W, C, ph, pw, ops._ptr(sc),
                                                                    ops._ptr(sh), ops._ptr(out), ops._ptr(cnt), s)),
         ]

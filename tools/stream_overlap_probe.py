@@ -60,7 +60,7 @@ def main():
     coef = torch.randn(3, C, device=dev)
 
     def bn_apply():
-        ops._call("sed_bn_bwd_apply", ops._ptr(e1), ops._ptr(e2), B * H * W, C, ops._ptr(coef), ops._stream())
+        ops._call("sed_bn_bwd_apply", ops._ptr(e1), ops._ptr(e2), B * H * W, C, ops._ptr(coef), None, ops._stream())
 
     for name, f, g in (("wgrad + dgrad", wgrad, dgrad), ("wgrad + elementwise", wgrad, elem), ("dgrad + elementwise", dgrad, elem),
                        ("wgrad + bn_bwd_apply", wgrad, bn_apply)):
