@@ -35,6 +35,7 @@ from sound_event_detection_dcase2017_task4_amd.pytorch.pytorch_utils import do_m
 from sound_event_detection_dcase2017_task4_amd.utils.utilities import Mixup
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+F16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: dense f16/bf16 MFMA (v_mfma_f32_32x32x16_f16), the pipe the split-f16 kernels run on
 HBM_PEAK_GBPS = 8000.0
 CTOR = (32000, 1024, 320, 64, 50, 14000, 17)
 
@@ -104,7 +105,7 @@ def pmc_traffic(substrings):
     return (round(tot / n) if n else None), "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes/launch)" % os.path.relpath(path, REPO)
 
 
-FAMILY_KERNELS = {"conv3x3_wino_mfma(fwd+dgrad)": ["conv_wino_kernel"], "conv3x3_wino2d_mfma(fwd+dgrad)": ["conv_wino2_kernel"],
+FAMILY_KERNELS = {"conv3x3_sf16_mfma(fwd+dgrad)": ["conv_sf16_kernel"], "conv3x3_wgrad_sf16_mfma(+slice reduce)": ["wgrad_sf16_"], "conv3x3_wino_mfma(fwd+dgrad)": ["conv_wino_kernel"], "conv3x3_wino2d_mfma(fwd+dgrad)": ["conv_wino2_kernel"],
                   "conv3x3_wgrad_wino2d_mfma(+slice reduce)": ["wgrad_wino2_"], "conv3x3_wgrad_wino_mfma(+slice reduce)": ["wgrad_wino_"],
                   "conv3x3_igemm_mfma(fwd+dgrad)": ["conv_igemm_kernel"], "conv3x3_wgrad_mfma(+slice reduce)": ["wgrad_kernel"]}
 
@@ -299,26 +300,36 @@ def main():
             print("# %-62s %3d launches  %8.3f ms/launch  %6.1f TFLOP/s" % (tag, v["launches"], v["avg_ms"], v["tflops"]),
                   file=sys.stderr)
     dom = max(kern, key=lambda k: kern[k]["ms_total"]) if kern else None
-    # Winograd kernels issue fewer MACs than the direct convolution whose flops 'achieved' counts
-    notes = {"conv3x3_wino_mfma(fwd+dgrad)": ("fused 1-D Winograd F(2,3) implicit GEMM on fp32 MFMA", 1.5),
-             "conv3x3_wino2d_mfma(fwd+dgrad)": ("fused 2-D Winograd F(2x2,3x3) implicit GEMM on fp32 MFMA", 2.25),
-             "conv3x3_wgrad_wino_mfma(+slice reduce)": ("Winograd-domain F(2,3) weight gradient on fp32 MFMA", 1.5),
-             "conv3x3_wgrad_wino2d_mfma(+slice reduce)": ("Winograd-domain F(2x2,3x3) weight gradient on fp32 MFMA", 2.25)}
+    # 'achieved' always counts the ALGORITHMIC direct-convolution flops.  Winograd kernels execute fewer MACs
+    # than that on the fp32 MFMA pipe; the split-f16 kernels execute THREE f16 MACs per algorithmic MAC on the f16 MFMA pipe.
+    notes = {"conv3x3_wino_mfma(fwd+dgrad)": ("fused 1-D Winograd F(2,3) implicit GEMM on fp32 MFMA", 1 / 1.5, FP32_MFMA_PEAK_TFLOPS),
+             "conv3x3_wino2d_mfma(fwd+dgrad)": ("fused 2-D Winograd F(2x2,3x3) implicit GEMM on fp32 MFMA", 1 / 2.25, FP32_MFMA_PEAK_TFLOPS),
+             "conv3x3_wgrad_wino_mfma(+slice reduce)": ("Winograd-domain F(2,3) weight gradient on fp32 MFMA", 1 / 1.5, FP32_MFMA_PEAK_TFLOPS),
+             "conv3x3_wgrad_wino2d_mfma(+slice reduce)": ("Winograd-domain F(2x2,3x3) weight gradient on fp32 MFMA", 1 / 2.25, FP32_MFMA_PEAK_TFLOPS),
+             "conv3x3_wgrad_sf16_mfma(+slice reduce)": ("weight gradient with split-f16 operands (LDS transpose reads) on the f16 MFMA pipe",
+                                                        3.0, F16_MFMA_PEAK_TFLOPS),
+             "conv3x3_sf16_mfma(fwd+dgrad)": ("direct 3x3 convolution with split-f16 operands (hi*hi + hi*lo + lo*hi, exact products, fp32 "
+                                              "accumulation: the error of a direct fp32 convolution) on the f16 MFMA pipe", 3.0, F16_MFMA_PEAK_TFLOPS)}
     roofline = None
     if dom is not None:
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        what, executed_per_alg, peak = notes.get(dom, ("fp32 MFMA implicit GEMM", 1.0, FP32_MFMA_PEAK_TFLOPS))
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / peak, 4), "traffic": None,
                     "launches_per_step": kern[dom]["launches"] // args.steps, "avg_launch_ms": kern[dom]["avg_ms"]}
-        if dom in notes:
-            what, fewer = notes[dom]
-            roofline["note"] = ("%s: 'achieved' counts the ALGORITHMIC direct-convolution flops (SURVEY.md 8d); the kernel "
-                                "executes %.4gx fewer" % (what, fewer))
-            roofline["executed_tflops"] = round(kern[dom]["tflops"] / fewer, 2)
-            roofline["executed_frac"] = round(kern[dom]["tflops"] / fewer / FP32_MFMA_PEAK_TFLOPS, 4)
+        roofline["note"] = ("%s: 'achieved' counts the ALGORITHMIC direct-convolution flops (SURVEY.md 8d), 'peak' is the dense "
+                            "peak of the MFMA pipe the kernel runs on; the kernel executes %.4gx the algorithmic flops there"
+                            % (what, executed_per_alg))
+        roofline["executed_tflops"] = round(kern[dom]["tflops"] * executed_per_alg, 2)
+        roofline["executed_frac"] = round(kern[dom]["tflops"] * executed_per_alg / peak, 4)
         if default_workload:
             roofline["traffic"], src = pmc_traffic(FAMILY_KERNELS.get(dom))
             if src:
                 roofline["traffic_source"] = src
+    # every MFMA kernel family of the step, same accounting (the dominant one above is the `roofline` object)
+    for tag, v in kern.items():
+        what, executed_per_alg, peak = notes.get(tag, ("fp32 MFMA implicit GEMM", 1.0, FP32_MFMA_PEAK_TFLOPS))
+        if v["tflops"]:
+            v["executed_frac_of_pipe_peak"] = round(v["tflops"] * executed_per_alg / peak, 4)
     conv_ms = sum(v["ms_total"] for v in kern.values())
     clips_per_s = B * world * args.steps / dt
     line = {
@@ -328,6 +339,9 @@ def main():
         "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "arithmetic": ("fp32 throughout; 3x3 convolution products (forward, dgrad) as three split-f16 MFMAs with fp32 accumulation "
+                       "-- the rounding error of a direct fp32 convolution (tests/test_gpu_sf16.py vs float64); weight gradients "
+                       "on fp32 MFMA (Winograd)") if ops.USE_SF16 else "fp32 throughout (fp32 MFMA, Winograd F(2x2,3x3))",
         "config": {"workload": wl.describe(args.seconds, args.int16) + ("; BASELINE.json configs[1]" if default_workload else
                                                                          " (modified by flags)"),
                    "global_batch": B * world, "waveforms_per_step": B2 * world,

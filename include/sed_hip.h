@@ -186,6 +186,14 @@ int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale, float*
                      int Cout, const float* in_scale, const float* in_shift, int epi, float* partials,
                      const float* yprev, const float* p_scale, const float* p_shift, const float* p_mean,
                      const float* p_invstd, const float* x_amax, float sa, sed_stream_t stream);
+/* Weight gradient with split-f16 operands (csrc/conv_sf16.hip): same contract as sed_conv3x3_wgrad; gy_amax = device
+ * pointer to max |gy| (sed_amax or the producer kernels), sa = fixed power-of-two scale of the activations.
+ * Needs W in {8,16,32,64}, Cin % 32 == 0, Cout % 64 == 0; partial: sed_wgrad_sf16_partial_floats(...) floats. */
+int sed_wgrad_sf16_supported(int H, int W, int Cin, int Cout);
+long sed_wgrad_sf16_partial_floats(int B, int H, int W, int Cin, int Cout);
+int sed_conv3x3_wgrad_sf16(const float* x, const float* gy, float* dw_oihw, float* partial, int B, int H, int W,
+                           int Cin, int Cout, const float* in_scale, const float* in_shift, const float* gy_amax,
+                           float sa, sed_stream_t stream);
 /* Winograd-domain weight gradient (12 instead of 18 MACs per output pair); same contract as sed_conv3x3_wgrad.
  * Needs W a power of two <= 64 and Cin, Cout % 64 == 0; partial: sed_wgrad_wino_partial_floats(...) floats. */
 long sed_wgrad_wino_partial_floats(long M, int Cin, int Cout, int* nslices_out, int* pix_per_slice_out);

@@ -213,42 +213,74 @@ __global__ __launch_bounds__(256, 2) void conv_sf16_kernel(Sf16P p) {
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy, ++step) {
             const int st = step & 1;
+#ifndef SF_ABL_NODMA       // timing experiment: no weight DMA after the first stage (results wrong)
             if (step + 1 < nsteps) {
                 if (st) { sf_bdma(step + 1, 0) } else { sf_bdma(step + 1, 1) }
             }
+#endif
+#ifndef SF_ABL_NOALOAD
             if (dy == 0 && ks + 1 < KT) sf_aload(ks + 1);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
             const unsigned char* const Bst = Bs + st * BSTAGE;
+            // fragments of tap dx+1 are requested before the MFMAs of tap dx are issued (two register sets): the LDS latency
+            // hides behind 12 MFMAs instead of stalling every group of four
+            half8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
+#define SF_FRAGS(SET, DX)                                                                                       \
+            _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) {                                                  \
+                ah[SET][mb] = *reinterpret_cast<const half8*>(As + aoffs[mb][dy * 3 + (DX)]);                   \
+                al[SET][mb] = *reinterpret_cast<const half8*>(As + APLANE + aoffs[mb][dy * 3 + (DX)]);          \
+            }                                                                                                   \
+            _Pragma("unroll") for (int nk = 0; nk < 2; ++nk) {                                                  \
+                bh[SET][nk] = *reinterpret_cast<const half8*>(Bst + boffs[nk][DX]);                             \
+                bl[SET][nk] = *reinterpret_cast<const half8*>(Bst + BPLANE + boffs[nk][DX]);                    \
+            }
+#ifdef SF_ABL_NOFRAG      // timing experiment: fragments read once per kernel
+            if (step == 0) { SF_FRAGS(0, 0) SF_FRAGS(1, 1) }
+#else
+            SF_FRAGS(0, 0)
+#endif
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                half8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb) {
-                    ah[mb] = *reinterpret_cast<const half8*>(As + aoffs[mb][dy * 3 + dx]);
-                    al[mb] = *reinterpret_cast<const half8*>(As + APLANE + aoffs[mb][dy * 3 + dx]);
-                }
-#pragma unroll
-                for (int nk = 0; nk < 2; ++nk) {
-                    bh[nk] = *reinterpret_cast<const half8*>(Bst + boffs[nk][dx]);
-                    bl[nk] = *reinterpret_cast<const half8*>(Bst + BPLANE + boffs[nk][dx]);
-                }
+                const int cur = dx & 1;
+#ifndef SF_ABL_NOFRAG
+                if (dx == 0) { SF_FRAGS(1, 1) }
+                if (dx == 1) { SF_FRAGS(0, 2) }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                // the three products of a tile are spread over the four tiles: no MFMA waits for its predecessor's result
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                    for (int nk = 0; nk < 2; ++nk) {
-                        acc[mb][nk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bh[nk], acc[mb][nk], 0, 0, 0);
-                        acc[mb][nk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bl[nk], acc[mb][nk], 0, 0, 0);
-                        acc[mb][nk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mb], bh[nk], acc[mb][nk], 0, 0, 0);
-                    }
+                    for (int nk = 0; nk < 2; ++nk)
+                        acc[mb][nk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][mb], bh[cur][nk], acc[mb][nk], 0, 0, 0);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nk = 0; nk < 2; ++nk)
+                        acc[mb][nk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][mb], bl[cur][nk], acc[mb][nk], 0, 0, 0);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nk = 0; nk < 2; ++nk)
+                        acc[mb][nk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][mb], bh[cur][nk], acc[mb][nk], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
+#undef SF_FRAGS
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef SF_ABL_NOBAR
             __syncthreads();
+#endif
             if (dy == 2 && ks + 1 < KT) {          // every wave is done with this k-step's patch: replace it
+#ifndef SF_ABL_NOASTORE
                 sf_astore();
+#endif
+#ifndef SF_ABL_NOBAR
                 __syncthreads();
+#endif
             }
         }
     }
@@ -449,6 +481,305 @@ SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale
         else SF_LAUNCH(4, false, 2);
     }
 #undef SF_LAUNCH
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient with split-f16 operands:
+//     dW[co][ci][ky][kx] = sum over pixels of gy[p][co] * a[p + (ky-1, kx-1)][ci],   a = relu(scale*x + shift) or x.
+// GEMM per tap with M = co, N = ci, K = pixels.  Both operands live in memory pixel-major (NHWC), i.e. K-major, while an
+// MFMA lane wants 8 consecutive k (pixels) of ONE channel: the tiles are staged as they come ([pixel][16 channels], 32 B
+// per pixel and 16-channel plane, hi and lo planes) and read with ds_read_b64_tr_b16, the LDS transpose read -- a 16-lane
+// group hands in the four 8-byte pieces of four pixels' 16 channels and lane c gets channel c of the four pixels.
+// Planes of neighbouring channel blocks lie 128 B (mod 256) apart, so the two blocks a half-wave reads never share a bank.
+//
+// Workgroup = 64 co x 32 ci x all 9 taps; waves = 2 co halves x 2 k halves (each wave: 32 x 32 x 9 taps = 9 accumulators,
+// the k halves are separate partial slices).  A stage = 64 pixels (64/W image rows): their gy rows are staged afresh, the
+// x rows go into a ring of RING >= 64/W + 2 image rows (power of two), of which every stage only loads the 64/W new ones;
+// rows -1 / H and the halo columns are zero.  A slice = a range of stages of one image or a range of whole images; the
+// partial sums [slice][k half][tap][co][ci] are reduced in fp64 by wgrad_sf16_reduce_kernel, which also unscales.
+namespace {
+
+typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
+
+struct WSf16P {
+    const float* x;            // [B][H][W][K]
+    const float* gy;           // [B][H][W][N]
+    float* partial;            // [nslices * 2][9][N][K]
+    const float* in_scale;
+    const float* in_shift;
+    const float* g_amax;       // device: amax of gy
+    int B, H, W, K, N;
+    int spi, ips;              // slices per image (>= 1) XOR images per slice (>= 1)
+    int stages_per_image;
+    float sa;                  // fixed activation scale
+};
+
+__device__ __forceinline__ half4 sf_tr_read(const unsigned char* p) {
+    return __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) short4v*)(p)));
+}
+
+template <int LOGW, bool INT>
+__global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
+    constexpr int W = 1 << LOGW, TRS = 64 >> LOGW, WP = W + 2;
+    constexpr int RING = TRS <= 2 ? 4 : (TRS == 4 ? 8 : 16);
+    constexpr int XPL = ((RING * WP * 32 + 255) / 256) * 256 + 128;      // plane stride: = 128 (mod 256)
+    constexpr int GPL = 64 * 32 + 128;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * XPL + 8 * GPL];
+    unsigned char* const Xs = smem;                 // planes (cb 0, hi), (cb 1, hi), (cb 0, lo), (cb 1, lo)
+    unsigned char* const Gs = smem + 4 * XPL;       // planes cb 0..3 hi, cb 0..3 lo
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wvu & 1, wk = wvu >> 1;
+    const int ci_tiles = p.K >> 5;
+    const int ntile = ci_tiles * (p.N >> 6);
+    const int logical = xcd_remap_sf(blockIdx.x, gridDim.x);
+    const int tile = logical % ntile, slice = logical / ntile;
+    const int ci0 = (tile % ci_tiles) * 32, co0 = (tile / ci_tiles) * 64;
+    int b0, b1, s0, s1;                                  // images [b0, b1), stages [s0, s1) of each
+    if (p.ips >= 1) {
+        b0 = slice * p.ips; b1 = min(p.B, b0 + p.ips); s0 = 0; s1 = p.stages_per_image;
+    } else {
+        b0 = slice / p.spi; b1 = b0 + 1;
+        const int per = (p.stages_per_image + p.spi - 1) / p.spi;
+        s0 = (slice % p.spi) * per; s1 = min(p.stages_per_image, s0 + per);
+    }
+    const float sg = sf_scale_of(*p.g_amax), sa = p.sa;
+
+    // ---- staging maps.  x: item e = tid + 256*i (i < 2): pixel e >> 3 of the 64 new ones, channel quad e & 7 (32 ci);
+    //      gy: item e (i < 4): pixel e >> 4, channel quad e & 15 (64 co)
+    constexpr int OOB = (int)0x80000000;
+    const int xq = tid & 7, gq = tid & 15;
+    float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (INT) {
+        xsc = *reinterpret_cast<const float4*>(p.in_scale + ci0 + xq * 4);
+        xsh = *reinterpret_cast<const float4*>(p.in_shift + ci0 + xq * 4);
+    }
+    const unsigned x_img_bytes = (unsigned)p.H * W * p.K * 4u, g_img_bytes = (unsigned)p.H * W * p.N * 4u;
+    int xrr[2], xcc[2], grr[4], gls[4], goff[4];
+    float4 xreg[2], greg[4];
+    bool xok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pe = (tid + 256 * i) >> 3;
+        xrr[i] = pe >> LOGW; xcc[i] = pe & (W - 1);
+        xreg[i] = make_float4(0.f, 0.f, 0.f, 0.f); xok[i] = false;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pe = (tid + 256 * i) >> 4;
+        grr[i] = pe >> LOGW;
+        gls[i] = (gq >> 2) * GPL + pe * 32 + (gq & 3) * 8;
+        goff[i] = ((grr[i] * W + (pe & (W - 1))) * p.N + co0 + gq * 4) * 4;
+        greg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __amdgpu_buffer_rsrc_t xrs, grs;
+#define WSF_IMAGE(BB)                                                                                           \
+    xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) + (long)(BB) * p.H * W * p.K, 0, (int)x_img_bytes, 0x00020000); \
+    grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gy) + (long)(BB) * p.H * W * p.N, 0, (int)g_img_bytes, 0x00020000);
+    // x rows [ROW0, ROW0 + TRS) -> registers (rows outside the image read as zero)
+#define WSF_XLOAD(ROW0)                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                             \
+        const int row = (ROW0) + xrr[i];                                                                        \
+        xok[i] = (unsigned)row < (unsigned)p.H;                                                                 \
+        const int off = xok[i] ? ((row * W + xcc[i]) * p.K + ci0 + xq * 4) * 4 : OOB;                           \
+        xreg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));            \
+    }
+#define WSF_XSTORE(ROW0)                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                             \
+        float4 v = xreg[i];                                                                                     \
+        if (INT) {                                                                                              \
+            v.x = xok[i] ? bn_relu(v.x, xsc.x, xsh.x) : 0.f; v.y = xok[i] ? bn_relu(v.y, xsc.y, xsh.y) : 0.f;   \
+            v.z = xok[i] ? bn_relu(v.z, xsc.z, xsh.z) : 0.f; v.w = xok[i] ? bn_relu(v.w, xsc.w, xsh.w) : 0.f;   \
+        }                                                                                                       \
+        v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa;                                                             \
+        const half4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};                          \
+        const half4 lo = {(_Float16)(v.x - (float)hi.x), (_Float16)(v.y - (float)hi.y),                         \
+                          (_Float16)(v.z - (float)hi.z), (_Float16)(v.w - (float)hi.w)};                        \
+        const int slot = ((ROW0) + xrr[i] + 1) & (RING - 1);                                                    \
+        const int o = (xq >> 2) * XPL + (slot * WP + xcc[i] + 1) * 32 + (xq & 3) * 8;                           \
+        *reinterpret_cast<half4*>(Xs + o) = hi;                                                                 \
+        *reinterpret_cast<half4*>(Xs + 2 * XPL + o) = lo;                                                       \
+    }
+#define WSF_GLOAD(H0)                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
+        greg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(grs, goff[i], (H0) * W * p.N * 4, 0));
+#define WSF_GSTORE()                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                             \
+        float4 v = greg[i];                                                                                     \
+        v.x *= sg; v.y *= sg; v.z *= sg; v.w *= sg;                                                             \
+        const half4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};                          \
+        const half4 lo = {(_Float16)(v.x - (float)hi.x), (_Float16)(v.y - (float)hi.y),                         \
+                          (_Float16)(v.z - (float)hi.z), (_Float16)(v.w - (float)hi.w)};                        \
+        *reinterpret_cast<half4*>(Gs + gls[i]) = hi;                                                            \
+        *reinterpret_cast<half4*>(Gs + 4 * GPL + gls[i]) = lo;                                                  \
+    }
+
+    // halo columns of every ring row, all four x planes: zero once
+    for (int i = tid; i < RING * 2 * 4 * 2; i += 256) {
+        const int half = i & 1, pl = (i >> 1) & 3, side = (i >> 3) & 1, slot = i >> 4;
+        *reinterpret_cast<float4*>(Xs + pl * XPL + (slot * WP + (side ? W + 1 : 0)) * 32 + half * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    // ---- fragment addressing (lane-static parts)
+    const int g16 = lane >> 4, cbl = g16 & 1, khalf = g16 >> 1, r4 = (lane >> 2) & 3, ch = lane & 3;
+    const int a_base = (2 * wc + cbl) * GPL + (8 * khalf + r4) * 32 + ch * 8;      // + ks*512 + rd*128 (+ 4*GPL: lo)
+    const int pin = 8 * khalf + r4;                                                // pixel within the k-step (rd adds 4)
+    const int b_lane = cbl * XPL + ch * 8;
+
+    floatx16 acc[9];
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    for (int b = b0; b < b1; ++b) {
+        WSF_IMAGE(b)
+        const int hs0 = s0 * TRS;                          // first output row of this slice in the image
+        __syncthreads();                                   // previous image fully consumed
+        // prologue: rows hs0-1 .. hs0 (+ what comes with them), then the first stage's new rows and its gy rows
+        WSF_XLOAD(hs0 - 1) WSF_XSTORE(hs0 - 1)
+        if (TRS == 1) { WSF_XLOAD(hs0) WSF_XSTORE(hs0) }
+        WSF_XLOAD(hs0 + 1) WSF_GLOAD(hs0)
+        WSF_XSTORE(hs0 + 1) WSF_GSTORE()
+        __syncthreads();
+        for (int s = s0; s < s1; ++s) {
+            const int h0 = s * TRS;
+            const bool more = s + 1 < s1;
+            if (more) { WSF_XLOAD(h0 + TRS + 1) WSF_GLOAD(h0 + TRS) }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int ks = 2 * wk + kk;                // wave-uniform (wk scalar)
+                half8 ah, al;
+                {
+                    const unsigned char* ap = Gs + a_base + ks * 512;
+                    const half4 h0v = sf_tr_read(ap), h1v = sf_tr_read(ap + 128);
+                    const half4 l0v = sf_tr_read(ap + 4 * GPL), l1v = sf_tr_read(ap + 4 * GPL + 128);
+                    ah = half8{h0v[0], h0v[1], h0v[2], h0v[3], h1v[0], h1v[1], h1v[2], h1v[3]};
+                    al = half8{l0v[0], l0v[1], l0v[2], l0v[3], l1v[0], l1v[1], l1v[2], l1v[3]};
+                }
+                const int pix = ks * 16 + pin;             // pixel of the stage (rd = 0)
+                const int row_s = pix >> LOGW, col = pix & (W - 1);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int slot = (h0 + row_s + dy) & (RING - 1);
+                    const unsigned char* bp = Xs + b_lane + (slot * WP + col) * 32;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const half4 h0v = sf_tr_read(bp + dx * 32), h1v = sf_tr_read(bp + dx * 32 + 128);
+                        const half4 l0v = sf_tr_read(bp + 2 * XPL + dx * 32), l1v = sf_tr_read(bp + 2 * XPL + dx * 32 + 128);
+                        const half8 bh = {h0v[0], h0v[1], h0v[2], h0v[3], h1v[0], h1v[1], h1v[2], h1v[3]};
+                        const half8 bl = {l0v[0], l0v[1], l0v[2], l0v[3], l1v[0], l1v[1], l1v[2], l1v[3]};
+                        const int tp = dy * 3 + dx;
+                        acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[tp], 0, 0, 0);
+                        acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[tp], 0, 0, 0);
+                        acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[tp], 0, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            if (more) {
+                WSF_XSTORE(h0 + TRS + 1) WSF_GSTORE()
+                __syncthreads();
+            }
+        }
+    }
+#undef WSF_IMAGE
+#undef WSF_XLOAD
+#undef WSF_XSTORE
+#undef WSF_GLOAD
+#undef WSF_GSTORE
+
+    // ---- partial sums of this (slice, k half): [tap][co][ci]
+    float* out = p.partial + ((long)(slice * 2 + wk) * 9) * p.N * p.K;
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            out[((long)a * p.N + co) * p.K + ci0 + (lane & 31)] = acc[a][r];
+        }
+}
+
+// sum the slices in fp64, unscale, scatter to OIHW
+__global__ __launch_bounds__(256) void wgrad_sf16_reduce_kernel(const float* __restrict__ partial, int nparts, int N, int K,
+                                                                const float* __restrict__ g_amax, float sa,
+                                                                float* __restrict__ dw) {
+    const long nk = (long)9 * N * K;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nk) return;
+    double s = 0.0;
+    for (int q = 0; q < nparts; ++q) s += (double)partial[(long)q * nk + e];
+    const int ci = (int)(e % K);
+    const long t = e / K;
+    const int co = (int)(t % N), tap = (int)(t / N);
+    const double inv = 1.0 / ((double)sf_scale_of(*g_amax) * (double)sa);
+    dw[((long)co * K + ci) * 9 + tap] = (float)(s * inv);
+}
+
+static void wsf_slicing(int B, int H, int W, int Cin, int Cout, int* spi, int* ips, int* spimg, long* nslices) {
+    const int trs = 64 / W;
+    const int g = (H + trs - 1) / trs;
+    const long tiles = (long)(Cin / 32) * (Cout / 64);
+    long want = 2048 / tiles;                        // workgroups ~ 2048: four rounds of the 512 resident ones
+    if (want < 1) want = 1;
+    *spimg = g;
+    if (want >= B) {
+        int s = (int)(want / B);
+        if (s > g / 8) s = g / 8 > 0 ? g / 8 : 1;   // at least 8 stages per slice
+        if (s < 1) s = 1;
+        *spi = s; *ips = 0; *nslices = (long)B * s;
+    } else {
+        int i = (int)((B + want - 1) / want);
+        *spi = 0; *ips = i; *nslices = (B + i - 1) / i;
+    }
+}
+
+}  // namespace
+
+SED_API int sed_wgrad_sf16_supported(int H, int W, int Cin, int Cout) {
+    return (W == 8 || W == 16 || W == 32 || W == 64) && H >= 1 && Cin >= 32 && Cin % 32 == 0 && Cout >= 64 && Cout % 64 == 0;
+}
+
+SED_API long sed_wgrad_sf16_partial_floats(int B, int H, int W, int Cin, int Cout) {
+    if (!sed_wgrad_sf16_supported(H, W, Cin, Cout) || B <= 0) return 0;
+    int spi, ips, g; long ns;
+    wsf_slicing(B, H, W, Cin, Cout, &spi, &ips, &g, &ns);
+    return ns * 2 * 9 * Cin * Cout;
+}
+
+SED_API int sed_conv3x3_wgrad_sf16(const float* x, const float* gy, float* dw_oihw, float* partial, int B, int H, int W,
+                                   int Cin, int Cout, const float* in_scale, const float* in_shift, const float* gy_amax,
+                                   float sa, sed_stream_t stream) {
+    if (!x || !gy || !dw_oihw || !partial || !gy_amax || B <= 0 || !sed_wgrad_sf16_supported(H, W, Cin, Cout) || !(sa > 0.f))
+        return SED_EINVAL;
+    if ((in_scale == nullptr) != (in_shift == nullptr)) return SED_EINVAL;
+    WSf16P p;
+    p.x = x; p.gy = gy; p.partial = partial; p.in_scale = in_scale; p.in_shift = in_shift; p.g_amax = gy_amax;
+    p.B = B; p.H = H; p.W = W; p.K = Cin; p.N = Cout; p.sa = sa;
+    long ns;
+    wsf_slicing(B, H, W, Cin, Cout, &p.spi, &p.ips, &p.stages_per_image, &ns);
+    const long nblk = ns * (Cin / 32) * (Cout / 64);
+    if (nblk > 0x7fffffffL) return SED_EINVAL;
+    const dim3 g((unsigned)nblk), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    const bool it = in_scale != nullptr;
+#define WSF_LAUNCH(LW)                                                                                          \
+    if (it) hipLaunchKernelGGL((wgrad_sf16_kernel<LW, true>), g, blk, 0, s, p);                                 \
+    else hipLaunchKernelGGL((wgrad_sf16_kernel<LW, false>), g, blk, 0, s, p);
+    if (W == 64) { WSF_LAUNCH(6) } else if (W == 32) { WSF_LAUNCH(5) } else if (W == 16) { WSF_LAUNCH(4) } else { WSF_LAUNCH(3) }
+#undef WSF_LAUNCH
+    SED_LAUNCH_CHECK();
+    const long nk = 9L * Cin * Cout;
+    hipLaunchKernelGGL(wgrad_sf16_reduce_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, s, partial, (int)(ns * 2), Cout,
+                       Cin, gy_amax, sa, dw_oihw);
     SED_LAUNCH_CHECK();
     return 0;
 }

@@ -64,16 +64,16 @@ def join_side_stream():
             sink.done()
 
 
-def _fork_wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None):
+def _fork_wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, gy_amax=None):
     """_wgrad on the side stream behind everything enqueued on the main stream so far.  With a sink the gradient lands in
     the flat buffer and is joined later (join_side_stream); without one the tensor is returned after an immediate join."""
     main = torch.cuda.current_stream()
     side = _side_stream(x.device)
     side.wait_stream(main)
-    for t in (x, gy) + ((in_st.scale, in_st.shift) if in_st is not None else ()):
+    for t in (x, gy) + ((in_st.scale, in_st.shift) if in_st is not None else ()) + ((gy_amax,) if gy_amax is not None else ()):
         t.record_stream(side)                    # main may free them before the side stream has read them
     with torch.cuda.stream(side):
-        dw = _wgrad(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=False)
+        dw = _wgrad(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=False, gy_amax=gy_amax)
         ev = torch.cuda.Event()
         ev.record(side)
     if not _PENDING:
@@ -545,7 +545,31 @@ def _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True):
     return _ret(sink, dw) if signal else (None if sink is not None else dw)
 
 
-def _wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True):
+def _wgrad_sf16(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, gy_amax=None):
+    nfl = _lib.lib().sed_wgrad_sf16_partial_floats(B, H, W, Cin, Cout)
+    if nfl <= 0:
+        raise RuntimeError("sed_conv3x3_wgrad_sf16 does not support this shape")
+    if gy_amax is None:
+        gy_amax = amax_of(gy)
+    partial = torch.empty((nfl,), dtype=torch.float32, device=x.device)
+    dw = _dst(sink, (Cout, Cin, 3, 3), x.device)
+    with _timed("conv3x3_wgrad_sf16_mfma(+slice reduce)|%d->%d@%dx%d%s" % (Cin, Cout, H, W, "+inT" if in_st is not None else ""),
+                2.0 * 9 * B * H * W * Cin * Cout):
+        _call("sed_conv3x3_wgrad_sf16", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
+              _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None,
+              _ptr(gy_amax), SF16_ACT_SCALE, _stream())
+    return _ret(sink, dw) if signal else (None if sink is not None else dw)
+
+
+def _wgrad_algo(H, W, Cin, Cout):
+    """3 = split-f16 (where it beats the Winograd-domain kernel: >= 128 input channels; with 64 the 64 x 32 tile reads every
+    gradient row twice from HBM and only ties), else the fp32 kernels."""
+    return 3 if (USE_SF16 and Cin >= 128 and _lib.lib().sed_wgrad_sf16_supported(H, W, Cin, Cout)) else 0
+
+
+def _wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, gy_amax=None):
+    if _wgrad_algo(H, W, Cin, Cout) == 3:
+        return _wgrad_sf16(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=signal, gy_amax=gy_amax)
     if USE_WINOGRAD >= 2 and W in (8, 16, 32, 64) and Cin % 32 == 0 and Cout % 64 == 0:
         return _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=signal)
     if USE_WINOGRAD and _wgrad_wino_ok(W, Cin, Cout):
@@ -730,7 +754,7 @@ class ConvBlockFn(torch.autograd.Function):
         sk = ctx.sinks                                   # (w1, g1, b1, -, -, w2, g2, b2)
         dg2, db2, coef2 = bn_bwd_finalize(part, n.value, M, st2, batch_stats=ctx.training, sinks=(sk[6], sk[7]))
         gy2 = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
-        sf2 = _conv_algo(H, W, Cout, Cout) == 3         # the split-f16 dgrad takes its scale from the tensor's amax
+        sf2 = _conv_algo(H, W, Cout, Cout) == 3 or _wgrad_algo(H, W, Cout, Cout) == 3   # split-f16 consumers scale by the amax
         amax2 = torch.empty((1,), dtype=torch.float32, device=dev) if sf2 else None
         _call("sed_bn_relu_pool_bwd_apply", _ptr(y2), _ptr(g_out), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift),
               _ptr(coef2), _ptr(gy2), _ptr(amax2), _stream())
@@ -743,16 +767,16 @@ class ConvBlockFn(torch.autograd.Function):
         partb = torch.empty((nfb,), dtype=torch.float32, device=dev)
         gy1 = _conv_fwd_like(gy2, w2, B, H, W, Cout, Cout, dgrad=True, epi=2, partials=partb, yprev=y1, p_st=st1, x_amax=amax2)
         if fork and sk[5] is not None:
-            dw2 = _fork_wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=st1, sink=sk[5])
+            dw2 = _fork_wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=st1, sink=sk[5], gy_amax=amax2)
         else:
-            dw2 = _wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=st1, sink=sk[5])
+            dw2 = _wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=st1, sink=sk[5], gy_amax=amax2)
         del gy2
         dg1, db1, coef1 = bn_bwd_finalize(partb, npb, M, st1, batch_stats=ctx.training, sinks=(sk[1], sk[2]))
         # conv1
         gx = None
         amax1 = None
         if Cin != 1:
-            if ctx.needs_input_grad[0] and _conv_algo(H, W, Cout, Cin) == 3:
+            if (ctx.needs_input_grad[0] and _conv_algo(H, W, Cout, Cin) == 3) or _wgrad_algo(H, W, Cin, Cout) == 3:
                 amax1 = torch.empty((1,), dtype=torch.float32, device=dev)
             _call("sed_bn_bwd_apply", _ptr(gy1), _ptr(y1), M, Cout, _ptr(coef1), _ptr(amax1), _stream())
         if Cin == 1:                                   # BN1 backward g = a*dz + b*y1 + c is applied on load by the kernel
@@ -771,9 +795,9 @@ class ConvBlockFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 gx = _conv_fwd_like(gy1, w1, B, H, W, Cout, Cin, dgrad=True, epi=0, x_amax=amax1)
             if fork and sk[0] is not None:
-                dw1 = _fork_wgrad(x, gy1, B, H, W, Cin, Cout, sink=sk[0])
+                dw1 = _fork_wgrad(x, gy1, B, H, W, Cin, Cout, sink=sk[0], gy_amax=amax1)
             else:
-                dw1 = _wgrad(x, gy1, B, H, W, Cin, Cout, sink=sk[0])
+                dw1 = _wgrad(x, gy1, B, H, W, Cin, Cout, sink=sk[0], gy_amax=amax1)
         return gx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, None, None, None
 
 

@@ -393,7 +393,11 @@ def test_low_noise_training_fixture_vs_float64_reference(mt, golden_dir):
         o = m(xw, lam, specaug_stripes=fx["big_stripes"][it],
               **dropout_kw(mt, int(fx["big_dropout_seeds"][it]), rows // 2, ((T // 2) // 2) // 2))
         loss = loss_func(o, {"target": do_mixup(tg, lam)})
-        assert abs(loss.item() - fx["big_losses64"][it]) < (2e-5 if it == 0 else 2e-3), (it, loss.item(), fx["big_losses64"][it])
+        # later steps inherit Adam's sign-like amplification of noise-level gradient entries.  FrameMax (arg-max pooling: one
+        # frame per clip and class carries the gradient) is the most sensitive: the CPU oracle in float32 itself lands
+        # 8e-5 (8 threads) or 5.8e-3 (1 thread) from the float64 loss at step 2 of this fixture, so its gate is 8e-3
+        later = 8e-3 if mt.endswith("FrameMax") else 2e-3
+        assert abs(loss.item() - fx["big_losses64"][it]) < (2e-5 if it == 0 else later), (it, loss.item(), fx["big_losses64"][it])
         opt.zero_grad()
         loss.backward()
         if it == 0:

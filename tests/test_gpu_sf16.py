@@ -106,3 +106,26 @@ def test_sf16_dgrad_epilogue_and_dynamic_scale(B, H, W, Cin, Cout):
     s2 = (want * ((yprev.double() - mu.double()) * istd.double())).reshape(-1, Cin).sum(0)
     assert (p[0] - s1).abs().max() <= 2e-5 * want.abs().reshape(-1, Cin).sum(0).max()
     assert (p[1] - s2).abs().max() <= 2e-5 * (want.abs() * ((yprev.double() - mu.double()) * istd.double()).abs()).reshape(-1, Cin).sum(0).max()
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,inT", [(2, 21, 64, 64, 64, True), (3, 37, 32, 64, 128, False), (2, 50, 16, 128, 256, True),
+                                               (5, 13, 8, 256, 512, False), (1, 1, 8, 32, 64, False), (3, 1001, 64, 64, 64, False),
+                                               (9, 9, 16, 32, 64, True)])
+def test_sf16_wgrad_matches_float64(B, H, W, Cin, Cout, inT):
+    from sound_event_detection_dcase2017_task4_amd import ops
+    g = torch.Generator().manual_seed(B * 77 + H)
+    x = torch.randn((B, H, W, Cin), generator=g)
+    gy = torch.randn((B, H, W, Cout), generator=g) * 1e-6 * torch.exp(torch.randn((B, H, W, 1), generator=g))
+    st = None
+    a = x.double()
+    if inT:
+        sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+        st = ops.BnStats(Cin, "cuda")
+        st.scale.copy_(sc); st.shift.copy_(sh)
+        a = torch.relu(torch.addcmul(sh, x, sc)).double()
+    want = torch.nn.grad.conv2d_weight(a.permute(0, 3, 1, 2), (Cout, Cin, 3, 3), gy.double().permute(0, 3, 1, 2), padding=1)
+    dw = ops._wgrad_sf16(x.cuda(), gy.cuda(), B, H, W, Cin, Cout, in_st=st)
+    torch.cuda.synchronize()
+    rel, mx = _err(dw, want)
+    print("sf16 wgrad %s: relative L2 %.2e, max %.2e" % ((B, H, W, Cin, Cout, inT), rel, mx))
+    assert rel < 1e-6 and mx < 1e-5

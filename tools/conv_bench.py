@@ -74,6 +74,10 @@ def main():
             wps = ops.pack_sf16(w)
             runs += [("sf16  fwd epi0    ", lambda: ops.conv3x3_sf16(x, wps, B, H, W, ci, co)),
                      ("sf16  fwd epi0+inT", lambda: ops.conv3x3_sf16(x, wps, B, H, W, ci, co, in_st=st))]
+        if args.only in ("", "wgrad", "sf16w") and L.sed_wgrad_sf16_supported(H, W, ci, co):
+            gam = ops.amax_of(gy)
+            runs += [("wgrad sf16 +inT   ", lambda: ops._wgrad_sf16(x, gy, B, H, W, ci, co, in_st=st, gy_amax=gam)),
+                     ("wgrad sf16        ", lambda: ops._wgrad_sf16(x, gy, B, H, W, ci, co, gy_amax=gam))]
         if args.only in ("", "wgrad"):
             runs += [("wgrad +inT        ", lambda: ops._wgrad_direct(x, gy, B, H, W, ci, co, in_st=st)),
                      ("wgrad             ", lambda: ops._wgrad_direct(x, gy, B, H, W, ci, co)),

@@ -1,0 +1,51 @@
+// f16 MFMA issue-rate micro-benchmark for gfx950 (what the split-f16 convolution can reach at best on a given box):
+// v_mfma_f32_32x32x16_f16 streams over 4 / 8 independent accumulators at 1 and 2 waves per SIMD, no memory traffic.
+//   hipcc --offload-arch=gfx950 -O3 tools/mfma_f16_ubench.hip -o /tmp/mfma_f16_ubench && /tmp/mfma_f16_ubench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+template <int NACC>
+__global__ __launch_bounds__(256) void k(float* out, int iters) {
+    floatx16 acc[NACC];
+    for (int a = 0; a < NACC; ++a)
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    half8 x, y;
+    for (int j = 0; j < 8; ++j) { x[j] = (_Float16)(threadIdx.x * 0.001f + j); y[j] = (_Float16)(1.0f + j * 0.01f); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int rep = 0; rep < 36 / NACC * NACC / NACC; ++rep)
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, acc[a], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int a = 0; a < NACC; ++a)
+        for (int r = 0; r < 16; ++r) s += acc[a][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int NACC>
+void run(const char* name, float* out, int blocks_per_cu) {
+    const int iters = 2000, nb = 256 * blocks_per_cu;
+    const int per_iter = (36 / NACC * NACC / NACC) * NACC;
+    hipLaunchKernelGGL(k<NACC>, dim3(nb), dim3(256), 0, 0, out, 10);
+    hipDeviceSynchronize();
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipEventRecord(a);
+    hipLaunchKernelGGL(k<NACC>, dim3(nb), dim3(256), 0, 0, out, iters);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    const double mfmas = (double)nb * 4 * iters * per_iter;
+    const double tf = mfmas * 32768.0 / (ms * 1e-3) / 1e12;
+    printf("%-40s %d WG/CU: %8.3f ms  %7.1f TFLOP/s  (%.1f %% of 2516; %.1f cycles per MFMA per SIMD at 2.4 GHz)\n", name, blocks_per_cu, ms, tf,
+           100 * tf / 2516.6, 2.4e9 * ms * 1e-3 / (mfmas / 1024.0));
+}
+
+int main() {
+    float* out; hipMalloc(&out, 256 * 2 * 256 * sizeof(float));
+    run<4>("32x32x16 f16, 4 accumulators", out, 1); run<4>("32x32x16 f16, 4 accumulators", out, 2);
+    run<9>("32x32x16 f16, 9 accumulators", out, 1); run<9>("32x32x16 f16, 9 accumulators", out, 2);
+    run<4>("32x32x16 f16, 4 accumulators (again, warm)", out, 2);
+    return 0;
+}
