@@ -729,6 +729,8 @@ static void wsf_slicing(int B, int H, int W, int Cin, int Cout, int* spi, int* i
     const int g = (H + trs - 1) / trs;
     const long tiles = (long)(Cin / 32) * (Cout / 64);
     long want = 2048 / tiles;                        // workgroups ~ 2048: four rounds of the 512 resident ones
+    const long most = ((long)B * g) / 64;            // ... but at least 64 stages per slice (the 74 KB partial write per
+    if (want > most) want = most;                    // workgroup and k half must stay small next to its K loop)
     if (want < 1) want = 1;
     *spimg = g;
     if (want >= B) {
