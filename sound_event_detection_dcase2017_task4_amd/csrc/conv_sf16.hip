@@ -499,6 +499,8 @@ SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale
 // x rows go into a ring of RING >= 64/W + 2 image rows (power of two), of which every stage only loads the 64/W new ones;
 // rows -1 / H and the halo columns are zero.  A slice = a range of stages of one image or a range of whole images; the
 // partial sums [slice][k half][tap][co][ci] are reduced in fp64 by wgrad_sf16_reduce_kernel, which also unscales.
+// (A 64 co x 64 ci variant for the 64-input-channel layers was tried: 256 VGPRs with 10-119 spilled registers and no gain
+// where it did not spill; those two layers keep the Winograd-domain kernel.)
 namespace {
 
 typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
@@ -731,6 +733,9 @@ static void wsf_slicing(int B, int H, int W, int Cin, int Cout, int* spi, int* i
     long want = 2048 / tiles;                        // workgroups ~ 2048: four rounds of the 512 resident ones
     const long most = ((long)B * g) / 64;            // ... but at least 64 stages per slice (the 74 KB partial write per
     if (want > most) want = most;                    // workgroup and k half must stay small next to its K loop)
+    const long least = ((long)B * g + 255) / 256;    // ... and at most 256 stages (16384 pixels) per fp32 accumulation chain
+    if (want < least) want = least;                  // (7e-7 relative at 125 stages, tests/test_gpu_sf16.py); beyond a slice
+                                                     // the sums continue in fp64 (reduce kernel)
     if (want < 1) want = 1;
     *spimg = g;
     if (want >= B) {
