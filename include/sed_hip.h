@@ -175,7 +175,8 @@ int sed_conv3x3_wgrad_wino2(const float* x, const float* gy, float* dw_oihw, flo
  * pixel counts appended for epi 1).  wp: sed_conv_sf16_pack_halfs(...) f16 values and wscale[2] (amax, scale) written by
  * sed_pack_conv_weights_sf16 (dgrad = 1: operand of the transposed convolution).  Activation scale: x_amax (device
  * pointer to the amax of x, e.g. from sed_amax or a producer kernel) or, when null, the fixed power of two `sa`
- * (|sa*x| must stay below 65504).  Needs W in {8,16,32,64}, Cin % 16 == 0, Cout % 64 == 0. */
+ * (|sa*x| must stay below 65504: otherwise, or on a non-finite operand, the kernel stores 1 through err_host, a
+ * nullable host-mapped int -- never a silent saturation).  Needs W in {8,16,32,64}, Cin % 16 == 0, Cout % 64 == 0. */
 int sed_conv3x3_sf16_supported(int H, int W, int Cin, int Cout);
 long sed_conv_sf16_pack_halfs(int Cin, int Cout);
 long sed_conv_sf16_num_parts(int B, int H, int W, int Cout);
@@ -185,7 +186,7 @@ int sed_pack_conv_weights_sf16(const float* w_oihw, int Cout, int Cin, int dgrad
 int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale, float* y, int B, int H, int W, int Cin,
                      int Cout, const float* in_scale, const float* in_shift, int epi, float* partials,
                      const float* yprev, const float* p_scale, const float* p_shift, const float* p_mean,
-                     const float* p_invstd, const float* x_amax, float sa, sed_stream_t stream);
+                     const float* p_invstd, const float* x_amax, float sa, int* err_host, sed_stream_t stream);
 /* Weight gradient with split-f16 operands (csrc/conv_sf16.hip): same contract as sed_conv3x3_wgrad; gy_amax = device
  * pointer to max |gy| (sed_amax or the producer kernels), sa = fixed power-of-two scale of the activations.
  * Needs W in {8,16,32,64}, Cin % 32 == 0, Cout % 64 == 0; partial: sed_wgrad_sf16_partial_floats(...) floats. */
@@ -193,7 +194,7 @@ int sed_wgrad_sf16_supported(int H, int W, int Cin, int Cout);
 long sed_wgrad_sf16_partial_floats(int B, int H, int W, int Cin, int Cout);
 int sed_conv3x3_wgrad_sf16(const float* x, const float* gy, float* dw_oihw, float* partial, int B, int H, int W,
                            int Cin, int Cout, const float* in_scale, const float* in_shift, const float* gy_amax,
-                           float sa, sed_stream_t stream);
+                           float sa, int* err_host, sed_stream_t stream);
 /* Winograd-domain weight gradient (12 instead of 18 MACs per output pair); same contract as sed_conv3x3_wgrad.
  * Needs W a power of two <= 64 and Cin, Cout % 64 == 0; partial: sed_wgrad_wino_partial_floats(...) floats. */
 long sed_wgrad_wino_partial_floats(long M, int Cin, int Cout, int* nslices_out, int* pix_per_slice_out);

@@ -46,6 +46,7 @@ struct Sf16P {
     int B, H, W, K, N;
     int logW, TR, ntile;
     float sa;
+    int* err_host;             // nullable, host-mapped: set to 1 when a scaled activation leaves the f16 range
 };
 
 __device__ __forceinline__ int sf_sw(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 3) & 1)) << 4); }
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(256, 2) void conv_sf16_kernel(Sf16P p) {
     SF_META(0) SF_META(1) SF_META(2) SF_META(3) SF_META(4) SF_META(5)
 #undef SF_META
     float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool overflow = false;      // a scaled operand outside the f16 range (or not finite): reported, never silent
 
 #define SF_ALOAD(i) if (i < NI) areg##i = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, aoff##i, k_off, 0));
 #define sf_aload(KS)                                                                                            \
@@ -140,6 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv_sf16_kernel(Sf16P p) {
             v.w = sok##i ? bn_relu(v.w, sc4.w, sh4.w) : 0.f;                                                    \
         }                                                                                                       \
         v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa;                                                             \
+        overflow |= !(fabsf(v.x) < 65504.f) | !(fabsf(v.y) < 65504.f) | !(fabsf(v.z) < 65504.f) | !(fabsf(v.w) < 65504.f); /* NaN too */ \
         const half4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};                          \
         const half4 lo = {(_Float16)(v.x - (float)hi.x), (_Float16)(v.y - (float)hi.y),                         \
                           (_Float16)(v.z - (float)hi.z), (_Float16)(v.w - (float)hi.w)};                        \
@@ -291,6 +294,8 @@ __global__ __launch_bounds__(256, 2) void conv_sf16_kernel(Sf16P p) {
 #undef SF_BDMA
 #undef sf_bdma
 
+    if (overflow && p.err_host) __hip_atomic_store(p.err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+
     // ---- epilogue: unscale, (mask,) statistics, store (rows past the image fall outside the descriptor and are dropped)
     const unsigned y_img_bytes = (unsigned)p.H * W * p.N * 4u;
     const __amdgpu_buffer_rsrc_t yrs =
@@ -425,8 +430,8 @@ SED_API int sed_amax(const float* x, long n, float* amax_out, sed_stream_t strea
     if (!x || !amax_out || n <= 0) return SED_EINVAL;
     hipError_t e = hipMemsetAsync(amax_out, 0, sizeof(float), (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
-    const long nb = (n + 255) / 256;
-    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)(nb > 1024 ? 1024 : nb)), dim3(256), 0, (hipStream_t)stream, x, n, amax_out);
+    const long nb = (n + 1023) / 1024;               // >= 4 elements per thread; few blocks: one atomic per wave, all on one word
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)(nb > 256 ? 256 : nb)), dim3(256), 0, (hipStream_t)stream, x, n, amax_out);
     SED_LAUNCH_CHECK();
     return 0;
 }
@@ -447,7 +452,7 @@ SED_API int sed_pack_conv_weights_sf16(const float* w_oihw, int Cout, int Cin, i
 SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale, float* y, int B, int H, int W, int Cin,
                              int Cout, const float* in_scale, const float* in_shift, int epi, float* partials,
                              const float* yprev, const float* p_scale, const float* p_shift, const float* p_mean,
-                             const float* p_invstd, const float* x_amax, float sa, sed_stream_t stream) {
+                             const float* p_invstd, const float* x_amax, float sa, int* err_host, sed_stream_t stream) {
     if (!x || !wp || !wscale || !y || B <= 0 || !sed_conv3x3_sf16_supported(H, W, Cin, Cout) || epi < 0 || epi > 2)
         return SED_EINVAL;
     if ((in_scale == nullptr) != (in_shift == nullptr)) return SED_EINVAL;
@@ -464,7 +469,7 @@ SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale
     const int mw = sf_mw(Cout);
     p.TR = (64 * mw) >> p.logW;
     p.ntile = (H + p.TR - 1) / p.TR;
-    p.sa = sa;
+    p.sa = sa; p.err_host = err_host;
     const long nblk = (long)B * p.ntile * (Cout / (mw == 2 ? 128 : 64));
     if (nblk > 0x7fffffffL) return SED_EINVAL;
     const dim3 g((unsigned)nblk), blk(256);
@@ -516,6 +521,7 @@ struct WSf16P {
     int spi, ips;              // slices per image (>= 1) XOR images per slice (>= 1)
     int stages_per_image;
     float sa;                  // fixed activation scale
+    int* err_host;             // nullable, host-mapped: set to 1 when a scaled activation leaves the f16 range
 };
 
 __device__ __forceinline__ half4 sf_tr_read(const unsigned char* p) {
@@ -561,6 +567,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
         xsh = *reinterpret_cast<const float4*>(p.in_shift + ci0 + xq * 4);
     }
     const unsigned x_img_bytes = (unsigned)p.H * W * p.K * 4u, g_img_bytes = (unsigned)p.H * W * p.N * 4u;
+    bool overflow = false;
     int xrr[2], xcc[2], grr[4], gls[4], goff[4];
     float4 xreg[2], greg[4];
     bool xok[2];
@@ -598,6 +605,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
             v.z = xok[i] ? bn_relu(v.z, xsc.z, xsh.z) : 0.f; v.w = xok[i] ? bn_relu(v.w, xsc.w, xsh.w) : 0.f;   \
         }                                                                                                       \
         v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa;                                                             \
+        overflow |= !(fabsf(v.x) < 65504.f) | !(fabsf(v.y) < 65504.f) | !(fabsf(v.z) < 65504.f) | !(fabsf(v.w) < 65504.f); /* NaN too */ \
         const half4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};                          \
         const half4 lo = {(_Float16)(v.x - (float)hi.x), (_Float16)(v.y - (float)hi.y),                         \
                           (_Float16)(v.z - (float)hi.z), (_Float16)(v.w - (float)hi.w)};                        \
@@ -699,6 +707,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
 #undef WSF_GLOAD
 #undef WSF_GSTORE
 
+    if (overflow && p.err_host) __hip_atomic_store(p.err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+
     // ---- partial sums of this (slice, k half): [tap][co][ci]
     float* out = p.partial + ((long)(slice * 2 + wk) * 9) * p.N * p.K;
 #pragma unroll
@@ -764,13 +774,13 @@ SED_API long sed_wgrad_sf16_partial_floats(int B, int H, int W, int Cin, int Cou
 
 SED_API int sed_conv3x3_wgrad_sf16(const float* x, const float* gy, float* dw_oihw, float* partial, int B, int H, int W,
                                    int Cin, int Cout, const float* in_scale, const float* in_shift, const float* gy_amax,
-                                   float sa, sed_stream_t stream) {
+                                   float sa, int* err_host, sed_stream_t stream) {
     if (!x || !gy || !dw_oihw || !partial || !gy_amax || B <= 0 || !sed_wgrad_sf16_supported(H, W, Cin, Cout) || !(sa > 0.f))
         return SED_EINVAL;
     if ((in_scale == nullptr) != (in_shift == nullptr)) return SED_EINVAL;
     WSf16P p;
     p.x = x; p.gy = gy; p.partial = partial; p.in_scale = in_scale; p.in_shift = in_shift; p.g_amax = gy_amax;
-    p.B = B; p.H = H; p.W = W; p.K = Cin; p.N = Cout; p.sa = sa;
+    p.B = B; p.H = H; p.W = W; p.K = Cin; p.N = Cout; p.sa = sa; p.err_host = err_host;
     long ns;
     wsf_slicing(B, H, W, Cin, Cout, &p.spi, &p.ips, &p.stages_per_image, &ns);
     const long nblk = ns * (Cin / 32) * (Cout / 64);

@@ -151,6 +151,11 @@ def _err_flag():
     return _ERR_FLAG
 
 
+def _sf16_err_ptr():
+    """Host-mapped word the split-f16 convolutions set when a scaled operand leaves the f16 range (slot 1 of the flag)."""
+    return ctypes.c_void_p(_err_flag().data_ptr() + 4)
+
+
 def check_device_errors(synchronize=False):
     """Raise if a kernel reported a run-time failure since the last check (no device synchronisation unless asked: the
     flag is written through host-mapped memory, so a failure surfaces at the next call after the kernel ran)."""
@@ -158,6 +163,12 @@ def check_device_errors(synchronize=False):
         return
     if synchronize:
         torch.cuda.synchronize()
+    if int(_ERR_FLAG[1]):
+        _ERR_FLAG.zero_()
+        raise RuntimeError(
+            "sound_event_detection_dcase2017_task4_amd: a split-f16 convolution met an activation outside the f16 range of its "
+            "fixed scale (|x| >= %g) or a non-finite value; its results are inf/NaN.  Diverged training, or activations far "
+            "from BatchNorm-ed magnitude: set SED_USE_SF16=0 (fp32 MFMA kernels) for such inputs." % (65504.0 / SF16_ACT_SCALE))
     code = int(_ERR_FLAG[0])
     if code:
         _ERR_FLAG.zero_()
@@ -557,7 +568,7 @@ def _wgrad_sf16(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, g
                 2.0 * 9 * B * H * W * Cin * Cout):
         _call("sed_conv3x3_wgrad_sf16", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
               _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None,
-              _ptr(gy_amax), SF16_ACT_SCALE, _stream())
+              _ptr(gy_amax), SF16_ACT_SCALE, _sf16_err_ptr(), _stream())
     return _ret(sink, dw) if signal else (None if sink is not None else dw)
 
 
@@ -621,7 +632,7 @@ def conv3x3_sf16(x, pack, B, H, W, Cin, Cout, in_st=None, epi=0, partials=None, 
               _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, epi,
               _ptr(partials), _ptr(yprev), _ptr(p_st.scale) if p_st is not None else None,
               _ptr(p_st.shift) if p_st is not None else None, _ptr(p_st.mean) if p_st is not None else None,
-              _ptr(p_st.invstd) if p_st is not None else None, _ptr(x_amax), SF16_ACT_SCALE, _stream())
+              _ptr(p_st.invstd) if p_st is not None else None, _ptr(x_amax), SF16_ACT_SCALE, _sf16_err_ptr(), _stream())
     return y
 
 
