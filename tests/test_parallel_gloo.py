@@ -211,5 +211,5 @@ def test_bench_roofline_traffic_lookup_matches_the_kernels_that_exist():
         assert sub in source, sub
     tr, src = bench.pmc_traffic([front])
     assert tr and tr > 786e6 and src.startswith("profiles/r"), (tr, src)       # >= the algorithmic 786.6 MB per launch
-    tr, _ = bench.pmc_traffic(bench.FAMILY_KERNELS["conv3x3_wino2d_mfma(fwd+dgrad)"])
+    tr, _ = bench.pmc_traffic(bench.FAMILY_KERNELS["conv3x3_sf16_mfma(fwd+dgrad)"])      # the default convolution path
     assert tr and tr > 1e9
