@@ -51,37 +51,50 @@ def _side_stream(device):
 
 def join_side_stream():
     """Main stream waits for every weight gradient issued on the side stream; their sinks report ready (the bucketed
-    all-reduce may fire here).  Called at the join points of ConvBlockFn.backward and once when the backward pass ends."""
+    all-reduce may fire here) and the tensors they used are released.  Called at the join points of ConvBlockFn.backward
+    and once when the backward pass ends."""
     if not _PENDING:
         return
     main = torch.cuda.current_stream()
     pend = list(_PENDING)
     del _PENDING[:]
-    for ev, sink in pend:
+    for ev, sink, keep in pend:
         main.wait_event(ev)
-    for ev, sink in pend:
+    for ev, sink, keep in pend:
         if sink is not None:
             sink.done()
+    del pend                                     # operands / temporaries die here, in main-stream order BEHIND the wait
+
+
+_STREAM_OVERRIDE = None     # set while kernels are being enqueued on the side stream (see _fork_wgrad)
 
 
 def _fork_wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, gy_amax=None):
     """_wgrad on the side stream behind everything enqueued on the main stream so far.  With a sink the gradient lands in
-    the flat buffer and is joined later (join_side_stream); without one the tensor is returned after an immediate join."""
+    the flat buffer and is joined later (join_side_stream); without one the tensor is returned after an immediate join.
+
+    Memory: torch's current stream stays the MAIN stream, so every tensor (operands, partial-sum buffers) belongs to the
+    main stream's allocator pool; only the kernel launches go to the side stream (_STREAM_OVERRIDE).  All of them are kept
+    referenced by the pending entry until the join, after which main-stream-ordered reuse is safe.  (The first version
+    used torch.cuda.stream(side) + Tensor.record_stream: correct, but the allocator then parks every such block until
+    the side stream's events are polled and reserved memory crept from 78 to 223 GB over 200 steps.)"""
+    global _STREAM_OVERRIDE
     main = torch.cuda.current_stream()
     side = _side_stream(x.device)
     side.wait_stream(main)
-    for t in (x, gy) + ((in_st.scale, in_st.shift) if in_st is not None else ()) + ((gy_amax,) if gy_amax is not None else ()):
-        t.record_stream(side)                    # main may free them before the side stream has read them
-    with torch.cuda.stream(side):
-        dw = _wgrad(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=False, gy_amax=gy_amax)
-        ev = torch.cuda.Event()
-        ev.record(side)
+    keep = [x, gy, in_st, gy_amax]
+    _STREAM_OVERRIDE = side
+    try:
+        dw = _wgrad(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=False, gy_amax=gy_amax, keep=keep)
+    finally:
+        _STREAM_OVERRIDE = None
+    ev = torch.cuda.Event()
+    ev.record(side)
     if not _PENDING:
         torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)    # end of this backward pass
-    _PENDING.append((ev, sink))
+    _PENDING.append((ev, sink, keep))
     if sink is None:
         join_side_stream()
-        dw.record_stream(main)
         return dw
     return None
 
@@ -99,11 +112,11 @@ class _timed(object):
         if TIMING is not None:
             self.a = torch.cuda.Event(enable_timing=True)
             self.b = torch.cuda.Event(enable_timing=True)
-            self.a.record()                      # torch's current stream == the stream the kernel is launched on
+            self.a.record(_STREAM_OVERRIDE)      # the stream the kernel is launched on (None = torch's current stream)
 
     def __exit__(self, *exc):
         if TIMING is not None:
-            self.b.record()
+            self.b.record(_STREAM_OVERRIDE)
             TIMING.setdefault(self.tag, []).append((self.a, self.b, self.flops))
         return False
 
@@ -115,7 +128,8 @@ def _ptr(t):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    st = _STREAM_OVERRIDE if _STREAM_OVERRIDE is not None else torch.cuda.current_stream()
+    return ctypes.c_void_p(st.cuda_stream)
 
 
 def _chk_dev(*ts):
@@ -530,11 +544,13 @@ def _wgrad_wino_ok(W, Cin, Cout):
     return W in (8, 16, 32, 64) and Cin % 64 == 0 and Cout % 64 == 0
 
 
-def _wgrad_wino(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True):
+def _wgrad_wino(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, keep=None):
     ns, pps = ctypes.c_int(0), ctypes.c_int(0)
     nfl = _lib.lib().sed_wgrad_wino_partial_floats(B * H * W, Cin, Cout, ctypes.byref(ns), ctypes.byref(pps))
     partial = torch.empty((nfl,), dtype=torch.float32, device=x.device)
     dw = _dst(sink, (Cout, Cin, 3, 3), x.device)
+    if keep is not None:
+        keep.extend((partial, dw))                   # alive until the side stream has been joined
     with _timed("conv3x3_wgrad_wino_mfma(+slice reduce)|%d->%d@%dx%d%s" % (Cin, Cout, H, W, "+inT" if in_st is not None else ""),
                 2.0 * 9 * B * H * W * Cin * Cout):
         _call("sed_conv3x3_wgrad_wino", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
@@ -542,13 +558,15 @@ def _wgrad_wino(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True):
     return _ret(sink, dw) if signal else (None if sink is not None else dw)
 
 
-def _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True):
+def _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, keep=None):
     ns, ups = ctypes.c_int(0), ctypes.c_int(0)
     nfl = _lib.lib().sed_wgrad_wino2_partial_floats(B, H, W, Cin, Cout, ctypes.byref(ns), ctypes.byref(ups))
     if nfl <= 0:
         raise RuntimeError("sed_conv3x3_wgrad_wino2 does not support this shape")
     partial = torch.empty((nfl,), dtype=torch.float32, device=x.device)
     dw = _dst(sink, (Cout, Cin, 3, 3), x.device)
+    if keep is not None:
+        keep.extend((partial, dw))                   # alive until the side stream has been joined
     with _timed("conv3x3_wgrad_wino2d_mfma(+slice reduce)|%d->%d@%dx%d%s" % (Cin, Cout, H, W, "+inT" if in_st is not None else ""),
                 2.0 * 9 * B * H * W * Cin * Cout):
         _call("sed_conv3x3_wgrad_wino2", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
@@ -556,14 +574,18 @@ def _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True):
     return _ret(sink, dw) if signal else (None if sink is not None else dw)
 
 
-def _wgrad_sf16(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, gy_amax=None):
+def _wgrad_sf16(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, gy_amax=None, keep=None):
     nfl = _lib.lib().sed_wgrad_sf16_partial_floats(B, H, W, Cin, Cout)
     if nfl <= 0:
         raise RuntimeError("sed_conv3x3_wgrad_sf16 does not support this shape")
     if gy_amax is None:
         gy_amax = amax_of(gy)
+        if keep is not None:
+            keep.append(gy_amax)
     partial = torch.empty((nfl,), dtype=torch.float32, device=x.device)
     dw = _dst(sink, (Cout, Cin, 3, 3), x.device)
+    if keep is not None:
+        keep.extend((partial, dw))                   # alive until the side stream has been joined
     with _timed("conv3x3_wgrad_sf16_mfma(+slice reduce)|%d->%d@%dx%d%s" % (Cin, Cout, H, W, "+inT" if in_st is not None else ""),
                 2.0 * 9 * B * H * W * Cin * Cout):
         _call("sed_conv3x3_wgrad_sf16", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
@@ -578,21 +600,23 @@ def _wgrad_algo(H, W, Cin, Cout):
     return 3 if (USE_SF16 and Cin >= 128 and _lib.lib().sed_wgrad_sf16_supported(H, W, Cin, Cout)) else 0
 
 
-def _wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, gy_amax=None):
+def _wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, gy_amax=None, keep=None):
     if _wgrad_algo(H, W, Cin, Cout) == 3:
-        return _wgrad_sf16(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=signal, gy_amax=gy_amax)
+        return _wgrad_sf16(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=signal, gy_amax=gy_amax, keep=keep)
     if USE_WINOGRAD >= 2 and W in (8, 16, 32, 64) and Cin % 32 == 0 and Cout % 64 == 0:
-        return _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=signal)
+        return _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=signal, keep=keep)
     if USE_WINOGRAD and _wgrad_wino_ok(W, Cin, Cout):
-        return _wgrad_wino(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=signal)
-    return _wgrad_direct(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=signal)
+        return _wgrad_wino(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=signal, keep=keep)
+    return _wgrad_direct(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=signal, keep=keep)
 
 
-def _wgrad_direct(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True):
+def _wgrad_direct(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, keep=None):
     ns, pps = ctypes.c_int(0), ctypes.c_int(0)
     nfl = _lib.lib().sed_wgrad_partial_floats(B * H * W, Cin, Cout, 9, ctypes.byref(ns), ctypes.byref(pps))
     partial = torch.empty((nfl,), dtype=torch.float32, device=x.device)
     dw = _dst(sink, (Cout, Cin, 3, 3), x.device)
+    if keep is not None:
+        keep.extend((partial, dw))                   # alive until the side stream has been joined
     with _timed("conv3x3_wgrad_mfma(+slice reduce)|%d->%d@%dx%d%s" % (Cin, Cout, H, W, "+inT" if in_st is not None else ""),
                 2.0 * 9 * B * H * W * Cin * Cout):
         _call("sed_conv3x3_wgrad", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
