@@ -55,25 +55,33 @@ int main(void) {
                 }
 
     printf("%s\n", sed_version());
-    float *dx, *dw, *dy, *dwf, *duf;
+    float *dx, *dw, *dy, *dwf, *duf, *dwscale;
+    void* dwp;
     CHECK_HIP(hipMalloc((void**)&dx, sizeof(float) * M * Cin));
     CHECK_HIP(hipMalloc((void**)&dw, sizeof(float) * Cout * Cin * 9));
     CHECK_HIP(hipMalloc((void**)&dy, sizeof(float) * M * Cout));
     CHECK_HIP(hipMalloc((void**)&dwf, sizeof(float) * 9 * Cout * Cin));
     CHECK_HIP(hipMalloc((void**)&duf, sizeof(float) * 16 * Cout * Cin));
+    CHECK_HIP(hipMalloc(&dwp, 2 * (size_t)sed_conv_sf16_pack_halfs(Cin, Cout)));   /* f16 (hi, lo) planes */
+    CHECK_HIP(hipMalloc((void**)&dwscale, sizeof(float) * 2));
     CHECK_HIP(hipMemcpy(dx, x, sizeof(float) * M * Cin, hipMemcpyHostToDevice));
     CHECK_HIP(hipMemcpy(dw, w, sizeof(float) * Cout * Cin * 9, hipMemcpyHostToDevice));
     hipStream_t stream;
     CHECK_HIP(hipStreamCreate(&stream));
 
     int rc = 0;
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < 3; ++pass) {
         CHECK_HIP(hipMemsetAsync(dy, 0, sizeof(float) * M * Cout, stream));
         if (pass == 0) {
             if (!sed_conv3x3_wino2_supported(H, W, Cin, Cout)) { fprintf(stderr, "wino2 not supported?\n"); return 4; }
             CHECK_SED(sed_pack_conv_weights_wino2(dw, Cout, Cin, duf, NULL, (sed_stream_t)stream));
             CHECK_SED(sed_conv3x3_wino2(dx, duf, dy, B, H, W, Cin, Cout, NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL,
                                         (sed_stream_t)stream));
+        } else if (pass == 2) {              /* the default path of the models: split-f16 operands on the f16 MFMA pipe */
+            if (!sed_conv3x3_sf16_supported(H, W, Cin, Cout)) { fprintf(stderr, "sf16 not supported?\n"); return 4; }
+            CHECK_SED(sed_pack_conv_weights_sf16(dw, Cout, Cin, 0, dwscale, dwp, (sed_stream_t)stream));
+            CHECK_SED(sed_conv3x3_sf16(dx, dwp, dwscale, dy, B, H, W, Cin, Cout, NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL,
+                                       NULL, 16.0f, NULL, (sed_stream_t)stream));
         } else {
             CHECK_SED(sed_pack_conv_weights(dw, Cout, Cin, dwf, NULL, (sed_stream_t)stream));
             CHECK_SED(sed_conv3x3_igemm(dx, dwf, dy, B, H, W, Cin, Cout, NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL,
@@ -86,13 +94,13 @@ int main(void) {
             const double e = fabs((double)got[i] - (double)ref[i]);
             if (e > worst) worst = e;
         }
-        printf("%s: max |gpu - cpu| = %.3g\n", pass == 0 ? "sed_conv3x3_wino2" : "sed_conv3x3_igemm", worst);
+        printf("%s: max |gpu - cpu| = %.3g\n", pass == 0 ? "sed_conv3x3_wino2" : (pass == 1 ? "sed_conv3x3_igemm" : "sed_conv3x3_sf16"), worst);
         if (!(worst < 1e-4)) rc = 1;
     }
     /* bad arguments are reported, not executed */
     if (sed_conv3x3_wino2(dx, duf, dy, B, H, 7, Cin, Cout, NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL,
                           (sed_stream_t)stream) != -22) { fprintf(stderr, "expected -22 for W=7\n"); rc = 1; }
-    hipFree(dx); hipFree(dw); hipFree(dy); hipFree(dwf); hipFree(duf);
+    hipFree(dx); hipFree(dw); hipFree(dy); hipFree(dwf); hipFree(duf); hipFree(dwp); hipFree(dwscale);
     hipStreamDestroy(stream);
     free(x); free(w); free(ref); free(got);
     printf(rc == 0 ? "capi_conv ok\n" : "capi_conv FAILED\n");

@@ -610,4 +610,4 @@ def test_plain_c_host_of_the_abi():
     assert os.path.exists(exe), "run `python -m sound_event_detection_dcase2017_task4_amd.build` first"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "capi_conv ok" in r.stdout
+    assert "capi_conv ok" in r.stdout and "sed_conv3x3_sf16" in r.stdout
