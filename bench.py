@@ -339,9 +339,10 @@ def main():
         "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "arithmetic": ("fp32 throughout; 3x3 convolution products (forward, dgrad) as three split-f16 MFMAs with fp32 accumulation "
-                       "-- the rounding error of a direct fp32 convolution (tests/test_gpu_sf16.py vs float64); weight gradients "
-                       "on fp32 MFMA (Winograd)") if ops.USE_SF16 else "fp32 throughout (fp32 MFMA, Winograd F(2x2,3x3))",
+        "arithmetic": ("fp32 throughout; 3x3 convolution products (forward, dgrad, weight gradients of the >= 128-channel layers) "
+                       "as three split-f16 MFMAs with fp32 accumulation -- the rounding error of a direct fp32 convolution "
+                       "(tests/test_gpu_sf16.py vs float64); the two 64-channel weight gradients on fp32 MFMA (Winograd)")
+                      if ops.USE_SF16 else "fp32 throughout (fp32 MFMA, Winograd F(2x2,3x3))",
         "config": {"workload": wl.describe(args.seconds, args.int16) + ("; BASELINE.json configs[1]" if default_workload else
                                                                          " (modified by flags)"),
                    "global_batch": B * world, "waveforms_per_step": B2 * world,
