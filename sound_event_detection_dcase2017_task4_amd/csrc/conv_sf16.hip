@@ -12,8 +12,8 @@
 // on the device -- no host synchronisation either way.
 //
 // Dataflow.  A workgroup owns 64*MW output pixels (TR rows x W columns of one image) x 64*NW output channels, MW x NW = 4
-// waves, each a 64 x 64 register tile (4 accumulators): MW = 2 for Cout % 128 == 0, MW = 4 (256 pixels x 64 channels) for
-// the 64-channel layers.  K-step = 16 input channels: the (TR+2) x (W+2) input patch is converted ONCE to (hi, lo) f16
+// waves, each a 64 x 64 register tile (4 accumulators): MW = 4 (256 pixels x 64 channels, three workgroups per CU) by
+// default, MW = 2 (128 x 128, two per CU) on request.  K-step = 16 input channels: the (TR+2) x (W+2) input patch is converted ONCE to (hi, lo) f16
 // planes when it is staged (32-byte LDS row per pixel and plane; the nine taps read shifted windows of it, so the
 // conversion is amortised over 9 taps x all output channels), the pre-split weights stream through LDS by LDS-DMA, three
 // taps (one kernel row) per stage, double-buffered.  16-byte chunk index XOR ((row >> 3) & 1) keeps every ds_read_b128
@@ -23,6 +23,7 @@
 // the per-part pixel count; epilogue 2 = ReLU mask of the previous activation + BN-backward sums.
 #include "common.h"
 #include "sed_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -68,7 +69,7 @@ __device__ __forceinline__ float sf_scale_of(float amax) {
 }
 
 template <int MW, bool INT, int EPI>
-__global__ __launch_bounds__(256, 2) void conv_sf16_kernel(Sf16P p) {
+__global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p) {
     constexpr int NW = 4 / MW, BN = 64 * NW, RB = BN / 32;
     constexpr int AROWS = MW == 2 ? 264 : 396;         // >= (TR+2) * (W+2)
     constexpr int APLANE = AROWS * 32;
@@ -227,50 +228,43 @@ __global__ __launch_bounds__(256, 2) void conv_sf16_kernel(Sf16P p) {
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
             const unsigned char* const Bst = Bs + st * BSTAGE;
-            // fragments of tap dx+1 are requested before the MFMAs of tap dx are issued (two register sets): the LDS latency
-            // hides behind 12 MFMAs instead of stalling every group of four
-            half8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
-#define SF_FRAGS(SET, DX)                                                                                       \
-            _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) {                                                  \
-                ah[SET][mb] = *reinterpret_cast<const half8*>(As + aoffs[mb][dy * 3 + (DX)]);                   \
-                al[SET][mb] = *reinterpret_cast<const half8*>(As + APLANE + aoffs[mb][dy * 3 + (DX)]);          \
-            }                                                                                                   \
-            _Pragma("unroll") for (int nk = 0; nk < 2; ++nk) {                                                  \
-                bh[SET][nk] = *reinterpret_cast<const half8*>(Bst + boffs[nk][DX]);                             \
-                bl[SET][nk] = *reinterpret_cast<const half8*>(Bst + BPLANE + boffs[nk][DX]);                    \
-            }
-#ifdef SF_ABL_NOFRAG      // timing experiment: fragments read once per kernel
-            if (step == 0) { SF_FRAGS(0, 0) SF_FRAGS(1, 1) }
-#else
-            SF_FRAGS(0, 0)
-#endif
+            // (requesting the fragments of tap dx+1 before the MFMAs of tap dx -- two register sets -- measured +-1 %: the
+            // second wave of the SIMD already hides the LDS latency; one set keeps the kernel at 3 waves per SIMD for MW = 4)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                const int cur = dx & 1;
-#ifndef SF_ABL_NOFRAG
-                if (dx == 0) { SF_FRAGS(1, 1) }
-                if (dx == 1) { SF_FRAGS(0, 2) }
+                half8 ah[2], al[2], bh[2], bl[2];
+#ifdef SF_ABL_NOFRAG      // timing experiment: fragments never read (results wrong)
+                if (step < 0)
 #endif
-                __builtin_amdgcn_sched_barrier(0);
+                {
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) {
+                        ah[mb] = *reinterpret_cast<const half8*>(As + aoffs[mb][dy * 3 + dx]);
+                        al[mb] = *reinterpret_cast<const half8*>(As + APLANE + aoffs[mb][dy * 3 + dx]);
+                    }
+#pragma unroll
+                    for (int nk = 0; nk < 2; ++nk) {
+                        bh[nk] = *reinterpret_cast<const half8*>(Bst + boffs[nk][dx]);
+                        bl[nk] = *reinterpret_cast<const half8*>(Bst + BPLANE + boffs[nk][dx]);
+                    }
+                }
                 // the three products of a tile are spread over the four tiles: no MFMA waits for its predecessor's result
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                     for (int nk = 0; nk < 2; ++nk)
-                        acc[mb][nk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][mb], bh[cur][nk], acc[mb][nk], 0, 0, 0);
+                        acc[mb][nk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mb], bh[nk], acc[mb][nk], 0, 0, 0);
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                     for (int nk = 0; nk < 2; ++nk)
-                        acc[mb][nk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][mb], bl[cur][nk], acc[mb][nk], 0, 0, 0);
+                        acc[mb][nk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bl[nk], acc[mb][nk], 0, 0, 0);
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                     for (int nk = 0; nk < 2; ++nk)
-                        acc[mb][nk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][mb], bh[cur][nk], acc[mb][nk], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                        acc[mb][nk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bh[nk], acc[mb][nk], 0, 0, 0);
             }
-#undef SF_FRAGS
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -410,7 +404,14 @@ __global__ __launch_bounds__(256) void pack_sf16_kernel(const float* __restrict_
 }
 
 static int sf_log2w(int W) { return W == 64 ? 6 : W == 32 ? 5 : W == 16 ? 4 : 3; }
-static int sf_mw(int Cout) { return Cout % 128 == 0 ? 2 : 4; }
+// tile choice: 256 px x 64 co (MW = 4: 50 KB LDS, <= 160 VGPRs, THREE workgroups per CU) for every layer -- 5 % faster than
+// 128 px x 128 co (MW = 2: 66 KB, two per CU) on the >= 128-channel layers although it converts each patch twice as
+// often: the third wave per SIMD hides more than the reuse saves.  SED_SF16_MW2=1 selects MW = 2 where Cout % 128 == 0.
+static int sf_mw(int Cout) {
+    static int mw2 = -1;
+    if (mw2 < 0) { const char* e = getenv("SED_SF16_MW2"); mw2 = (e && e[0] == '1') ? 1 : 0; }
+    return (Cout % 128 == 0 && mw2) ? 2 : 4;
+}
 
 }  // namespace
 
