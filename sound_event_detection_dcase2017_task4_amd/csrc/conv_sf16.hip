@@ -130,6 +130,8 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
         if (INT) {                                                                                              \
             sc4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(srs, q4 * 16, k_off, 0));    \
             sh4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(hrs, q4 * 16, k_off, 0));    \
+            /* the power-of-two operand scale rides on the affine: relu(sa*sc*x + sa*sh) == sa*relu(sc*x + sh) bit for bit */ \
+            sc4.x *= sa; sc4.y *= sa; sc4.z *= sa; sc4.w *= sa; sh4.x *= sa; sh4.y *= sa; sh4.z *= sa; sh4.w *= sa; \
         }                                                                                                       \
         SF_ALOAD(0) SF_ALOAD(1) SF_ALOAD(2) SF_ALOAD(3) SF_ALOAD(4) SF_ALOAD(5)                                 \
     }
@@ -142,8 +144,8 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
             v.z = sok##i ? bn_relu(v.z, sc4.z, sh4.z) : 0.f;                                                    \
             v.w = sok##i ? bn_relu(v.w, sc4.w, sh4.w) : 0.f;                                                    \
         }                                                                                                       \
-        v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa;                                                             \
-        overflow |= !(fabsf(v.x) < 65504.f) | !(fabsf(v.y) < 65504.f) | !(fabsf(v.z) < 65504.f) | !(fabsf(v.w) < 65504.f); /* NaN too */ \
+        if (!INT) { v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa; }                                               \
+        overflow |= !(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) < 65504.f);  /* 3 VALU; a NaN shows itself */ \
         const half4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};                          \
         const half4 lo = {(_Float16)(v.x - (float)hi.x), (_Float16)(v.y - (float)hi.y),                         \
                           (_Float16)(v.z - (float)hi.z), (_Float16)(v.w - (float)hi.w)};                        \
@@ -607,7 +609,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
             v.z = xok[i] ? bn_relu(v.z, xsc.z, xsh.z) : 0.f; v.w = xok[i] ? bn_relu(v.w, xsc.w, xsh.w) : 0.f;   \
         }                                                                                                       \
         v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa;                                                             \
-        overflow |= !(fabsf(v.x) < 65504.f) | !(fabsf(v.y) < 65504.f) | !(fabsf(v.z) < 65504.f) | !(fabsf(v.w) < 65504.f); /* NaN too */ \
+        overflow |= !(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) < 65504.f);  /* 3 VALU; a NaN shows itself */ \
         const half4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};                          \
         const half4 lo = {(_Float16)(v.x - (float)hi.x), (_Float16)(v.y - (float)hi.y),                         \
                           (_Float16)(v.z - (float)hi.z), (_Float16)(v.w - (float)hi.w)};                        \
