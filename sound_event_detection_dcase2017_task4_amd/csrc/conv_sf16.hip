@@ -569,6 +569,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
     if (INT) {
         xsc = *reinterpret_cast<const float4*>(p.in_scale + ci0 + xq * 4);
         xsh = *reinterpret_cast<const float4*>(p.in_shift + ci0 + xq * 4);
+        // the power-of-two operand scale rides on the affine: relu(sa*sc*x + sa*sh) == sa*relu(sc*x + sh) bit for bit
+        xsc.x *= p.sa; xsc.y *= p.sa; xsc.z *= p.sa; xsc.w *= p.sa; xsh.x *= p.sa; xsh.y *= p.sa; xsh.z *= p.sa; xsh.w *= p.sa;
     }
     const unsigned x_img_bytes = (unsigned)p.H * W * p.K * 4u, g_img_bytes = (unsigned)p.H * W * p.N * 4u;
     bool overflow = false;
@@ -607,8 +609,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
         if (INT) {                                                                                              \
             v.x = xok[i] ? bn_relu(v.x, xsc.x, xsh.x) : 0.f; v.y = xok[i] ? bn_relu(v.y, xsc.y, xsh.y) : 0.f;   \
             v.z = xok[i] ? bn_relu(v.z, xsc.z, xsh.z) : 0.f; v.w = xok[i] ? bn_relu(v.w, xsc.w, xsh.w) : 0.f;   \
+        } else {                                                                                                \
+            v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa;                                                         \
         }                                                                                                       \
-        v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa;                                                             \
         overflow |= !(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) < 65504.f);  /* 3 VALU; a NaN shows itself */ \
         const half4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};                          \
         const half4 lo = {(_Float16)(v.x - (float)hi.x), (_Float16)(v.y - (float)hi.y),                         \
