@@ -507,7 +507,9 @@ SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale
 // x rows go into a ring of RING >= 64/W + 2 image rows (power of two), of which every stage only loads the 64/W new ones;
 // rows -1 / H and the halo columns are zero.  A slice = a range of stages of one image or a range of whole images; the
 // partial sums [slice][k half][tap][co][ci] are reduced in fp64 by wgrad_sf16_reduce_kernel, which also unscales.
-// (Double-buffering gy and enlarging the ring to 2*64/W + 2 rows so that a stage needs ONE barrier instead of two measured
+// (Splitting the TAPS over six waves -- 2 co halves x 3 kernel rows, 3 accumulators and 120-160 VGPRs per wave, three to four
+// waves per SIMD -- measured 300-320 TFLOP/s against 335-360 for this layout: the gy fragments are then read three times.
+// Double-buffering gy and enlarging the ring to 2*64/W + 2 rows so that a stage needs ONE barrier instead of two measured
 // +-4 % layer by layer, no net gain.  A 64 co x 64 ci variant for the 64-input-channel layers was tried: 256 VGPRs with 10-119 spilled registers and no gain
 // where it did not spill; those two layers keep the Winograd-domain kernel.)
 namespace {
