@@ -110,6 +110,81 @@ FAMILY_KERNELS = {"conv3x3_sf16_mfma(fwd+dgrad)": ["conv_sf16_kernel"], "conv3x3
                   "conv3x3_igemm_mfma(fwd+dgrad)": ["conv_igemm_kernel"], "conv3x3_wgrad_mfma(+slice reduce)": ["wgrad_kernel"]}
 
 
+NOTES = {"conv3x3_wino_mfma(fwd+dgrad)": ("fused 1-D Winograd F(2,3) implicit GEMM on fp32 MFMA", 1 / 1.5, FP32_MFMA_PEAK_TFLOPS),
+         "conv3x3_wino2d_mfma(fwd+dgrad)": ("fused 2-D Winograd F(2x2,3x3) implicit GEMM on fp32 MFMA", 1 / 2.25, FP32_MFMA_PEAK_TFLOPS),
+         "conv3x3_wgrad_wino_mfma(+slice reduce)": ("Winograd-domain F(2,3) weight gradient on fp32 MFMA", 1 / 1.5, FP32_MFMA_PEAK_TFLOPS),
+         "conv3x3_wgrad_wino2d_mfma(+slice reduce)": ("Winograd-domain F(2x2,3x3) weight gradient on fp32 MFMA", 1 / 2.25, FP32_MFMA_PEAK_TFLOPS),
+         "conv3x3_wgrad_sf16_mfma(+slice reduce)": ("weight gradient with split-f16 operands (LDS transpose reads) on the f16 MFMA pipe",
+                                                    3.0, F16_MFMA_PEAK_TFLOPS),
+         "conv3x3_sf16_mfma(fwd+dgrad)": ("direct 3x3 convolution with split-f16 operands (hi*hi + hi*lo + lo*hi, exact products, fp32 "
+                                          "accumulation: the error of a direct fp32 convolution) on the f16 MFMA pipe", 3.0, F16_MFMA_PEAK_TFLOPS)}
+
+
+def kernel_report(timing, steps, B2, default_workload, by_shape=False, frames=1001):
+    """(per-family MFMA kernel table, `roofline` of the dominant family, `roofline_frontend`) from the HIP events ops.TIMING
+    collected inside a timed region.  'achieved' always counts the ALGORITHMIC direct-convolution flops:
+    Winograd kernels execute fewer MACs than that on the fp32 MFMA pipe, the split-f16 kernels THREE f16 MACs per
+    algorithmic MAC on the f16 MFMA pipe (`executed_*`)."""
+    timing = dict(timing or {})
+
+    def summarise(groups):
+        out = {}
+        for tag, evs in groups.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in evs)
+            fl = sum(f for _, _, f in evs)
+            out[tag] = {"launches": len(evs), "ms_total": round(ms, 3), "avg_ms": round(ms / max(len(evs), 1), 4),
+                        "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else None}
+        return out
+
+    fam = {}
+    fe = timing.pop("logmel_frontend", None)
+    for tag, evs in timing.items():
+        fam.setdefault(tag.split("|")[0], []).extend(evs)
+    kern = summarise(fam)
+    frontend = None
+    if fe:
+        ms = sum(a.elapsed_time(b) for a, b, _ in fe)
+        gbps = sum(nb for _, _, nb in fe) / (ms * 1e-3) / 1e9
+        tr, src = pmc_traffic(["logmel32_kernel"]) if default_workload else (None, None)
+        # what bounds it: the FFT runs on the vector ALU + LDS (DESIGN.md section 5: 4450 cycles per frame pair against a
+        # VALU-only floor of 2300 = 0.25 ms per 512 waveforms, tools/valu_ubench.hip); HBM traffic is 1.06x algorithmic
+        valu_floor_ms = 0.25 * (B2 * frames) / (512.0 * 1001.0)
+        frontend = {"kernel": "logmel32_kernel (STFT+mel+log, K1)", "bound": "valu", "achieved": round(gbps, 1),
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": tr,
+                    "traffic_source": src, "avg_launch_ms": round(ms / len(fe), 4),
+                    "bytes_per_waveform": int(fe[0][2] / B2),
+                    "valu_floor_ms": round(valu_floor_ms, 4), "frac_of_valu_floor": round(valu_floor_ms / (ms / len(fe)), 4),
+                    "note": "achieved / peak / frac are the HBM figures north_star asks for (algorithmic bytes / time vs 8 TB/s); "
+                            "the kernel is bound by the vector ALU + LDS of its radix-32 FFT, not by HBM (PMC traffic = 1.06x "
+                            "algorithmic): frac_of_valu_floor = the instruction-count floor of that FFT / measured time"}
+    if by_shape:
+        for tag, v in sorted(summarise(timing).items()):
+            print("# %-62s %3d launches  %8.3f ms/launch  %6.1f TFLOP/s" % (tag, v["launches"], v["avg_ms"], v["tflops"]),
+                  file=sys.stderr)
+    dom = max(kern, key=lambda k: kern[k]["ms_total"]) if kern else None
+    roofline = None
+    if dom is not None:
+        what, executed_per_alg, peak = NOTES.get(dom, ("fp32 MFMA implicit GEMM", 1.0, FP32_MFMA_PEAK_TFLOPS))
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / peak, 4), "traffic": None,
+                    "launches_per_step": kern[dom]["launches"] // steps, "avg_launch_ms": kern[dom]["avg_ms"]}
+        roofline["note"] = ("%s: 'achieved' counts the ALGORITHMIC direct-convolution flops (SURVEY.md 8d), 'peak' is the dense "
+                            "peak of the MFMA pipe the kernel runs on; the kernel executes %.4gx the algorithmic flops there"
+                            % (what, executed_per_alg))
+        roofline["executed_tflops"] = round(kern[dom]["tflops"] * executed_per_alg, 2)
+        roofline["executed_frac"] = round(kern[dom]["tflops"] * executed_per_alg / peak, 4)
+        if default_workload:
+            roofline["traffic"], src = pmc_traffic(FAMILY_KERNELS.get(dom))
+            if src:
+                roofline["traffic_source"] = src
+    # every MFMA kernel family of the step, same accounting (the dominant one above is the `roofline` object)
+    for tag, v in kern.items():
+        what, executed_per_alg, peak = NOTES.get(tag, ("fp32 MFMA implicit GEMM", 1.0, FP32_MFMA_PEAK_TFLOPS))
+        if v["tflops"]:
+            v["executed_frac_of_pipe_peak"] = round(v["tflops"] * executed_per_alg / peak, 4)
+    return kern, roofline, frontend
+
+
 class Workload(object):
     """One configuration of the hot path on this rank: model + optimiser + a resident pool of synthetic batches."""
 
@@ -200,27 +275,51 @@ class Workload(object):
 
 
 def extra_configs(rank, world, dev, steps=5, warmup=2):
-    """The other BASELINE.json configurations, a few steps each (single GPU, same process, after the headline run)."""
+    """The other BASELINE.json configurations, a few steps each (single GPU, same process, after the headline run).  The
+    metric's own batch size (bs=32, reference README) carries its own `roofline` + `kernels`."""
     out = []
-    for tag, mt, B, mix, inf in (
-            ("configs[2] Cnn_9layers_FrameAtt B=256 mixup", "Cnn_9layers_FrameAtt", 256, True, False),
-            ("configs[3] Cnn_9layers_Gru_FrameAtt B=256 mixup", "Cnn_9layers_Gru_FrameAtt", 256, True, False),
-            ("metric batch size: Cnn_9layers_FrameAvg B=32 mixup (reference README)", "Cnn_9layers_FrameAvg", 32, True, False),
-            ("configs[0] shape on the GPU: Cnn_9layers_FrameAvg B=32 no mixup", "Cnn_9layers_FrameAvg", 32, False, False),
-            ("inference (eval-mode forward) Cnn_9layers_FrameAvg 256 clips/step", "Cnn_9layers_FrameAvg", 256, False, True)):
+    for tag, mt, B, mix, inf, detail in (
+            ("configs[2] Cnn_9layers_FrameAtt B=256 mixup", "Cnn_9layers_FrameAtt", 256, True, False, False),
+            ("configs[3] Cnn_9layers_Gru_FrameAtt B=256 mixup", "Cnn_9layers_Gru_FrameAtt", 256, True, False, False),
+            ("metric batch size: Cnn_9layers_FrameAvg B=32 mixup (reference README)", "Cnn_9layers_FrameAvg", 32, True, False, True),
+            ("configs[0] shape on the GPU: Cnn_9layers_FrameAvg B=32 no mixup", "Cnn_9layers_FrameAvg", 32, False, False, False),
+            ("inference (eval-mode forward) Cnn_9layers_FrameAvg 256 clips/step", "Cnn_9layers_FrameAvg", 256, False, True, False)):
         try:
             w = Workload(mt, B, mix, rank, world, dev, inference=inf)
             k = steps * (4 if B <= 32 else 1)
-            dt, loss, _ = w.run(k, warmup)
-            out.append({"config": tag, "workload": w.describe(), "value": round(B * k / dt, 2), "unit": "clips/s", "steps": k,
-                        "warmup": warmup, "ms_per_step": round(dt / k * 1e3, 3),
-                        "metric": "inference clips/sec" if inf else "training clips/sec", "loss": round(loss, 5)})
+            dt, loss, tm = w.run(k, warmup, timing=detail)
+            row = {"config": tag, "workload": w.describe(), "value": round(B * k / dt, 2), "unit": "clips/s", "steps": k,
+                   "warmup": warmup, "ms_per_step": round(dt / k * 1e3, 3),
+                   "metric": "inference clips/sec" if inf else "training clips/sec", "loss": round(loss, 5)}
+            if detail:
+                kern, roof, fe = kernel_report(tm, k, w.B2, False)
+                row.update({"roofline": roof, "roofline_frontend": fe, "kernels": kern,
+                            "mfma_kernels_share_of_step": round(sum(v["ms_total"] for v in kern.values()) / (dt * 1e3), 4)})
+            out.append(row)
             del w
         except Exception as e:                 # a side number must never lose the headline line
             out.append({"config": tag, "value": None, "error": repr(e)})
         gc.collect()
         torch.cuda.empty_cache()
     return out
+
+
+def strict_fp32(mt, B, mix, rank, world, dev, steps=5, warmup=2):
+    """The same workload with every convolution on the fp32 MFMA pipe (ops.USE_SF16 = False: Winograd F(2x2,3x3)) -- the
+    strict-fp32 companion of the headline number."""
+    prev, ops.USE_SF16 = ops.USE_SF16, False
+    try:
+        w = Workload(mt, B, mix, rank, world, dev)
+        dt, loss, _ = w.run(steps, warmup)
+        return {"value": round(B * steps / dt, 2), "unit": "clips/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+                "warmup": warmup, "loss": round(loss, 5),
+                "arithmetic": "fp32 operands on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32), fused Winograd F(2x2,3x3)"}
+    except Exception as e:
+        return {"value": None, "error": repr(e)}
+    finally:
+        ops.USE_SF16 = prev
+        gc.collect()
+        torch.cuda.empty_cache()
 
 
 def main():
@@ -263,85 +362,42 @@ def main():
     wl = Workload(args.model_type, B, mix, rank, world, dev, seconds=args.seconds, inference=args.inference, int16=args.int16,
                   h2d=args.h2d)
     B2 = wl.B2
+    wl.opt.buckets.wait_events = []   # HIP events around the compute stream's wait for the gradient all-reduces
     dt, loss, timing = wl.run(args.steps, args.warmup, timing=True)
     bucket_order = list(wl.opt.buckets.last_issue_order)
+    waits = wl.opt.buckets.wait_events[-args.steps:]
+    dist_info = {"backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
+                 "world_size": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                 # time the compute stream sat behind the bucketed all-reduces in optimizer.step() = the EXPOSED part of the
+                 # gradient exchange (the rest ran beside the backward pass); null at 1 rank
+                 "allreduce_exposed_ms_per_step": (round(sum(a.elapsed_time(b) for a, b in waits) / max(len(waits), 1), 4)
+                                                   if waits else None),
+                 "flat_gradient_bytes": int(wl.opt.flat_grad.numel() * 4)}
+    wl.opt.buckets.wait_events = None
     parallel.shutdown()               # all ranks: barrier + destroy the process group; rank 0 then reports alone
     if rank != 0:
         return
     bucket_ranges = [[lo, hi] for lo, hi in wl.opt.buckets.ranges]
-
-    def summarise(groups):
-        out = {}
-        for tag, evs in groups.items():
-            ms = sum(a.elapsed_time(b) for a, b, _ in evs)
-            fl = sum(f for _, _, f in evs)
-            out[tag] = {"launches": len(evs), "ms_total": round(ms, 3), "avg_ms": round(ms / max(len(evs), 1), 4),
-                        "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else None}
-        return out
-
-    fam = {}
-    fe = timing.pop("logmel_frontend", None)
-    for tag, evs in timing.items():
-        fam.setdefault(tag.split("|")[0], []).extend(evs)
-    kern = summarise(fam)
     default_workload = (B == 256 and mix and args.model_type == "Cnn_9layers_FrameAvg" and not args.inference
                         and not args.h2d and not args.int16 and args.seconds == 10)
-    frontend = None
-    if fe:
-        ms = sum(a.elapsed_time(b) for a, b, _ in fe)
-        gbps = sum(nb for _, _, nb in fe) / (ms * 1e-3) / 1e9
-        tr, src = pmc_traffic(["logmel32_kernel"]) if default_workload else (None, None)
-        frontend = {"kernel": "logmel32_kernel (STFT+mel+log, K1)", "bound": "hbm", "achieved": round(gbps, 1),
-                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": tr,
-                    "traffic_source": src, "avg_launch_ms": round(ms / len(fe), 4),
-                    "bytes_per_waveform": int(fe[0][2] / B2)}
-    if args.by_shape:
-        for tag, v in sorted(summarise(timing).items()):
-            print("# %-62s %3d launches  %8.3f ms/launch  %6.1f TFLOP/s" % (tag, v["launches"], v["avg_ms"], v["tflops"]),
-                  file=sys.stderr)
-    dom = max(kern, key=lambda k: kern[k]["ms_total"]) if kern else None
-    # 'achieved' always counts the ALGORITHMIC direct-convolution flops.  Winograd kernels execute fewer MACs
-    # than that on the fp32 MFMA pipe; the split-f16 kernels execute THREE f16 MACs per algorithmic MAC on the f16 MFMA pipe.
-    notes = {"conv3x3_wino_mfma(fwd+dgrad)": ("fused 1-D Winograd F(2,3) implicit GEMM on fp32 MFMA", 1 / 1.5, FP32_MFMA_PEAK_TFLOPS),
-             "conv3x3_wino2d_mfma(fwd+dgrad)": ("fused 2-D Winograd F(2x2,3x3) implicit GEMM on fp32 MFMA", 1 / 2.25, FP32_MFMA_PEAK_TFLOPS),
-             "conv3x3_wgrad_wino_mfma(+slice reduce)": ("Winograd-domain F(2,3) weight gradient on fp32 MFMA", 1 / 1.5, FP32_MFMA_PEAK_TFLOPS),
-             "conv3x3_wgrad_wino2d_mfma(+slice reduce)": ("Winograd-domain F(2x2,3x3) weight gradient on fp32 MFMA", 1 / 2.25, FP32_MFMA_PEAK_TFLOPS),
-             "conv3x3_wgrad_sf16_mfma(+slice reduce)": ("weight gradient with split-f16 operands (LDS transpose reads) on the f16 MFMA pipe",
-                                                        3.0, F16_MFMA_PEAK_TFLOPS),
-             "conv3x3_sf16_mfma(fwd+dgrad)": ("direct 3x3 convolution with split-f16 operands (hi*hi + hi*lo + lo*hi, exact products, fp32 "
-                                              "accumulation: the error of a direct fp32 convolution) on the f16 MFMA pipe", 3.0, F16_MFMA_PEAK_TFLOPS)}
-    roofline = None
-    if dom is not None:
-        what, executed_per_alg, peak = notes.get(dom, ("fp32 MFMA implicit GEMM", 1.0, FP32_MFMA_PEAK_TFLOPS))
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / peak, 4), "traffic": None,
-                    "launches_per_step": kern[dom]["launches"] // args.steps, "avg_launch_ms": kern[dom]["avg_ms"]}
-        roofline["note"] = ("%s: 'achieved' counts the ALGORITHMIC direct-convolution flops (SURVEY.md 8d), 'peak' is the dense "
-                            "peak of the MFMA pipe the kernel runs on; the kernel executes %.4gx the algorithmic flops there"
-                            % (what, executed_per_alg))
-        roofline["executed_tflops"] = round(kern[dom]["tflops"] * executed_per_alg, 2)
-        roofline["executed_frac"] = round(kern[dom]["tflops"] * executed_per_alg / peak, 4)
-        if default_workload:
-            roofline["traffic"], src = pmc_traffic(FAMILY_KERNELS.get(dom))
-            if src:
-                roofline["traffic_source"] = src
-    # every MFMA kernel family of the step, same accounting (the dominant one above is the `roofline` object)
-    for tag, v in kern.items():
-        what, executed_per_alg, peak = notes.get(tag, ("fp32 MFMA implicit GEMM", 1.0, FP32_MFMA_PEAK_TFLOPS))
-        if v["tflops"]:
-            v["executed_frac_of_pipe_peak"] = round(v["tflops"] * executed_per_alg / peak, 4)
+
+    kern, roofline, frontend = kernel_report(timing, args.steps, B2, default_workload, by_shape=args.by_shape,
+                                             frames=32000 * args.seconds // 320 + 1)
     conv_ms = sum(v["ms_total"] for v in kern.values())
     clips_per_s = B * world * args.steps / dt
     line = {
-        "metric": ("inference clips/sec (10s@32kHz, eval mode) " + args.model_type) if args.inference else
-                  ("training clips/sec (10s@32kHz) Cnn_9layers_FrameAvg" if args.model_type == "Cnn_9layers_FrameAvg"
-                   else "training clips/sec (10s@32kHz) " + args.model_type),
+        # BASELINE.json: "training clips/sec (10s@32kHz) Cnn_9layers_FrameAvg bs=32 at 1/2/4/8 GPU"; the headline workload is
+        # configs[1] (bs=256 per GPU, mixup), the metric's own bs=32 run is extra_configs["metric batch size ..."]
+        "metric": ("inference clips/sec (10s@32kHz, eval mode) %s bs=%d per GPU at %d GPU" % (args.model_type, B, world))
+                  if args.inference else
+                  ("training clips/sec (10s@32kHz) %s bs=%d per GPU at %d GPU" % (args.model_type, B, world)),
         "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "arithmetic": ("fp32 throughout; 3x3 convolution products (forward, dgrad, weight gradients of the >= 128-channel layers) "
-                       "as three split-f16 MFMAs with fp32 accumulation -- the rounding error of a direct fp32 convolution "
-                       "(tests/test_gpu_sf16.py vs float64); the two 64-channel weight gradients on fp32 MFMA (Winograd)")
+        "arithmetic": ("fp32 storage and accumulation throughout; 3x3 convolution products (forward, dgrad, weight gradients) as "
+                       "three split-f16 MFMAs with fp32 accumulation, operand scales from device-side amax values -- the "
+                       "rounding error of a direct fp32 convolution at any magnitude (tests/test_gpu_sf16.py vs float64); "
+                       "`strict_fp32` = the same workload on the fp32 MFMA pipe")
                       if ops.USE_SF16 else "fp32 throughout (fp32 MFMA, Winograd F(2x2,3x3))",
         "config": {"workload": wl.describe(args.seconds, args.int16) + ("; BASELINE.json configs[1]" if default_workload else
                                                                          " (modified by flags)"),
@@ -351,6 +407,7 @@ def main():
                                      "order %s" % (len(bucket_ranges), bucket_ranges, bucket_order)},
         "waveforms_per_s": round(B2 * world * args.steps / dt, 2),
         "loss": round(loss, 5),
+        "dist": dist_info,
         "roofline": roofline,
         "roofline_frontend": frontend,
         "kernels": kern,
@@ -360,6 +417,8 @@ def main():
     gc.collect()
     torch.cuda.empty_cache()
     if world == 1 and default_workload and not args.no_extra:
+        if ops.USE_SF16:
+            line["strict_fp32"] = strict_fp32(args.model_type, B, mix, rank, world, dev)
         line["extra_configs"] = extra_configs(rank, world, dev)
     if world == 1 and not args.no_cpu_baseline:
         try:

@@ -55,7 +55,7 @@ int main(void) {
                 }
 
     printf("%s\n", sed_version());
-    float *dx, *dw, *dy, *dwf, *duf, *dwscale;
+    float *dx, *dw, *dy, *dwf, *duf, *dwscale, *dxamax;
     void* dwp;
     CHECK_HIP(hipMalloc((void**)&dx, sizeof(float) * M * Cin));
     CHECK_HIP(hipMalloc((void**)&dw, sizeof(float) * Cout * Cin * 9));
@@ -64,6 +64,7 @@ int main(void) {
     CHECK_HIP(hipMalloc((void**)&duf, sizeof(float) * 16 * Cout * Cin));
     CHECK_HIP(hipMalloc(&dwp, 2 * (size_t)sed_conv_sf16_pack_halfs(Cin, Cout)));   /* f16 (hi, lo) planes */
     CHECK_HIP(hipMalloc((void**)&dwscale, sizeof(float) * 2));
+    CHECK_HIP(hipMalloc((void**)&dxamax, sizeof(float)));
     CHECK_HIP(hipMemcpy(dx, x, sizeof(float) * M * Cin, hipMemcpyHostToDevice));
     CHECK_HIP(hipMemcpy(dw, w, sizeof(float) * Cout * Cin * 9, hipMemcpyHostToDevice));
     hipStream_t stream;
@@ -80,8 +81,9 @@ int main(void) {
         } else if (pass == 2) {              /* the default path of the models: split-f16 operands on the f16 MFMA pipe */
             if (!sed_conv3x3_sf16_supported(H, W, Cin, Cout)) { fprintf(stderr, "sf16 not supported?\n"); return 4; }
             CHECK_SED(sed_pack_conv_weights_sf16(dw, Cout, Cin, 0, dwscale, dwp, (sed_stream_t)stream));
+            CHECK_SED(sed_amax(dx, M * Cin, dxamax, (sed_stream_t)stream));      /* operand scale: taken on the device */
             CHECK_SED(sed_conv3x3_sf16(dx, dwp, dwscale, dy, B, H, W, Cin, Cout, NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL,
-                                       NULL, 16.0f, NULL, (sed_stream_t)stream));
+                                       dxamax, NULL, NULL, NULL, (sed_stream_t)stream));
         } else {
             CHECK_SED(sed_pack_conv_weights(dw, Cout, Cin, dwf, NULL, (sed_stream_t)stream));
             CHECK_SED(sed_conv3x3_igemm(dx, dwf, dy, B, H, W, Cin, Cout, NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL,

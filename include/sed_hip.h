@@ -90,13 +90,24 @@ int sed_bn0_aug_mix_bwd(const float* logmel, const float* g_out, int B2, int T, 
  * pass 2 writes
  * g_y = a*dy + b*y + c with dy = relu-mask * g_out/(ph*pw). */
 int sed_bn_relu_pool_fwd(const float* y, int B, int H, int W, int C, int ph, int pw, const float* scale,
-                         const float* shift, float* out, sed_stream_t stream);
+                         const float* shift, float* out, float* amax_out /* nullable, device: max of `out` */,
+                         sed_stream_t stream);
 /* forward that also writes cnt [B][H/ph][W/pw][C] bytes = how many of the ph*pw window inputs passed the ReLU; with
  * it and the pooled output, backward pass 1 runs at POOLED resolution (sum dy = sum g*cnt/n, sum dy*xhat =
  * sum g*(p - beta*cnt/n)/gamma, n = ph*pw) and never touches y.  The 1/gamma amplifies fp32 rounding of p: use the
  * full-resolution sed_bn_relu_pool_bwd_reduce when some |gamma| is small. */
 int sed_bn_relu_pool_fwd_cnt(const float* y, int B, int H, int W, int C, int ph, int pw, const float* scale,
-                             const float* shift, float* out, unsigned char* cnt, sed_stream_t stream);
+                             const float* shift, float* out, unsigned char* cnt, float* amax_out /* nullable */,
+                             sed_stream_t stream);
+/* amax of a = relu(scale*y + shift) -- the operand `conv2` of a ConvBlock (models.py:102-103) consumes without it ever
+ * being materialised -- for the split-f16 scale of that convolution.  sed_act_amax: from per-part per-channel (max, min)
+ * of y, minmax [nparts][2][C], which sed_conv1_fwd / sed_conv3x3_sf16 leave beside their statistics (the affine + ReLU
+ * is monotone, so the range ends give the exact amax; scale = shift = null: max |y|).  sed_act_amax_full: the same by one
+ * pass over y [nrows][C], for producers without range partials. */
+int sed_act_amax(const float* minmax, int nparts, int C, const float* scale, const float* shift, float* amax_out,
+                 sed_stream_t stream);
+int sed_act_amax_full(const float* y, long nrows, int C, const float* scale, const float* shift, float* amax_out,
+                      sed_stream_t stream);
 int sed_bn_relu_pool_bwd_reduce_win(const float* g_out, const float* pooled, const unsigned char* cnt, long Mp, int C,
                                     int window, const float* gamma, const float* beta, float* partials,
                                     int* nparts_out, sed_stream_t stream);
@@ -173,10 +184,14 @@ int sed_conv3x3_wgrad_wino2(const float* x, const float* gy, float* dw_oihw, flo
  * the error of a direct fp32 convolution at 3/16 of its MFMA issue time (csrc/conv_sf16.hip).  Same contract as
  * sed_conv3x3_wino2 (in_scale/in_shift operand transform, epi 0/1/2, partials = sed_conv_sf16_num_parts(...) parts with the
  * pixel counts appended for epi 1).  wp: sed_conv_sf16_pack_halfs(...) f16 values and wscale[2] (amax, scale) written by
- * sed_pack_conv_weights_sf16 (dgrad = 1: operand of the transposed convolution).  Activation scale: x_amax (device
- * pointer to the amax of x, e.g. from sed_amax or a producer kernel) or, when null, the fixed power of two `sa`
- * (|sa*x| must stay below 65504: otherwise, or on a non-finite operand, the kernel stores 1 through err_host, a
- * nullable host-mapped int -- never a silent saturation).  Needs W in {8,16,32,64}, Cin % 16 == 0, Cout % 64 == 0. */
+ * sed_pack_conv_weights_sf16 (dgrad = 1: operand of the transposed convolution).  Operand scale: x_amax = device pointer
+ * to the amax of the operand as the MFMAs see it (of relu(in_scale*x + in_shift) when that transform is fused: sed_act_amax;
+ * of x otherwise: sed_amax or the producer kernels' amax_out) -- the power of two that brings it to [2^13, 2^14) is
+ * taken on the device, so a finite operand neither overflows nor loses its low half to f16 subnormals at ANY magnitude.
+ * A non-finite operand stores 1 through err_host (nullable, host-mapped int) and err_dev (nullable, device int: the
+ * skip_flag of sed_adam_amsgrad) -- never silent.  minmax (nullable, epi 0 / 1): per-part (max, min) of the outputs per
+ * channel, [sed_conv_sf16_num_parts(...)][2][Cout], the input of sed_act_amax for the NEXT convolution.
+ * Needs W in {8,16,32,64}, Cin % 16 == 0, Cout % 64 == 0. */
 int sed_conv3x3_sf16_supported(int H, int W, int Cin, int Cout);
 long sed_conv_sf16_pack_halfs(int Cin, int Cout);
 long sed_conv_sf16_num_parts(int B, int H, int W, int Cout);
@@ -186,15 +201,17 @@ int sed_pack_conv_weights_sf16(const float* w_oihw, int Cout, int Cin, int dgrad
 int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale, float* y, int B, int H, int W, int Cin,
                      int Cout, const float* in_scale, const float* in_shift, int epi, float* partials,
                      const float* yprev, const float* p_scale, const float* p_shift, const float* p_mean,
-                     const float* p_invstd, const float* x_amax, float sa, int* err_host, sed_stream_t stream);
+                     const float* p_invstd, const float* x_amax, float* minmax, int* err_host, int* err_dev,
+                     sed_stream_t stream);
 /* Weight gradient with split-f16 operands (csrc/conv_sf16.hip): same contract as sed_conv3x3_wgrad; gy_amax = device
- * pointer to max |gy| (sed_amax or the producer kernels), sa = fixed power-of-two scale of the activations.
+ * pointer to max |gy| (sed_amax or the producer kernels), x_amax = device pointer to the amax of the activation operand
+ * (as for sed_conv3x3_sf16); err_host / err_dev as there.
  * Needs W in {8,16,32,64}, Cin % 32 == 0, Cout % 64 == 0; partial: sed_wgrad_sf16_partial_floats(...) floats. */
 int sed_wgrad_sf16_supported(int H, int W, int Cin, int Cout);
 long sed_wgrad_sf16_partial_floats(int B, int H, int W, int Cin, int Cout);
 int sed_conv3x3_wgrad_sf16(const float* x, const float* gy, float* dw_oihw, float* partial, int B, int H, int W,
                            int Cin, int Cout, const float* in_scale, const float* in_shift, const float* gy_amax,
-                           float sa, int* err_host, sed_stream_t stream);
+                           const float* x_amax, int* err_host, int* err_dev, sed_stream_t stream);
 /* Winograd-domain weight gradient (12 instead of 18 MACs per output pair); same contract as sed_conv3x3_wgrad.
  * Needs W a power of two <= 64 and Cin, Cout % 64 == 0; partial: sed_wgrad_wino_partial_floats(...) floats. */
 long sed_wgrad_wino_partial_floats(long M, int Cin, int Cout, int* nslices_out, int* pix_per_slice_out);
@@ -204,6 +221,7 @@ long sed_wgrad_partial_floats(long M, int Cin, int Cout, int ntaps, int* nslices
 int sed_conv3x3_wgrad(const float* x, const float* gy, float* dw_oihw, float* partial, int B, int H, int W, int Cin,
                       int Cout, const float* in_scale, const float* in_shift, sed_stream_t stream);
 int sed_conv1_fwd(const float* x0, const float* w_oihw, float* y, int B, int H, int W, float* partials,
+                  float* minmax /* nullable: [ceil(M/rows)][2][64] per-part (max, min) per channel, for sed_act_amax */,
                   sed_stream_t stream);
 int sed_conv1_rows_per_part(void);
 int sed_conv1_bwd(const float* x0, const float* w_oihw, const float* gy, const float* bn_y, const float* bn_coef, int B,
@@ -303,11 +321,16 @@ int sed_drop_relu_bwd(const float* g_y, const float* y, const unsigned char* kee
  * sed_clip_bce: losses.py:5-12 (F.binary_cross_entropy, mean, log clamped at -100) + d loss / d p.
  * sed_mixup_rows: pytorch_utils.py:80-93 on a [B2][D] matrix (the targets, main.py:246).
  * sed_adam_amsgrad: optim.Adam(betas=(0.9,0.999), eps=1e-8, weight_decay=0, amsgrad=True) (main.py:144-145,:258)
- *   over flat buffers; grad_scale is applied to the gradient first (1/world_size after the RCCL all-reduce). */
+ *   over flat buffers; grad_scale is applied to the gradient first (1/world_size after the RCCL all-reduce).
+ *   skip_flag (nullable, device int[2]) = found-non-finite guard: the gradient is first scanned for NaN / inf (which
+ *   raises skip_flag[0] and the nullable host-mapped err_host); when skip_flag[0] != 0 -- from that scan or because a
+ *   split-f16 kernel of this step met a non-finite operand (their err_dev word) -- parameters and moments are left
+ *   untouched and skip_flag[1] counts the refused step.  g must be 16-byte aligned when the guard is used. */
 int sed_clip_bce(const float* p, const float* y, long n, float* loss, float* grad, sed_stream_t stream);
 int sed_mixup_rows(const float* x, const float* lam, long B2, long D, float* out, sed_stream_t stream);
 int sed_adam_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, long n, int step, float lr,
-                     float beta1, float beta2, float eps, float grad_scale, sed_stream_t stream);
+                     float beta1, float beta2, float eps, float grad_scale, int* skip_flag, int* err_host,
+                     sed_stream_t stream);
 
 #ifdef __cplusplus
 }

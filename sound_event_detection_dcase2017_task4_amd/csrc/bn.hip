@@ -267,10 +267,13 @@ template <bool CNT>
 __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __restrict__ y, int B, int H, int W, int C,
                                                                int ph, int pw, const float* __restrict__ scale,
                                                                const float* __restrict__ shift,
-                                                               float* __restrict__ out, unsigned* __restrict__ cnt4) {
+                                                               float* __restrict__ out, unsigned* __restrict__ cnt4,
+                                                               float* __restrict__ amax_out) {
+    __shared__ float wmax[4];
     const int Ho = H / ph, Wo = W / pw, c4n = C >> 2;
     const long total = (long)B * Ho * Wo * c4n;
     const float inv = 1.0f / (float)(ph * pw);
+    float amax = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         int c4 = (int)(i % c4n);
         long p = i / c4n;
@@ -291,9 +294,65 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __re
                     n4 += (bn_relu_active(v.x, sc.x, sh.x) ? 1u : 0u) + (bn_relu_active(v.y, sc.y, sh.y) ? 0x100u : 0u) +
                           (bn_relu_active(v.z, sc.z, sh.z) ? 0x10000u : 0u) + (bn_relu_active(v.w, sc.w, sh.w) ? 0x1000000u : 0u);
             }
-        reinterpret_cast<float4*>(out)[i] = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+        const float4 o = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+        reinterpret_cast<float4*>(out)[i] = o;
+        amax = fmaxf(fmaxf(amax, fmaxf(o.x, o.y)), fmaxf(o.z, o.w));          // o >= 0
         if (CNT) cnt4[i] = n4;
     }
+    if (amax_out) {          // max of the pooled tensor = the split-f16 scale of the next ConvBlock's first convolution
+        amax = wave_max(amax);
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amax;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            atomicMax(reinterpret_cast<unsigned*>(amax_out), __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+    }
+}
+
+// amax of relu(scale*y + shift) over a tensor that is never materialised, from per-part per-channel (max, min) of y
+// [nparts][2][C] (conv epilogues): the affine + ReLU is monotone in y, so the extreme of every channel is taken at one of
+// its two range ends -- exact, no pass over the tensor.
+__global__ __launch_bounds__(256) void act_amax_kernel(const float* __restrict__ mm, int nparts, int C,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       int parts_per_block, float* __restrict__ amax_out) {
+    __shared__ float red[256];
+    const int p0 = blockIdx.x * parts_per_block, p1 = min(nparts, p0 + parts_per_block);
+    float best = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float mx = -__builtin_inff(), mn = __builtin_inff();
+        for (int q = p0; q < p1; ++q) {
+            mx = fmaxf(mx, mm[((long)q * 2 + 0) * C + c]);
+            mn = fminf(mn, mm[((long)q * 2 + 1) * C + c]);
+        }
+        if (mx >= mn) {
+            const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+            best = fmaxf(best, scale ? fmaxf(bn_relu(mx, sc, sh), bn_relu(mn, sc, sh)) : fmaxf(fabsf(mx), fabsf(mn)));
+        }
+    }
+    red[threadIdx.x] = best;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned*>(amax_out), __float_as_uint(red[0]));
+}
+
+// the same amax by a pass over y [nrows][C] (producers that leave no range partials)
+__global__ __launch_bounds__(256) void act_amax_full_kernel(const float* __restrict__ y, long nrows, int C,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            float* __restrict__ amax_out) {
+    const int c4n = C >> 2;
+    const long total = nrows * c4n;
+    float amax = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c4 = (int)(i % c4n);
+        const float4 v = reinterpret_cast<const float4*>(y)[i];
+        const float4 sc = reinterpret_cast<const float4*>(scale)[c4], sh = reinterpret_cast<const float4*>(shift)[c4];
+        amax = fmaxf(fmaxf(amax, fmaxf(bn_relu(v.x, sc.x, sh.x), bn_relu(v.y, sc.y, sh.y))),
+                     fmaxf(bn_relu(v.z, sc.z, sh.z), bn_relu(v.w, sc.w, sh.w)));
+    }
+    amax = wave_max(amax);
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(amax_out), __float_as_uint(amax));
 }
 
 // backward pass 1 / pass 2 of the same stage.  dy = g_out[pooled pos]/(ph*pw) * relu-mask (0 on dropped rows).
@@ -536,22 +595,31 @@ SED_API int sed_bn0_aug_mix_bwd(const float* logmel, const float* g_out, int B2,
 }
 
 SED_API int sed_bn_relu_pool_fwd(const float* y, int B, int H, int W, int C, int ph, int pw, const float* scale,
-                                 const float* shift, float* out, hipStream_t stream) {
+                                 const float* shift, float* out, float* amax_out, hipStream_t stream) {
     if (B <= 0 || (C & 3) || ph <= 0 || pw <= 0 || H / ph <= 0 || W / pw <= 0) return SED_EINVAL;
+    if (amax_out) {
+        hipError_t e = hipMemsetAsync(amax_out, 0, sizeof(float), stream);
+        if (e != hipSuccess) return (int)e;
+    }
     long total = (long)B * (H / ph) * (W / pw) * (C / 4);
     hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<false>, dim3(stream_grid(total)), dim3(256), 0, stream, y, B, H, W, C, ph, pw,
-                       scale, shift, out, (unsigned*)nullptr);
+                       scale, shift, out, (unsigned*)nullptr, amax_out);
     SED_LAUNCH_CHECK();
     return 0;
 }
 
 // Same, also writing cnt [B][H/ph][W/pw][C] bytes = number of window inputs that passed the ReLU (ph*pw <= 255).
 SED_API int sed_bn_relu_pool_fwd_cnt(const float* y, int B, int H, int W, int C, int ph, int pw, const float* scale,
-                                     const float* shift, float* out, unsigned char* cnt, hipStream_t stream) {
+                                     const float* shift, float* out, unsigned char* cnt, float* amax_out,
+                                     hipStream_t stream) {
     if (B <= 0 || (C & 3) || ph <= 0 || pw <= 0 || H / ph <= 0 || W / pw <= 0 || ph * pw > 255 || !cnt) return SED_EINVAL;
+    if (amax_out) {
+        hipError_t e = hipMemsetAsync(amax_out, 0, sizeof(float), stream);
+        if (e != hipSuccess) return (int)e;
+    }
     long total = (long)B * (H / ph) * (W / pw) * (C / 4);
     hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<true>, dim3(stream_grid(total)), dim3(256), 0, stream, y, B, H, W, C, ph, pw,
-                       scale, shift, out, reinterpret_cast<unsigned*>(cnt));
+                       scale, shift, out, reinterpret_cast<unsigned*>(cnt), amax_out);
     SED_LAUNCH_CHECK();
     return 0;
 }
@@ -637,6 +705,33 @@ SED_API int sed_bn_relu_pool_bwd_apply(const float* y, const float* g_out, int B
     int nblk = sed_cdiv((long)B * H * W, rpb);
     hipLaunchKernelGGL(bn_relu_pool_bwd_kernel<2>, dim3(nblk), dim3(256), 0, stream, y, g_out, B, H, W, C, ph, pw, scale, shift,
                        (const float*)nullptr, (const float*)nullptr, coef, rpb, (float*)nullptr, gy, (const float*)nullptr, 0.f, amax_out);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// amax of relu(scale*y + shift) (scale / shift null: of |y|) from range partials minmax [nparts][2][C] = per-part
+// (max, min) per channel, as left by sed_conv1_fwd / sed_conv3x3_sf16.
+SED_API int sed_act_amax(const float* minmax, int nparts, int C, const float* scale, const float* shift, float* amax_out,
+                         hipStream_t stream) {
+    if (!minmax || !amax_out || nparts <= 0 || C <= 0 || ((scale == nullptr) != (shift == nullptr))) return SED_EINVAL;
+    hipError_t e = hipMemsetAsync(amax_out, 0, sizeof(float), stream);
+    if (e != hipSuccess) return (int)e;
+    int ppb = sed_cdiv(nparts, 1024);
+    if (ppb < 8) ppb = 8;
+    hipLaunchKernelGGL(act_amax_kernel, dim3(sed_cdiv(nparts, ppb)), dim3(256), 0, stream, minmax, nparts, C, scale, shift, ppb,
+                       amax_out);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// The same quantity by one pass over y [nrows][C] (for producers without range partials).
+SED_API int sed_act_amax_full(const float* y, long nrows, int C, const float* scale, const float* shift, float* amax_out,
+                              hipStream_t stream) {
+    if (!y || !amax_out || !scale || !shift || nrows <= 0 || (C & 3)) return SED_EINVAL;
+    hipError_t e = hipMemsetAsync(amax_out, 0, sizeof(float), stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(act_amax_full_kernel, dim3(stream_grid(nrows * (C / 4))), dim3(256), 0, stream, y, nrows, C, scale, shift,
+                       amax_out);
     SED_LAUNCH_CHECK();
     return 0;
 }

@@ -527,7 +527,7 @@ struct C1Walk {
 
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x0, const float* __restrict__ w,
                                                         long M, int H, int W, float* __restrict__ y,
-                                                        float* __restrict__ partials) {
+                                                        float* __restrict__ partials, float* __restrict__ minmax) {
     __shared__ float4 red_s[256], red_q[256];
     const int c4 = threadIdx.x & 15, pl = threadIdx.x >> 4;
     float wr[9][4];
@@ -548,6 +548,9 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
             for (int k = 0; k < 4; ++k) piv[k] = fmaf(xs[t], wr[t][k], piv[k]);
     }
     float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    float mx[4], mn[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { mx[k] = -__builtin_inff(); mn[k] = __builtin_inff(); }
     C1Walk pos(base + pl, H, W);
     for (int r = pl; r < nrows; r += 16, pos.advance(16, H, W)) {
         long pm = base + r;
@@ -559,7 +562,27 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
             for (int k = 0; k < 4; ++k) o[k] = fmaf(xs[t], wr[t][k], o[k]);
         reinterpret_cast<float4*>(y)[pm * 16 + c4] = make_float4(o[0], o[1], o[2], o[3]);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { float d = o[k] - piv[k]; s[k] += d; q[k] = fmaf(d, d, q[k]); }
+        for (int k = 0; k < 4; ++k) {
+            float d = o[k] - piv[k]; s[k] += d; q[k] = fmaf(d, d, q[k]);
+            mx[k] = fmaxf(mx[k], o[k]); mn[k] = fminf(mn[k], o[k]);
+        }
+    }
+    if (minmax) {        // per-channel range of this block's rows: sed_act_amax turns it into the amax of relu(bn1(y))
+        red_s[threadIdx.x] = make_float4(mx[0], mx[1], mx[2], mx[3]);
+        red_q[threadIdx.x] = make_float4(mn[0], mn[1], mn[2], mn[3]);
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            float4 a = red_s[threadIdx.x], b = red_q[threadIdx.x];
+            for (int j = 1; j < 16; ++j) {
+                float4 a2 = red_s[threadIdx.x + 16 * j], b2 = red_q[threadIdx.x + 16 * j];
+                a.x = fmaxf(a.x, a2.x); a.y = fmaxf(a.y, a2.y); a.z = fmaxf(a.z, a2.z); a.w = fmaxf(a.w, a2.w);
+                b.x = fminf(b.x, b2.x); b.y = fminf(b.y, b2.y); b.z = fminf(b.z, b2.z); b.w = fminf(b.w, b2.w);
+            }
+            float4* po = reinterpret_cast<float4*>(minmax + (long)blockIdx.x * 128);
+            po[threadIdx.x] = a;
+            po[16 + threadIdx.x] = b;
+        }
+        __syncthreads();
     }
     if (partials) {
         red_s[threadIdx.x] = make_float4(s[0], s[1], s[2], s[3]);
@@ -852,11 +875,11 @@ SED_API int sed_pack_conv_weights(const float* w_oihw, int Cout, int Cin, float*
 }
 
 // conv_block1.conv1 (Cin=1, Cout=64).  partials (nullable): ceil(M/256)*128 floats, rows per part = 256.
-SED_API int sed_conv1_fwd(const float* x0, const float* w_oihw, float* y, int B, int H, int W, float* partials,
+SED_API int sed_conv1_fwd(const float* x0, const float* w_oihw, float* y, int B, int H, int W, float* partials, float* minmax,
                           hipStream_t stream) {
     long M = (long)B * H * W;
     if (M <= 0 || M >= (1L << 31)) return SED_EINVAL;
-    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(sed_cdiv(M, C1_ROWS)), dim3(256), 0, stream, x0, w_oihw, M, H, W, y, partials);
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(sed_cdiv(M, C1_ROWS)), dim3(256), 0, stream, x0, w_oihw, M, H, W, y, partials, minmax);
     SED_LAUNCH_CHECK();
     return 0;
 }

@@ -7,9 +7,11 @@
 // direct-convolution MAC count, 0.42x of the fused Winograd F(2x2,3x3) kernels' MFMA time, at the error of a direct fp32
 // convolution (tools/split_f16_study.py: 1.5e-7 relative L2 on this model's layer statistics; the dropped lo*lo term is
 // 2^-22; tests/test_gpu_sf16.py checks the kernel against float64).  Scales: the weights' from their amax (pack kernels,
-// kept on the device), the activations' either fixed (BatchNorm-ed / pooled activations are O(1); 2^4 leaves room up to
-// |x| < 4094 and a NaN shows in the statistics otherwise) or from an amax the producer kernel of a gradient tensor left
-// on the device -- no host synchronisation either way.
+// kept on the device), every activation / gradient operand's from an amax its PRODUCER kernel left on the device (pooled
+// outputs: the pool kernel; relu(bn(y)) operands that are never materialised: per-channel max / min of y from the conv
+// epilogue, pushed through the BatchNorm affine by sed_act_amax; gradients: the BatchNorm-backward apply kernels) -- so
+// a finite operand can neither overflow nor fall into the f16 subnormals at any magnitude, and there is no host
+// synchronisation.  A NON-FINITE operand raises the error words (host-mapped + device; the Adam kernel skips its update).
 //
 // Dataflow.  A workgroup owns 64*MW output pixels (TR rows x W columns of one image) x 64*NW output channels, MW x NW = 4
 // waves, each a 64 x 64 register tile (4 accumulators): MW = 4 (256 pixels x 64 channels, three workgroups per CU) by
@@ -34,7 +36,7 @@ struct Sf16P {
     const float* x;            // [B][H][W][K]
     const _Float16* wp;        // [K/16][3 dy][2 planes][3 dx][N][16]
     const float* wscale;       // [2]: weights' amax, scale sw (written by the pack kernels)
-    const float* x_amax;       // nullable: amax of x (device), else the fixed scale sa
+    const float* x_amax;       // device: amax of the operand AS THE MFMAs SEE IT (relu(scale*x+shift) when fused)
     float* y;                  // [B][H][W][N]
     const float* in_scale;
     const float* in_shift;
@@ -46,8 +48,9 @@ struct Sf16P {
     const float* p_invstd;
     int B, H, W, K, N;
     int logW, TR, ntile;
-    float sa;
-    int* err_host;             // nullable, host-mapped: set to 1 when a scaled activation leaves the f16 range
+    float* mm;                 // nullable: per-part (max, min) of the outputs per channel, [nparts][2][N] (EPI 0 / 1)
+    int* err_host;             // nullable, host-mapped: set to 1 when an operand is not finite
+    int* err_dev;              // nullable, device: same (read by sed_adam_amsgrad)
 };
 
 __device__ __forceinline__ int sf_sw(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 3) & 1)) << 4); }
@@ -60,7 +63,7 @@ __device__ __forceinline__ int xcd_remap_sf(int bid, int nblk) {
 
 // power of two that brings a tensor of this amax to [2^13, 2^14)
 __device__ __forceinline__ float sf_scale_of(float amax) {
-    if (!(amax > 0.f)) return 1.f;
+    if (!(amax > 0.f) || !(amax < __builtin_inff())) return 1.f;     // zero tensor; NaN / inf are reported by the staging code
     int e;
     frexpf(amax, &e);
     e = 14 - e;
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
     const int h0 = tile * TR;
     const int KT = p.K >> 4;
 
-    const float sa = p.x_amax ? sf_scale_of(*p.x_amax) : p.sa;
+    const float sa = sf_scale_of(*p.x_amax);
     const float inv = 1.0f / (sa * p.wscale[1]);
 
     // ---- A staging: item e = tid + 256*i -> patch pixel e >> 2 (row rr, column c), channel quad e & 3
@@ -290,7 +293,10 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
 #undef SF_BDMA
 #undef sf_bdma
 
-    if (overflow && p.err_host) __hip_atomic_store(p.err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (overflow) {
+        if (p.err_host) __hip_atomic_store(p.err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (p.err_dev) __hip_atomic_store(p.err_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     // ---- epilogue: unscale, (mask,) statistics, store (rows past the image fall outside the descriptor and are dropped)
     const unsigned y_img_bytes = (unsigned)p.H * W * p.N * 4u;
@@ -312,6 +318,7 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
     for (int nk = 0; nk < 2; ++nk) {
         const int col = colb + 32 * nk;
         float s1 = 0.f, s2 = 0.f;
+        float vmx = -__builtin_inff(), vmn = __builtin_inff();
         float e_sc = 0.f, e_sh = 0.f, e_mu = 0.f, e_is = 0.f;
         if (EPI == 2) { e_sc = p.p_scale[col]; e_sh = p.p_shift[col]; e_mu = p.p_mean[col]; e_is = p.p_invstd[col]; }
 #pragma unroll
@@ -334,8 +341,20 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
                     v = ok ? v : 0.f;
                     s1 += v;
                 }
+                if (EPI != 2 && p.mm) {
+                    vmx = fmaxf(vmx, ok ? v : -__builtin_inff());
+                    vmn = fminf(vmn, ok ? v : __builtin_inff());
+                }
                 acc[mb][nk][r] = v;
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, yoff[mb][r], nk * 128, 0);
+            }
+        }
+        if (EPI != 2 && p.mm) {      // range of this wave's 64 pixels per channel: the consumer's operand amax comes from it
+            vmx = fmaxf(vmx, __shfl_xor(vmx, 32, 64));
+            vmn = fminf(vmn, __shfl_xor(vmn, 32, 64));
+            if (kh == 0) {
+                p.mm[(part * 2 + 0) * p.N + col] = vmx;
+                p.mm[(part * 2 + 1) * p.N + col] = vmn;
             }
         }
         if (EPI == 1) {
@@ -455,14 +474,15 @@ SED_API int sed_pack_conv_weights_sf16(const float* w_oihw, int Cout, int Cin, i
 SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale, float* y, int B, int H, int W, int Cin,
                              int Cout, const float* in_scale, const float* in_shift, int epi, float* partials,
                              const float* yprev, const float* p_scale, const float* p_shift, const float* p_mean,
-                             const float* p_invstd, const float* x_amax, float sa, int* err_host, sed_stream_t stream) {
-    if (!x || !wp || !wscale || !y || B <= 0 || !sed_conv3x3_sf16_supported(H, W, Cin, Cout) || epi < 0 || epi > 2)
+                             const float* p_invstd, const float* x_amax, float* minmax, int* err_host, int* err_dev,
+                             sed_stream_t stream) {
+    if (!x || !wp || !wscale || !y || !x_amax || B <= 0 || !sed_conv3x3_sf16_supported(H, W, Cin, Cout) || epi < 0 || epi > 2)
         return SED_EINVAL;
+    if (minmax && epi == 2) return SED_EINVAL;
     if ((in_scale == nullptr) != (in_shift == nullptr)) return SED_EINVAL;
     if (epi >= 1 && !partials) return SED_EINVAL;
     if (epi == 2 && (!yprev || !p_scale || !p_shift || !p_mean || !p_invstd)) return SED_EINVAL;
     if (epi == 2 && in_scale) return SED_EINVAL;        // not instantiated (never needed by the models)
-    if (!x_amax && !(sa > 0.f)) return SED_EINVAL;
     Sf16P p;
     p.x = x; p.wp = (const _Float16*)wp; p.wscale = wscale; p.x_amax = x_amax; p.y = y;
     p.in_scale = in_scale; p.in_shift = in_shift; p.partials = partials; p.yprev = yprev;
@@ -472,7 +492,7 @@ SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale
     const int mw = sf_mw(Cout);
     p.TR = (64 * mw) >> p.logW;
     p.ntile = (H + p.TR - 1) / p.TR;
-    p.sa = sa; p.err_host = err_host;
+    p.mm = minmax; p.err_host = err_host; p.err_dev = err_dev;
     const long nblk = (long)B * p.ntile * (Cout / (mw == 2 ? 128 : 64));
     if (nblk > 0x7fffffffL) return SED_EINVAL;
     const dim3 g((unsigned)nblk), blk(256);
@@ -523,11 +543,12 @@ struct WSf16P {
     const float* in_scale;
     const float* in_shift;
     const float* g_amax;       // device: amax of gy
+    const float* x_amax;       // device: amax of the activation operand (relu(scale*x+shift) when fused)
     int B, H, W, K, N;
     int spi, ips;              // slices per image (>= 1) XOR images per slice (>= 1)
     int stages_per_image;
-    float sa;                  // fixed activation scale
-    int* err_host;             // nullable, host-mapped: set to 1 when a scaled activation leaves the f16 range
+    int* err_host;             // nullable, host-mapped: set to 1 when an operand is not finite
+    int* err_dev;              // nullable, device: same
 };
 
 __device__ __forceinline__ half4 sf_tr_read(const unsigned char* p) {
@@ -561,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
         const int per = (p.stages_per_image + p.spi - 1) / p.spi;
         s0 = (slice % p.spi) * per; s1 = min(p.stages_per_image, s0 + per);
     }
-    const float sg = sf_scale_of(*p.g_amax), sa = p.sa;
+    const float sg = sf_scale_of(*p.g_amax), sa = sf_scale_of(*p.x_amax);
 
     // ---- staging maps.  x: item e = tid + 256*i (i < 2): pixel e >> 3 of the 64 new ones, channel quad e & 7 (32 ci);
     //      gy: item e (i < 4): pixel e >> 4, channel quad e & 15 (64 co)
@@ -572,7 +593,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
         xsc = *reinterpret_cast<const float4*>(p.in_scale + ci0 + xq * 4);
         xsh = *reinterpret_cast<const float4*>(p.in_shift + ci0 + xq * 4);
         // the power-of-two operand scale rides on the affine: relu(sa*sc*x + sa*sh) == sa*relu(sc*x + sh) bit for bit
-        xsc.x *= p.sa; xsc.y *= p.sa; xsc.z *= p.sa; xsc.w *= p.sa; xsh.x *= p.sa; xsh.y *= p.sa; xsh.z *= p.sa; xsh.w *= p.sa;
+        xsc.x *= sa; xsc.y *= sa; xsc.z *= sa; xsc.w *= sa; xsh.x *= sa; xsh.y *= sa; xsh.z *= sa; xsh.w *= sa;
     }
     const unsigned x_img_bytes = (unsigned)p.H * W * p.K * 4u, g_img_bytes = (unsigned)p.H * W * p.N * 4u;
     bool overflow = false;
@@ -630,6 +651,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                             \
         float4 v = greg[i];                                                                                     \
         v.x *= sg; v.y *= sg; v.z *= sg; v.w *= sg;                                                             \
+        overflow |= !(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) < 65504.f);          \
         const half4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};                          \
         const half4 lo = {(_Float16)(v.x - (float)hi.x), (_Float16)(v.y - (float)hi.y),                         \
                           (_Float16)(v.z - (float)hi.z), (_Float16)(v.w - (float)hi.w)};                        \
@@ -716,7 +738,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
 #undef WSF_GLOAD
 #undef WSF_GSTORE
 
-    if (overflow && p.err_host) __hip_atomic_store(p.err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (overflow) {
+        if (p.err_host) __hip_atomic_store(p.err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (p.err_dev) __hip_atomic_store(p.err_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     // ---- partial sums of this (slice, k half): [tap][co][ci]
     float* out = p.partial + ((long)(slice * 2 + wk) * 9) * p.N * p.K;
@@ -731,7 +756,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
 
 // sum the slices in fp64, unscale, scatter to OIHW
 __global__ __launch_bounds__(256) void wgrad_sf16_reduce_kernel(const float* __restrict__ partial, int nparts, int N, int K,
-                                                                const float* __restrict__ g_amax, float sa,
+                                                                const float* __restrict__ g_amax,
+                                                                const float* __restrict__ x_amax,
                                                                 float* __restrict__ dw) {
     const long nk = (long)9 * N * K;
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
@@ -741,7 +767,7 @@ __global__ __launch_bounds__(256) void wgrad_sf16_reduce_kernel(const float* __r
     const int ci = (int)(e % K);
     const long t = e / K;
     const int co = (int)(t % N), tap = (int)(t / N);
-    const double inv = 1.0 / ((double)sf_scale_of(*g_amax) * (double)sa);
+    const double inv = 1.0 / ((double)sf_scale_of(*g_amax) * (double)sf_scale_of(*x_amax));
     dw[((long)co * K + ci) * 9 + tap] = (float)(s * inv);
 }
 
@@ -783,13 +809,14 @@ SED_API long sed_wgrad_sf16_partial_floats(int B, int H, int W, int Cin, int Cou
 
 SED_API int sed_conv3x3_wgrad_sf16(const float* x, const float* gy, float* dw_oihw, float* partial, int B, int H, int W,
                                    int Cin, int Cout, const float* in_scale, const float* in_shift, const float* gy_amax,
-                                   float sa, int* err_host, sed_stream_t stream) {
-    if (!x || !gy || !dw_oihw || !partial || !gy_amax || B <= 0 || !sed_wgrad_sf16_supported(H, W, Cin, Cout) || !(sa > 0.f))
+                                   const float* x_amax, int* err_host, int* err_dev, sed_stream_t stream) {
+    if (!x || !gy || !dw_oihw || !partial || !gy_amax || !x_amax || B <= 0 || !sed_wgrad_sf16_supported(H, W, Cin, Cout))
         return SED_EINVAL;
     if ((in_scale == nullptr) != (in_shift == nullptr)) return SED_EINVAL;
     WSf16P p;
     p.x = x; p.gy = gy; p.partial = partial; p.in_scale = in_scale; p.in_shift = in_shift; p.g_amax = gy_amax;
-    p.B = B; p.H = H; p.W = W; p.K = Cin; p.N = Cout; p.sa = sa; p.err_host = err_host;
+    p.x_amax = x_amax;
+    p.B = B; p.H = H; p.W = W; p.K = Cin; p.N = Cout; p.err_host = err_host; p.err_dev = err_dev;
     long ns;
     wsf_slicing(B, H, W, Cin, Cout, &p.spi, &p.ips, &p.stages_per_image, &ns);
     const long nblk = ns * (Cin / 32) * (Cout / 64);
@@ -805,7 +832,7 @@ SED_API int sed_conv3x3_wgrad_sf16(const float* x, const float* gy, float* dw_oi
     SED_LAUNCH_CHECK();
     const long nk = 9L * Cin * Cout;
     hipLaunchKernelGGL(wgrad_sf16_reduce_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, s, partial, (int)(ns * 2), Cout,
-                       Cin, gy_amax, sa, dw_oihw);
+                       Cin, gy_amax, x_amax, dw_oihw);
     SED_LAUNCH_CHECK();
     return 0;
 }

@@ -204,11 +204,35 @@ __global__ __launch_bounds__(256) void mixup_rows_kernel(const float* __restrict
 }
 
 // ---- Adam(amsgrad=True, weight_decay=0) over one flat buffer ----------------------------------------------------
+// found-non-finite guard of the optimiser step: any NaN / inf gradient (after the all-reduce, so every rank of a
+// data-parallel job sees what one rank's poisoned step produced) raises the skip flag and the host-mapped error word
+__global__ __launch_bounds__(256) void grad_finite_check_kernel(const float* __restrict__ g, long n, int* __restrict__ skip_flag,
+                                                                int* __restrict__ err_host) {
+    bool bad = false;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(g)[i];
+        bad |= !(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) < __builtin_inff()) ||
+               v.x != v.x || v.y != v.y || v.z != v.z || v.w != v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[n4 * 4 + threadIdx.x]; bad |= !(fabsf(v) < __builtin_inff()); }
+    if (__any(bad) && (threadIdx.x & 63) == 0) {
+        __hip_atomic_store(skip_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (err_host) __hip_atomic_store(err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 __global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                            float* __restrict__ m, float* __restrict__ v,
                                                            float* __restrict__ vmax, long n, float lr, float beta1,
                                                            float beta2, float eps, float bc1, float bc2_sqrt,
-                                                           float grad_scale) {
+                                                           float grad_scale, int* __restrict__ skip_flag) {
+    // found-non-finite skip: a kernel of this step met a NaN / inf operand (skip_flag[0] != 0): leave parameters and
+    // moments untouched and count the refused step in skip_flag[1] -- the host learns about it without synchronising
+    if (skip_flag && __hip_atomic_load(skip_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skip_flag + 1, 1);
+        return;
+    }
     const float step_size = lr / bc1;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         float gi = g[i] * grad_scale;
@@ -391,12 +415,19 @@ SED_API int sed_mixup_rows(const float* x, const float* lam, long B2, long D, fl
 
 // One Adam-amsgrad step (step >= 1) over flat buffers; grad_scale multiplies the gradient first (1/world_size).
 SED_API int sed_adam_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, long n, int step, float lr,
-                             float beta1, float beta2, float eps, float grad_scale, hipStream_t stream) {
+                             float beta1, float beta2, float eps, float grad_scale, int* skip_flag, int* err_host,
+                             hipStream_t stream) {
     if (n <= 0 || step < 1) return SED_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(g) & 15) != 0 && skip_flag) return SED_EINVAL;
+    if (skip_flag) {
+        const long nb = (n / 4 + 255) / 256;
+        hipLaunchKernelGGL(grad_finite_check_kernel, dim3((unsigned)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb))), dim3(256), 0, stream, g,
+                           n, skip_flag, err_host);
+    }
     double bc1 = 1.0 - pow((double)beta1, (double)step);
     double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_amsgrad_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, m, v, vmax, n, lr, beta1, beta2, eps,
-                       (float)bc1, (float)sqrt(bc2), grad_scale);
+                       (float)bc1, (float)sqrt(bc2), grad_scale, skip_flag);
     SED_LAUNCH_CHECK();
     return 0;
 }

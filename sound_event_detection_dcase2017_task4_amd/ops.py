@@ -66,10 +66,26 @@ def join_side_stream():
     del pend                                     # operands / temporaries die here, in main-stream order BEHIND the wait
 
 
+def pending_sink_indices(opt=None):
+    """Parameter indices (of optimiser `opt`, or of any) whose weight gradient is still un-joined on the side stream."""
+    return {sink.index for ev, sink, keep in _PENDING if sink is not None and (opt is None or sink.opt is opt)}
+
+
+def drop_pending_wgrads():
+    """Forget side-stream weight gradients of a backward pass that did not finish (it raised between a fork and its
+    join): the main stream waits for the side stream, the entries' tensors are released, and NO sink reports ready --
+    the gradients of that pass are void.  Called by FusedAdamAmsgrad.zero_grad()."""
+    if _PENDING:
+        main = torch.cuda.current_stream()
+        for ev, sink, keep in _PENDING:
+            main.wait_event(ev)
+        del _PENDING[:]
+
+
 _STREAM_OVERRIDE = None     # set while kernels are being enqueued on the side stream (see _fork_wgrad)
 
 
-def _fork_wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, gy_amax=None):
+def _fork_wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, gy_amax=None, x_amax=None):
     """_wgrad on the side stream behind everything enqueued on the main stream so far.  With a sink the gradient lands in
     the flat buffer and is joined later (join_side_stream); without one the tensor is returned after an immediate join.
 
@@ -82,10 +98,10 @@ def _fork_wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, gy_amax=None):
     main = torch.cuda.current_stream()
     side = _side_stream(x.device)
     side.wait_stream(main)
-    keep = [x, gy, in_st, gy_amax]
+    keep = [x, gy, in_st, gy_amax, x_amax]
     _STREAM_OVERRIDE = side
     try:
-        dw = _wgrad(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=False, gy_amax=gy_amax, keep=keep)
+        dw = _wgrad(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=False, gy_amax=gy_amax, x_amax=x_amax, keep=keep)
     finally:
         _STREAM_OVERRIDE = None
     ev = torch.cuda.Event()
@@ -155,37 +171,73 @@ def _call(name, *args):
 # raise it with a system-scope store, the host polls it without synchronising.
 
 _ERR_FLAG = None
+_ERR_DEV = {}
+
+
+class NonFiniteOperand(RuntimeError):
+    """A split-f16 convolution met a NaN / inf operand.  The Adam kernel refuses every step from that point on (parameters
+    and moments stay as they were before the poisoned step) until the error has been reported through
+    check_device_errors(); `skipped_steps` says how many optimiser steps that were."""
+
+    def __init__(self, msg, skipped_steps=0):
+        super(NonFiniteOperand, self).__init__(msg)
+        self.skipped_steps = skipped_steps
 
 
 def _err_flag():
-    """One pinned int32[4] per process; its device-visible address is handed to the kernels that can fail at run time."""
+    """One pinned int32[4] per process; its device-visible address is handed to the kernels that can fail at run time.
+    Slot 0: fused GRU give-up, slot 1: non-finite operand of a split-f16 convolution."""
     global _ERR_FLAG
     if _ERR_FLAG is None:
         _ERR_FLAG = torch.zeros((4,), dtype=torch.int32).pin_memory()
     return _ERR_FLAG
 
 
+def _err_dev(device=None):
+    """Device int32[2] per GPU: [0] = non-finite operand seen (written by the split-f16 kernels, read by the Adam kernel as
+    its skip flag), [1] = optimiser steps the Adam kernel refused since."""
+    idx = torch.device(device).index if device is not None and torch.device(device).index is not None \
+        else torch.cuda.current_device()
+    t = _ERR_DEV.get(idx)
+    if t is None:
+        t = _ERR_DEV[idx] = torch.zeros((2,), dtype=torch.int32, device=torch.device("cuda", idx))
+    return t
+
+
 def _sf16_err_ptr():
-    """Host-mapped word the split-f16 convolutions set when a scaled operand leaves the f16 range (slot 1 of the flag)."""
+    """Host-mapped word the split-f16 convolutions set when an operand is not finite (slot 1 of the flag)."""
     return ctypes.c_void_p(_err_flag().data_ptr() + 4)
+
+
+def _sf16_err_dev_ptr(device=None):
+    return ctypes.c_void_p(_err_dev(device).data_ptr())
 
 
 def check_device_errors(synchronize=False):
     """Raise if a kernel reported a run-time failure since the last check (no device synchronisation unless asked: the
-    flag is written through host-mapped memory, so a failure surfaces at the next call after the kernel ran)."""
+    flag is written through host-mapped memory, so a failure surfaces at the next call after the kernel ran).  Only the
+    slot that is reported is cleared."""
     if _ERR_FLAG is None:
         return
     if synchronize:
         torch.cuda.synchronize()
     if int(_ERR_FLAG[1]):
-        _ERR_FLAG.zero_()
-        raise RuntimeError(
-            "sound_event_detection_dcase2017_task4_amd: a split-f16 convolution met an activation outside the f16 range of its "
-            "fixed scale (|x| >= %g) or a non-finite value; its results are inf/NaN.  Diverged training, or activations far "
-            "from BatchNorm-ed magnitude: set SED_USE_SF16=0 (fp32 MFMA kernels) for such inputs." % (65504.0 / SF16_ACT_SCALE))
+        torch.cuda.synchronize()                      # rare path: settle, then read how many steps the Adam kernel refused
+        skipped = 0
+        for t in _ERR_DEV.values():
+            skipped = max(skipped, int(t[1].item()))
+            t.zero_()
+        torch.cuda.synchronize()
+        _ERR_FLAG[1] = 0
+        raise NonFiniteOperand(
+            "sound_event_detection_dcase2017_task4_amd: a split-f16 convolution met a NaN / inf operand (diverged training or "
+            "non-finite input): its results are NaN.  The Adam kernel refused the %d optimiser step(s) since -- parameters and "
+            "moments are those from before the poisoned step.  (Operand scales come from device-side amax values, so a FINITE "
+            "operand cannot overflow at any magnitude.)  The train CLI re-runs such a step on the fp32 MFMA kernels "
+            "(ops.USE_SF16 = False), which propagate NaN exactly like the reference." % skipped, skipped)
     code = int(_ERR_FLAG[0])
     if code:
-        _ERR_FLAG.zero_()
+        _ERR_FLAG[0] = 0
         raise RuntimeError(
             "sound_event_detection_dcase2017_task4_amd: the fused GRU recurrence (sed_gru_seq_%s) gave up waiting for its "
             "partner workgroups -- its 128 persistent workgroups were not all resident (CU mask, partitioned GPU or a "
@@ -574,7 +626,7 @@ def _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, 
     return _ret(sink, dw) if signal else (None if sink is not None else dw)
 
 
-def _wgrad_sf16(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, gy_amax=None, keep=None):
+def _wgrad_sf16(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, gy_amax=None, x_amax=None, keep=None):
     nfl = _lib.lib().sed_wgrad_sf16_partial_floats(B, H, W, Cin, Cout)
     if nfl <= 0:
         raise RuntimeError("sed_conv3x3_wgrad_sf16 does not support this shape")
@@ -582,6 +634,10 @@ def _wgrad_sf16(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, g
         gy_amax = amax_of(gy)
         if keep is not None:
             keep.append(gy_amax)
+    if x_amax is None:                               # callers on the hot path pass the amax their producer left
+        x_amax = act_amax_full(x, in_st) if in_st is not None else amax_of(x)
+        if keep is not None:
+            keep.append(x_amax)
     partial = torch.empty((nfl,), dtype=torch.float32, device=x.device)
     dw = _dst(sink, (Cout, Cin, 3, 3), x.device)
     if keep is not None:
@@ -590,7 +646,7 @@ def _wgrad_sf16(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, g
                 2.0 * 9 * B * H * W * Cin * Cout):
         _call("sed_conv3x3_wgrad_sf16", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
               _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None,
-              _ptr(gy_amax), SF16_ACT_SCALE, _sf16_err_ptr(), _stream())
+              _ptr(gy_amax), _ptr(x_amax), _sf16_err_ptr(), _sf16_err_dev_ptr(x.device), _stream())
     return _ret(sink, dw) if signal else (None if sink is not None else dw)
 
 
@@ -600,9 +656,10 @@ def _wgrad_algo(H, W, Cin, Cout):
     return 3 if (USE_SF16 and Cin >= 128 and _lib.lib().sed_wgrad_sf16_supported(H, W, Cin, Cout)) else 0
 
 
-def _wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, gy_amax=None, keep=None):
+def _wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, gy_amax=None, x_amax=None, keep=None):
     if _wgrad_algo(H, W, Cin, Cout) == 3:
-        return _wgrad_sf16(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=signal, gy_amax=gy_amax, keep=keep)
+        return _wgrad_sf16(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=signal, gy_amax=gy_amax, x_amax=x_amax,
+                           keep=keep)
     if USE_WINOGRAD >= 2 and W in (8, 16, 32, 64) and Cin % 32 == 0 and Cout % 64 == 0:
         return _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=signal, keep=keep)
     if USE_WINOGRAD and _wgrad_wino_ok(W, Cin, Cout):
@@ -627,9 +684,6 @@ def _wgrad_direct(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True,
 
 # ---- split-f16 convolution (csrc/conv_sf16.hip)
 
-SF16_ACT_SCALE = 16.0        # fixed power of two for BatchNorm-ed / pooled activations (|x| < 4094)
-
-
 def pack_sf16(w_oihw, dgrad=False):
     """OIHW fp32 weights -> (split-f16 operand [hi, lo planes], wscale[2] = (amax, power-of-two scale) on the device)."""
     Cout, Cin = w_oihw.shape[0], w_oihw.shape[1]
@@ -640,15 +694,37 @@ def pack_sf16(w_oihw, dgrad=False):
 
 
 def amax_of(x):
+    """max |x| as a device scalar (one pass)."""
     out = torch.empty((1,), dtype=torch.float32, device=x.device)
     _call("sed_amax", _ptr(x), x.numel(), _ptr(out), _stream())
     return out
 
 
-def conv3x3_sf16(x, pack, B, H, W, Cin, Cout, in_st=None, epi=0, partials=None, yprev=None, p_st=None, x_amax=None):
+def act_amax(minmax, nparts, C, st=None):
+    """amax of relu(scale*y + shift) (st given) or of |y| from the per-part per-channel (max, min) a conv epilogue left --
+    the split-f16 scale of a convolution whose operand is never materialised.  No pass over the tensor."""
+    out = torch.empty((1,), dtype=torch.float32, device=minmax.device)
+    _call("sed_act_amax", _ptr(minmax), nparts, C, _ptr(st.scale) if st is not None else None,
+          _ptr(st.shift) if st is not None else None, _ptr(out), _stream())
+    return out
+
+
+def act_amax_full(y, st):
+    """The same amax by one pass over y (producers that leave no range partials; off the default path)."""
+    C = y.shape[-1]
+    out = torch.empty((1,), dtype=torch.float32, device=y.device)
+    _call("sed_act_amax_full", _ptr(y), y.numel() // C, C, _ptr(st.scale), _ptr(st.shift), _ptr(out), _stream())
+    return out
+
+
+def conv3x3_sf16(x, pack, B, H, W, Cin, Cout, in_st=None, epi=0, partials=None, yprev=None, p_st=None, x_amax=None,
+                 minmax=None):
     """y = conv3x3(relu(scale*x + shift) or x) on the f16 MFMA pipe with split operands; x NHWC fp32 -> y NHWC fp32.
-    x_amax: device scalar with the amax of x (gradients); None = the fixed activation scale."""
+    x_amax: device scalar = amax of the operand as the MFMAs see it (None: computed here by a pass over x);
+    minmax: optional [nparts][2][Cout] buffer that receives the per-part range of y (for act_amax of the next conv)."""
     wp, wscale = pack
+    if x_amax is None:
+        x_amax = act_amax_full(x, in_st) if in_st is not None else amax_of(x)
     y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
     with _timed("conv3x3_sf16_mfma(fwd+dgrad)|%d->%d@%dx%d epi%d%s" % (Cin, Cout, H, W, epi, "+inT" if in_st is not None else ""),
                 2.0 * 9 * B * H * W * Cin * Cout):
@@ -656,7 +732,8 @@ def conv3x3_sf16(x, pack, B, H, W, Cin, Cout, in_st=None, epi=0, partials=None, 
               _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, epi,
               _ptr(partials), _ptr(yprev), _ptr(p_st.scale) if p_st is not None else None,
               _ptr(p_st.shift) if p_st is not None else None, _ptr(p_st.mean) if p_st is not None else None,
-              _ptr(p_st.invstd) if p_st is not None else None, _ptr(x_amax), SF16_ACT_SCALE, _sf16_err_ptr(), _stream())
+              _ptr(p_st.invstd) if p_st is not None else None, _ptr(x_amax), _ptr(minmax), _sf16_err_ptr(),
+              _sf16_err_dev_ptr(x.device), _stream())
     return y
 
 
@@ -677,10 +754,9 @@ def _conv_fwd_like(x, w_oihw, B, H, W, Cin, Cout, dgrad=False, **kw):
     then the channel counts of the INPUT/OUTPUT of this call)."""
     algo = _conv_algo(H, W, Cin, Cout)
     x_amax = kw.pop("x_amax", None)
+    minmax = kw.pop("minmax", None)
     if algo == 3:
-        if dgrad and x_amax is None:
-            x_amax = amax_of(x)                      # gradients have no fixed magnitude: scale from their amax
-        return conv3x3_sf16(x, pack_sf16(w_oihw, dgrad=dgrad), B, H, W, Cin, Cout, x_amax=x_amax, **kw)
+        return conv3x3_sf16(x, pack_sf16(w_oihw, dgrad=dgrad), B, H, W, Cin, Cout, x_amax=x_amax, minmax=minmax, **kw)
     if algo == 2:
         uf, ud = _pack_wino2(w_oihw, want_f=not dgrad, want_d=dgrad)
         return _conv_wino2(x, ud if dgrad else uf, B, H, W, Cin, Cout, **kw)
@@ -716,7 +792,8 @@ class ConvBlockFn(torch.autograd.Function):
     on the fly by the consumers."""
 
     @staticmethod
-    def forward(ctx, x, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, training, ph, pw):
+    def forward(ctx, x, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, training, ph, pw, x_amax=None):
+        """Returns (out, out_amax): out_amax = device scalar max(out) for the next block's split-f16 scale (x_amax there)."""
         _chk_dev(x, w1, w2)
         x = _f32c(x)
         B, H, W, Cin = x.shape
@@ -725,42 +802,62 @@ class ConvBlockFn(torch.autograd.Function):
         L = _lib.lib()
         M = B * H * W
         w1c, w2c = _f32c(w1), _f32c(w2)
-        # conv1 (+ statistics)
+        # split-f16 operand scales come from the amax of each operand, left on the device by its producer
+        sf_c1 = Cin != 1 and _conv_algo(H, W, Cin, Cout) == 3
+        need_xa = sf_c1 or (training and Cin != 1 and _wgrad_algo(H, W, Cin, Cout) == 3)
+        need_a1 = _conv_algo(H, W, Cout, Cout) == 3 or (training and _wgrad_algo(H, W, Cout, Cout) == 3)
+        if need_xa and x_amax is None:
+            x_amax = amax_of(x)                          # standalone use; inside a model the previous block's pool supplies it
+        if not need_xa:
+            x_amax = None
+        # conv1 (+ statistics, + per-channel output range for the amax of relu(bn1(y1)))
+        mm1 = None
         if Cin == 1:
             rpp1 = L.sed_conv1_rows_per_part()
             np1 = (M + rpp1 - 1) // rpp1
             part1 = torch.empty((np1, 2, Cout), dtype=torch.float32, device=dev) if training else None
+            mm1 = torch.empty((np1, 2, Cout), dtype=torch.float32, device=dev) if need_a1 else None
             y1 = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
-            _call("sed_conv1_fwd", _ptr(x), _ptr(w1c), _ptr(y1), B, H, W, _ptr(part1), _stream())
+            _call("sed_conv1_fwd", _ptr(x), _ptr(w1c), _ptr(y1), B, H, W, _ptr(part1), _ptr(mm1), _stream())
         else:
             np1, rpp1, nf1 = _conv_parts(B, H, W, Cin, Cout)
             part1 = torch.empty((nf1,), dtype=torch.float32, device=dev) if training else None
-            y1 = _conv_fwd_like(x, w1c, B, H, W, Cin, Cout, epi=1 if training else 0, partials=part1)
+            if need_a1 and sf_c1:
+                mm1 = torch.empty((np1, 2, Cout), dtype=torch.float32, device=dev)
+            y1 = _conv_fwd_like(x, w1c, B, H, W, Cin, Cout, epi=1 if training else 0, partials=part1, x_amax=x_amax, minmax=mm1)
         st1 = bn_finalize(part1, np1, rpp1, M, g1, b1, rm1, rv1) if training else bn_eval_affine(g1, b1, rm1, rv1)
+        a1 = None
+        if need_a1:
+            a1 = act_amax(mm1, np1, Cout, st1) if mm1 is not None else act_amax_full(y1, st1)
+        del mm1
         # conv2 over relu(bn1(y1)) computed on the fly (+ statistics)
         np2, rpp2, nf2 = _conv_parts(B, H, W, Cout, Cout)
         part2 = torch.empty((nf2,), dtype=torch.float32, device=dev) if training else None
-        y2 = _conv_fwd_like(y1, w2c, B, H, W, Cout, Cout, in_st=st1, epi=1 if training else 0, partials=part2)
+        y2 = _conv_fwd_like(y1, w2c, B, H, W, Cout, Cout, in_st=st1, epi=1 if training else 0, partials=part2, x_amax=a1)
         st2 = bn_finalize(part2, np2, rpp2, M, g2, b2, rm2, rv2) if training else bn_eval_affine(g2, b2, rm2, rv2)
         out = torch.empty((B, H // ph, W // pw, Cout), dtype=torch.float32, device=dev)
+        out_amax = torch.empty((1,), dtype=torch.float32, device=dev)
         cnt = None
         if training and POOL_BWD_WINDOWED and ph * pw > 1:
             # per-window ReLU counts: with them backward pass 1 runs on the pooled tensors and never reads y2
             cnt = torch.empty((B, H // ph, W // pw, Cout), dtype=torch.uint8, device=dev)
             _call("sed_bn_relu_pool_fwd_cnt", _ptr(y2), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift), _ptr(out),
-                  _ptr(cnt), _stream())
+                  _ptr(cnt), _ptr(out_amax), _stream())
         else:
-            _call("sed_bn_relu_pool_fwd", _ptr(y2), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift), _ptr(out), _stream())
+            _call("sed_bn_relu_pool_fwd", _ptr(y2), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift), _ptr(out),
+                  _ptr(out_amax), _stream())
         if cnt is not None:
             ctx.save_for_backward(x, y1, y2, w1c, w2c, out, cnt, _f32c(g2), _f32c(b2))
         else:
             ctx.save_for_backward(x, y1, y2, w1c, w2c)
         ctx.st1, ctx.st2, ctx.pool, ctx.training = st1, st2, (ph, pw), bool(training)
+        ctx.xa, ctx.a1 = x_amax, a1
         ctx.sinks = _sinks(ctx, (w1, g1, b1, None, None, w2, g2, b2), 1)
-        return out
+        ctx.mark_non_differentiable(out_amax)
+        return out, out_amax
 
     @staticmethod
-    def backward(ctx, g_out):
+    def backward(ctx, g_out, _g_amax=None):
         x, y1, y2, w1, w2 = ctx.saved_tensors[:5]
         win = ctx.saved_tensors[5:] if len(ctx.saved_tensors) > 5 else None
         st1, st2 = ctx.st1, ctx.st2
@@ -802,9 +899,9 @@ class ConvBlockFn(torch.autograd.Function):
         partb = torch.empty((nfb,), dtype=torch.float32, device=dev)
         gy1 = _conv_fwd_like(gy2, w2, B, H, W, Cout, Cout, dgrad=True, epi=2, partials=partb, yprev=y1, p_st=st1, x_amax=amax2)
         if fork and sk[5] is not None:
-            dw2 = _fork_wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=st1, sink=sk[5], gy_amax=amax2)
+            dw2 = _fork_wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=st1, sink=sk[5], gy_amax=amax2, x_amax=ctx.a1)
         else:
-            dw2 = _wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=st1, sink=sk[5], gy_amax=amax2)
+            dw2 = _wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=st1, sink=sk[5], gy_amax=amax2, x_amax=ctx.a1)
         del gy2
         dg1, db1, coef1 = bn_bwd_finalize(partb, npb, M, st1, batch_stats=ctx.training, sinks=(sk[1], sk[2]))
         # conv1
@@ -830,10 +927,10 @@ class ConvBlockFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 gx = _conv_fwd_like(gy1, w1, B, H, W, Cout, Cin, dgrad=True, epi=0, x_amax=amax1)
             if fork and sk[0] is not None:
-                dw1 = _fork_wgrad(x, gy1, B, H, W, Cin, Cout, sink=sk[0], gy_amax=amax1)
+                dw1 = _fork_wgrad(x, gy1, B, H, W, Cin, Cout, sink=sk[0], gy_amax=amax1, x_amax=ctx.xa)
             else:
-                dw1 = _wgrad(x, gy1, B, H, W, Cin, Cout, sink=sk[0], gy_amax=amax1)
-        return gx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, None, None, None
+                dw1 = _wgrad(x, gy1, B, H, W, Cin, Cout, sink=sk[0], gy_amax=amax1, x_amax=ctx.xa)
+        return gx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -1220,8 +1317,13 @@ def mixup_rows(x, lam):
     return out
 
 
-def adam_amsgrad_(p, g, m, v, vmax, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+def adam_amsgrad_(p, g, m, v, vmax, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, guard=None):
+    """guard (default: on while the split-f16 kernels are in use): found-non-finite skip -- the update is refused when a
+    split-f16 kernel of this step met a NaN / inf operand or the (all-reduced) gradient holds one; see NonFiniteOperand.
+    With ops.USE_SF16 = False the step behaves exactly like torch.optim.Adam (NaN gradients make NaN parameters)."""
     _chk_dev(p, g)
+    if guard is None:
+        guard = USE_SF16
     invalidate_weight_caches()                     # parameters change through raw pointers: `_version` does not see it
     _call("sed_adam_amsgrad", _ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vmax), p.numel(), step, lr, beta1, beta2, eps,
-          grad_scale, _stream())
+          grad_scale, _sf16_err_dev_ptr(p.device) if guard else None, _sf16_err_ptr() if guard else None, _stream())

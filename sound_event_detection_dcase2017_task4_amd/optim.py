@@ -94,25 +94,56 @@ class FusedAdamAmsgrad(object):
         if cuts == "auto":
             cuts = bucket_cuts(names, self.offsets, numels)
         self.buckets = parallel.GradBuckets(self.flat_grad, self.offsets, numels, cuts)
+        self.buckets.pre_fire_check = self._assert_joined
         for i, p in enumerate(params):
             p._sed_sink = GradSink(self, i, p.grad) if self.direct_grads else None
         self.step_count = 0
+        self.skipped_steps = 0             # optimiser steps the Adam kernel refused (device error word set, see step())
+        ops.invalidate_weight_caches()     # parameters moved into the flat buffer: operands derived from them are stale
+
+    def _assert_joined(self, bucket, indices):
+        """A bucket must not go to RCCL while a weight gradient inside it is still running on the side stream and the main
+        stream has not waited for it (the collective is ordered behind the MAIN stream only)."""
+        pending = ops.pending_sink_indices(self)
+        late = pending.intersection(indices)
+        if late:
+            raise RuntimeError("gradient bucket %d would be all-reduced before the side-stream weight gradients of "
+                               "parameters %s were joined" % (bucket, sorted(late)))
+
+    def _view(self, i):
+        off = self.offsets[i]
+        return self.flat_grad[off:off + self.params[i].numel()].view(self.params[i].shape)
 
     def zero_grad(self, set_to_none=False):
+        ops.drop_pending_wgrads()          # a backward pass that raised may have left side-stream work behind
         self.buckets.new_gradients()
         self.flat_grad.zero_()
         for i, (p, off) in enumerate(zip(self.params, self.offsets)):   # re-attach if user code detached the views
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
-                p.grad = self.flat_grad[off:off + p.numel()].view(p.shape)
+                p.grad = self._view(i)
                 if self.direct_grads:
                     p._sed_sink = GradSink(self, i, p.grad)
 
     def _gather(self):
-        for p, off in zip(self.params, self.offsets):
+        """Bring gradients that do NOT already sit in the flat buffer into it.  With direct_grads the backward kernels
+        wrote theirs through the sinks and handed autograd None, so after `model.zero_grad()` (set_to_none) such a
+        parameter has `p.grad is None` although its slice holds this step's gradient: re-attach the view, never zero it.
+        Only slices that received nothing this cycle are cleared."""
+        written = self.buckets.written if self.direct_grads else ()
+        for i, (p, off) in enumerate(zip(self.params, self.offsets)):
+            sl = self.flat_grad[off:off + p.numel()]
             if p.grad is None:
-                self.flat_grad[off:off + p.numel()].zero_()
+                if i in written:
+                    p.grad = self._view(i)
+                else:
+                    sl.zero_()
             elif p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
-                self.flat_grad[off:off + p.numel()].copy_(p.grad.reshape(-1))
+                g = p.grad.reshape(-1)
+                if i in written:           # a sink write AND an autograd-delivered gradient (parameter used twice)
+                    sl.add_(g)
+                else:
+                    sl.copy_(g)
+                p.grad = self._view(i)
 
     def reduce_gradients(self):
         """Finish the data-parallel exchange of this step's gradients (buckets not yet triggered by the backward pass
@@ -122,12 +153,21 @@ class FusedAdamAmsgrad(object):
 
     @torch.no_grad()
     def step(self):
+        """One Adam-amsgrad update.  Found-non-finite guard: the kernel reads the device error word of the split-f16
+        convolutions and leaves parameters and moments untouched when a kernel of this step met a NaN / inf operand; the
+        host learns about it (no synchronisation: host-mapped flag) at this or a later call and raises
+        ops.NonFiniteOperand after taking the refused steps back out of `step_count`."""
         self.reduce_gradients()
         self.buckets.begin_step()
         self.step_count += 1
         ops.adam_amsgrad_(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq, self.step_count,
                           self.lr, self.betas[0], self.betas[1], self.eps, 1.0 / float(self.world_size))
-        ops.check_device_errors()
+        try:
+            ops.check_device_errors()
+        except ops.NonFiniteOperand as e:
+            self.step_count -= e.skipped_steps
+            self.skipped_steps += e.skipped_steps
+            raise
 
     def state_dict(self):
         return {"step": self.step_count, "lr": self.lr, "betas": self.betas, "eps": self.eps,
@@ -137,3 +177,4 @@ class FusedAdamAmsgrad(object):
         self.step_count = int(sd["step"])
         for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
             getattr(self, k).copy_(sd[k])
+        ops.invalidate_weight_caches()

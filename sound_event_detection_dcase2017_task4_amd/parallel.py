@@ -101,6 +101,8 @@ def broadcast_flat(flat, src=0):
     """Rank `src`'s flat parameter buffer becomes everyone's (one-time, at start)."""
     if world_size() > 1:
         dist.broadcast(flat, src=src)
+    from . import ops                      # in-place write through the flat buffer: neither `_version` of the parameter
+    ops.invalidate_weight_caches()         # views nor the optimiser generation saw it (padded head / stacked GRU operands)
 
 
 def broadcast_buffers(module, src=0):
@@ -158,6 +160,8 @@ class GradBuckets(object):
         for off in self.offsets:
             self.bucket_of.append(next(b for b, (lo, hi) in enumerate(self.ranges) if lo <= off < hi))
         self.issue_order = []          # bucket indices in the order they were handed to the backend (for tests / logs)
+        self.pre_fire_check = None     # callable(bucket index, param indices) run before a bucket goes to the backend
+        self.wait_events = None        # bench: list that receives (start, end) CUDA event pairs around the waits of finish()
         self.begin_step()
         self.last_issue_order = []
 
@@ -196,6 +200,10 @@ class GradBuckets(object):
                 self._fire(b)
 
     def _fire(self, b):
+        if self.pre_fire_check is not None:
+            # ordering contract: every gradient of this bucket is complete IN MAIN-STREAM ORDER before the collective is
+            # enqueued behind that stream (side-stream weight gradients must have been joined: ops.join_side_stream)
+            self.pre_fire_check(b, [i for i, bb in enumerate(self.bucket_of) if bb == b])
         self.fired[b] = True
         self.issue_order.append(b)
         if world_size() > 1:
@@ -204,6 +212,8 @@ class GradBuckets(object):
 
     def finish(self):
         if self.rewritten:
+            for h in self.handles:         # all-reduces already in flight on this buffer finish before the state is dropped
+                h.wait()
             self.begin_step()
             raise RuntimeError("backward() ran more than once between two optimiser steps: with direct_grads=True a "
                                "backward pass DEFINES the gradients (it overwrites, and buckets may already have been "
@@ -211,8 +221,15 @@ class GradBuckets(object):
         for b in reversed(range(len(self.ranges))):
             if not self.fired[b]:
                 self._fire(b)
+        timed = self.wait_events is not None and self.handles and self.flat_grad.is_cuda
+        if timed:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for h in self.handles:
             h.wait()                   # stream-level wait for nccl (no host block), completion for gloo
+        if timed:
+            ev[1].record()             # time the compute stream sits behind the collectives = the exposed all-reduce
+            self.wait_events.append(ev)
         self.handles = []
 
 

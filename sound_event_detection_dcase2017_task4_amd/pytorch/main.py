@@ -166,17 +166,32 @@ def train(args):
         # of this rank: the stripes do not depend on the number of ranks
         stripes = draw_specaug_stripes(rows_global, wave.shape[1] // hop_size + 1, mel_bins)[row_lo:row_hi]
         model.train()
-        if mix:
-            lam = move_data_to_device(batch_data_dict['mixup_lambda'], device)
+        lam = move_data_to_device(batch_data_dict['mixup_lambda'], device) if mix else None
+
+        def one_step():
             batch_output_dict = model(wave, lam, specaug_stripes=stripes)
-            batch_target_dict = {'target': do_mixup(target, lam)}
-        else:
-            batch_output_dict = model(wave, None, specaug_stripes=stripes)
-            batch_target_dict = {'target': target}
-        loss = loss_func(batch_output_dict, batch_target_dict)
-        optimizer.zero_grad()
-        loss.backward()                                  # gradient buckets are handed to RCCL as they complete
-        optimizer.step()                                 # waits for them; 1/world is folded into the Adam kernel
+            batch_target_dict = {'target': do_mixup(target, lam) if mix else target}
+            step_loss = loss_func(batch_output_dict, batch_target_dict)
+            optimizer.zero_grad()
+            step_loss.backward()                         # gradient buckets are handed to RCCL as they complete
+            optimizer.step()                             # waits for them; 1/world is folded into the Adam kernel
+            return step_loss
+
+        try:
+            loss = one_step()
+        except ops.NonFiniteOperand as err:
+            if world > 1:
+                raise                                    # ranks notice at different iterations: a one-rank re-run would
+                                                         # unbalance the all-reduces.  (Every rank's guard has refused the
+                                                         # poisoned updates: the last checkpoint / parameters are intact.)
+            # a split-f16 convolution met NaN / inf; the Adam kernel refused every update since (parameters are intact).
+            # From here on the run uses the fp32 MFMA kernels, which carry non-finite values exactly like the reference's
+            # torch ops; this batch is run again on them.
+            logging.warning('iteration %d: %s', iteration, err)
+            logging.warning('%d optimiser step(s) were refused; switching to the fp32 MFMA kernels (ops.USE_SF16 = False) '
+                            'and re-running this batch', err.skipped_steps)
+            ops.USE_SF16 = False
+            loss = one_step()
         if rank == 0 and args.print_every and iteration % args.print_every == 0:
             print(iteration, loss.item())
         if iteration == args.stop_iteration:

@@ -39,7 +39,9 @@ def init_bn(bn):
 
 
 def init_gru(rnn):
-    """models.py:30-55: per-gate uniform(+-sqrt(3/fan_in)) for W_ih and the r,z blocks of W_hh, orthogonal n block."""
+    """models.py:30-55: per-gate uniform(+-sqrt(3/fan_in)) for W_ih and the r,z blocks of W_hh, orthogonal n block, zero
+    biases -- for `weight_*_l{i}` / `bias_*_l{i}` ONLY.  The reference loop never names the `_reverse` parameters, so the
+    backward direction of its bidirectional GRU keeps nn.GRU's default U(+-1/sqrt(hidden)) weights AND biases; same here."""
     def _concat_init(tensor, init_funcs):
         (length, fan_out) = tensor.shape
         fan_in = length // len(init_funcs)
@@ -51,12 +53,10 @@ def init_gru(rnn):
         nn.init.uniform_(tensor, -math.sqrt(3 / fan_in), math.sqrt(3 / fan_in))
 
     for i in range(rnn.num_layers):
-        for sfx in ('', '_reverse') if rnn.bidirectional else ('',):
-            _concat_init(getattr(rnn, 'weight_ih_l{}{}'.format(i, sfx)), [_inner_uniform] * 3)
-            torch.nn.init.constant_(getattr(rnn, 'bias_ih_l{}{}'.format(i, sfx)), 0)
-            _concat_init(getattr(rnn, 'weight_hh_l{}{}'.format(i, sfx)),
-                         [_inner_uniform, _inner_uniform, nn.init.orthogonal_])
-            torch.nn.init.constant_(getattr(rnn, 'bias_hh_l{}{}'.format(i, sfx)), 0)
+        _concat_init(getattr(rnn, 'weight_ih_l{}'.format(i)), [_inner_uniform] * 3)
+        torch.nn.init.constant_(getattr(rnn, 'bias_ih_l{}'.format(i)), 0)
+        _concat_init(getattr(rnn, 'weight_hh_l{}'.format(i)), [_inner_uniform, _inner_uniform, nn.init.orthogonal_])
+        torch.nn.init.constant_(getattr(rnn, 'bias_hh_l{}'.format(i)), 0)
 
 
 def interpolate(x, ratio):
@@ -153,9 +153,13 @@ class ConvBlock(nn.Module):
     def forward(self, input, pool_size=(2, 2), pool_type='avg'):
         if pool_type != 'avg':
             raise Exception('Incorrect argument!')
-        out = ops.ConvBlockFn.apply(input, self.conv1.weight, self.bn1.weight, self.bn1.bias, self.bn1.running_mean,
-                                    self.bn1.running_var, self.conv2.weight, self.bn2.weight, self.bn2.bias,
-                                    self.bn2.running_mean, self.bn2.running_var, self.training, pool_size[0], pool_size[1])
+        # the amax of a block's output (left on the device by its pool kernel) rides on the tensor to the next block, whose
+        # split-f16 convolution takes its operand scale from it -- no extra pass, no host synchronisation
+        out, out_amax = ops.ConvBlockFn.apply(input, self.conv1.weight, self.bn1.weight, self.bn1.bias,
+                                              self.bn1.running_mean, self.bn1.running_var, self.conv2.weight,
+                                              self.bn2.weight, self.bn2.bias, self.bn2.running_mean, self.bn2.running_var,
+                                              self.training, pool_size[0], pool_size[1], getattr(input, '_sed_amax', None))
+        out._sed_amax = out_amax
         if self.training:
             self.bn1.num_batches_tracked += 1
             self.bn2.num_batches_tracked += 1

@@ -1,4 +1,5 @@
 """Tensor utilities on the hot path; same names and behaviour as reference pytorch/pytorch_utils.py."""
+import logging
 from collections import defaultdict
 
 import numpy as np
@@ -42,10 +43,24 @@ def forward(model, data_loader, return_input=False, return_target=False):
         wave_dev = wave.to(device) if torch.is_tensor(wave) else move_data_to_device(wave, device)
         with torch.no_grad():
             out = model(wave_dev)
+        host = {key: out[key].detach().cpu().numpy() for key in ('clipwise_output', 'framewise_output') if key in out}
+        try:
+            ops.check_device_errors()                    # the copies above synchronised: the flag is current
+        except ops.NonFiniteOperand:
+            # a non-finite operand in a split-f16 convolution: redo this batch on the fp32 MFMA kernels, which propagate
+            # NaN / inf exactly like the reference's torch ops
+            logging.warning('non-finite activations in batch %d of the inference loop: re-running it on the fp32 kernels',
+                            len(collected['audio_name']))
+            prev, ops.USE_SF16 = ops.USE_SF16, False
+            try:
+                with torch.no_grad():
+                    out = model(wave_dev)
+                host = {key: out[key].detach().cpu().numpy() for key in ('clipwise_output', 'framewise_output') if key in out}
+            finally:
+                ops.USE_SF16 = prev
         collected['audio_name'].append(batch['audio_name'])
-        for key in ('clipwise_output', 'framewise_output'):
-            if key in out:
-                collected[key].append(out[key].detach().cpu().numpy())
+        for key, val in host.items():
+            collected[key].append(val)
         for key in wanted_from_batch:
             if key in batch:
                 collected[key].append(_to_host(batch[key]))

@@ -49,7 +49,8 @@ def test_argument_errors_are_reported_not_crashes():
     assert h.sed_logmel_f32(None, 1, 100, None, None, None, 105, None, 4, None, 866, 1e-10, None, None) == -22     # L <= 512
     assert h.sed_gru_seq_fwd(None, None, None, None, None, 4, 5, 128, None, None, None, None, None, None) == -22        # hidden size != 256
     assert h.sed_mixup_rows(None, None, 3, 17, None, None) == -22
-    assert h.sed_adam_amsgrad(None, None, None, None, None, 10, 0, 1e-3, 0.9, 0.999, 1e-8, 1.0, None) == -22
+    assert h.sed_adam_amsgrad(None, None, None, None, None, 10, 0, 1e-3, 0.9, 0.999, 1e-8, 1.0, None, None, None) == -22
+    assert h.sed_act_amax(None, 4, 64, None, None, None, None) == -22
 
 
 def test_product_refuses_cpu_tensors():
@@ -229,15 +230,26 @@ def test_parameter_initialisation_follows_the_reference_recipes():
         w = sd[name + ".weight"]
         assert w.shape == (17, 512, 1) and w.abs().max() <= (6.0 / (512 + 17)) ** 0.5 * (1 + 1e-6)
         assert torch.all(sd[name + ".bias"] == 0)
-    for sfx in ("", "_reverse"):
-        w_ih, w_hh = sd["gru.weight_ih_l0" + sfx], sd["gru.weight_hh_l0" + sfx]
-        assert w_ih.shape == (768, 512) and w_hh.shape == (768, 256)
-        assert w_ih.abs().max() <= (3.0 / 512) ** 0.5 * (1 + 1e-6) and abs(w_ih.std().item() / (1.0 / 512) ** 0.5 - 1) < 0.03
-        rz = w_hh[:512]
-        assert rz.abs().max() <= (3.0 / 256) ** 0.5 * (1 + 1e-6) and abs(rz.std().item() / (1.0 / 256) ** 0.5 - 1) < 0.03
-        n = w_hh[512:].double()
-        assert (n @ n.T - torch.eye(256, dtype=torch.float64)).abs().max() < 1e-5
-        assert torch.all(sd["gru.bias_ih_l0" + sfx] == 0) and torch.all(sd["gru.bias_hh_l0" + sfx] == 0)
+    # forward direction: the reference's init_gru recipe (models.py:44-55)
+    w_ih, w_hh = sd["gru.weight_ih_l0"], sd["gru.weight_hh_l0"]
+    assert w_ih.shape == (768, 512) and w_hh.shape == (768, 256)
+    assert w_ih.abs().max() <= (3.0 / 512) ** 0.5 * (1 + 1e-6) and abs(w_ih.std().item() / (1.0 / 512) ** 0.5 - 1) < 0.03
+    rz = w_hh[:512]
+    assert rz.abs().max() <= (3.0 / 256) ** 0.5 * (1 + 1e-6) and abs(rz.std().item() / (1.0 / 256) ** 0.5 - 1) < 0.03
+    n = w_hh[512:].double()
+    assert (n @ n.T - torch.eye(256, dtype=torch.float64)).abs().max() < 1e-5
+    assert torch.all(sd["gru.bias_ih_l0"] == 0) and torch.all(sd["gru.bias_hh_l0"] == 0)
+    # reverse direction: the reference loop never touches `*_reverse`, so nn.GRU's default U(+-1/sqrt(256)) stays -- weights
+    # AND (non-zero) biases
+    k = 1.0 / 256 ** 0.5
+    for name, shape in (("weight_ih_l0_reverse", (768, 512)), ("weight_hh_l0_reverse", (768, 256)),
+                        ("bias_ih_l0_reverse", (768,)), ("bias_hh_l0_reverse", (768,))):
+        t = sd["gru." + name]
+        assert tuple(t.shape) == shape
+        assert t.abs().max() <= k * (1 + 1e-6) and abs(t.std().item() / (k / 3 ** 0.5) - 1) < 0.08, name
+        assert t.abs().max() > 0.9 * k, name
+    nr = sd["gru.weight_hh_l0_reverse"][512:].double()
+    assert (nr @ nr.T - torch.eye(256, dtype=torch.float64)).abs().max() > 0.1          # NOT orthogonalised
 
 
 def test_mel_task_tables_reproduce_the_filter_bank_and_are_bank_conflict_free():

@@ -68,6 +68,15 @@ def fp64_oracle_grads(mt, seed, stripes, unused, dropout_seed=None):
         ofe._CACHE.clear()
 
 
+@pytest.fixture(params=["sf16", "fp32"])
+def conv_path(request, monkeypatch):
+    """Both convolution paths through the WHOLE model: the default split-f16 MFMA kernels and the fp32 MFMA (Winograd)
+    kernels that `ops.USE_SF16 = False` / SED_USE_SF16=0 selects -- the fallback of the non-finite guard."""
+    from sound_event_detection_dcase2017_task4_amd import ops
+    monkeypatch.setattr(ops, "USE_SF16", request.param == "sf16")
+    return request.param
+
+
 def build(mt):
     from sound_event_detection_dcase2017_task4_amd.pytorch import models
     m = getattr(models, mt)(*CTOR)
@@ -76,7 +85,7 @@ def build(mt):
 
 
 @pytest.mark.parametrize("mt", om.MODEL_TYPES)
-def test_eval_forward_matches_reference(mt, golden_dir):
+def test_eval_forward_matches_reference(mt, golden_dir, conv_path):
     fx = np.load(os.path.join(golden_dir, mt + ".npz"))
     m = build(mt).eval()
     with torch.no_grad():
@@ -102,7 +111,7 @@ def test_eval_forward_10s_clip(golden_dir):
 
 
 @pytest.mark.parametrize("mt", om.MODEL_TYPES)
-def test_train_forward_matches_reference(mt, golden_dir):
+def test_train_forward_matches_reference(mt, golden_dir, conv_path):
     fx = np.load(os.path.join(golden_dir, mt + ".npz"))
     seed = SEEDS[mt]
     m = build(mt).train()
@@ -121,7 +130,7 @@ def test_train_forward_matches_reference(mt, golden_dir):
 
 
 @pytest.mark.parametrize("mt", om.MODEL_TYPES)
-def test_three_train_steps_match_reference(mt, golden_dir):
+def test_three_train_steps_match_reference(mt, golden_dir, conv_path):
     from sound_event_detection_dcase2017_task4_amd.pytorch.losses import get_loss_func
     from sound_event_detection_dcase2017_task4_amd.pytorch.pytorch_utils import move_data_to_device, do_mixup
     from sound_event_detection_dcase2017_task4_amd.optim import FusedAdamAmsgrad
@@ -321,7 +330,7 @@ LONG_MODELS = ("Cnn_9layers_FrameAvg", "Cnn_9layers_FrameAtt", "Cnn_9layers_Gru_
 
 
 @pytest.mark.parametrize("mt", LONG_MODELS)
-def test_full_length_clips_match_reference(mt, golden_dir):
+def test_full_length_clips_match_reference(mt, golden_dir, conv_path):
     """10 s clips (L = 320000 -> T = 1001 frames, T' = 125: the production sequence length of the attention pooling and of
     the BiGRU) through the genuine reference model: eval forward and train forward (mixup + SpecAugment), 1e-4 gate."""
     fx = np.load(os.path.join(golden_dir, mt + "__big.npz"))
@@ -348,7 +357,7 @@ def sample_index(numel, cap=2048):
 
 
 @pytest.mark.parametrize("mt", om.MODEL_TYPES)
-def test_low_noise_training_fixture_vs_float64_reference(mt, golden_dir):
+def test_low_noise_training_fixture_vs_float64_reference(mt, golden_dir, conv_path):
     """Gradient gate of SURVEY.md 8(d) -- relative error <= 1e-3 -- against the genuine reference model evaluated in
     FLOAT64 on a batch large enough (32 x 2 s waveforms) that single ReLU flips no longer dominate.
 
@@ -415,7 +424,7 @@ def test_low_noise_training_fixture_vs_float64_reference(mt, golden_dir):
                 got = g[sample_index(g.size)]
                 err = float(np.sqrt(((got - want) ** 2).sum() / max((want ** 2).sum(), 1e-300)))
                 ref = float(fx["big_ref32err/" + k][0])
-                gate = max(3e-3, 3.0 * ref)
+                gate = max(3e-3 if conv_path == "sf16" else 2e-3, 3.0 * ref)      # fp32 kernels: the floor of before round 2
                 report[k] = (err, ref)
                 if err > gate:
                     bad[k] = (err, ref, gate)

@@ -148,7 +148,8 @@ def test_conv_block_vs_oracle(ops, Cin, Cout, H, W, ph, pw, training):
               dev["cb.bn2.running_mean"], dev["cb.bn2.running_var"]]
     for i in (0, 1, 2, 5, 6, 7):
         params[i].requires_grad_(True)
-    out = ops.ConvBlockFn.apply(xg, *params, training, ph, pw)
+    out, out_amax = ops.ConvBlockFn.apply(xg, *params, training, ph, pw)
+    assert float(out_amax) == float(out.detach().max())      # the pool kernel's amax (next block's split-f16 scale): exact
     assert (nchw(out.detach()) - ref.detach()).abs().max().item() < 2e-5
     out.backward(nhwc(gout))
     assert rel(nchw(xg.grad), xr.grad) < 2e-4
@@ -167,7 +168,7 @@ def test_conv_block_arithmetic_precision_without_relu_flips(ops, Cin, Cout, H, W
     """Precision of the ConvBlock arithmetic alone, against FLOAT64.  With BatchNorm biases of +8 every pre-activation is
     far from zero, so no ReLU mask can differ between fp32 and fp64 (the mechanism behind the 1e-3-level model-gradient
     differences of tests/test_gpu_model.py); what remains is rounding, including the cancellation inside the BatchNorm
-    backward.  Gate: forward 2e-6 and every gradient 2e-5, max error relative to the tensor max."""
+    backward.  Gate: forward 2e-6 and every gradient 1e-5, max error relative to the tensor max."""
     B = 4
     g = torch.Generator().manual_seed(Cin + H)
     x = torch.relu(torch.randn(B, Cin, H, W, generator=g)) * 0.7
@@ -197,7 +198,7 @@ def test_conv_block_arithmetic_precision_without_relu_flips(ops, Cin, Cout, H, W
               dev["cb.bn2.running_mean"], dev["cb.bn2.running_var"]]
     for i in (0, 1, 2, 5, 6, 7):
         params[i].requires_grad_(True)
-    out = ops.ConvBlockFn.apply(xg, *params, True, ph, pw)
+    out, _ = ops.ConvBlockFn.apply(xg, *params, True, ph, pw)
     assert rel(nchw(out.detach()).cpu(), ref.detach()) < 2e-6
     out.backward(nhwc(gout).cuda())
     report = {"dx": rel(nchw(xg.grad).cpu(), x64.grad)}

@@ -233,3 +233,100 @@ def test_side_stream_weight_gradients_are_joined_and_bit_identical(monkeypatch):
     for a, b in zip(results[False], results[True]):
         assert torch.equal(a, b)
     assert float(results[True][0].abs().sum()) > 0
+
+
+def test_model_zero_grad_does_not_wipe_direct_gradients():
+    """`model.zero_grad()` sets every `.grad` to None (torch default); the backward kernels still write through their sinks
+    into the flat buffer.  `_gather()` must re-attach those slices, not zero them: the parameters move exactly as with
+    `optimizer.zero_grad()`."""
+    from sound_event_detection_dcase2017_task4_amd.optim import FusedAdamAmsgrad
+    from sound_event_detection_dcase2017_task4_amd.pytorch.losses import clip_bce
+    x, y, lam, stripes = _batch(rows=4)
+    flats = []
+    for use_model_zero_grad in (False, True):
+        m = _build("Cnn_9layers_FrameAtt")
+        opt = FusedAdamAmsgrad(m, lr=1e-3)
+        start = opt.flat.clone()
+        for _ in range(2):
+            loss = clip_bce(m(x, None, specaug_stripes=stripes), {"target": y})
+            if use_model_zero_grad:
+                m.zero_grad()
+                assert all(p.grad is None for p in opt.params)
+            else:
+                opt.zero_grad()
+            loss.backward()
+            opt.step()
+        assert (opt.flat - start).abs().max().item() > 5e-4            # two Adam steps of lr 1e-3
+        assert all(p.grad is not None and p.grad.data_ptr() == opt.flat_grad.data_ptr() + 4 * off
+                   for p, off in zip(opt.params, opt.offsets))
+        flats.append(opt.flat.clone())
+    assert torch.equal(flats[0], flats[1])
+
+
+def test_backward_that_raises_leaves_no_stale_side_stream_state(monkeypatch):
+    """A backward pass that dies between a side-stream fork and its join must not poison the next one (stale sinks
+    reporting ready -> a spurious 'backward() ran more than once')."""
+    from sound_event_detection_dcase2017_task4_amd import ops
+    from sound_event_detection_dcase2017_task4_amd.optim import FusedAdamAmsgrad
+    from sound_event_detection_dcase2017_task4_amd.pytorch.losses import clip_bce
+    m = _build("Cnn_9layers_FrameAvg")
+    opt = FusedAdamAmsgrad(m, lr=1e-3)
+    x, y, lam, stripes = _batch(rows=4)
+    real = ops.bn_bwd_finalize
+    calls = {"n": 0}
+
+    def dying(*a, **k):
+        calls["n"] += 1
+        if calls["n"] == 4:                                  # somewhere in the middle of the conv stack's backward
+            raise RuntimeError("injected failure")
+        return real(*a, **k)
+
+    monkeypatch.setattr(ops, "bn_bwd_finalize", dying)
+    loss = clip_bce(m(x, None, specaug_stripes=stripes), {"target": y})
+    opt.zero_grad()
+    with pytest.raises(RuntimeError, match="injected failure"):
+        loss.backward()
+    monkeypatch.setattr(ops, "bn_bwd_finalize", real)
+    before = opt.flat.clone()
+    loss = clip_bce(m(x, None, specaug_stripes=stripes), {"target": y})
+    opt.zero_grad()                                          # drops what the dead pass left behind
+    assert not ops._PENDING
+    loss.backward()
+    opt.step()
+    torch.cuda.synchronize()
+    assert (opt.flat - before).abs().max().item() > 5e-4
+
+
+def test_nan_input_is_refused_by_the_guard_and_fp32_fallback_matches_torch_semantics():
+    """A NaN waveform: with the split-f16 kernels the optimiser refuses the step and raises NonFiniteOperand (parameters
+    intact); with ops.USE_SF16 = False the step goes through like torch.optim.Adam would (NaN parameters) -- which is what
+    the train CLI switches to."""
+    from sound_event_detection_dcase2017_task4_amd import ops
+    from sound_event_detection_dcase2017_task4_amd.optim import FusedAdamAmsgrad
+    from sound_event_detection_dcase2017_task4_amd.pytorch.losses import clip_bce
+    m = _build("Cnn_9layers_FrameAvg")
+    opt = FusedAdamAmsgrad(m, lr=1e-3)
+    x, y, lam, stripes = _batch(rows=4)
+    xb = x.clone(); xb[1, 5000] = float("nan")
+    start = opt.flat.clone()
+    ops.check_device_errors(synchronize=True)
+    loss = clip_bce(m(xb, None, specaug_stripes=stripes), {"target": y})
+    opt.zero_grad(); loss.backward()
+    with pytest.raises(ops.NonFiniteOperand):
+        opt.step()
+        ops.check_device_errors(synchronize=True)            # (the flag is host-mapped: normally seen by step() itself)
+    assert torch.equal(opt.flat, start) and opt.step_count == 0 and opt.skipped_steps == 1
+    # a clean batch trains normally afterwards
+    loss = clip_bce(m(x, None, specaug_stripes=stripes), {"target": y})
+    opt.zero_grad(); loss.backward(); opt.step()
+    ops.check_device_errors(synchronize=True)
+    assert opt.step_count == 1 and torch.isfinite(opt.flat).all() and not torch.equal(opt.flat, start)
+    # reference semantics on the fp32 kernels
+    prev, ops.USE_SF16 = ops.USE_SF16, False
+    try:
+        loss = clip_bce(m(xb, None, specaug_stripes=stripes), {"target": y})
+        opt.zero_grad(); loss.backward(); opt.step()
+        ops.check_device_errors(synchronize=True)
+        assert torch.isnan(opt.flat).any()
+    finally:
+        ops.USE_SF16 = prev

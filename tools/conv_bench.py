@@ -71,13 +71,21 @@ def main():
                      ("wino2 fwd epi0    ", lambda: ops._conv_wino2(x, uf2, B, H, W, ci, co)),
                      ("wino2 dgrad epi2  ", lambda: ops._conv_wino2(gy, ud2, B, H, W, co, ci, epi=2, partials=pwb2, yprev=x, p_st=sto))]
         if args.only in ("", "wino2", "sf16") and L.sed_conv3x3_sf16_supported(H, W, ci, co):
-            wps = ops.pack_sf16(w)
-            runs += [("sf16  fwd epi0    ", lambda: ops.conv3x3_sf16(x, wps, B, H, W, ci, co)),
-                     ("sf16  fwd epi0+inT", lambda: ops.conv3x3_sf16(x, wps, B, H, W, ci, co, in_st=st))]
+            wps, wpsd = ops.pack_sf16(w), ops.pack_sf16(w, dgrad=True)
+            xam, xamT, gam0 = ops.amax_of(x), ops.act_amax_full(x, st), ops.amax_of(gy)
+            Ps = int(L.sed_conv_sf16_num_parts(B, H, W, co))
+            ps1 = torch.empty((Ps * 2 * co + Ps,), device="cuda")
+            mm1 = torch.empty((Ps, 2, co), device="cuda")
+            psb = torch.empty((int(L.sed_conv_sf16_num_parts(B, H, W, ci)) * 2 * ci,), device="cuda")
+            runs += [("sf16  fwd epi0    ", lambda: ops.conv3x3_sf16(x, wps, B, H, W, ci, co, x_amax=xam)),
+                     ("sf16  fwd epi0+inT", lambda: ops.conv3x3_sf16(x, wps, B, H, W, ci, co, in_st=st, x_amax=xamT)),
+                     ("sf16  fwd epi1+inT", lambda: ops.conv3x3_sf16(x, wps, B, H, W, ci, co, in_st=st, x_amax=xamT, epi=1, partials=ps1)),
+                     ("sf16  fwd epi1+mm ", lambda: ops.conv3x3_sf16(x, wps, B, H, W, ci, co, x_amax=xam, epi=1, partials=ps1, minmax=mm1)),
+                     ("sf16  dgrad epi2  ", lambda: ops.conv3x3_sf16(gy, wpsd, B, H, W, co, ci, x_amax=gam0, epi=2, partials=psb, yprev=x, p_st=sto))]
         if args.only in ("", "wgrad", "sf16w") and L.sed_wgrad_sf16_supported(H, W, ci, co):
-            gam = ops.amax_of(gy)
-            runs += [("wgrad sf16 +inT   ", lambda: ops._wgrad_sf16(x, gy, B, H, W, ci, co, in_st=st, gy_amax=gam)),
-                     ("wgrad sf16        ", lambda: ops._wgrad_sf16(x, gy, B, H, W, ci, co, gy_amax=gam))]
+            gam, xam2, xamT2 = ops.amax_of(gy), ops.amax_of(x), ops.act_amax_full(x, st)
+            runs += [("wgrad sf16 +inT   ", lambda: ops._wgrad_sf16(x, gy, B, H, W, ci, co, in_st=st, gy_amax=gam, x_amax=xamT2)),
+                     ("wgrad sf16        ", lambda: ops._wgrad_sf16(x, gy, B, H, W, ci, co, gy_amax=gam, x_amax=xam2))]
         if args.only in ("", "wgrad"):
             runs += [("wgrad +inT        ", lambda: ops._wgrad_direct(x, gy, B, H, W, ci, co, in_st=st)),
                      ("wgrad             ", lambda: ops._wgrad_direct(x, gy, B, H, W, ci, co)),

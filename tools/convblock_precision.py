@@ -50,7 +50,7 @@ for (B, Cin, Cout, H, W, ph, pw, gmode) in ((16, 256, 512, 25, 8, 1, 8, "rand"),
               dev["cb.bn2.running_mean"], dev["cb.bn2.running_var"]]
     for i in (0, 1, 2, 5, 6, 7):
         params[i].requires_grad_(True)
-    out = ops.ConvBlockFn.apply(xg, *params, True, ph, pw)
+    out, _ = ops.ConvBlockFn.apply(xg, *params, True, ph, pw)
     out.backward(nhwc(gout).cuda())
     print("== B%d %d->%d %dx%d pool(%d,%d) gout=%s  USE_WINOGRAD=%d" % (B, Cin, Cout, H, W, ph, pw, gmode, ops.USE_WINOGRAD))
     print("  %-18s hip %.2e   cpu-fp32 %.2e" % ("out", rel(nchw(out.detach()).cpu(), ref64.detach()), rel(ref32.detach(), ref64.detach())))
