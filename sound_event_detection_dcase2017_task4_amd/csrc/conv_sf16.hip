@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
             v.w = sok##i ? bn_relu(v.w, sc4.w, sh4.w) : 0.f;                                                    \
         }                                                                                                       \
         if (!INT) { v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa; }                                               \
-        overflow |= !(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) < 65504.f);  /* 3 VALU; a NaN shows itself */ \
+        overflow |= !((fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w)) < 3.0e5f);  /* 3 adds (|.| is a source modifier): inf AND NaN propagate; finite values are < 2^14 each */ \
         const half4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};                          \
         const half4 lo = {(_Float16)(v.x - (float)hi.x), (_Float16)(v.y - (float)hi.y),                         \
                           (_Float16)(v.z - (float)hi.z), (_Float16)(v.w - (float)hi.w)};                        \
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
         } else {                                                                                                \
             v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa;                                                         \
         }                                                                                                       \
-        overflow |= !(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) < 65504.f);  /* 3 VALU; a NaN shows itself */ \
+        overflow |= !((fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w)) < 3.0e5f);  /* 3 adds (|.| is a source modifier): inf AND NaN propagate; finite values are < 2^14 each */ \
         const half4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};                          \
         const half4 lo = {(_Float16)(v.x - (float)hi.x), (_Float16)(v.y - (float)hi.y),                         \
                           (_Float16)(v.z - (float)hi.z), (_Float16)(v.w - (float)hi.w)};                        \
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                             \
         float4 v = greg[i];                                                                                     \
         v.x *= sg; v.y *= sg; v.z *= sg; v.w *= sg;                                                             \
-        overflow |= !(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) < 65504.f);          \
+        overflow |= !((fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w)) < 3.0e5f);                         \
         const half4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};                          \
         const half4 lo = {(_Float16)(v.x - (float)hi.x), (_Float16)(v.y - (float)hi.y),                         \
                           (_Float16)(v.z - (float)hi.z), (_Float16)(v.w - (float)hi.w)};                        \

@@ -315,8 +315,8 @@ __global__ __launch_bounds__(256, 2) void logmel32_kernel(const T* __restrict__ 
             f2 m = {0.f, 0.f};
             band_sum(mp, bd, max_band_tasks, m);
             float* o = out + ((long)b * T_frames + tu) * 64 + lane;
-            if (tu < T_frames) o[0] = m.x > amin ? 3.0102999566398120f * __log2f(m.x) : floor_db;
-            if (tu + 1 < T_frames) o[64] = m.y > amin ? 3.0102999566398120f * __log2f(m.y) : floor_db;
+            if (tu < T_frames) o[0] = !(m.x <= amin) ? 3.0102999566398120f * __log2f(m.x) : floor_db;     // NaN takes the log branch: propagates like torch.clamp
+            if (tu + 1 < T_frames) o[64] = !(m.y <= amin) ? 3.0102999566398120f * __log2f(m.y) : floor_db;
         }
     }
 }

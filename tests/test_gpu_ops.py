@@ -96,7 +96,7 @@ def test_conv1_direct_fwd_bwd(ops):
     rpp = L.sed_conv1_rows_per_part()
     part = torch.zeros(((M + rpp - 1) // rpp, 2, 64), device="cuda")
     xd, wdev, gyd = nhwc(x), w.cuda(), nhwc(gy)          # keep the device buffers alive across the raw-pointer calls
-    ops._call("sed_conv1_fwd", ops._ptr(xd), ops._ptr(wdev), ops._ptr(y), B, H, W, ops._ptr(part), ops._stream())
+    ops._call("sed_conv1_fwd", ops._ptr(xd), ops._ptr(wdev), ops._ptr(y), B, H, W, ops._ptr(part), None, ops._stream())
     assert rel(nchw(y), y_ref.detach()) < 2e-6
     st = ops.bn_finalize(part, part.shape[0], rpp, M, torch.ones(64).cuda(), torch.zeros(64).cuda(), None, None)
     assert (st.mean.cpu() - y_ref.mean(dim=(0, 2, 3))).abs().max() < 1e-5
@@ -312,13 +312,15 @@ def test_pool_bwd_windowed_pass1_matches_full_resolution_pass(ops, ph, pw, H, W,
     s = ops._stream()
     out = torch.empty(B, Ho, Wo, C, device="cuda")
     cnt = torch.empty(B, Ho, Wo, C, dtype=torch.uint8, device="cuda")
+    amax = torch.empty(1, device="cuda")
     ops._call("sed_bn_relu_pool_fwd_cnt", ops._ptr(y), B, H, W, C, ph, pw, ops._ptr(scale), ops._ptr(shift), ops._ptr(out),
-              ops._ptr(cnt), s)
+              ops._ptr(cnt), ops._ptr(amax), s)
+    assert float(amax) == float(out.max())
     act = (y * scale + shift) > 0
     ref_cnt = act[:, :Ho * ph, :Wo * pw].view(B, Ho, ph, Wo, pw, C).sum(dim=(2, 4))
     assert torch.equal(cnt.long(), ref_cnt.long())
     out0 = torch.empty_like(out)
-    ops._call("sed_bn_relu_pool_fwd", ops._ptr(y), B, H, W, C, ph, pw, ops._ptr(scale), ops._ptr(shift), ops._ptr(out0), s)
+    ops._call("sed_bn_relu_pool_fwd", ops._ptr(y), B, H, W, C, ph, pw, ops._ptr(scale), ops._ptr(shift), ops._ptr(out0), None, s)
     assert torch.equal(out, out0)
 
     def sums(part, n):
