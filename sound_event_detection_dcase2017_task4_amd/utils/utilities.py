@@ -166,8 +166,10 @@ def segment_based_metrics(reference_event_list, estimated_event_list, time_resol
     lists become binary segment x label rolls (onset floored, offset ceiled to the resolution, the shorter roll
     zero-padded); per segment Ntp / Nfp / Nfn give substitutions S = min(Nref, Nsys) - Ntp, deletions
     D = max(0, Nref - Nsys), insertions I = max(0, Nsys - Nref); ER = (S + D + I) / Nref and micro-averaged
-    precision / recall / F accumulate over all segments of all files that appear in the reference.  PARITY UNPINNED
-    against sed_eval itself (known-answer tests only).  Returns the same nested dict layout as sed_eval's results()."""
+    precision / recall / F accumulate over all segments of all files that appear in the reference.  Pinned to the
+    PUBLISHED algorithm by hand-derived known-answer vectors (tests/golden/segment_metrics_cases.json); unpinned against
+    sed_eval's own code.  Returns the nested dict layout of sed_eval's results(): 'overall' (f_measure, error_rate,
+    accuracy, count), 'class_wise', 'class_wise_average'."""
     def by_file(events):
         d = {}
         for e in events:
@@ -181,8 +183,8 @@ def segment_based_metrics(reference_event_list, estimated_event_list, time_resol
         event_label_list = sorted({e['event_label'] for e in reference_event_list if e.get('event_label') is not None})
     lab = {l: i for i, l in enumerate(event_label_list)}
     L = len(event_label_list)
-    tot = dict(Ntp=0.0, Nfp=0.0, Nfn=0.0, Nref=0.0, Nsys=0.0, S=0.0, D=0.0, I=0.0)
-    cw = {l: dict(Ntp=0.0, Nfp=0.0, Nfn=0.0, Nref=0.0, Nsys=0.0) for l in event_label_list}
+    tot = dict(Ntp=0.0, Ntn=0.0, Nfp=0.0, Nfn=0.0, Nref=0.0, Nsys=0.0, S=0.0, D=0.0, I=0.0)
+    cw = {l: dict(Ntp=0.0, Ntn=0.0, Nfp=0.0, Nfn=0.0, Nref=0.0, Nsys=0.0) for l in event_label_list}
 
     def roll(events):
         events = [e for e in events if e['event_label'] in lab]
@@ -198,15 +200,16 @@ def segment_based_metrics(reference_event_list, estimated_event_list, time_resol
         r, s = roll(ref_files[fname]), roll(est_files.get(fname, []))
         n = max(len(r), len(s))
         r = np.vstack([r, np.zeros((n - len(r), L))]); s = np.vstack([s, np.zeros((n - len(s), L))])
-        tp, fp, fn = (r + s > 1), (s - r > 0), (r - s > 0)
+        tp, tn, fp, fn = (r + s > 1), (r + s == 0), (s - r > 0), (r - s > 0)
         nref, nsys, ntp = r.sum(1), s.sum(1), tp.sum(1)
-        tot['Ntp'] += ntp.sum(); tot['Nfp'] += fp.sum(); tot['Nfn'] += fn.sum(); tot['Nref'] += nref.sum(); tot['Nsys'] += nsys.sum()
+        tot['Ntp'] += ntp.sum(); tot['Ntn'] += tn.sum(); tot['Nfp'] += fp.sum(); tot['Nfn'] += fn.sum()
+        tot['Nref'] += nref.sum(); tot['Nsys'] += nsys.sum()
         tot['S'] += (np.minimum(nref, nsys) - ntp).sum()
         tot['D'] += np.maximum(0, nref - nsys).sum()
         tot['I'] += np.maximum(0, nsys - nref).sum()
         for l, i in lab.items():
             c = cw[l]
-            c['Ntp'] += tp[:, i].sum(); c['Nfp'] += fp[:, i].sum(); c['Nfn'] += fn[:, i].sum()
+            c['Ntp'] += tp[:, i].sum(); c['Ntn'] += tn[:, i].sum(); c['Nfp'] += fp[:, i].sum(); c['Nfn'] += fn[:, i].sum()
             c['Nref'] += r[:, i].sum(); c['Nsys'] += s[:, i].sum()
 
     def prf(ntp, nref, nsys):
@@ -218,6 +221,13 @@ def segment_based_metrics(reference_event_list, estimated_event_list, time_resol
         d = nref if nref > 0 else 1.0
         return {'error_rate': (S + D + I) / d, 'substitution_rate': S / d, 'deletion_rate': D / d, 'insertion_rate': I / d}
 
+    def acc(c):
+        sens = c['Ntp'] / (c['Ntp'] + c['Nfn']) if c['Ntp'] + c['Nfn'] > 0 else 0.0
+        spec = c['Ntn'] / (c['Ntn'] + c['Nfp']) if c['Ntn'] + c['Nfp'] > 0 else 0.0
+        n = c['Ntp'] + c['Ntn'] + c['Nfp'] + c['Nfn']
+        return {'accuracy': (c['Ntp'] + c['Ntn']) / n if n > 0 else 0.0, 'balanced_accuracy': 0.5 * (sens + spec),
+                'sensitivity': sens, 'specificity': spec}
+
     class_wise = {}
     for l, c in cw.items():
         d_, i_ = c['Nfn'], c['Nfp']
@@ -225,11 +235,21 @@ def segment_based_metrics(reference_event_list, estimated_event_list, time_resol
                          'error_rate': {'error_rate': (d_ + i_) / (c['Nref'] if c['Nref'] > 0 else 1.0),
                                         'deletion_rate': d_ / (c['Nref'] if c['Nref'] > 0 else 1.0),
                                         'insertion_rate': i_ / (c['Nref'] if c['Nref'] > 0 else 1.0)},
+                         'accuracy': acc(c),
                          'count': {'Nref': c['Nref'], 'Nsys': c['Nsys']}}
+
+    def mean_of(group, key):
+        vals = [v[group][key] for v in class_wise.values()]
+        return float(np.mean(vals)) if vals else 0.0
+
+    average = {'f_measure': {k: mean_of('f_measure', k) for k in ('f_measure', 'precision', 'recall')},
+               'error_rate': {k: mean_of('error_rate', k) for k in ('error_rate', 'deletion_rate', 'insertion_rate')},
+               'accuracy': {k: mean_of('accuracy', k) for k in ('accuracy', 'balanced_accuracy', 'sensitivity', 'specificity')}}
     return {'overall': {'f_measure': prf(tot['Ntp'], tot['Nref'], tot['Nsys']),
                         'error_rate': er(tot['S'], tot['D'], tot['I'], tot['Nref']),
+                        'accuracy': acc(tot),
                         'count': {'Nref': tot['Nref'], 'Nsys': tot['Nsys']}},
-            'class_wise': class_wise}
+            'class_wise': class_wise, 'class_wise_average': average}
 
 
 def official_evaluate(reference_csv_path, prediction_csv_path):
