@@ -63,8 +63,8 @@ int main(void) {
     CHECK_HIP(hipMalloc((void**)&dwf, sizeof(float) * 9 * Cout * Cin));
     CHECK_HIP(hipMalloc((void**)&duf, sizeof(float) * 16 * Cout * Cin));
     CHECK_HIP(hipMalloc(&dwp, 2 * (size_t)sed_conv_sf16_pack_halfs(Cin, Cout)));   /* f16 (hi, lo) planes */
-    CHECK_HIP(hipMalloc((void**)&dwscale, sizeof(float) * 2));
-    CHECK_HIP(hipMalloc((void**)&dxamax, sizeof(float)));
+    CHECK_HIP(hipMalloc((void**)&dwscale, sizeof(float) * (sed_amax_slots() + 1)));   /* amax slots + scale */
+    CHECK_HIP(hipMalloc((void**)&dxamax, sizeof(float) * sed_amax_slots()));
     CHECK_HIP(hipMemcpy(dx, x, sizeof(float) * M * Cin, hipMemcpyHostToDevice));
     CHECK_HIP(hipMemcpy(dw, w, sizeof(float) * Cout * Cin * 9, hipMemcpyHostToDevice));
     hipStream_t stream;

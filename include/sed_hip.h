@@ -183,7 +183,7 @@ int sed_conv3x3_wgrad_wino2(const float* x, const float* gy, float* dw_oihw, flo
  * power of two per tensor, three f16 MFMAs (hi*hi + hi*lo + lo*hi, exact products, fp32 accumulation) per product slab --
  * the error of a direct fp32 convolution at 3/16 of its MFMA issue time (csrc/conv_sf16.hip).  Same contract as
  * sed_conv3x3_wino2 (in_scale/in_shift operand transform, epi 0/1/2, partials = sed_conv_sf16_num_parts(...) parts with the
- * pixel counts appended for epi 1).  wp: sed_conv_sf16_pack_halfs(...) f16 values and wscale[2] (amax, scale) written by
+ * pixel counts appended for epi 1).  wp: sed_conv_sf16_pack_halfs(...) f16 values and wscale[65] (64 amax slots, scale) written by
  * sed_pack_conv_weights_sf16 (dgrad = 1: operand of the transposed convolution).  Operand scale: x_amax = device pointer
  * to the amax of the operand as the MFMAs see it (of relu(in_scale*x + in_shift) when that transform is fused: sed_act_amax;
  * of x otherwise: sed_amax or the producer kernels' amax_out) -- the power of two that brings it to [2^13, 2^14) is
@@ -195,6 +195,13 @@ int sed_conv3x3_wgrad_wino2(const float* x, const float* gy, float* dw_oihw, flo
 int sed_conv3x3_sf16_supported(int H, int W, int Cin, int Cout);
 long sed_conv_sf16_pack_halfs(int Cin, int Cout);
 long sed_conv_sf16_num_parts(int B, int H, int W, int Cout);
+/* Device-resident amax values are float[sed_amax_slots()] (= 64), NOT one float: producers publish one atomic per block
+ * into slot (block id mod 64) -- thousands of atomics on one word serialise in the L2 -- and consumers take the maximum over
+ * the slots.  Every `amax_out` / `*_amax` pointer of this header is such a vector.  The entry points zero amax_out
+ * themselves unless sed_amax_caller_zeroes(1) was called (the caller then hands in zeroed buffers, e.g. slices of one
+ * zeroed pool: saves the per-launch memsets).  wscale of the weight packs = [64 amax slots][1 power-of-two scale]. */
+int sed_amax_slots(void);
+int sed_amax_caller_zeroes(int on);
 int sed_amax(const float* x, long n, float* amax_out, sed_stream_t stream);
 int sed_pack_conv_weights_sf16(const float* w_oihw, int Cout, int Cin, int dgrad, float* wscale, void* wp,
                                sed_stream_t stream);

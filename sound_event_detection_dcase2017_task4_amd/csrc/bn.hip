@@ -83,14 +83,15 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restri
 
 // stage 2 (training): mean / invstd / folded scale,shift / running-stat update.  nn.BatchNorm2d semantics:
 // biased variance normalises, unbiased variance is tracked, momentum 0.1 (reference models.py:87-88, :264).
-// Both finalize kernels: one 16-lane group per channel sums the <= 1024 chunk rows of ws (a serial loop per channel
-// made these "tiny" kernels 0.2 ms each, 3 ms per training step), fixed-order xor-shuffle tree -> deterministic.
+// Both finalize kernels: one WAVE per channel sums the <= 1024 chunk rows of ws (a serial loop per channel made these
+// "tiny" kernels 0.2 ms each; 16 lanes per channel still cost 25 us on the 64-channel layers: 64 dependent fp64 loads
+// per lane on 4 workgroups), fixed-order xor-shuffle tree -> deterministic.
 __device__ __forceinline__ void chunk_sums16(const double* __restrict__ ws, int nchunks, int C, int c, int sub,
                                              double& s1, double& s2) {
     s1 = 0.0; s2 = 0.0;
-    for (int k = sub; k < nchunks; k += 16) { s1 += ws[(long)k * 2 * C + c]; s2 += ws[(long)k * 2 * C + C + c]; }
+    for (int k = sub; k < nchunks; k += 64) { s1 += ws[(long)k * 2 * C + c]; s2 += ws[(long)k * 2 * C + C + c]; }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
 }
 
 __global__ void bn_finalize_kernel(const double* __restrict__ ws, int nchunks, int C, long N,
@@ -98,7 +99,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, int nchunks, i
                                    float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                    float* __restrict__ scale_out, float* __restrict__ shift_out) {
-    const int c = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;   // 256 threads = 16 channels x 16 lanes
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), sub = threadIdx.x & 63;    // 256 threads = 4 channels x one wave
     if (c >= C) return;
     double s1, s2;
     chunk_sums16(ws, nchunks, C, c, sub, s1, s2);
@@ -136,7 +137,7 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int nchunk
                                        const float* __restrict__ scale, int batch_stats,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ coef /*[3][C]*/) {
-    const int c = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), sub = threadIdx.x & 63;
     if (c >= C) return;
     double s1, s2;
     chunk_sums16(ws, nchunks, C, c, sub, s1, s2);
@@ -269,7 +270,6 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __re
                                                                const float* __restrict__ shift,
                                                                float* __restrict__ out, unsigned* __restrict__ cnt4,
                                                                float* __restrict__ amax_out) {
-    __shared__ float wmax[4];
     const int Ho = H / ph, Wo = W / pw, c4n = C >> 2;
     const long total = (long)B * Ho * Wo * c4n;
     const float inv = 1.0f / (float)(ph * pw);
@@ -299,13 +299,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __re
         amax = fmaxf(fmaxf(amax, fmaxf(o.x, o.y)), fmaxf(o.z, o.w));          // o >= 0
         if (CNT) cnt4[i] = n4;
     }
-    if (amax_out) {          // max of the pooled tensor = the split-f16 scale of the next ConvBlock's first convolution
-        amax = wave_max(amax);
-        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amax;
-        __syncthreads();
-        if (threadIdx.x == 0)
-            atomicMax(reinterpret_cast<unsigned*>(amax_out), __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
-    }
+    if (amax_out) amax_publish_block(amax_out, amax);   // max of the pooled tensor = the split-f16 scale of the next block's conv1
 }
 
 // amax of relu(scale*y + shift) over a tensor that is never materialised, from per-part per-channel (max, min) of y
@@ -334,7 +328,8 @@ __global__ __launch_bounds__(256) void act_amax_kernel(const float* __restrict__
         if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned*>(amax_out), __float_as_uint(red[0]));
+    if (threadIdx.x == 0)
+        atomicMax(reinterpret_cast<unsigned*>(amax_out) + (blockIdx.x & (SED_AMAX_SLOTS - 1)), __float_as_uint(red[0]));
 }
 
 // the same amax by a pass over y [nrows][C] (producers that leave no range partials)
@@ -351,8 +346,7 @@ __global__ __launch_bounds__(256) void act_amax_full_kernel(const float* __restr
         amax = fmaxf(fmaxf(amax, fmaxf(bn_relu(v.x, sc.x, sh.x), bn_relu(v.y, sc.y, sh.y))),
                      fmaxf(bn_relu(v.z, sc.z, sh.z), bn_relu(v.w, sc.w, sh.w)));
     }
-    amax = wave_max(amax);
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(amax_out), __float_as_uint(amax));
+    amax_publish_block(amax_out, amax);
 }
 
 // backward pass 1 / pass 2 of the same stage.  dy = g_out[pooled pos]/(ph*pw) * relu-mask (0 on dropped rows).
@@ -416,8 +410,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const float* __re
         }
     }
     if (PASS == 2 && amax_out) {        // amax of the tensor just written, for the split-f16 consumers (conv_sf16.hip)
-        amax = wave_max(amax);
-        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(amax_out), __float_as_uint(amax));
+        amax_publish_block(amax_out, amax);
     }
     if (PASS == 1) {
         red_a[threadIdx.x] = sa; red_b[threadIdx.x] = sb;
@@ -501,10 +494,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ d
         amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
     if (amax_out) {
-        amax = wave_max(amax);
-        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(amax_out), __float_as_uint(amax));
+        amax_publish_block(amax_out, amax);
     }
 }
+
+}  // namespace
+
+int sed_amax_prezeroed__ = 0;
+// The caller promises that every amax_out buffer it hands in is already zero (e.g. slices of one zeroed pool): the entry
+// points then skip their 256-byte memset launches (33 per training step).
+SED_API int sed_amax_caller_zeroes(int on) { sed_amax_prezeroed__ = on ? 1 : 0; return 0; }
+SED_API int sed_amax_slots(void) { return SED_AMAX_SLOTS; }
+
+namespace {
 
 int stream_grid(long work_items) {
     long blocks = (work_items + 255) / 256;
@@ -542,7 +544,7 @@ SED_API int sed_bn_finalize(const float* partials, int nparts, int rows_per_part
     int ppc = reduce_chunks(nparts), nchunks = sed_cdiv(nparts, ppc), K = 2 * C;
     hipLaunchKernelGGL(reduce_parts_kernel<1>, dim3(nchunks, sed_cdiv(K, 256)), dim3(256), 0, stream, partials, nparts, K,
                        ppc, N, rows_per_part, ws);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(sed_cdiv(C, 16)), dim3(256), 0, stream, ws, nchunks, C, N, gamma, beta, eps,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(sed_cdiv(C, 4)), dim3(256), 0, stream, ws, nchunks, C, N, gamma, beta, eps,
                        momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out);
     SED_LAUNCH_CHECK();
     return 0;
@@ -565,7 +567,7 @@ SED_API int sed_bn_bwd_finalize(const float* partials, int nparts, long N, int C
     int ppc = reduce_chunks(nparts), nchunks = sed_cdiv(nparts, ppc), K = 2 * C;
     hipLaunchKernelGGL(reduce_parts_kernel<0>, dim3(nchunks, sed_cdiv(K, 256)), dim3(256), 0, stream, partials, nparts, K,
                        ppc, N, 0, ws);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sed_cdiv(C, 16)), dim3(256), 0, stream, ws, nchunks, C, N, mean, invstd,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sed_cdiv(C, 4)), dim3(256), 0, stream, ws, nchunks, C, N, mean, invstd,
                        scale, batch_stats, dgamma, dbeta, coef);
     SED_LAUNCH_CHECK();
     return 0;
@@ -598,7 +600,7 @@ SED_API int sed_bn_relu_pool_fwd(const float* y, int B, int H, int W, int C, int
                                  const float* shift, float* out, float* amax_out, hipStream_t stream) {
     if (B <= 0 || (C & 3) || ph <= 0 || pw <= 0 || H / ph <= 0 || W / pw <= 0) return SED_EINVAL;
     if (amax_out) {
-        hipError_t e = hipMemsetAsync(amax_out, 0, sizeof(float), stream);
+        hipError_t e = sed_amax_clear(amax_out, stream);
         if (e != hipSuccess) return (int)e;
     }
     long total = (long)B * (H / ph) * (W / pw) * (C / 4);
@@ -614,7 +616,7 @@ SED_API int sed_bn_relu_pool_fwd_cnt(const float* y, int B, int H, int W, int C,
                                      hipStream_t stream) {
     if (B <= 0 || (C & 3) || ph <= 0 || pw <= 0 || H / ph <= 0 || W / pw <= 0 || ph * pw > 255 || !cnt) return SED_EINVAL;
     if (amax_out) {
-        hipError_t e = hipMemsetAsync(amax_out, 0, sizeof(float), stream);
+        hipError_t e = sed_amax_clear(amax_out, stream);
         if (e != hipSuccess) return (int)e;
     }
     long total = (long)B * (H / ph) * (W / pw) * (C / 4);
@@ -698,7 +700,7 @@ SED_API int sed_bn_relu_pool_bwd_apply(const float* y, const float* g_out, int B
                                        float* amax_out, hipStream_t stream) {
     if (B <= 0 || C < 64 || C > 512 || (256 % (C / 4)) != 0) return SED_EINVAL;
     if (amax_out) {
-        hipError_t e = hipMemsetAsync(amax_out, 0, sizeof(float), stream);
+        hipError_t e = sed_amax_clear(amax_out, stream);
         if (e != hipSuccess) return (int)e;
     }
     const int rpb = sed_pool_bwd_rows_per_block((long)B * H * W);
@@ -714,7 +716,7 @@ SED_API int sed_bn_relu_pool_bwd_apply(const float* y, const float* g_out, int B
 SED_API int sed_act_amax(const float* minmax, int nparts, int C, const float* scale, const float* shift, float* amax_out,
                          hipStream_t stream) {
     if (!minmax || !amax_out || nparts <= 0 || C <= 0 || ((scale == nullptr) != (shift == nullptr))) return SED_EINVAL;
-    hipError_t e = hipMemsetAsync(amax_out, 0, sizeof(float), stream);
+    hipError_t e = sed_amax_clear(amax_out, stream);
     if (e != hipSuccess) return (int)e;
     int ppb = sed_cdiv(nparts, 1024);
     if (ppb < 8) ppb = 8;
@@ -728,7 +730,7 @@ SED_API int sed_act_amax(const float* minmax, int nparts, int C, const float* sc
 SED_API int sed_act_amax_full(const float* y, long nrows, int C, const float* scale, const float* shift, float* amax_out,
                               hipStream_t stream) {
     if (!y || !amax_out || !scale || !shift || nrows <= 0 || (C & 3)) return SED_EINVAL;
-    hipError_t e = hipMemsetAsync(amax_out, 0, sizeof(float), stream);
+    hipError_t e = sed_amax_clear(amax_out, stream);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(act_amax_full_kernel, dim3(stream_grid(nrows * (C / 4))), dim3(256), 0, stream, y, nrows, C, scale, shift,
                        amax_out);
@@ -740,7 +742,7 @@ SED_API int sed_bn_bwd_apply(float* dy_inout, const float* y, long nrows, int C,
                              hipStream_t stream) {
     if (nrows <= 0 || (C & 3)) return SED_EINVAL;
     if (amax_out) {
-        hipError_t e = hipMemsetAsync(amax_out, 0, sizeof(float), stream);
+        hipError_t e = sed_amax_clear(amax_out, stream);
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(nrows * (C / 4))), dim3(256), 0, stream, dy_inout, y, nrows, C,

@@ -34,6 +34,28 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Device-resident amax values (the split-f16 operand scales) are SED_AMAX_SLOTS floats, not one: a producer block
+// publishes its maximum (>= 0, so the uint order of the bits is the float order) with ONE atomic on slot (block id mod
+// slots), a consumer takes the maximum over the slots.  Thousands of atomics on a single word serialise in the L2 at
+// ~12 ns each: bn_bwd_apply with one atomic per wave spent 190 us per launch in them at batch 32 (profiles/r03).
+#define SED_AMAX_SLOTS 64
+__device__ __forceinline__ void amax_publish_block(float* __restrict__ out, float v) {   // every thread of the block calls
+    __shared__ float amax_wm__[16];
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) amax_wm__[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = amax_wm__[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, amax_wm__[w]);
+        atomicMax(reinterpret_cast<unsigned*>(out) + (blockIdx.x & (SED_AMAX_SLOTS - 1)), __float_as_uint(m));
+    }
+}
+__device__ __forceinline__ float amax_read(const float* __restrict__ p) { return wave_max(p[threadIdx.x & (SED_AMAX_SLOTS - 1)]); }
+extern int sed_amax_prezeroed__;      // host flag: the caller hands in zeroed amax buffers (sed_amax_caller_zeroes)
+static inline hipError_t sed_amax_clear(float* amax_out, hipStream_t stream) {
+    return (amax_out && !sed_amax_prezeroed__) ? hipMemsetAsync(amax_out, 0, SED_AMAX_SLOTS * sizeof(float), stream) : hipSuccess;
+}
+
 // The ONE expression used everywhere for "BatchNorm (folded to scale/shift) then ReLU", so the
 // forward value and every recomputed backward mask agree bit for bit.
 __device__ __forceinline__ float bn_relu(float y, float scale, float shift) {

@@ -35,7 +35,7 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 struct Sf16P {
     const float* x;            // [B][H][W][K]
     const _Float16* wp;        // [K/16][3 dy][2 planes][3 dx][N][16]
-    const float* wscale;       // [2]: weights' amax, scale sw (written by the pack kernels)
+    const float* wscale;       // [SED_AMAX_SLOTS + 1]: weights' amax slots, then the scale sw (written by the pack kernels)
     const float* x_amax;       // device: amax of the operand AS THE MFMAs SEE IT (relu(scale*x+shift) when fused)
     float* y;                  // [B][H][W][N]
     const float* in_scale;
@@ -71,6 +71,17 @@ __device__ __forceinline__ float sf_scale_of(float amax) {
     return ldexpf(1.f, e);
 }
 
+// (hi, lo) f16 pairs of two fp32 values, hi = f16(v) (round to nearest even), lo = f16(v - hi): the difference is exact
+// in fp32, so ONE mixed-precision fma per value (f16 hi read straight from its packed half, fp32 v, f16 result written into
+// its half of the packed destination) replaces cvt-back + subtract + cvt + pack -- 3 VALU per pair instead of 8.
+__device__ __forceinline__ void sf_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+        "v_fma_mixlo_f16 %1, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(hi), "=&v"(lo)
+        : "v"(a), "v"(b));
+}
+
 template <int MW, bool INT, int EPI>
 __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p) {
     constexpr int NW = 4 / MW, BN = 64 * NW, RB = BN / 32;
@@ -95,8 +106,8 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
     const int h0 = tile * TR;
     const int KT = p.K >> 4;
 
-    const float sa = sf_scale_of(*p.x_amax);
-    const float inv = 1.0f / (sa * p.wscale[1]);
+    const float sa = sf_scale_of(amax_read(p.x_amax));
+    const float inv = 1.0f / (sa * p.wscale[SED_AMAX_SLOTS]);
 
     // ---- A staging: item e = tid + 256*i -> patch pixel e >> 2 (row rr, column c), channel quad e & 3
     constexpr int OOB = (int)0x80000000;
@@ -139,21 +150,20 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
         SF_ALOAD(0) SF_ALOAD(1) SF_ALOAD(2) SF_ALOAD(3) SF_ALOAD(4) SF_ALOAD(5)                                 \
     }
 #define SF_ASTORE(i)                                                                                            \
-    if (i < NI && val##i) {                                                                                     \
+    if (i < NI && (INT ? sok##i : val##i)) {   /* INT: rows outside the image were zeroed once and are never written */ \
         float4 v = areg##i;                                                                                     \
         if (INT) {                                                                                              \
-            v.x = sok##i ? bn_relu(v.x, sc4.x, sh4.x) : 0.f;                                                    \
-            v.y = sok##i ? bn_relu(v.y, sc4.y, sh4.y) : 0.f;                                                    \
-            v.z = sok##i ? bn_relu(v.z, sc4.z, sh4.z) : 0.f;                                                    \
-            v.w = sok##i ? bn_relu(v.w, sc4.w, sh4.w) : 0.f;                                                    \
+            v.x = bn_relu(v.x, sc4.x, sh4.x); v.y = bn_relu(v.y, sc4.y, sh4.y);                                 \
+            v.z = bn_relu(v.z, sc4.z, sh4.z); v.w = bn_relu(v.w, sc4.w, sh4.w);                                 \
+        } else {                                                                                                \
+            v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa;        /* out-of-image loads returned 0 */              \
         }                                                                                                       \
-        if (!INT) { v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa; }                                               \
         overflow |= !((fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w)) < 3.0e5f);  /* 3 adds (|.| is a source modifier): inf AND NaN propagate; finite values are < 2^14 each */ \
-        const half4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};                          \
-        const half4 lo = {(_Float16)(v.x - (float)hi.x), (_Float16)(v.y - (float)hi.y),                         \
-                          (_Float16)(v.z - (float)hi.z), (_Float16)(v.w - (float)hi.w)};                        \
-        *reinterpret_cast<half4*>(As + lso##i) = hi;                                                            \
-        *reinterpret_cast<half4*>(As + APLANE + lso##i) = lo;                                                   \
+        unsigned h01, l01, h23, l23;                                                                            \
+        sf_split2(v.x, v.y, h01, l01);                                                                          \
+        sf_split2(v.z, v.w, h23, l23);                                                                          \
+        *reinterpret_cast<uint2*>(As + lso##i) = make_uint2(h01, h23);                                          \
+        *reinterpret_cast<uint2*>(As + APLANE + lso##i) = make_uint2(l01, l23);                                 \
     }
 #define sf_astore() { SF_ASTORE(0) SF_ASTORE(1) SF_ASTORE(2) SF_ASTORE(3) SF_ASTORE(4) SF_ASTORE(5) }
 
@@ -184,6 +194,15 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
         const int rr = i >> 3, side = (i >> 2) & 1, pl = (i >> 1) & 1, ch = i & 1;
         const int ridx = rr * WP + (side ? W + 1 : 0);
         *reinterpret_cast<float4*>(As + pl * APLANE + sf_sw(ridx, ch)) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (INT) {      // patch rows outside the image (first / last tile): zero, once -- the staging skips them
+#define SF_AZERO(i)                                                                                             \
+        if (i < NI && val##i && !sok##i) {                                                                      \
+            *reinterpret_cast<uint2*>(As + lso##i) = make_uint2(0u, 0u);                                        \
+            *reinterpret_cast<uint2*>(As + APLANE + lso##i) = make_uint2(0u, 0u);                               \
+        }
+        SF_AZERO(0) SF_AZERO(1) SF_AZERO(2) SF_AZERO(3) SF_AZERO(4) SF_AZERO(5)
+#undef SF_AZERO
     }
     sf_aload(0);
     sf_bdma(0, 0);
@@ -396,14 +415,13 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
     float m = 0.f;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[e]));
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+    amax_publish_block(out, m);
 }
 
 __global__ __launch_bounds__(256) void pack_sf16_kernel(const float* __restrict__ w, int Cout, int Cin, int dgrad,
                                                         float* __restrict__ wscale, _Float16* __restrict__ wp) {
-    const float sw = sf_scale_of(wscale[0]);
-    if (blockIdx.x == 0 && threadIdx.x == 0) wscale[1] = sw;
+    const float sw = sf_scale_of(amax_read(wscale));
+    if (blockIdx.x == 0 && threadIdx.x == 0) wscale[SED_AMAX_SLOTS] = sw;
     const int No = dgrad ? Cin : Cout, Ki = dgrad ? Cout : Cin;
     const long total = 9L * No * Ki;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
@@ -450,7 +468,7 @@ SED_API long sed_conv_sf16_num_parts(int B, int H, int W, int Cout) {
 
 SED_API int sed_amax(const float* x, long n, float* amax_out, sed_stream_t stream) {
     if (!x || !amax_out || n <= 0) return SED_EINVAL;
-    hipError_t e = hipMemsetAsync(amax_out, 0, sizeof(float), (hipStream_t)stream);
+    hipError_t e = sed_amax_clear(amax_out, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     const long nb = (n + 1023) / 1024;               // >= 4 elements per thread; few blocks: one atomic per wave, all on one word
     hipLaunchKernelGGL(amax_kernel, dim3((unsigned)(nb > 256 ? 256 : nb)), dim3(256), 0, (hipStream_t)stream, x, n, amax_out);
@@ -460,13 +478,17 @@ SED_API int sed_amax(const float* x, long n, float* amax_out, sed_stream_t strea
 
 SED_API int sed_pack_conv_weights_sf16(const float* w_oihw, int Cout, int Cin, int dgrad, float* wscale, void* wp,
                                        sed_stream_t stream) {
-    if (!w_oihw || !wp || !wscale || Cout <= 0 || Cin <= 0 || (dgrad ? Cout : Cin) % 16) return SED_EINVAL;
+    // dgrad: bit 0 = layout of the transposed convolution; bit 1 = wscale already holds the amax slots of w (skip that pass)
+    const int dg = dgrad & 1, have_amax = dgrad & 2;
+    if (!w_oihw || !wp || !wscale || Cout <= 0 || Cin <= 0 || (dg ? Cout : Cin) % 16 || (dgrad & ~3)) return SED_EINVAL;
     const long total = 9L * Cout * Cin;
-    int rc = sed_amax(w_oihw, total, wscale, stream);
-    if (rc) return rc;
+    if (!have_amax) {
+        int rc = sed_amax(w_oihw, total, wscale, stream);
+        if (rc) return rc;
+    }
     const long nb = (total + 255) / 256;
     hipLaunchKernelGGL(pack_sf16_kernel, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, (hipStream_t)stream, w_oihw,
-                       Cout, Cin, dgrad, wscale, (_Float16*)wp);
+                       Cout, Cin, dg, wscale, (_Float16*)wp);
     SED_LAUNCH_CHECK();
     return 0;
 }
@@ -582,7 +604,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
         const int per = (p.stages_per_image + p.spi - 1) / p.spi;
         s0 = (slice % p.spi) * per; s1 = min(p.stages_per_image, s0 + per);
     }
-    const float sg = sf_scale_of(*p.g_amax), sa = sf_scale_of(*p.x_amax);
+    const float sg = sf_scale_of(amax_read(p.g_amax)), sa = sf_scale_of(amax_read(p.x_amax));
 
     // ---- staging maps.  x: item e = tid + 256*i (i < 2): pixel e >> 3 of the 64 new ones, channel quad e & 7 (32 ci);
     //      gy: item e (i < 4): pixel e >> 4, channel quad e & 15 (64 co)
@@ -630,19 +652,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                             \
         float4 v = xreg[i];                                                                                     \
         if (INT) {                                                                                              \
-            v.x = xok[i] ? bn_relu(v.x, xsc.x, xsh.x) : 0.f; v.y = xok[i] ? bn_relu(v.y, xsc.y, xsh.y) : 0.f;   \
-            v.z = xok[i] ? bn_relu(v.z, xsc.z, xsh.z) : 0.f; v.w = xok[i] ? bn_relu(v.w, xsc.w, xsh.w) : 0.f;   \
+            v.x = bn_relu(v.x, xsc.x, xsh.x); v.y = bn_relu(v.y, xsc.y, xsh.y);                                 \
+            v.z = bn_relu(v.z, xsc.z, xsh.z); v.w = bn_relu(v.w, xsc.w, xsh.w);                                 \
         } else {                                                                                                \
             v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa;                                                         \
         }                                                                                                       \
-        overflow |= !((fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w)) < 3.0e5f);  /* 3 adds (|.| is a source modifier): inf AND NaN propagate; finite values are < 2^14 each */ \
-        const half4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};                          \
-        const half4 lo = {(_Float16)(v.x - (float)hi.x), (_Float16)(v.y - (float)hi.y),                         \
-                          (_Float16)(v.z - (float)hi.z), (_Float16)(v.w - (float)hi.w)};                        \
+        overflow |= !((fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w)) < 3.0e5f);  /* inf and NaN propagate through the adds */ \
+        unsigned h01, l01, h23, l23;                                                                            \
+        sf_split2(v.x, v.y, h01, l01);                                                                          \
+        sf_split2(v.z, v.w, h23, l23);                                                                          \
+        if (INT && !xok[i]) { h01 = h23 = l01 = l23 = 0u; }    /* rows outside the image: the ring slot gets zeros */ \
         const int slot = ((ROW0) + xrr[i] + 1) & (RING - 1);                                                    \
         const int o = (xq >> 2) * XPL + (slot * WP + xcc[i] + 1) * 32 + (xq & 3) * 8;                           \
-        *reinterpret_cast<half4*>(Xs + o) = hi;                                                                 \
-        *reinterpret_cast<half4*>(Xs + 2 * XPL + o) = lo;                                                       \
+        *reinterpret_cast<uint2*>(Xs + o) = make_uint2(h01, h23);                                               \
+        *reinterpret_cast<uint2*>(Xs + 2 * XPL + o) = make_uint2(l01, l23);                                     \
     }
 #define WSF_GLOAD(H0)                                                                                           \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
@@ -652,11 +675,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
         float4 v = greg[i];                                                                                     \
         v.x *= sg; v.y *= sg; v.z *= sg; v.w *= sg;                                                             \
         overflow |= !((fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w)) < 3.0e5f);                         \
-        const half4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};                          \
-        const half4 lo = {(_Float16)(v.x - (float)hi.x), (_Float16)(v.y - (float)hi.y),                         \
-                          (_Float16)(v.z - (float)hi.z), (_Float16)(v.w - (float)hi.w)};                        \
-        *reinterpret_cast<half4*>(Gs + gls[i]) = hi;                                                            \
-        *reinterpret_cast<half4*>(Gs + 4 * GPL + gls[i]) = lo;                                                  \
+        unsigned h01, l01, h23, l23;                                                                            \
+        sf_split2(v.x, v.y, h01, l01);                                                                          \
+        sf_split2(v.z, v.w, h23, l23);                                                                          \
+        *reinterpret_cast<uint2*>(Gs + gls[i]) = make_uint2(h01, h23);                                          \
+        *reinterpret_cast<uint2*>(Gs + 4 * GPL + gls[i]) = make_uint2(l01, l23);                                \
     }
 
     // halo columns of every ring row, all four x planes: zero once
@@ -755,20 +778,36 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
 }
 
 // sum the slices in fp64, unscale, scatter to OIHW
+// 64 elements x 4 part groups per block: group g sums parts g, g+4, ... (four independent loads in flight per thread),
+// the groups meet in LDS -- a fixed order, so the result is deterministic.  (One thread per element walking all parts in a
+// dependent chain took 315 us for the 1000 partials of the 64 -> 64 layer at batch 32.)
 __global__ __launch_bounds__(256) void wgrad_sf16_reduce_kernel(const float* __restrict__ partial, int nparts, int N, int K,
                                                                 const float* __restrict__ g_amax,
                                                                 const float* __restrict__ x_amax,
                                                                 float* __restrict__ dw) {
-    const long nk = (long)9 * N * K;
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= nk) return;
-    double s = 0.0;
-    for (int q = 0; q < nparts; ++q) s += (double)partial[(long)q * nk + e];
-    const int ci = (int)(e % K);
-    const long t = e / K;
-    const int co = (int)(t % N), tap = (int)(t / N);
-    const double inv = 1.0 / ((double)sf_scale_of(*g_amax) * (double)sf_scale_of(*x_amax));
-    dw[((long)co * K + ci) * 9 + tap] = (float)(s * inv);
+    __shared__ double red[256];
+    const long nk = (long)9 * N * K;                       // a multiple of 64
+    const long e = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int grp = threadIdx.x >> 6;
+    const double inv = 1.0 / ((double)sf_scale_of(amax_read(g_amax)) * (double)sf_scale_of(amax_read(x_amax)));
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int q = grp;
+    for (; q + 12 < nparts; q += 16) {
+        s0 += (double)partial[(long)q * nk + e];
+        s1 += (double)partial[(long)(q + 4) * nk + e];
+        s2 += (double)partial[(long)(q + 8) * nk + e];
+        s3 += (double)partial[(long)(q + 12) * nk + e];
+    }
+    for (; q < nparts; q += 4) s0 += (double)partial[(long)q * nk + e];
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp == 0) {
+        const double s = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+        const int ci = (int)(e % K);
+        const long t = e / K;
+        const int co = (int)(t % N), tap = (int)(t / N);
+        dw[((long)co * K + ci) * 9 + tap] = (float)(s * inv);
+    }
 }
 
 static void wsf_slicing(int B, int H, int W, int Cin, int Cout, int* spi, int* ips, int* spimg, long* nslices) {
@@ -831,7 +870,7 @@ SED_API int sed_conv3x3_wgrad_sf16(const float* x, const float* gy, float* dw_oi
 #undef WSF_LAUNCH
     SED_LAUNCH_CHECK();
     const long nk = 9L * Cin * Cout;
-    hipLaunchKernelGGL(wgrad_sf16_reduce_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, s, partial, (int)(ns * 2), Cout,
+    hipLaunchKernelGGL(wgrad_sf16_reduce_kernel, dim3((unsigned)(nk / 64)), dim3(256), 0, s, partial, (int)(ns * 2), Cout,
                        Cin, gy_amax, x_amax, dw_oihw);
     SED_LAUNCH_CHECK();
     return 0;

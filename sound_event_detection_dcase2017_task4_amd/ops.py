@@ -650,10 +650,14 @@ def _wgrad_sf16(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, g
     return _ret(sink, dw) if signal else (None if sink is not None else dw)
 
 
+WGRAD_SF16_MIN_CIN = int(os.environ.get("SED_WGRAD_SF16_MIN_CIN", "64"))
+
+
 def _wgrad_algo(H, W, Cin, Cout):
-    """3 = split-f16 (where it beats the Winograd-domain kernel: >= 128 input channels; with 64 the 64 x 32 tile reads every
-    gradient row twice from HBM and only ties), else the fp32 kernels."""
-    return 3 if (USE_SF16 and Cin >= 128 and _lib.lib().sed_wgrad_sf16_supported(H, W, Cin, Cout)) else 0
+    """3 = split-f16 (every layer it supports: Cin % 32 == 0.  Until round 3 the two 64-input-channel layers kept the
+    Winograd-domain fp32 kernel -- the 64 x 32 tile reads every gradient row twice and only tied; with the 3-VALU split of
+    round 3 it is 12-20 % faster there too), else the fp32 kernels."""
+    return 3 if (USE_SF16 and Cin >= WGRAD_SF16_MIN_CIN and _lib.lib().sed_wgrad_sf16_supported(H, W, Cin, Cout)) else 0
 
 
 def _wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, gy_amax=None, x_amax=None, keep=None):
@@ -684,18 +688,61 @@ def _wgrad_direct(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True,
 
 # ---- split-f16 convolution (csrc/conv_sf16.hip)
 
-def pack_sf16(w_oihw, dgrad=False):
-    """OIHW fp32 weights -> (split-f16 operand [hi, lo planes], wscale[2] = (amax, power-of-two scale) on the device)."""
+AMAX_SLOTS = 64          # = sed_amax_slots(): device amax values are 64 floats (one atomic per producer block, spread over
+                         # the slots; consumers take the max) -- see include/sed_hip.h
+_AMAX_POOL = {}
+
+
+def _amax_buf(device):
+    """A ZEROED float[64] amax vector: a slice of a pool that is zeroed 64 vectors at a time (one fill kernel instead of one
+    memset per producer launch; the library is told that amax buffers arrive zeroed: sed_amax_caller_zeroes).  Each slice is
+    handed out once; the views keep their pool alive."""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    ent = _AMAX_POOL.get(key)
+    if ent is None or ent[1] >= ent[0].shape[0]:
+        if ent is None:
+            _lib.lib().sed_amax_caller_zeroes(1)
+        ent = _AMAX_POOL[key] = [torch.zeros((64, AMAX_SLOTS), dtype=torch.float32, device=torch.device("cuda", key)), 0]
+    v = ent[0][ent[1]]
+    ent[1] += 1
+    return v
+
+
+def amax_value(a):
+    """Host float of a device amax vector (tests / debugging; synchronises)."""
+    return float(a.max())
+
+
+def pack_sf16(w_oihw, dgrad=False, wscale=None):
+    """OIHW fp32 weights -> (split-f16 operand [hi, lo planes], wscale[65] = (64 amax slots, power-of-two scale) on the
+    device).  wscale given: the amax pass is skipped (the second layout of a weight whose amax is already known)."""
     Cout, Cin = w_oihw.shape[0], w_oihw.shape[1]
     wp = torch.empty((_lib.lib().sed_conv_sf16_pack_halfs(Cin, Cout),), dtype=torch.float16, device=w_oihw.device)
-    wscale = torch.empty((2,), dtype=torch.float32, device=w_oihw.device)
-    _call("sed_pack_conv_weights_sf16", _ptr(_f32c(w_oihw)), Cout, Cin, 1 if dgrad else 0, _ptr(wscale), _ptr(wp), _stream())
+    have = wscale is not None
+    if not have:
+        wscale = torch.zeros((AMAX_SLOTS + 1,), dtype=torch.float32, device=w_oihw.device)
+    _call("sed_pack_conv_weights_sf16", _ptr(_f32c(w_oihw)), Cout, Cin, (1 if dgrad else 0) | (2 if have else 0), _ptr(wscale),
+          _ptr(wp), _stream())
     return wp, wscale
 
 
+def sf16_packs(w, want_dgrad):
+    """(forward pack, dgrad pack or None) of a conv weight, cached per parameter object and parameter state (the same
+    stamp as the other derived weight operands: storage address, version counter, optimiser generation): one amax pass
+    and the packs per optimiser step instead of one of each per use; static weights (inference) are packed once."""
+    def build():
+        fwd = pack_sf16(w, dgrad=False)
+        return [fwd, None]
+    ent = _cached("sf16_packs", (w,), build)
+    if want_dgrad and ent[1] is None:
+        ent[1] = pack_sf16(w, dgrad=True, wscale=ent[0][1])
+    return ent[0], ent[1]
+
+
 def amax_of(x):
-    """max |x| as a device scalar (one pass)."""
-    out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    """max |x| as a device amax vector (one pass)."""
+    out = _amax_buf(x.device)
     _call("sed_amax", _ptr(x), x.numel(), _ptr(out), _stream())
     return out
 
@@ -703,7 +750,7 @@ def amax_of(x):
 def act_amax(minmax, nparts, C, st=None):
     """amax of relu(scale*y + shift) (st given) or of |y| from the per-part per-channel (max, min) a conv epilogue left --
     the split-f16 scale of a convolution whose operand is never materialised.  No pass over the tensor."""
-    out = torch.empty((1,), dtype=torch.float32, device=minmax.device)
+    out = _amax_buf(minmax.device)
     _call("sed_act_amax", _ptr(minmax), nparts, C, _ptr(st.scale) if st is not None else None,
           _ptr(st.shift) if st is not None else None, _ptr(out), _stream())
     return out
@@ -712,7 +759,7 @@ def act_amax(minmax, nparts, C, st=None):
 def act_amax_full(y, st):
     """The same amax by one pass over y (producers that leave no range partials; off the default path)."""
     C = y.shape[-1]
-    out = torch.empty((1,), dtype=torch.float32, device=y.device)
+    out = _amax_buf(y.device)
     _call("sed_act_amax_full", _ptr(y), y.numel() // C, C, _ptr(st.scale), _ptr(st.shift), _ptr(out), _stream())
     return out
 
@@ -755,8 +802,12 @@ def _conv_fwd_like(x, w_oihw, B, H, W, Cin, Cout, dgrad=False, **kw):
     algo = _conv_algo(H, W, Cin, Cout)
     x_amax = kw.pop("x_amax", None)
     minmax = kw.pop("minmax", None)
+    packs = kw.pop("packs", None)                    # (forward, dgrad) split-f16 packs of w_oihw, when the caller holds them
     if algo == 3:
-        return conv3x3_sf16(x, pack_sf16(w_oihw, dgrad=dgrad), B, H, W, Cin, Cout, x_amax=x_amax, minmax=minmax, **kw)
+        pack = packs[1 if dgrad else 0] if packs is not None else None
+        if pack is None:
+            pack = sf16_packs(w_oihw, dgrad)[1 if dgrad else 0]
+        return conv3x3_sf16(x, pack, B, H, W, Cin, Cout, x_amax=x_amax, minmax=minmax, **kw)
     if algo == 2:
         uf, ud = _pack_wino2(w_oihw, want_f=not dgrad, want_d=dgrad)
         return _conv_wino2(x, ud if dgrad else uf, B, H, W, Cin, Cout, **kw)
@@ -810,6 +861,10 @@ class ConvBlockFn(torch.autograd.Function):
             x_amax = amax_of(x)                          # standalone use; inside a model the previous block's pool supplies it
         if not need_xa:
             x_amax = None
+        # split-f16 weight operands: one amax pass + packs per weight and optimiser step (cached per parameter), both
+        # layouts at once when a backward pass will follow
+        pk1 = sf16_packs(w1c, bool(training) and ctx.needs_input_grad[0]) if sf_c1 else None
+        pk2 = sf16_packs(w2c, bool(training)) if _conv_algo(H, W, Cout, Cout) == 3 else None
         # conv1 (+ statistics, + per-channel output range for the amax of relu(bn1(y1)))
         mm1 = None
         if Cin == 1:
@@ -824,7 +879,8 @@ class ConvBlockFn(torch.autograd.Function):
             part1 = torch.empty((nf1,), dtype=torch.float32, device=dev) if training else None
             if need_a1 and sf_c1:
                 mm1 = torch.empty((np1, 2, Cout), dtype=torch.float32, device=dev)
-            y1 = _conv_fwd_like(x, w1c, B, H, W, Cin, Cout, epi=1 if training else 0, partials=part1, x_amax=x_amax, minmax=mm1)
+            y1 = _conv_fwd_like(x, w1c, B, H, W, Cin, Cout, epi=1 if training else 0, partials=part1, x_amax=x_amax, minmax=mm1,
+                                packs=pk1)
         st1 = bn_finalize(part1, np1, rpp1, M, g1, b1, rm1, rv1) if training else bn_eval_affine(g1, b1, rm1, rv1)
         a1 = None
         if need_a1:
@@ -833,10 +889,11 @@ class ConvBlockFn(torch.autograd.Function):
         # conv2 over relu(bn1(y1)) computed on the fly (+ statistics)
         np2, rpp2, nf2 = _conv_parts(B, H, W, Cout, Cout)
         part2 = torch.empty((nf2,), dtype=torch.float32, device=dev) if training else None
-        y2 = _conv_fwd_like(y1, w2c, B, H, W, Cout, Cout, in_st=st1, epi=1 if training else 0, partials=part2, x_amax=a1)
+        y2 = _conv_fwd_like(y1, w2c, B, H, W, Cout, Cout, in_st=st1, epi=1 if training else 0, partials=part2, x_amax=a1,
+                            packs=pk2)
         st2 = bn_finalize(part2, np2, rpp2, M, g2, b2, rm2, rv2) if training else bn_eval_affine(g2, b2, rm2, rv2)
         out = torch.empty((B, H // ph, W // pw, Cout), dtype=torch.float32, device=dev)
-        out_amax = torch.empty((1,), dtype=torch.float32, device=dev)
+        out_amax = _amax_buf(dev)
         cnt = None
         if training and POOL_BWD_WINDOWED and ph * pw > 1:
             # per-window ReLU counts: with them backward pass 1 runs on the pooled tensors and never reads y2
@@ -852,6 +909,7 @@ class ConvBlockFn(torch.autograd.Function):
             ctx.save_for_backward(x, y1, y2, w1c, w2c)
         ctx.st1, ctx.st2, ctx.pool, ctx.training = st1, st2, (ph, pw), bool(training)
         ctx.xa, ctx.a1 = x_amax, a1
+        ctx.pk1, ctx.pk2 = pk1, pk2
         ctx.sinks = _sinks(ctx, (w1, g1, b1, None, None, w2, g2, b2), 1)
         ctx.mark_non_differentiable(out_amax)
         return out, out_amax
@@ -887,7 +945,7 @@ class ConvBlockFn(torch.autograd.Function):
         dg2, db2, coef2 = bn_bwd_finalize(part, n.value, M, st2, batch_stats=ctx.training, sinks=(sk[6], sk[7]))
         gy2 = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
         sf2 = _conv_algo(H, W, Cout, Cout) == 3 or _wgrad_algo(H, W, Cout, Cout) == 3   # split-f16 consumers scale by the amax
-        amax2 = torch.empty((1,), dtype=torch.float32, device=dev) if sf2 else None
+        amax2 = _amax_buf(dev) if sf2 else None
         _call("sed_bn_relu_pool_bwd_apply", _ptr(y2), _ptr(g_out), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift),
               _ptr(coef2), _ptr(gy2), _ptr(amax2), _stream())
         # conv2: dgrad fused with relu-mask + BN1 backward sums, then the weight gradient (operand relu(bn1(y1)) on the
@@ -897,7 +955,8 @@ class ConvBlockFn(torch.autograd.Function):
         fork = WGRAD_SIDE_STREAM
         npb, _, nfb = _conv_parts(B, H, W, Cout, Cout)
         partb = torch.empty((nfb,), dtype=torch.float32, device=dev)
-        gy1 = _conv_fwd_like(gy2, w2, B, H, W, Cout, Cout, dgrad=True, epi=2, partials=partb, yprev=y1, p_st=st1, x_amax=amax2)
+        gy1 = _conv_fwd_like(gy2, w2, B, H, W, Cout, Cout, dgrad=True, epi=2, partials=partb, yprev=y1, p_st=st1, x_amax=amax2,
+                             packs=ctx.pk2)
         if fork and sk[5] is not None:
             dw2 = _fork_wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=st1, sink=sk[5], gy_amax=amax2, x_amax=ctx.a1)
         else:
@@ -909,7 +968,7 @@ class ConvBlockFn(torch.autograd.Function):
         amax1 = None
         if Cin != 1:
             if (ctx.needs_input_grad[0] and _conv_algo(H, W, Cout, Cin) == 3) or _wgrad_algo(H, W, Cin, Cout) == 3:
-                amax1 = torch.empty((1,), dtype=torch.float32, device=dev)
+                amax1 = _amax_buf(dev)
             _call("sed_bn_bwd_apply", _ptr(gy1), _ptr(y1), M, Cout, _ptr(coef1), _ptr(amax1), _stream())
         if Cin == 1:                                   # BN1 backward g = a*dz + b*y1 + c is applied on load by the kernel
             nblk = (M + 1023) // 1024
@@ -925,7 +984,7 @@ class ConvBlockFn(torch.autograd.Function):
         else:
             join_side_stream()                         # conv2's weight gradient is done before the next MFMA kernel starts
             if ctx.needs_input_grad[0]:
-                gx = _conv_fwd_like(gy1, w1, B, H, W, Cout, Cin, dgrad=True, epi=0, x_amax=amax1)
+                gx = _conv_fwd_like(gy1, w1, B, H, W, Cout, Cin, dgrad=True, epi=0, x_amax=amax1, packs=ctx.pk1)
             if fork and sk[0] is not None:
                 dw1 = _fork_wgrad(x, gy1, B, H, W, Cin, Cout, sink=sk[0], gy_amax=amax1, x_amax=ctx.xa)
             else:

@@ -208,9 +208,10 @@ def test_act_amax_from_range_partials_is_exact():
     y = ops.conv3x3_sf16(x, ops.pack_sf16(w), B, H, W, Cin, Cout, minmax=mm)
     a, b, c = ops.act_amax(mm, P, Cout, st), ops.act_amax_full(y, st), ops.act_amax(mm, P, Cout)
     torch.cuda.synchronize()
-    assert float(a) == float(b) > 0 and float(c) == float(y.abs().max())
+    a, b, c = ops.amax_value(a), ops.amax_value(b), ops.amax_value(c)          # device amax vectors: max over the 64 slots
+    assert a == b > 0 and c == float(y.abs().max())
     ref = torch.relu(y.double() * st.scale.double() + st.shift.double()).max()
-    assert abs(float(a) - float(ref)) <= 1e-6 * float(ref)
+    assert abs(a - float(ref)) <= 1e-6 * float(ref)
     # direct kernel of block 1 (Cin = 1)
     B, H, W = 2, 101, 64
     x0 = torch.randn((B, H, W, 1), generator=g).cuda()
@@ -222,7 +223,7 @@ def test_act_amax_from_range_partials_is_exact():
     ops._call("sed_conv1_fwd", ops._ptr(x0), ops._ptr(w1), ops._ptr(y1), B, H, W, None, ops._ptr(mm1), ops._stream())
     st1 = ops.BnStats(64, "cuda")
     st1.scale.copy_(torch.randn(64, generator=g)); st1.shift.copy_(torch.randn(64, generator=g))
-    assert float(ops.act_amax(mm1, n, 64, st1)) == float(ops.act_amax_full(y1, st1)) > 0
+    assert ops.amax_value(ops.act_amax(mm1, n, 64, st1)) == ops.amax_value(ops.act_amax_full(y1, st1)) > 0
 
 
 def test_sf16_nonfinite_operand_is_reported_and_adam_refuses_the_step():
