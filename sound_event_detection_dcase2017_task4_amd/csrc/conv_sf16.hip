@@ -418,27 +418,40 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
     amax_publish_block(out, m);
 }
 
-__global__ __launch_bounds__(256) void pack_sf16_kernel(const float* __restrict__ w, int Cout, int Cin, int dgrad,
+__device__ __forceinline__ void pack_sf16_one(const float* __restrict__ w, int Cout, int Cin, int dgrad, float sw, long e,
+                                              _Float16* __restrict__ wp) {
+    const int No = dgrad ? Cin : Cout;
+    const int il = (int)(e & 15);
+    long q = e >> 4;
+    const int o = (int)(q % No); q /= No;
+    const int dx = (int)(q % 3); q /= 3;
+    const int dy = (int)(q % 3); q /= 3;
+    const int ks = (int)q;
+    const int i = ks * 16 + il;
+    const float v = (dgrad ? w[(((long)i * Cin + o) * 3 + (2 - dy)) * 3 + (2 - dx)]
+                           : w[(((long)o * Cin + i) * 3 + dy) * 3 + dx]) * sw;
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    const long base = ((long)(ks * 3 + dy) * 2) * 3 * No * 16;
+    wp[base + ((long)dx * No + o) * 16 + il] = hi;
+    wp[base + 3L * No * 16 + ((long)dx * No + o) * 16 + il] = lo;
+}
+
+// mode 0 / 1: the forward / dgrad layout into wp; mode 2: BOTH, the forward pack followed by the dgrad pack (18*Cin*Cout
+// halfs each) -- one launch per weight and optimiser step
+__global__ __launch_bounds__(256) void pack_sf16_kernel(const float* __restrict__ w, int Cout, int Cin, int mode,
                                                         float* __restrict__ wscale, _Float16* __restrict__ wp) {
     const float sw = sf_scale_of(amax_read(wscale));
     if (blockIdx.x == 0 && threadIdx.x == 0) wscale[SED_AMAX_SLOTS] = sw;
-    const int No = dgrad ? Cin : Cout, Ki = dgrad ? Cout : Cin;
-    const long total = 9L * No * Ki;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const int il = (int)(e & 15);
-        long q = e >> 4;
-        const int o = (int)(q % No); q /= No;
-        const int dx = (int)(q % 3); q /= 3;
-        const int dy = (int)(q % 3); q /= 3;
-        const int ks = (int)q;
-        const int i = ks * 16 + il;
-        const float v = (dgrad ? w[(((long)i * Cin + o) * 3 + (2 - dy)) * 3 + (2 - dx)]
-                               : w[(((long)o * Cin + i) * 3 + dy) * 3 + dx]) * sw;
-        const _Float16 hi = (_Float16)v;
-        const _Float16 lo = (_Float16)(v - (float)hi);
-        const long base = ((long)(ks * 3 + dy) * 2) * 3 * No * 16;
-        wp[base + ((long)dx * No + o) * 16 + il] = hi;
-        wp[base + 3L * No * 16 + ((long)dx * No + o) * 16 + il] = lo;
+    const long total = 9L * Cout * Cin;
+    const long n = mode == 2 ? 2 * total : total;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        if (mode == 2) {
+            if (e < total) pack_sf16_one(w, Cout, Cin, 0, sw, e, wp);
+            else pack_sf16_one(w, Cout, Cin, 1, sw, e - total, wp + 2 * total);
+        } else {
+            pack_sf16_one(w, Cout, Cin, mode, sw, e, wp);
+        }
     }
 }
 
@@ -478,17 +491,19 @@ SED_API int sed_amax(const float* x, long n, float* amax_out, sed_stream_t strea
 
 SED_API int sed_pack_conv_weights_sf16(const float* w_oihw, int Cout, int Cin, int dgrad, float* wscale, void* wp,
                                        sed_stream_t stream) {
-    // dgrad: bit 0 = layout of the transposed convolution; bit 1 = wscale already holds the amax slots of w (skip that pass)
-    const int dg = dgrad & 1, have_amax = dgrad & 2;
-    if (!w_oihw || !wp || !wscale || Cout <= 0 || Cin <= 0 || (dg ? Cout : Cin) % 16 || (dgrad & ~3)) return SED_EINVAL;
+    // dgrad: bit 0 = layout of the transposed convolution; bit 1 = wscale already holds the amax slots of w (skip that
+    // pass); bit 2 = BOTH layouts, wp = forward pack followed by the dgrad pack (sed_conv_sf16_pack_halfs(...) halfs each)
+    const int both = dgrad & 4, dg = dgrad & 1, have_amax = dgrad & 2;
+    if (!w_oihw || !wp || !wscale || Cout <= 0 || Cin <= 0 || (dgrad & ~7) || (both && dg)) return SED_EINVAL;
+    if (((both || !dg) && Cin % 16) || ((both || dg) && Cout % 16)) return SED_EINVAL;
     const long total = 9L * Cout * Cin;
     if (!have_amax) {
         int rc = sed_amax(w_oihw, total, wscale, stream);
         if (rc) return rc;
     }
-    const long nb = (total + 255) / 256;
+    const long nb = ((both ? 2 : 1) * total + 255) / 256;
     hipLaunchKernelGGL(pack_sf16_kernel, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, (hipStream_t)stream, w_oihw,
-                       Cout, Cin, dg, wscale, (_Float16*)wp);
+                       Cout, Cin, both ? 2 : dg, wscale, (_Float16*)wp);
     SED_LAUNCH_CHECK();
     return 0;
 }

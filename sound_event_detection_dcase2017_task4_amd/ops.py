@@ -691,20 +691,21 @@ def _wgrad_direct(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True,
 AMAX_SLOTS = 64          # = sed_amax_slots(): device amax values are 64 floats (one atomic per producer block, spread over
                          # the slots; consumers take the max) -- see include/sed_hip.h
 _AMAX_POOL = {}
+_POOL_ROW = 128          # floats per pool row: an amax vector uses the first 64, a weight scale record 65
 
 
-def _amax_buf(device):
-    """A ZEROED float[64] amax vector: a slice of a pool that is zeroed 64 vectors at a time (one fill kernel instead of one
-    memset per producer launch; the library is told that amax buffers arrive zeroed: sed_amax_caller_zeroes).  Each slice is
-    handed out once; the views keep their pool alive."""
+def _amax_buf(device, n=AMAX_SLOTS):
+    """A ZEROED float[n] (n <= 128; default: a 64-slot amax vector): a slice of a pool that is zeroed 64 rows at a time
+    (one fill kernel instead of one memset per producer launch; the library is told that amax buffers arrive zeroed:
+    sed_amax_caller_zeroes).  Each row is handed out once; the views keep their pool alive."""
     dev = torch.device(device)
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     ent = _AMAX_POOL.get(key)
     if ent is None or ent[1] >= ent[0].shape[0]:
         if ent is None:
             _lib.lib().sed_amax_caller_zeroes(1)
-        ent = _AMAX_POOL[key] = [torch.zeros((64, AMAX_SLOTS), dtype=torch.float32, device=torch.device("cuda", key)), 0]
-    v = ent[0][ent[1]]
+        ent = _AMAX_POOL[key] = [torch.zeros((64, _POOL_ROW), dtype=torch.float32, device=torch.device("cuda", key)), 0]
+    v = ent[0][ent[1]][:n]
     ent[1] += 1
     return v
 
@@ -714,26 +715,32 @@ def amax_value(a):
     return float(a.max())
 
 
-def pack_sf16(w_oihw, dgrad=False, wscale=None):
+def pack_sf16(w_oihw, dgrad=False, wscale=None, both=False):
     """OIHW fp32 weights -> (split-f16 operand [hi, lo planes], wscale[65] = (64 amax slots, power-of-two scale) on the
-    device).  wscale given: the amax pass is skipped (the second layout of a weight whose amax is already known)."""
+    device).  wscale given: the amax pass is skipped (the second layout of a weight whose amax is already known).
+    both: ONE launch writes the forward and the dgrad layout; returns ((fwd, wscale), (dgrad, wscale))."""
     Cout, Cin = w_oihw.shape[0], w_oihw.shape[1]
-    wp = torch.empty((_lib.lib().sed_conv_sf16_pack_halfs(Cin, Cout),), dtype=torch.float16, device=w_oihw.device)
+    halfs = _lib.lib().sed_conv_sf16_pack_halfs(Cin, Cout)
+    wp = torch.empty((2 * halfs if both else halfs,), dtype=torch.float16, device=w_oihw.device)
     have = wscale is not None
     if not have:
-        wscale = torch.zeros((AMAX_SLOTS + 1,), dtype=torch.float32, device=w_oihw.device)
-    _call("sed_pack_conv_weights_sf16", _ptr(_f32c(w_oihw)), Cout, Cin, (1 if dgrad else 0) | (2 if have else 0), _ptr(wscale),
-          _ptr(wp), _stream())
+        wscale = _amax_buf(w_oihw.device, AMAX_SLOTS + 1)
+    _call("sed_pack_conv_weights_sf16", _ptr(_f32c(w_oihw)), Cout, Cin, (4 if both else (1 if dgrad else 0)) | (2 if have else 0),
+          _ptr(wscale), _ptr(wp), _stream())
+    if both:
+        return (wp[:halfs], wscale), (wp[halfs:], wscale)
     return wp, wscale
 
 
 def sf16_packs(w, want_dgrad):
     """(forward pack, dgrad pack or None) of a conv weight, cached per parameter object and parameter state (the same
     stamp as the other derived weight operands: storage address, version counter, optimiser generation): one amax pass
-    and the packs per optimiser step instead of one of each per use; static weights (inference) are packed once."""
+    and ONE pack launch per weight and optimiser step instead of one of each per use; static weights (inference) are
+    packed once."""
     def build():
-        fwd = pack_sf16(w, dgrad=False)
-        return [fwd, None]
+        if want_dgrad and w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0:
+            return list(pack_sf16(w, both=True))
+        return [pack_sf16(w, dgrad=False), None]
     ent = _cached("sf16_packs", (w,), build)
     if want_dgrad and ent[1] is None:
         ent[1] = pack_sf16(w, dgrad=True, wscale=ent[0][1])

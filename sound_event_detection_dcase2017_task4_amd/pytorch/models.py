@@ -160,7 +160,7 @@ class ConvBlock(nn.Module):
                                               self.bn2.weight, self.bn2.bias, self.bn2.running_mean, self.bn2.running_var,
                                               self.training, pool_size[0], pool_size[1], getattr(input, '_sed_amax', None))
         out._sed_amax = out_amax
-        if self.training:
+        if self.training and not getattr(self, '_defer_counters', False):
             self.bn1.num_batches_tracked += 1
             self.bn2.num_batches_tracked += 1
         return out
@@ -256,6 +256,8 @@ class _Cnn9Base(nn.Module):
         self.conv_block4 = ConvBlock(in_channels=256, out_channels=512)
         self._tables = None
         self._tables_key = None
+        for blk in (self.conv_block1, self.conv_block2, self.conv_block3, self.conv_block4):
+            blk._defer_counters = True          # the trunk bumps all nine num_batches_tracked in ONE launch
 
     # -- front-end tables: rebuilt when the frozen parameters move device or are reloaded
     def _frontend(self):
@@ -288,8 +290,9 @@ class _Cnn9Base(nn.Module):
             stripes = None
         x = ops.Bn0AugMix.apply(lm, self.bn0.weight, self.bn0.bias, self.bn0.running_mean, self.bn0.running_var,
                                 self.training, stripes, lam)
-        if self.training:
-            self.bn0.num_batches_tracked += 1
+        if self.training:                                                # nn.BatchNorm2d bookkeeping: one foreach launch
+            torch._foreach_add_([self.bn0.num_batches_tracked] + [bn.num_batches_tracked for blk in (
+                self.conv_block1, self.conv_block2, self.conv_block3, self.conv_block4) for bn in (blk.bn1, blk.bn2)], 1)
         x = x.view(x.shape[0], T, M, 1)                                  # NHWC, C = 1
         x = self.conv_block1(x, pool_size=(2, 2), pool_type='avg')
         x = self.conv_block2(x, pool_size=(2, 2), pool_type='avg')
