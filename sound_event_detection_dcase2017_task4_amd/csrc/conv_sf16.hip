@@ -54,6 +54,17 @@ struct Sf16P {
 };
 
 __device__ __forceinline__ int sf_sw(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 3) & 1)) << 4); }
+// Patch (A) rows.  A ds_read_b128 is served in groups of 16 lanes -- pixels {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} of a
+// 32-pixel MFMA block -- and is conflict-free when their 16-byte pieces fall on 16 different slots of a 256-byte bank row:
+// every LDS row index mod 8 exactly twice, the two in different halves (the XOR key).  With W >= 32 the 32 pixels are
+// consecutive LDS rows and key = (row >> 3) & 1 does that for any tap shift.  With W = 16 a block is two image rows and
+// with W = 8 four, WP = W + 2 LDS rows apart: the pairs sharing a row index mod 8 then sit in image rows of different
+// parity, so the key is the PATCH ROW's parity, and W = 8 needs a row pitch = 4 (mod 8) -- 12 instead of 10 -- for the
+// "exactly twice" part.  (Round 2 used (row >> 3) & 1 everywhere: 47 % of the LDS cycles of the W = 8 layers were bank
+// conflicts, profiles/r03.)
+__device__ __forceinline__ int sf_swA(int rr, int f, int chunk, bool rowkey) {
+    return f * 32 + ((chunk ^ ((rowkey ? rr : (f >> 3)) & 1)) << 4);
+}
 
 __device__ __forceinline__ int xcd_remap_sf(int bid, int nblk) {
     int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
@@ -85,7 +96,7 @@ __device__ __forceinline__ void sf_split2(float a, float b, unsigned& hi, unsign
 template <int MW, bool INT, int EPI>
 __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p) {
     constexpr int NW = 4 / MW, BN = 64 * NW, RB = BN / 32;
-    constexpr int AROWS = MW == 2 ? 264 : 396;         // >= (TR+2) * (W+2)
+    constexpr int AROWS = MW == 2 ? 264 : 408;         // >= (TR+2) * WP over the supported W (W = 8: 34 * 12)
     constexpr int APLANE = AROWS * 32;
     constexpr int BPLANE = 3 * BN * 32, BSTAGE = 2 * BPLANE;
     constexpr int NI = MW == 2 ? 4 : 6;                // staging items per thread
@@ -102,7 +113,8 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
     const int n0 = (logical % nb) * BN;
     const int t = logical / nb;
     const int b = t / p.ntile, tile = t % p.ntile;
-    const int W = p.W, logW = p.logW, TR = p.TR, WP = W + 2;
+    const int W = p.W, logW = p.logW, TR = p.TR, WP = W == 8 ? 12 : W + 2;
+    const bool rowkey = W < 32;
     const int h0 = tile * TR;
     const int KT = p.K >> 4;
 
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
         val##i = rr < TR + 2;                                                                                   \
         sok##i = val##i && (unsigned)h < (unsigned)p.H;                                                         \
         const int ridx = rr * WP + c + 1;                                                                       \
-        lso##i = sf_sw(ridx, q4 >> 1) + (q4 & 1) * 8;                                                           \
+        lso##i = sf_swA(rr, ridx, q4 >> 1, rowkey) + (q4 & 1) * 8;                                              \
         aoff##i = sok##i ? ((h * W + c) * p.K + q4 * 4) * 4 : OOB;                                              \
     }
     SF_META(0) SF_META(1) SF_META(2) SF_META(3) SF_META(4) SF_META(5)
@@ -193,7 +205,7 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
     for (int i = tid; i < (TR + 2) * 8; i += 256) {
         const int rr = i >> 3, side = (i >> 2) & 1, pl = (i >> 1) & 1, ch = i & 1;
         const int ridx = rr * WP + (side ? W + 1 : 0);
-        *reinterpret_cast<float4*>(As + pl * APLANE + sf_sw(ridx, ch)) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(As + pl * APLANE + sf_swA(rr, ridx, ch, rowkey)) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (INT) {      // patch rows outside the image (first / last tile): zero, once -- the staging skips them
 #define SF_AZERO(i)                                                                                             \
@@ -218,7 +230,7 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
         const int pix = 64 * wm + 32 * mb + (lane & 31);
         const int r = pix >> logW, c = pix & (W - 1);
 #pragma unroll
-        for (int tp = 0; tp < 9; ++tp) aoffs[mb][tp] = sf_sw((r + tp / 3) * WP + c + tp % 3, kh);
+        for (int tp = 0; tp < 9; ++tp) aoffs[mb][tp] = sf_swA(r + tp / 3, (r + tp / 3) * WP + c + tp % 3, kh, rowkey);
     }
 #pragma unroll
     for (int nk = 0; nk < 2; ++nk) {
@@ -597,11 +609,17 @@ template <int LOGW, bool INT>
 __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
     constexpr int W = 1 << LOGW, TRS = 64 >> LOGW, WP = W + 2;
     constexpr int RING = TRS <= 2 ? 4 : (TRS == 4 ? 8 : 16);
-    constexpr int XPL = ((RING * WP * 32 + 255) / 256) * 256 + 128;      // plane stride: = 128 (mod 256)
-    constexpr int GPL = 64 * 32 + 128;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * XPL + 8 * GPL];
-    unsigned char* const Xs = smem;                 // planes (cb 0, hi), (cb 1, hi), (cb 0, lo), (cb 1, lo)
-    unsigned char* const Gs = smem + 4 * XPL;       // planes cb 0..3 hi, cb 0..3 lo
+    // LDS images (round 3: conflict-free for the STORES too -- the per-channel-block planes of round 2, 128 B (mod 256)
+    // apart for the transpose reads, put the 16 lanes of a ds_write_b64 group 2-way (x) / 4-way (gy) on the same banks:
+    // 35 % of the LDS cycles were conflicts).  x: one 64-byte row per pixel = its two 16-channel blocks side by side;
+    // gy: one 128-byte row per pixel = its four blocks, block index XOR (pixel & 2): a 16-lane store group writes one
+    // contiguous row (pair), and a transpose read -- 4 consecutive pixels x 32 B of one block per 16 lanes, the
+    // neighbouring block in the other 16 -- still covers all 64 banks exactly once.
+    constexpr int XPL = RING * WP * 64;             // x plane (hi); lo follows
+    constexpr int GPL = 64 * 128;                   // gy plane (hi); lo follows
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * XPL + 2 * GPL];
+    unsigned char* const Xs = smem;
+    unsigned char* const Gs = smem + 2 * XPL;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -647,7 +665,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
     for (int i = 0; i < 4; ++i) {
         const int pe = (tid + 256 * i) >> 4;
         grr[i] = pe >> LOGW;
-        gls[i] = (gq >> 2) * GPL + pe * 32 + (gq & 3) * 8;
+        gls[i] = pe * 128 + (((gq >> 2) ^ (pe & 2)) << 5) + (gq & 3) * 8;
         goff[i] = ((grr[i] * W + (pe & (W - 1))) * p.N + co0 + gq * 4) * 4;
         greg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -678,9 +696,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
         sf_split2(v.z, v.w, h23, l23);                                                                          \
         if (INT && !xok[i]) { h01 = h23 = l01 = l23 = 0u; }    /* rows outside the image: the ring slot gets zeros */ \
         const int slot = ((ROW0) + xrr[i] + 1) & (RING - 1);                                                    \
-        const int o = (xq >> 2) * XPL + (slot * WP + xcc[i] + 1) * 32 + (xq & 3) * 8;                           \
+        const int o = (slot * WP + xcc[i] + 1) * 64 + xq * 8;                                                   \
         *reinterpret_cast<uint2*>(Xs + o) = make_uint2(h01, h23);                                               \
-        *reinterpret_cast<uint2*>(Xs + 2 * XPL + o) = make_uint2(l01, l23);                                     \
+        *reinterpret_cast<uint2*>(Xs + XPL + o) = make_uint2(l01, l23);                                         \
     }
 #define WSF_GLOAD(H0)                                                                                           \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
@@ -694,20 +712,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
         sf_split2(v.x, v.y, h01, l01);                                                                          \
         sf_split2(v.z, v.w, h23, l23);                                                                          \
         *reinterpret_cast<uint2*>(Gs + gls[i]) = make_uint2(h01, h23);                                          \
-        *reinterpret_cast<uint2*>(Gs + 4 * GPL + gls[i]) = make_uint2(l01, l23);                                \
+        *reinterpret_cast<uint2*>(Gs + GPL + gls[i]) = make_uint2(l01, l23);                                    \
     }
 
-    // halo columns of every ring row, all four x planes: zero once
-    for (int i = tid; i < RING * 2 * 4 * 2; i += 256) {
-        const int half = i & 1, pl = (i >> 1) & 3, side = (i >> 3) & 1, slot = i >> 4;
-        *reinterpret_cast<float4*>(Xs + pl * XPL + (slot * WP + (side ? W + 1 : 0)) * 32 + half * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+    // halo columns of every ring row, both x planes: zero once
+    for (int i = tid; i < RING * 2 * 2 * 4; i += 256) {
+        const int piece = i & 3, pl = (i >> 2) & 1, side = (i >> 3) & 1, slot = i >> 4;
+        *reinterpret_cast<float4*>(Xs + pl * XPL + (slot * WP + (side ? W + 1 : 0)) * 64 + piece * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
     // ---- fragment addressing (lane-static parts)
     const int g16 = lane >> 4, cbl = g16 & 1, khalf = g16 >> 1, r4 = (lane >> 2) & 3, ch = lane & 3;
-    const int a_base = (2 * wc + cbl) * GPL + (8 * khalf + r4) * 32 + ch * 8;      // + ks*512 + rd*128 (+ 4*GPL: lo)
+    const int a_base = (8 * khalf + r4) * 128 + (((2 * wc + cbl) ^ (r4 & 2)) << 5) + ch * 8;   // + ks*2048 + rd*512 (+ GPL: lo)
     const int pin = 8 * khalf + r4;                                                // pixel within the k-step (rd adds 4)
-    const int b_lane = cbl * XPL + ch * 8;
+    const int b_lane = cbl * 32 + ch * 8;
 
     floatx16 acc[9];
 #pragma unroll
@@ -736,9 +754,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
                 const int ks = 2 * wk + kk;                // wave-uniform (wk scalar)
                 half8 ah, al;
                 {
-                    const unsigned char* ap = Gs + a_base + ks * 512;
-                    const half4 h0v = sf_tr_read(ap), h1v = sf_tr_read(ap + 128);
-                    const half4 l0v = sf_tr_read(ap + 4 * GPL), l1v = sf_tr_read(ap + 4 * GPL + 128);
+                    const unsigned char* ap = Gs + a_base + ks * 2048;
+                    const half4 h0v = sf_tr_read(ap), h1v = sf_tr_read(ap + 512);
+                    const half4 l0v = sf_tr_read(ap + GPL), l1v = sf_tr_read(ap + GPL + 512);
                     ah = half8{h0v[0], h0v[1], h0v[2], h0v[3], h1v[0], h1v[1], h1v[2], h1v[3]};
                     al = half8{l0v[0], l0v[1], l0v[2], l0v[3], l1v[0], l1v[1], l1v[2], l1v[3]};
                 }
@@ -747,11 +765,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
                     const int slot = (h0 + row_s + dy) & (RING - 1);
-                    const unsigned char* bp = Xs + b_lane + (slot * WP + col) * 32;
+                    const unsigned char* bp = Xs + b_lane + (slot * WP + col) * 64;
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx) {
-                        const half4 h0v = sf_tr_read(bp + dx * 32), h1v = sf_tr_read(bp + dx * 32 + 128);
-                        const half4 l0v = sf_tr_read(bp + 2 * XPL + dx * 32), l1v = sf_tr_read(bp + 2 * XPL + dx * 32 + 128);
+                        const half4 h0v = sf_tr_read(bp + dx * 64), h1v = sf_tr_read(bp + dx * 64 + 256);
+                        const half4 l0v = sf_tr_read(bp + XPL + dx * 64), l1v = sf_tr_read(bp + XPL + dx * 64 + 256);
                         const half8 bh = {h0v[0], h0v[1], h0v[2], h0v[3], h1v[0], h1v[1], h1v[2], h1v[3]};
                         const half8 bl = {l0v[0], l0v[1], l0v[2], l0v[3], l1v[0], l1v[1], l1v[2], l1v[3]};
                         const int tp = dy * 3 + dx;
