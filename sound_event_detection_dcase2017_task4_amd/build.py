@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsed_hip.so")
 SOURCES = ["logmel.hip", "bn.hip", "conv.hip", "conv_wino.hip", "conv_wino2.hip", "conv_sf16.hip", "heads.hip", "attention.hip", "gru.hip"]
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-I", INCLUDE]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-I", INCLUDE] + os.environ.get("SED_HIPCC_FLAGS", "").split()   # SED_HIPCC_FLAGS: kernel experiments (-DSF_ABL_*, ...)
 
 
 def _stale(target, deps):

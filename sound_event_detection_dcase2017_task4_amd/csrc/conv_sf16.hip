@@ -266,6 +266,57 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
             const unsigned char* const Bst = Bs + st * BSTAGE;
             // (requesting the fragments of tap dx+1 before the MFMAs of tap dx -- two register sets -- measured +-1 %: the
             // second wave of the SIMD already hides the LDS latency; one set keeps the kernel at 3 waves per SIMD for MW = 4)
+#ifdef SF_PIPE  // experiment kept for the record (round 3): 8.62 ms vs 8.62 ms over the seven layers at B = 128 -- NO gain: with
+            // three waves per SIMD the co-resident waves already cover a wave's LDS latency (and the fused-input variants spill
+            // 18 registers at the 168-VGPR budget).  PMC: the MFMA pipe is busy 72-77 % of the cycles at the ~1.75 GHz the
+            // part sustains under this load; what is left is barrier / staging / tail time, not fragment latency.
+            // Software-pipelined fragment reads within a stage (3 taps): every operand is requested one MFMA phase (4 MFMAs
+            // = 128 pipe cycles) before its first use, into the registers its predecessor has just vacated -- al after
+            // phase 1, bl (and the next bh, the one double-buffered operand) after phase 2, ah after phase 3 -- so only the
+            // first tap of a stage waits for LDS with nothing to issue.
+            {
+#define SF_LD_A(dst, plane, DX) _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) dst[mb] = *reinterpret_cast<const half8*>(As + (plane) + aoffs[mb][dy * 3 + (DX)]);
+#define SF_LD_B(dst, plane, DX) _Pragma("unroll") for (int nk = 0; nk < 2; ++nk) dst[nk] = *reinterpret_cast<const half8*>(Bst + (plane) + boffs[nk][(DX)]);
+#define SF_MM(A, B) _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) _Pragma("unroll") for (int nk = 0; nk < 2; ++nk) \
+                        acc[mb][nk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[mb], B[nk], acc[mb][nk], 0, 0, 0);
+                half8 ah[2], al[2], bl[2], bhA[2], bhB[2];
+                SF_LD_A(al, APLANE, 0) SF_LD_B(bhA, 0, 0) SF_LD_A(ah, 0, 0) SF_LD_B(bl, BPLANE, 0)
+                __builtin_amdgcn_sched_barrier(0);
+                // tap 0
+                SF_MM(al, bhA)
+                __builtin_amdgcn_sched_barrier(0);
+                SF_LD_A(al, APLANE, 1)
+                __builtin_amdgcn_sched_barrier(0);
+                SF_MM(ah, bl)
+                __builtin_amdgcn_sched_barrier(0);
+                SF_LD_B(bhB, 0, 1) SF_LD_B(bl, BPLANE, 1)
+                __builtin_amdgcn_sched_barrier(0);
+                SF_MM(ah, bhA)
+                __builtin_amdgcn_sched_barrier(0);
+                SF_LD_A(ah, 0, 1)
+                __builtin_amdgcn_sched_barrier(0);
+                // tap 1
+                SF_MM(al, bhB)
+                __builtin_amdgcn_sched_barrier(0);
+                SF_LD_A(al, APLANE, 2)
+                __builtin_amdgcn_sched_barrier(0);
+                SF_MM(ah, bl)
+                __builtin_amdgcn_sched_barrier(0);
+                SF_LD_B(bhA, 0, 2) SF_LD_B(bl, BPLANE, 2)
+                __builtin_amdgcn_sched_barrier(0);
+                SF_MM(ah, bhB)
+                __builtin_amdgcn_sched_barrier(0);
+                SF_LD_A(ah, 0, 2)
+                __builtin_amdgcn_sched_barrier(0);
+                // tap 2
+                SF_MM(al, bhA)
+                SF_MM(ah, bl)
+                SF_MM(ah, bhA)
+#undef SF_LD_A
+#undef SF_LD_B
+#undef SF_MM
+            }
+#else
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 half8 ah[2], al[2], bh[2], bl[2];
@@ -301,6 +352,7 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
                     for (int nk = 0; nk < 2; ++nk)
                         acc[mb][nk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bh[nk], acc[mb][nk], 0, 0, 0);
             }
+#endif
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
