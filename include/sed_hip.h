@@ -305,7 +305,10 @@ int sed_gru_seq_fwd(const float* gi, const float* w_hh_f, const float* w_hh_b, c
                     const float* b_hh_b, int B, int T, int Hd, float* hs, float* saves, float* out, float* ws,
                     int* err_host, sed_stream_t stream);
 int sed_gru_seq_bwd(const float* g_out, const float* wt_f, const float* wt_b, const float* hs, const float* saves,
-                    int B, int T, int Hd, float* dgi, float* dgh, float* ws, int* err_host, sed_stream_t stream);
+                    int B, int T, int Hd, float* dgi, float* dgh,
+                    float* dbias_parts /* nullable: [2 directions][ceil(B/32)][4: dr, dz, dn, dn*r][Hd] sums over time and the
+                                          32 rows of a block: db_ih = (dr, dz, dn), db_hh = (dr, dz, dn*r) summed over blocks */,
+                    float* ws, int* err_host, sed_stream_t stream);
 int sed_gru_set_spin_limit(long spins);
 int sed_debug_occupy(int blocks, int lds_bytes, long microseconds, sed_stream_t stream);
 

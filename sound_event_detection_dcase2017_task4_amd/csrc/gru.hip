@@ -205,6 +205,7 @@ struct GruSeqBwdP {
     const float* saves;        // [2][T][B][4H]
     float* dgi;                // [B][T][6H]
     float* dgh;                // [2][T][B][3H]
+    float* dbias;              // nullable: [2 directions][row blocks][4: dr, dz, dn, dn*r][H] sums over (t, the block's rows)
     int* flags;
     int B, T, ngroups;
     long spin_limit;
@@ -237,6 +238,9 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqBwdP p) {
     const int rowc = live ? row : B - 1;
     const int j = j0 + (lp & 31);
     float2 dhz = make_float2(0.f, 0.f);                // dh * z of the step processed before (the later time step)
+    // bias gradients (db_ih = column sums of dgi, db_hh = of dgh) accumulate here over the time steps: the two column-sum
+    // passes over dgi / dgh (0.44 ms per step at B = 256) disappear
+    float2 sb_r = make_float2(0.f, 0.f), sb_z = sb_r, sb_n = sb_r, sb_nr = sb_r;
 
     for (int k = T - 1, done = 0; k >= 0; --k, ++done) {
         const int t = d ? T - 1 - k : k;
@@ -310,8 +314,26 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqBwdP p) {
             st_coherent(gh_o, dr_pre);
             st_coherent(gh_o + GH, dz_pre);
             st_coherent(gh_o + 2 * GH, dn_r);
+            sb_r.x += dr_pre.x; sb_r.y += dr_pre.y; sb_z.x += dz_pre.x; sb_z.y += dz_pre.y;
+            sb_n.x += dn_pre.x; sb_n.y += dn_pre.y; sb_nr.x += dn_r.x; sb_nr.y += dn_r.y;
         }
         if (k > 0) group_arrive(counter);
+    }
+    if (p.dbias) {                                     // rows of the block: 16 r x 2 halves per hidden pair -> LDS -> 128 sums
+        __syncthreads();
+        float* o = red + tid * 8;
+        o[0] = sb_r.x; o[1] = sb_r.y; o[2] = sb_z.x; o[3] = sb_z.y; o[4] = sb_n.x; o[5] = sb_n.y; o[6] = sb_nr.x; o[7] = sb_nr.y;
+        __syncthreads();
+        if (tid < 128) {
+            const int kind = tid >> 5, jj = tid & 31;              // hidden unit j0 + jj lives in the threads with (q & 15) == jj / 2
+            float acc = 0.f;
+#pragma unroll 4
+            for (int rr = 0; rr < 16; ++rr)
+#pragma unroll
+                for (int half = 0; half < 2; ++half)
+                    acc += red[(rr * 32 + half * 16 + (jj >> 1)) * 8 + kind * 2 + (jj & 1)];
+            p.dbias[(((long)d * (p.ngroups >> 1) + (group >> 1)) * 4 + kind) * GH + j0 + jj] = acc;
+        }
     }
 }
 
@@ -397,12 +419,13 @@ SED_API int sed_gru_seq_fwd(const float* gi, const float* w_hh_f, const float* w
 
 // Whole backward recurrence in one launch (reverse processing order).
 SED_API int sed_gru_seq_bwd(const float* g_out, const float* wt_f, const float* wt_b, const float* hs, const float* saves,
-                            int B, int T, int Hd, float* dgi, float* dgh, float* ws, int* err_host, hipStream_t stream) {
+                            int B, int T, int Hd, float* dgi, float* dgh, float* dbias_parts, float* ws, int* err_host,
+                            hipStream_t stream) {
     const int ngroups = 2 * sed_cdiv(B, 32);
     if (B <= 0 || T <= 0 || Hd != GH || ngroups > GRU_MAX_GROUPS || ngroups * (GH / 32) > 256) return SED_EINVAL;
     hipError_t e = hipMemsetAsync(ws, 0, GRU_FLAG_INTS * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
-    GruSeqBwdP p{g_out, {wt_f, wt_b}, hs, saves, dgi, dgh, reinterpret_cast<int*>(ws), B, T, ngroups, g_spin_limit};
+    GruSeqBwdP p{g_out, {wt_f, wt_b}, hs, saves, dgi, dgh, dbias_parts, reinterpret_cast<int*>(ws), B, T, ngroups, g_spin_limit};
     hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(ngroups * (GH / 32)), dim3(512), 0, stream, p);
     SED_LAUNCH_CHECK();
     hipLaunchKernelGGL(gru_seq_check_kernel, dim3(256), dim3(256), 0, stream, reinterpret_cast<const int*>(ws), err_host, 2, dgi,

@@ -1309,10 +1309,13 @@ class GruFn(torch.autograd.Function):
         wt = _cached("gru_hh_t", (w_hh_f, w_hh_b), lambda: (                          # (H, 3H): dh = dgh x W_hh
             transpose_b(w_hh_f.view(1, 3 * Hd, Hd)).view(Hd, 3 * Hd), transpose_b(w_hh_b.view(1, 3 * Hd, Hd)).view(Hd, 3 * Hd)))
         fused = ctx.fused
+        dbp = None
         if fused:
             ws = torch.empty((_lib.lib().sed_gru_seq_ws_floats(),), dtype=torch.float32, device=dev)
+            nrb = (B + 31) // 32
+            dbp = torch.empty((2, nrb, 4 * Hd), dtype=torch.float32, device=dev)     # bias-gradient sums per row block
             _call("sed_gru_seq_bwd", _ptr(g_out), _ptr(wt[0]), _ptr(wt[1]), _ptr(hs), _ptr(saves), B, T, Hd,
-                  _ptr(dgi), _ptr(dgh), _ptr(ws), _ptr(_err_flag()), s)
+                  _ptr(dgi), _ptr(dgh), _ptr(dbp), _ptr(ws), _ptr(_err_flag()), s)
         direct = [torch.empty((2, B, Hd), dtype=torch.float32, device=dev) for _ in range(2)]   # ping-pong
         rec = [torch.empty((2, B, Hd), dtype=torch.float32, device=dev) for _ in range(2)]
         have = False
@@ -1339,14 +1342,22 @@ class GruFn(torch.autograd.Function):
                               out=_dst(sk[5], (3 * Hd, Hd), dev))
         else:
             dw_hh_f, dw_hh_b = _dst(sk[1], (3 * Hd, Hd), dev).zero_(), _dst(sk[5], (3 * Hd, Hd), dev).zero_()
-        db_hh_f = col_sums(dgh[0].view(T * B, 3 * Hd), out=_dst(sk[3], (3 * Hd,), dev))
-        db_hh_b = col_sums(dgh[1].view(T * B, 3 * Hd), out=_dst(sk[7], (3 * Hd,), dev))
         dgi2 = dgi.view(B * T, 6 * Hd)
+        if dbp is not None:
+            # the fused recurrence summed the bias gradients over (time, rows of a block) as it went: (dr, dz, dn, dn*r) per
+            # direction; db_ih = (dr, dz, dn), db_hh = (dr, dz, dn*r) -- no pass over dgi / dgh
+            sums = [col_sums(dbp[dd]) for dd in range(2)]                                # (4H,) each, over the row blocks
+            db_ih = torch.cat([sums[0][:3 * Hd], sums[1][:3 * Hd]])
+            db_hh_f = _put(sk[3], torch.cat([sums[0][:2 * Hd], sums[0][3 * Hd:]]))
+            db_hh_b = _put(sk[7], torch.cat([sums[1][:2 * Hd], sums[1][3 * Hd:]]))
+        else:
+            db_hh_f = _ret(sk[3], col_sums(dgh[0].view(T * B, 3 * Hd), out=_dst(sk[3], (3 * Hd,), dev)))
+            db_hh_b = _ret(sk[7], col_sums(dgh[1].view(T * B, 3 * Hd), out=_dst(sk[7], (3 * Hd,), dev)))
+            db_ih = col_sums(dgi2)
         gx = gemm_nt(dgi2, w_ih_t).view(B, T, I)
         dw_ih = gemm_tn(x.view(B * T, I), dgi2)                                          # (6H, I)
-        db_ih = col_sums(dgi2)
-        return (gx, _put(sk[0], dw_ih[:3 * Hd]), _ret(sk[1], dw_hh_f), _put(sk[2], db_ih[:3 * Hd]), _ret(sk[3], db_hh_f),
-                _put(sk[4], dw_ih[3 * Hd:]), _ret(sk[5], dw_hh_b), _put(sk[6], db_ih[3 * Hd:]), _ret(sk[7], db_hh_b))
+        return (gx, _put(sk[0], dw_ih[:3 * Hd]), _ret(sk[1], dw_hh_f), _put(sk[2], db_ih[:3 * Hd]), db_hh_f,
+                _put(sk[4], dw_ih[3 * Hd:]), _ret(sk[5], dw_hh_b), _put(sk[6], db_ih[3 * Hd:]), db_hh_b)
 
 
 class ClipBceFn(torch.autograd.Function):
