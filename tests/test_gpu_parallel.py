@@ -124,6 +124,12 @@ def _run_two_ranks(tmp_path, backend, mt, world=2):
     return gerr, perr
 
 
+# first in the file on purpose: a GPUTEST box with >= 2 GPUs reaches the one test that carries bytes over RCCL early
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL refuses two ranks on one device)")
+def test_two_ranks_rccl(tmp_path):
+    _run_two_ranks(tmp_path, "nccl", "Cnn_9layers_Gru_FrameAtt")
+
+
 @pytest.mark.parametrize("mt", ["Cnn_9layers_Gru_FrameAtt", "Cnn_9layers_FrameAvg"])
 def test_two_ranks_one_gpu_gloo(tmp_path, mt):
     _run_two_ranks(tmp_path, "gloo", mt)
@@ -132,11 +138,6 @@ def test_two_ranks_one_gpu_gloo(tmp_path, mt):
 def test_four_ranks_one_gpu_gloo(tmp_path):
     """world_size 4 (4 waveforms = 2 mixup pairs per rank): same contract."""
     _run_two_ranks(tmp_path, "gloo", "Cnn_9layers_FrameAvg", world=4)
-
-
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL refuses two ranks on one device)")
-def test_two_ranks_rccl(tmp_path):
-    _run_two_ranks(tmp_path, "nccl", "Cnn_9layers_Gru_FrameAtt")
 
 
 def test_bench_gpus_2_spawns_ranks_or_fails_loudly():

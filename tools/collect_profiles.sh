@@ -20,7 +20,7 @@ export SED_WGRAD_SIDE_STREAM=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_serial -o bench -- $B --steps 5 --warmup 2 > $OUT/bench_line_under_rocprofv3_main_stream_only.json 2> $OUT/stats_serial.err
 $B --steps 10 --warmup 3 --by_shape > $OUT/bench_line_steps10_warmup3.json 2> $OUT/by_shape.txt
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sqA SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_WAVES" "sqB SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" \
-            "sqC SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES" "sqD MfmaUtil"; do
+            "sqC SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES" "sqD MfmaUtil" "sqE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" "sqF GRBM_GUI_ACTIVE"; do
   set -- $pass; name=$1; shift
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_$name -o p -- $B --steps 1 --warmup 1 > /dev/null 2> $OUT/pmc_$name.err
 done
@@ -30,4 +30,10 @@ SED_WGRAD_SIDE_STREAM=0 $B --steps 20 --warmup 3 > $OUT/bench_line_main_stream_o
 rocprofv3 --kernel-trace --output-format csv -d $OUT/timeline -o t -- $B --steps 2 --warmup 1 > /dev/null 2> $OUT/timeline.err
 python $R/tools/timeline_overlap.py $OUT/timeline/t_kernel_trace.csv > $OUT/timeline_overlap_default_schedule.txt 2>&1
 rm -rf $OUT/timeline
+# the metric's own batch size (bs=32): serial kernel trace + per-step gap digest + by-shape table
+SED_WGRAD_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_b32 -o bench -- $B --batch_size 32 --steps 6 --warmup 3 > $OUT/bench_line_b32_under_rocprofv3_main_stream_only.json 2> $OUT/stats_b32.err
+python $R/tools/step_gaps.py $(find $OUT/stats_b32 -name "*kernel_trace.csv") 5 > $OUT/step_digest_b32_main_stream_only.txt 2>&1
+python $R/tools/step_gaps.py $(find $OUT/stats_serial -name "*kernel_trace.csv") 4 > $OUT/step_digest_b256_main_stream_only.txt 2>&1
+$B --batch_size 32 --steps 40 --warmup 5 --by_shape > $OUT/bench_line_b32.json 2> $OUT/by_shape_b32.txt
+find $OUT -name "*kernel_trace.csv" -size +30M -delete
 ls $OUT
