@@ -36,6 +36,10 @@ from sound_event_detection_dcase2017_task4_amd.utils.utilities import Mixup
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 F16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: dense f16/bf16 MFMA (v_mfma_f32_32x32x16_f16), the pipe the split-f16 kernels run on
+# What a BARE stream of that MFMA sustains on these boxes with RANDOM operands (tools/mfma_f16_ubench.hip, no memory traffic at
+# all; profiles/r03/mfma_f16_ubench.txt): the part clocks to its power budget and switching activity is data dependent --
+# 2.04-2.17 PF with smooth operands, 1.62-1.64 PF with random mantissas (what hi / lo halves of real activations are).
+F16_MFMA_SUSTAINED_RANDOM_TFLOPS = 1630.0
 HBM_PEAK_GBPS = 8000.0
 CTOR = (32000, 1024, 320, 64, 50, 14000, 17)
 
@@ -173,10 +177,24 @@ def kernel_report(timing, steps, B2, default_workload, by_shape=False, frames=10
                             % (what, executed_per_alg))
         roofline["executed_tflops"] = round(kern[dom]["tflops"] * executed_per_alg, 2)
         roofline["executed_frac"] = round(kern[dom]["tflops"] * executed_per_alg / peak, 4)
+        if peak == F16_MFMA_PEAK_TFLOPS:
+            roofline["sustained_peak_random_operands"] = F16_MFMA_SUSTAINED_RANDOM_TFLOPS
+            roofline["executed_frac_of_sustained"] = round(kern[dom]["tflops"] * executed_per_alg / F16_MFMA_SUSTAINED_RANDOM_TFLOPS, 4)
+            roofline["sustained_note"] = ("a bare v_mfma_f32_32x32x16_f16 stream with random operands sustains 1.62-1.64 PF on this part "
+                                          "(power-limited clock; 2.04-2.17 PF with smooth operands): profiles/r03/mfma_f16_ubench.txt, "
+                                          "tools/mfma_f16_ubench.hip -- `frac` / `executed_frac` stay relative to the 2.5 PF datasheet peak")
         if default_workload:
             roofline["traffic"], src = pmc_traffic(FAMILY_KERNELS.get(dom))
             if src:
                 roofline["traffic_source"] = src
+        busy = latest_profile("pmc_mfma_busy.json")
+        if busy:                                    # committed PMC evidence: share of GPU cycles the MFMA pipe is executing
+            for key, sub in FAMILY_KERNELS.items():
+                if key == dom:
+                    for fam, v in json.load(open(busy)).items():
+                        if any(fam.startswith(x.rstrip("_")) or x.rstrip("_") in fam for x in sub):
+                            roofline["mfma_pipe_busy_frac"] = [v["mfma_busy_frac_min"], v["mfma_busy_frac_max"]]
+                            roofline["mfma_pipe_busy_source"] = "%s (%s)" % (os.path.relpath(busy, REPO), v["definition"])
     # every MFMA kernel family of the step, same accounting (the dominant one above is the `roofline` object)
     for tag, v in kern.items():
         what, executed_per_alg, peak = NOTES.get(tag, ("fp32 MFMA implicit GEMM", 1.0, FP32_MFMA_PEAK_TFLOPS))

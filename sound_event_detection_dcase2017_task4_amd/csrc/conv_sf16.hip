@@ -317,11 +317,19 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
 #undef SF_MM
             }
 #else
+#ifdef SF_ABL_FRAGONCE     // timing experiment: fragments read for the first tap of a stage only, reused for the other two
+            half8 ah[2], al[2], bh[2], bl[2];   // (results wrong; the MFMAs still consume real data: separates LDS cost from DVFS)
+#endif
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
+#ifndef SF_ABL_FRAGONCE
                 half8 ah[2], al[2], bh[2], bl[2];
+#endif
 #ifdef SF_ABL_NOFRAG      // timing experiment: fragments never read (results wrong)
                 if (step < 0)
+#endif
+#ifdef SF_ABL_FRAGONCE
+                if (dx == 0)
 #endif
                 {
 #pragma unroll
