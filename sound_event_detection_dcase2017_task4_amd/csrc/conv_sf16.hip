@@ -809,6 +809,48 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
             if (more) { WSF_XLOAD(h0 + TRS + 1) WSF_GLOAD(h0 + TRS) }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
+#ifdef WSF_PIPE  // experiment kept for the record (round 3): 9.43 ms vs 9.36 ms over the seven layers at B = 128 -- NO gain.
+            // Software-pipelined fragment reads: a tap's four transpose reads (latency ~100+ cycles) sit in front of its three
+            // dependent MFMAs (96 cycles); here the x fragments of tap t+1 (and the gy fragments of the second k-step) are
+            // requested BEFORE the MFMAs of tap t, into a second set (no spills: 242-254 VGPRs).  That it changes nothing says
+            // the co-resident wave covers the latency; what bounds the kernel is the staging phase between the barriers
+            // (~150 VALU + 12 stores per stage and wave during which that wave issues no MFMA) and the clock.
+            {
+#define WSF_ALOAD(AH, AL, KK) {                                                                                  \
+                    const unsigned char* ap = Gs + a_base + (2 * wk + (KK)) * 2048;                              \
+                    const half4 h0v = sf_tr_read(ap), h1v = sf_tr_read(ap + 512);                                \
+                    const half4 l0v = sf_tr_read(ap + GPL), l1v = sf_tr_read(ap + GPL + 512);                    \
+                    AH = half8{h0v[0], h0v[1], h0v[2], h0v[3], h1v[0], h1v[1], h1v[2], h1v[3]};                  \
+                    AL = half8{l0v[0], l0v[1], l0v[2], l0v[3], l1v[0], l1v[1], l1v[2], l1v[3]}; }
+#define WSF_BLOAD(BH, BL, KK, DY, DX) {                                                                          \
+                    const int pix_ = (2 * wk + (KK)) * 16 + pin;                                                 \
+                    const int slot_ = (h0 + (pix_ >> LOGW) + (DY)) & (RING - 1);                                 \
+                    const unsigned char* bp = Xs + b_lane + (slot_ * WP + (pix_ & (W - 1))) * 64 + (DX) * 64;    \
+                    const half4 h0v = sf_tr_read(bp), h1v = sf_tr_read(bp + 256);                                \
+                    const half4 l0v = sf_tr_read(bp + XPL), l1v = sf_tr_read(bp + XPL + 256);                    \
+                    BH = half8{h0v[0], h0v[1], h0v[2], h0v[3], h1v[0], h1v[1], h1v[2], h1v[3]};                  \
+                    BL = half8{l0v[0], l0v[1], l0v[2], l0v[3], l1v[0], l1v[1], l1v[2], l1v[3]}; }
+                half8 ah[2], al[2], bh[2], bl[2];
+                WSF_ALOAD(ah[0], al[0], 0)
+                WSF_BLOAD(bh[0], bl[0], 0, 0, 0)
+#pragma unroll
+                for (int t = 0; t < 18; ++t) {
+                    const int kk = t / 9, tp = t % 9;
+                    if (t + 1 < 18) {                                   // next tap's operands first
+                        const int tn = t + 1, kkn = tn / 9, tpn = tn % 9;
+                        if (tn == 9) WSF_ALOAD(ah[1], al[1], 1)
+                        WSF_BLOAD(bh[tn & 1], bl[tn & 1], kkn, tpn / 3, tpn % 3)
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kk], bh[t & 1], acc[tp], 0, 0, 0);
+                    acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], bl[t & 1], acc[tp], 0, 0, 0);
+                    acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], bh[t & 1], acc[tp], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#undef WSF_ALOAD
+#undef WSF_BLOAD
+            }
+#else
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int ks = 2 * wk + kk;                // wave-uniform (wk scalar)
@@ -839,6 +881,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
                     }
                 }
             }
+#endif
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
