@@ -248,7 +248,7 @@ class Workload(object):
                 out = self.model(wave, None)
             return out["clipwise_output"].sum()
         if self.mix:
-            lam = torch.from_numpy(self.mixup.get_lambda(self.B2).astype(np.float32)).to(self.dev, non_blocking=True)
+            lam = ops.upload_small(self.mixup.get_lambda(self.B2), self.dev, torch.float32)   # pinned staging, async
             out = self.model(wave, lam)
             tgt = do_mixup(target, lam)
         else:
@@ -357,6 +357,8 @@ def main():
     ap.add_argument("--no_extra", action="store_true", help="skip the extra_configs runs (other BASELINE.json configurations)")
     ap.add_argument("--int16", action="store_true", help="feed int16 waveforms (the HDF5 storage dtype)")
     ap.add_argument("--by_shape", action="store_true", help="print a per-layer MFMA kernel table to stderr")
+    ap.add_argument("--no_kernel_events", action="store_true",
+                    help="diagnostic: no HIP event pairs around the MFMA kernel launches in the timed region (roofline = null)")
     ap.add_argument("--cpu_threads", type=int, default=0)
     ap.add_argument("--inference", action="store_true",
                     help="secondary metric (SURVEY.md 8d): eval-mode forward only, clips/s over --batch_size waveforms per step")
@@ -384,7 +386,7 @@ def main():
                   h2d=args.h2d)
     B2 = wl.B2
     wl.opt.buckets.wait_events = []   # HIP events around the compute stream's wait for the gradient all-reduces
-    dt, loss, timing = wl.run(args.steps, args.warmup, timing=True)
+    dt, loss, timing = wl.run(args.steps, args.warmup, timing=not args.no_kernel_events)
     bucket_order = list(wl.opt.buckets.last_issue_order)
     waits = wl.opt.buckets.wait_events[-args.steps:]
     dist_info = {"backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,

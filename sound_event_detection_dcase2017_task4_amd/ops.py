@@ -143,6 +143,34 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+# Small per-step host arrays (mixup lambdas, SpecAugment stripe tables) go up through a ring of PINNED staging buffers with a
+# truly asynchronous copy.  `tensor.to(device)` from pageable memory blocks the host until the copy has run, i.e. until the
+# GPU has drained everything enqueued before it: once per step the CPU lost its lead and the GPU idled while the first
+# kernels of the next step were being launched (~0.3 ms of a 9 ms step at batch 32).
+_PIN_RING = {}
+
+
+def upload_small(arr, device, dtype=torch.float32, slots=8):
+    a = torch.as_tensor(np.ascontiguousarray(arr)).to(dtype).contiguous()            # host tensor (cheap: <= a few KB)
+    dev = torch.device(device)
+    key = (dev.index, dtype, a.numel())
+    ring = _PIN_RING.get(key)
+    if ring is None:
+        ring = _PIN_RING[key] = {"i": 0, "buf": [torch.empty((a.numel(),), dtype=dtype).pin_memory() for _ in range(slots)],
+                                 "ev": [None] * slots}
+    k = ring["i"] % slots
+    ring["i"] += 1
+    if ring["ev"][k] is not None:
+        ring["ev"][k].synchronize()                  # the copy that last used this slot (8 uploads ago) is long done
+    ring["buf"][k].copy_(a.view(-1))
+    out = torch.empty(a.shape, dtype=dtype, device=dev)
+    out.view(-1).copy_(ring["buf"][k], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    ring["ev"][k] = ev
+    return out
+
+
 def _stream():
     st = _STREAM_OVERRIDE if _STREAM_OVERRIDE is not None else torch.cuda.current_stream()
     return ctypes.c_void_p(st.cuda_stream)

@@ -166,7 +166,8 @@ def train(args):
         # of this rank: the stripes do not depend on the number of ranks
         stripes = draw_specaug_stripes(rows_global, wave.shape[1] // hop_size + 1, mel_bins)[row_lo:row_hi]
         model.train()
-        lam = move_data_to_device(batch_data_dict['mixup_lambda'], device) if mix else None
+        # (move_data_to_device's pageable copy would block the host until the GPU has drained: pinned staging instead)
+        lam = ops.upload_small(batch_data_dict['mixup_lambda'], device, torch.float32) if mix else None
 
         def one_step():
             batch_output_dict = model(wave, lam, specaug_stripes=stripes)

@@ -283,7 +283,9 @@ class _Cnn9Base(nn.Module):
         if self.training:
             if stripes is None:
                 stripes = self.spec_augmenter.draw(B2, T, M)
-            stripes = torch.as_tensor(np.ascontiguousarray(stripes), dtype=torch.int32).to(lm.device, non_blocking=True)
+            if not (torch.is_tensor(stripes) and stripes.is_cuda):
+                stripes = ops.upload_small(stripes, lm.device, torch.int32)      # pinned staging: the host never waits for the GPU
+            stripes = stripes.to(device=lm.device, dtype=torch.int32).contiguous()
             if mixup_lambda is not None:
                 lam = mixup_lambda.to(device=lm.device, dtype=torch.float32).contiguous()
         else:
