@@ -99,6 +99,17 @@ int sed_bn_relu_pool_fwd(const float* y, int B, int H, int W, int C, int ph, int
 int sed_bn_relu_pool_fwd_cnt(const float* y, int B, int H, int W, int C, int ph, int pw, const float* scale,
                              const float* shift, float* out, unsigned char* cnt, float* amax_out /* nullable */,
                              sed_stream_t stream);
+/* The same three stages for ANY pool_type of ConvBlock.forward (models.py:104-111): pool_mode 0 = 'avg' (what every model
+ * selects; identical to the entry points above), 1 = 'max' (F.max_pool2d: the gradient goes to the first maximum of a
+ * window), 2 = 'avg+max'. */
+int sed_bn_relu_pool_fwd_mode(const float* y, int B, int H, int W, int C, int ph, int pw, int pool_mode, const float* scale,
+                              const float* shift, float* out, float* amax_out, sed_stream_t stream);
+int sed_bn_relu_pool_bwd_reduce_mode(const float* y, const float* g_out, int B, int H, int W, int C, int ph, int pw,
+                                     int pool_mode, const float* scale, const float* shift, const float* mean,
+                                     const float* invstd, float* partials, int* nparts_out, sed_stream_t stream);
+int sed_bn_relu_pool_bwd_apply_mode(const float* y, const float* g_out, int B, int H, int W, int C, int ph, int pw,
+                                    int pool_mode, const float* scale, const float* shift, const float* coef, float* gy,
+                                    float* amax_out, sed_stream_t stream);
 /* amax of a = relu(scale*y + shift) -- the operand `conv2` of a ConvBlock (models.py:102-103) consumes without it ever
  * being materialised -- for the split-f16 scale of that convolution.  sed_act_amax: from per-part per-channel (max, min)
  * of y, minmax [nparts][2][C], which sed_conv1_fwd / sed_conv3x3_sf16 leave beside their statistics (the affine + ReLU

@@ -122,11 +122,17 @@ def _bn(x, st, prefix, training, track):
     return y
 
 
-def conv_block(x, st, prefix, pool, training, track):
-    """models.py:99-115 with pool_type='avg'."""
+def conv_block(x, st, prefix, pool, training, track, pool_type="avg"):
+    """models.py:99-115 (pool_type 'avg' is what every model selects; 'max' / 'avg+max': :104-111)."""
     x = F.relu(_bn(F.conv2d(x, st[prefix + ".conv1.weight"], padding=1), st, prefix + ".bn1", training, track))
     x = F.relu(_bn(F.conv2d(x, st[prefix + ".conv2.weight"], padding=1), st, prefix + ".bn2", training, track))
-    return F.avg_pool2d(x, kernel_size=pool)
+    if pool_type == "max":
+        return F.max_pool2d(x, kernel_size=pool)
+    if pool_type == "avg":
+        return F.avg_pool2d(x, kernel_size=pool)
+    if pool_type == "avg+max":
+        return F.avg_pool2d(x, kernel_size=pool) + F.max_pool2d(x, kernel_size=pool)
+    raise Exception("Incorrect argument!")
 
 
 def gru_bidir(x, st):

@@ -264,7 +264,8 @@ __device__ __forceinline__ bool any_small_gamma(const float* __restrict__ gamma,
 // CNT: also write, per pooled element, how many of its ph*pw inputs passed the ReLU (one byte per channel, packed 4 to a
 // word like the float4 lanes) -- with the pooled output itself that is all backward pass 1 needs (see
 // pool_bwd_reduce_win_kernel).
-template <bool CNT>
+// MODE: 0 = avg_pool2d (every model of the reference), 1 = max_pool2d, 2 = avg + max (models.py:104-111).
+template <bool CNT, int MODE = 0>
 __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __restrict__ y, int B, int H, int W, int C,
                                                                int ph, int pw, const float* __restrict__ scale,
                                                                const float* __restrict__ shift,
@@ -282,19 +283,23 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __re
         int ho = (int)(q % Ho);
         int b = (int)(q / Ho);
         float4 sc = reinterpret_cast<const float4*>(scale)[c4], sh = reinterpret_cast<const float4*>(shift)[c4];
-        float4 acc = make_float4(0, 0, 0, 0);
+        float4 acc = make_float4(0, 0, 0, 0), mx = make_float4(0, 0, 0, 0);       // relu(.) >= 0: 0 is the identity of max
         unsigned n4 = 0;
         for (int dh = 0; dh < ph; ++dh)
             for (int dw = 0; dw < pw; ++dw) {
                 long src = (((long)b * H + ho * ph + dh) * W + wo * pw + dw) * c4n + c4;
                 float4 v = reinterpret_cast<const float4*>(y)[src];
-                acc.x += bn_relu(v.x, sc.x, sh.x); acc.y += bn_relu(v.y, sc.y, sh.y);
-                acc.z += bn_relu(v.z, sc.z, sh.z); acc.w += bn_relu(v.w, sc.w, sh.w);
+                const float4 a = make_float4(bn_relu(v.x, sc.x, sh.x), bn_relu(v.y, sc.y, sh.y), bn_relu(v.z, sc.z, sh.z),
+                                             bn_relu(v.w, sc.w, sh.w));
+                acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+                if (MODE != 0) { mx.x = fmaxf(mx.x, a.x); mx.y = fmaxf(mx.y, a.y); mx.z = fmaxf(mx.z, a.z); mx.w = fmaxf(mx.w, a.w); }
                 if (CNT)
                     n4 += (bn_relu_active(v.x, sc.x, sh.x) ? 1u : 0u) + (bn_relu_active(v.y, sc.y, sh.y) ? 0x100u : 0u) +
                           (bn_relu_active(v.z, sc.z, sh.z) ? 0x10000u : 0u) + (bn_relu_active(v.w, sc.w, sh.w) ? 0x1000000u : 0u);
             }
-        const float4 o = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+        float4 o = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+        if (MODE == 1) o = mx;
+        if (MODE == 2) { o.x += mx.x; o.y += mx.y; o.z += mx.z; o.w += mx.w; }
         reinterpret_cast<float4*>(out)[i] = o;
         amax = fmaxf(fmaxf(amax, fmaxf(o.x, o.y)), fmaxf(o.z, o.w));          // o >= 0
         if (CNT) cnt4[i] = n4;
@@ -352,7 +357,9 @@ __global__ __launch_bounds__(256) void act_amax_full_kernel(const float* __restr
 // backward pass 1 / pass 2 of the same stage.  dy = g_out[pooled pos]/(ph*pw) * relu-mask (0 on dropped rows).
 // PASS 1: per-block partial sums (sum dy, sum dy*xhat) -> partials[nblk][2][C]
 // PASS 2: g_y = a*dy + b*y + c  -> gy [B][H][W][C]
-template <int PASS>
+// MODE (0 avg / 1 max / 2 avg + max): what reaches an input element from the pooled gradient g: g/n (avg), g if the element is the
+// FIRST maximum of its window in scan order (torch's max_pool2d keeps the first of equal maxima), or both.
+template <int PASS, int MODE = 0>
 __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const float* __restrict__ y,
                                                                const float* __restrict__ gout, int B, int H, int W,
                                                                int C, int ph, int pw, const float* __restrict__ scale,
@@ -392,11 +399,31 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const float* __re
         float4 v = reinterpret_cast<const float4*>(y)[r * c4n + c4];
         float4 g = make_float4(0, 0, 0, 0);
         if (ho < Ho && wo < Wo) g = reinterpret_cast<const float4*>(gout)[(((long)b * Ho + ho) * Wo + wo) * c4n + c4];
+        float4 wgt = make_float4(inv, inv, inv, inv);       // share of the pooled gradient this element receives
+        if (MODE != 0 && ho < Ho && wo < Wo) {
+            const float4 self = make_float4(bn_relu(v.x, sc.x, sh.x), bn_relu(v.y, sc.y, sh.y), bn_relu(v.z, sc.z, sh.z),
+                                            bn_relu(v.w, sc.w, sh.w));
+            // first maximum of the window: no earlier element (scan order) is >= self, no later element is > self
+            bool fx = true, fy = true, fz = true, fw = true;
+            const int my = (h - ho * ph) * pw + (w - wo * pw);
+            for (int dh = 0; dh < ph; ++dh)
+                for (int dw = 0; dw < pw; ++dw) {
+                    const int k = dh * pw + dw;
+                    if (k == my) continue;
+                    const float4 u = reinterpret_cast<const float4*>(y)[(((long)b * H + ho * ph + dh) * W + wo * pw + dw) * c4n + c4];
+                    const float4 a = make_float4(bn_relu(u.x, sc.x, sh.x), bn_relu(u.y, sc.y, sh.y), bn_relu(u.z, sc.z, sh.z),
+                                                 bn_relu(u.w, sc.w, sh.w));
+                    if (k < my) { fx &= a.x < self.x; fy &= a.y < self.y; fz &= a.z < self.z; fw &= a.w < self.w; }
+                    else { fx &= a.x <= self.x; fy &= a.y <= self.y; fz &= a.z <= self.z; fw &= a.w <= self.w; }
+                }
+            const float base = MODE == 2 ? inv : 0.f;
+            wgt = make_float4(base + (fx ? 1.f : 0.f), base + (fy ? 1.f : 0.f), base + (fz ? 1.f : 0.f), base + (fw ? 1.f : 0.f));
+        }
         float4 dy;
-        dy.x = bn_relu_active(v.x, sc.x, sh.x) ? g.x * inv : 0.f;
-        dy.y = bn_relu_active(v.y, sc.y, sh.y) ? g.y * inv : 0.f;
-        dy.z = bn_relu_active(v.z, sc.z, sh.z) ? g.z * inv : 0.f;
-        dy.w = bn_relu_active(v.w, sc.w, sh.w) ? g.w * inv : 0.f;
+        dy.x = bn_relu_active(v.x, sc.x, sh.x) ? g.x * wgt.x : 0.f;
+        dy.y = bn_relu_active(v.y, sc.y, sh.y) ? g.y * wgt.y : 0.f;
+        dy.z = bn_relu_active(v.z, sc.z, sh.z) ? g.z * wgt.z : 0.f;
+        dy.w = bn_relu_active(v.w, sc.w, sh.w) ? g.w * wgt.w : 0.f;
         if (PASS == 1) {
             sa.x += dy.x; sa.y += dy.y; sa.z += dy.z; sa.w += dy.w;
             sb.x = fmaf(dy.x, (v.x - mu.x) * is.x, sb.x); sb.y = fmaf(dy.y, (v.y - mu.y) * is.y, sb.y);
@@ -707,6 +734,68 @@ SED_API int sed_bn_relu_pool_bwd_apply(const float* y, const float* g_out, int B
     int nblk = sed_cdiv((long)B * H * W, rpb);
     hipLaunchKernelGGL(bn_relu_pool_bwd_kernel<2>, dim3(nblk), dim3(256), 0, stream, y, g_out, B, H, W, C, ph, pw, scale, shift,
                        (const float*)nullptr, (const float*)nullptr, coef, rpb, (float*)nullptr, gy, (const float*)nullptr, 0.f, amax_out);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- the same three stages for any pool_type of ConvBlock (models.py:104-111): pool_mode 0 = 'avg', 1 = 'max', 2 = 'avg+max'.
+// No model of the reference selects 1 or 2; they run the exact full-resolution backward pass 1 (the windowed shortcut is an
+// identity of the average) and re-read each element's window to find the first maximum.
+SED_API int sed_bn_relu_pool_fwd_mode(const float* y, int B, int H, int W, int C, int ph, int pw, int pool_mode, const float* scale,
+                                      const float* shift, float* out, float* amax_out, hipStream_t stream) {
+    if (pool_mode == 0) return sed_bn_relu_pool_fwd(y, B, H, W, C, ph, pw, scale, shift, out, amax_out, stream);
+    if (B <= 0 || (C & 3) || ph <= 0 || pw <= 0 || H / ph <= 0 || W / pw <= 0 || pool_mode < 0 || pool_mode > 2) return SED_EINVAL;
+    if (amax_out) {
+        hipError_t e = sed_amax_clear(amax_out, stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    long total = (long)B * (H / ph) * (W / pw) * (C / 4);
+    if (pool_mode == 1)
+        hipLaunchKernelGGL((bn_relu_pool_fwd_kernel<false, 1>), dim3(stream_grid(total)), dim3(256), 0, stream, y, B, H, W, C, ph, pw,
+                           scale, shift, out, (unsigned*)nullptr, amax_out);
+    else
+        hipLaunchKernelGGL((bn_relu_pool_fwd_kernel<false, 2>), dim3(stream_grid(total)), dim3(256), 0, stream, y, B, H, W, C, ph, pw,
+                           scale, shift, out, (unsigned*)nullptr, amax_out);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+SED_API int sed_bn_relu_pool_bwd_reduce_mode(const float* y, const float* g_out, int B, int H, int W, int C, int ph, int pw,
+                                             int pool_mode, const float* scale, const float* shift, const float* mean,
+                                             const float* invstd, float* partials, int* nparts_out, hipStream_t stream) {
+    if (pool_mode == 0)
+        return sed_bn_relu_pool_bwd_reduce(y, g_out, B, H, W, C, ph, pw, scale, shift, mean, invstd, partials, nparts_out, stream);
+    if (B <= 0 || C < 64 || C > 512 || (256 % (C / 4)) != 0 || pool_mode < 0 || pool_mode > 2) return SED_EINVAL;
+    const int rpb = sed_pool_bwd_rows_per_block((long)B * H * W);
+    int nblk = sed_cdiv((long)B * H * W, rpb);
+    if (pool_mode == 1)
+        hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<1, 1>), dim3(nblk), dim3(256), 0, stream, y, g_out, B, H, W, C, ph, pw, scale, shift,
+                           mean, invstd, (const float*)nullptr, rpb, partials, (float*)nullptr, (const float*)nullptr, 0.f, (float*)nullptr);
+    else
+        hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<1, 2>), dim3(nblk), dim3(256), 0, stream, y, g_out, B, H, W, C, ph, pw, scale, shift,
+                           mean, invstd, (const float*)nullptr, rpb, partials, (float*)nullptr, (const float*)nullptr, 0.f, (float*)nullptr);
+    if (nparts_out) *nparts_out = nblk;
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+SED_API int sed_bn_relu_pool_bwd_apply_mode(const float* y, const float* g_out, int B, int H, int W, int C, int ph, int pw,
+                                            int pool_mode, const float* scale, const float* shift, const float* coef, float* gy,
+                                            float* amax_out, hipStream_t stream) {
+    if (pool_mode == 0) return sed_bn_relu_pool_bwd_apply(y, g_out, B, H, W, C, ph, pw, scale, shift, coef, gy, amax_out, stream);
+    if (B <= 0 || C < 64 || C > 512 || (256 % (C / 4)) != 0 || pool_mode < 0 || pool_mode > 2) return SED_EINVAL;
+    if (amax_out) {
+        hipError_t e = sed_amax_clear(amax_out, stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    const int rpb = sed_pool_bwd_rows_per_block((long)B * H * W);
+    int nblk = sed_cdiv((long)B * H * W, rpb);
+    if (pool_mode == 1)
+        hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<2, 1>), dim3(nblk), dim3(256), 0, stream, y, g_out, B, H, W, C, ph, pw, scale, shift,
+                           (const float*)nullptr, (const float*)nullptr, coef, rpb, (float*)nullptr, gy, (const float*)nullptr, 0.f, amax_out);
+    else
+        hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<2, 2>), dim3(nblk), dim3(256), 0, stream, y, g_out, B, H, W, C, ph, pw, scale, shift,
+                           (const float*)nullptr, (const float*)nullptr, coef, rpb, (float*)nullptr, gy, (const float*)nullptr, 0.f, amax_out);
     SED_LAUNCH_CHECK();
     return 0;
 }

@@ -878,8 +878,9 @@ class ConvBlockFn(torch.autograd.Function):
     on the fly by the consumers."""
 
     @staticmethod
-    def forward(ctx, x, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, training, ph, pw, x_amax=None):
-        """Returns (out, out_amax): out_amax = device scalar max(out) for the next block's split-f16 scale (x_amax there)."""
+    def forward(ctx, x, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, training, ph, pw, x_amax=None, pool_mode=0):
+        """Returns (out, out_amax): out_amax = device amax vector of `out` for the next block's split-f16 scale (x_amax
+        there).  pool_mode: 0 = 'avg' (every model), 1 = 'max', 2 = 'avg+max' (models.py:104-111)."""
         _chk_dev(x, w1, w2)
         x = _f32c(x)
         B, H, W, Cin = x.shape
@@ -930,7 +931,10 @@ class ConvBlockFn(torch.autograd.Function):
         out = torch.empty((B, H // ph, W // pw, Cout), dtype=torch.float32, device=dev)
         out_amax = _amax_buf(dev)
         cnt = None
-        if training and POOL_BWD_WINDOWED and ph * pw > 1:
+        if pool_mode != 0:
+            _call("sed_bn_relu_pool_fwd_mode", _ptr(y2), B, H, W, Cout, ph, pw, int(pool_mode), _ptr(st2.scale), _ptr(st2.shift),
+                  _ptr(out), _ptr(out_amax), _stream())
+        elif training and POOL_BWD_WINDOWED and ph * pw > 1:
             # per-window ReLU counts: with them backward pass 1 runs on the pooled tensors and never reads y2
             cnt = torch.empty((B, H // ph, W // pw, Cout), dtype=torch.uint8, device=dev)
             _call("sed_bn_relu_pool_fwd_cnt", _ptr(y2), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift), _ptr(out),
@@ -942,7 +946,7 @@ class ConvBlockFn(torch.autograd.Function):
             ctx.save_for_backward(x, y1, y2, w1c, w2c, out, cnt, _f32c(g2), _f32c(b2))
         else:
             ctx.save_for_backward(x, y1, y2, w1c, w2c)
-        ctx.st1, ctx.st2, ctx.pool, ctx.training = st1, st2, (ph, pw), bool(training)
+        ctx.st1, ctx.st2, ctx.pool, ctx.training, ctx.pool_mode = st1, st2, (ph, pw), bool(training), int(pool_mode)
         ctx.xa, ctx.a1 = x_amax, a1
         ctx.pk1, ctx.pk2 = pk1, pk2
         ctx.sinks = _sinks(ctx, (w1, g1, b1, None, None, w2, g2, b2), 1)
@@ -974,15 +978,15 @@ class ConvBlockFn(torch.autograd.Function):
             rpb = _lib.lib().sed_pool_bwd_rows_per_block(M)
             npmax = (M + rpb - 1) // rpb
             part = torch.empty((npmax, 2, Cout), dtype=torch.float32, device=dev)
-            _call("sed_bn_relu_pool_bwd_reduce", _ptr(y2), _ptr(g_out), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift),
-                  _ptr(st2.mean), _ptr(st2.invstd), _ptr(part), ctypes.byref(n), _stream())
+            _call("sed_bn_relu_pool_bwd_reduce_mode", _ptr(y2), _ptr(g_out), B, H, W, Cout, ph, pw, ctx.pool_mode, _ptr(st2.scale),
+                  _ptr(st2.shift), _ptr(st2.mean), _ptr(st2.invstd), _ptr(part), ctypes.byref(n), _stream())
         sk = ctx.sinks                                   # (w1, g1, b1, -, -, w2, g2, b2)
         dg2, db2, coef2 = bn_bwd_finalize(part, n.value, M, st2, batch_stats=ctx.training, sinks=(sk[6], sk[7]))
         gy2 = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
         sf2 = _conv_algo(H, W, Cout, Cout) == 3 or _wgrad_algo(H, W, Cout, Cout) == 3   # split-f16 consumers scale by the amax
         amax2 = _amax_buf(dev) if sf2 else None
-        _call("sed_bn_relu_pool_bwd_apply", _ptr(y2), _ptr(g_out), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift),
-              _ptr(coef2), _ptr(gy2), _ptr(amax2), _stream())
+        _call("sed_bn_relu_pool_bwd_apply_mode", _ptr(y2), _ptr(g_out), B, H, W, Cout, ph, pw, ctx.pool_mode, _ptr(st2.scale),
+              _ptr(st2.shift), _ptr(coef2), _ptr(gy2), _ptr(amax2), _stream())
         # conv2: dgrad fused with relu-mask + BN1 backward sums, then the weight gradient (operand relu(bn1(y1)) on the
         # fly).  With gradient sinks the weight gradients run on the side stream: conv2's beside BN1's backward passes
         # below, conv1's beside the NEXT block's pool backward (joined there, right here, before its first MFMA kernel).
@@ -1024,7 +1028,7 @@ class ConvBlockFn(torch.autograd.Function):
                 dw1 = _fork_wgrad(x, gy1, B, H, W, Cin, Cout, sink=sk[0], gy_amax=amax1, x_amax=ctx.xa)
             else:
                 dw1 = _wgrad(x, gy1, B, H, W, Cin, Cout, sink=sk[0], gy_amax=amax1, x_amax=ctx.xa)
-        return gx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, None, None, None, None
+        return gx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------------------

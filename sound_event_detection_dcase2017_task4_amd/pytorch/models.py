@@ -133,8 +133,9 @@ class SpecAugmentation(nn.Module):
 # ---- building blocks ---------------------------------------------------------------------------------------------
 
 class ConvBlock(nn.Module):
-    """models.py:72-115.  NHWC in/out: (B,H,W,Cin) -> (B,H//ph,W//pw,Cout); only pool_type='avg' (the only one any
-    model selects)."""
+    """models.py:72-115.  NHWC in/out: (B,H,W,Cin) -> (B,H//ph,W//pw,Cout); pool_type 'avg' (what every model selects),
+    'max' or 'avg+max' (:104-111), anything else raises like the reference."""
+    POOL_MODES = {'avg': 0, 'max': 1, 'avg+max': 2}
 
     def __init__(self, in_channels, out_channels):
         super(ConvBlock, self).__init__()
@@ -151,14 +152,15 @@ class ConvBlock(nn.Module):
         init_bn(self.bn2)
 
     def forward(self, input, pool_size=(2, 2), pool_type='avg'):
-        if pool_type != 'avg':
+        if pool_type not in self.POOL_MODES:
             raise Exception('Incorrect argument!')
         # the amax of a block's output (left on the device by its pool kernel) rides on the tensor to the next block, whose
         # split-f16 convolution takes its operand scale from it -- no extra pass, no host synchronisation
         out, out_amax = ops.ConvBlockFn.apply(input, self.conv1.weight, self.bn1.weight, self.bn1.bias,
                                               self.bn1.running_mean, self.bn1.running_var, self.conv2.weight,
                                               self.bn2.weight, self.bn2.bias, self.bn2.running_mean, self.bn2.running_var,
-                                              self.training, pool_size[0], pool_size[1], getattr(input, '_sed_amax', None))
+                                              self.training, pool_size[0], pool_size[1], getattr(input, '_sed_amax', None),
+                                              self.POOL_MODES[pool_type])
         out._sed_amax = out_amax
         if self.training and not getattr(self, '_defer_counters', False):
             self.bn1.num_batches_tracked += 1

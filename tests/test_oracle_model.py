@@ -138,3 +138,26 @@ def test_misc_known_answers(golden_dir):
     np.testing.assert_allclose(loss.numpy(), misc["bce_loss"], rtol=1e-6)
     # log clamp at -100: p=0 with y=1 contributes exactly 100
     assert abs(float(misc["bce_loss"]) * 5 - (100 + 100 + 0.6931472 + 100 + 16.118) ) < 0.5
+
+
+def test_oracle_conv_block_pool_types_vs_reference(golden_dir):
+    """oracle.model.conv_block with pool_type 'avg' / 'max' / 'avg+max' against the genuine reference ConvBlock
+    (tests/golden/convblock_pool.npz, made by make_golden_pool.py): output and input gradient."""
+    import os
+    src = open(os.path.join(golden_dir, "make_golden_pool.py")).read()
+    ns = {"np": np}
+    exec(src[src.index("CIN, COUT, B, H, W"):src.index("def main():")], ns)
+    p, x, gout = ns["recipe"]()
+    fx = np.load(os.path.join(golden_dir, "convblock_pool.npz"))
+    for pt in ("avg", "max", "avg+max"):
+        st = {"cb." + k: torch.from_numpy(v) for k, v in p.items()}
+        for i in (1, 2):
+            st["cb.bn%d.running_mean" % i] = torch.zeros(ns["COUT"])
+            st["cb.bn%d.running_var" % i] = torch.ones(ns["COUT"])
+            st["cb.bn%d.num_batches_tracked" % i] = torch.tensor(0)
+        xt = torch.from_numpy(x).requires_grad_(True)
+        y = om.conv_block(xt, st, "cb", (2, 2), True, True, pool_type=pt)
+        y.backward(torch.from_numpy(gout))
+        tag = pt.replace("+", "_")
+        assert np.abs(y.detach().numpy() - fx[tag + "/out"]).max() < 1e-5
+        assert np.abs(xt.grad.numpy().reshape(-1)[::7] - fx[tag + "/dx/sample7"]).max() <= 1e-4 * np.abs(fx[tag + "/dx/sample7"]).max()
