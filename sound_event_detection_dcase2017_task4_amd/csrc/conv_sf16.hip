@@ -668,7 +668,14 @@ __device__ __forceinline__ half4 sf_tr_read(const unsigned char* p) {
 template <int LOGW, bool INT>
 __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
     constexpr int W = 1 << LOGW, TRS = 64 >> LOGW, WP = W + 2;
+#ifndef WSF_OVERLAP
     constexpr int RING = TRS <= 2 ? 4 : (TRS == 4 ? 8 : 16);
+    constexpr int GBUF = 1;
+#else
+    // (experiment) the next stage's rows are stored WHILE this stage is being read: 2 TRS + 2 ring rows, two gy buffers
+    constexpr int RING = TRS == 1 ? 4 : (TRS == 2 ? 8 : (TRS == 4 ? 16 : 32));
+    constexpr int GBUF = 2;
+#endif
     // LDS images (round 3: conflict-free for the STORES too -- the per-channel-block planes of round 2, 128 B (mod 256)
     // apart for the transpose reads, put the 16 lanes of a ds_write_b64 group 2-way (x) / 4-way (gy) on the same banks:
     // 35 % of the LDS cycles were conflicts).  x: one 64-byte row per pixel = its two 16-channel blocks side by side;
@@ -677,7 +684,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
     // neighbouring block in the other 16 -- still covers all 64 banks exactly once.
     constexpr int XPL = RING * WP * 64;             // x plane (hi); lo follows
     constexpr int GPL = 64 * 128;                   // gy plane (hi); lo follows
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * XPL + 2 * GPL];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * XPL + 2 * GPL * GBUF];
     unsigned char* const Xs = smem;
     unsigned char* const Gs = smem + 2 * XPL;
 
@@ -763,7 +770,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
 #define WSF_GLOAD(H0)                                                                                           \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
         greg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(grs, goff[i], (H0) * W * p.N * 4, 0));
-#define WSF_GSTORE()                                                                                            \
+#define WSF_GSTORE(GB)                                                                                          \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                             \
         float4 v = greg[i];                                                                                     \
         v.x *= sg; v.y *= sg; v.z *= sg; v.w *= sg;                                                             \
@@ -771,8 +778,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
         unsigned h01, l01, h23, l23;                                                                            \
         sf_split2(v.x, v.y, h01, l01);                                                                          \
         sf_split2(v.z, v.w, h23, l23);                                                                          \
-        *reinterpret_cast<uint2*>(Gs + gls[i]) = make_uint2(h01, h23);                                          \
-        *reinterpret_cast<uint2*>(Gs + GPL + gls[i]) = make_uint2(l01, l23);                                    \
+        *reinterpret_cast<uint2*>(Gs + (GB) + gls[i]) = make_uint2(h01, h23);                                   \
+        *reinterpret_cast<uint2*>(Gs + (GB) + GPL + gls[i]) = make_uint2(l01, l23);                             \
     }
 
     // halo columns of every ring row, both x planes: zero once
@@ -801,62 +808,51 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
         WSF_XLOAD(hs0 - 1) WSF_XSTORE(hs0 - 1)
         if (TRS == 1) { WSF_XLOAD(hs0) WSF_XSTORE(hs0) }
         WSF_XLOAD(hs0 + 1) WSF_GLOAD(hs0)
-        WSF_XSTORE(hs0 + 1) WSF_GSTORE()
+        WSF_XSTORE(hs0 + 1) WSF_GSTORE(0)
+#ifdef WSF_OVERLAP
+        if (s0 + 1 < s1) { WSF_XLOAD(hs0 + TRS + 1) WSF_GLOAD(hs0 + TRS) }      // the second stage's rows are in flight
+        int gb = 0;                                                              // gy buffer this stage reads
+#endif
         __syncthreads();
         for (int s = s0; s < s1; ++s) {
             const int h0 = s * TRS;
             const bool more = s + 1 < s1;
+#ifndef WSF_OVERLAP
+#ifndef WSF_ABL_NOLOAD     // timing experiments (results wrong): WSF_ABL_NOLOAD / _NOSTAGE / _NOBAR
             if (more) { WSF_XLOAD(h0 + TRS + 1) WSF_GLOAD(h0 + TRS) }
+#endif
+#endif
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
-#ifdef WSF_PIPE  // experiment kept for the record (round 3): 9.43 ms vs 9.36 ms over the seven layers at B = 128 -- NO gain.
-            // Software-pipelined fragment reads: a tap's four transpose reads (latency ~100+ cycles) sit in front of its three
-            // dependent MFMAs (96 cycles); here the x fragments of tap t+1 (and the gy fragments of the second k-step) are
-            // requested BEFORE the MFMAs of tap t, into a second set (no spills: 242-254 VGPRs).  That it changes nothing says
-            // the co-resident wave covers the latency; what bounds the kernel is the staging phase between the barriers
-            // (~150 VALU + 12 stores per stage and wave during which that wave issues no MFMA) and the clock.
-            {
-#define WSF_ALOAD(AH, AL, KK) {                                                                                  \
-                    const unsigned char* ap = Gs + a_base + (2 * wk + (KK)) * 2048;                              \
-                    const half4 h0v = sf_tr_read(ap), h1v = sf_tr_read(ap + 512);                                \
-                    const half4 l0v = sf_tr_read(ap + GPL), l1v = sf_tr_read(ap + GPL + 512);                    \
-                    AH = half8{h0v[0], h0v[1], h0v[2], h0v[3], h1v[0], h1v[1], h1v[2], h1v[3]};                  \
-                    AL = half8{l0v[0], l0v[1], l0v[2], l0v[3], l1v[0], l1v[1], l1v[2], l1v[3]}; }
-#define WSF_BLOAD(BH, BL, KK, DY, DX) {                                                                          \
-                    const int pix_ = (2 * wk + (KK)) * 16 + pin;                                                 \
-                    const int slot_ = (h0 + (pix_ >> LOGW) + (DY)) & (RING - 1);                                 \
-                    const unsigned char* bp = Xs + b_lane + (slot_ * WP + (pix_ & (W - 1))) * 64 + (DX) * 64;    \
-                    const half4 h0v = sf_tr_read(bp), h1v = sf_tr_read(bp + 256);                                \
-                    const half4 l0v = sf_tr_read(bp + XPL), l1v = sf_tr_read(bp + XPL + 256);                    \
-                    BH = half8{h0v[0], h0v[1], h0v[2], h0v[3], h1v[0], h1v[1], h1v[2], h1v[3]};                  \
-                    BL = half8{l0v[0], l0v[1], l0v[2], l0v[3], l1v[0], l1v[1], l1v[2], l1v[3]}; }
-                half8 ah[2], al[2], bh[2], bl[2];
-                WSF_ALOAD(ah[0], al[0], 0)
-                WSF_BLOAD(bh[0], bl[0], 0, 0, 0)
-#pragma unroll
-                for (int t = 0; t < 18; ++t) {
-                    const int kk = t / 9, tp = t % 9;
-                    if (t + 1 < 18) {                                   // next tap's operands first
-                        const int tn = t + 1, kkn = tn / 9, tpn = tn % 9;
-                        if (tn == 9) WSF_ALOAD(ah[1], al[1], 1)
-                        WSF_BLOAD(bh[tn & 1], bl[tn & 1], kkn, tpn / 3, tpn % 3)
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kk], bh[t & 1], acc[tp], 0, 0, 0);
-                    acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], bl[t & 1], acc[tp], 0, 0, 0);
-                    acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], bh[t & 1], acc[tp], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#undef WSF_ALOAD
-#undef WSF_BLOAD
-            }
-#else
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int ks = 2 * wk + kk;                // wave-uniform (wk scalar)
+#ifdef WSF_OVERLAP
+                if (kk == 1) {
+                    // EXPERIMENT (-DWSF_OVERLAP, round 3; measured 9.60 vs 9.36-9.43 ms over the seven layers: NO gain, not the
+                    // default).  Between the two k-steps of the stage: convert and store the NEXT stage's rows (into ring slots /
+                    // a second gy buffer nobody reads during this stage) and request the rows of the stage after it -- one
+                    // barrier per stage, the staging VALU beside the partner wave's MFMAs.  The ablation that suggested it
+                    // (no staging: +27-37 %) was a DVFS artefact: without staging the MFMA operands repeat, switching
+                    // activity and power drop and the clock rises -- like every "remove X" experiment on this
+                    // power-limited part (tools/mfma_f16_ubench.hip: 1.63 PF with random operands, 2.1 PF with smooth ones).
+                    __builtin_amdgcn_s_setprio(0);
+#ifndef WSF_ABL_NOSTAGE
+                    if (more) { WSF_XSTORE(h0 + TRS + 1) WSF_GSTORE((gb ^ 1) * 2 * GPL) }
+#endif
+#ifndef WSF_ABL_NOLOAD
+                    if (s + 2 < s1) { WSF_XLOAD(h0 + 2 * TRS + 1) WSF_GLOAD(h0 + 2 * TRS) }
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
+                }
+                const unsigned char* const Gcur = Gs + gb * 2 * GPL;
+#else
+                const unsigned char* const Gcur = Gs;
+#endif
                 half8 ah, al;
                 {
-                    const unsigned char* ap = Gs + a_base + ks * 2048;
+                    const unsigned char* ap = Gcur + a_base + ks * 2048;
                     const half4 h0v = sf_tr_read(ap), h1v = sf_tr_read(ap + 512);
                     const half4 l0v = sf_tr_read(ap + GPL), l1v = sf_tr_read(ap + GPL + 512);
                     ah = half8{h0v[0], h0v[1], h0v[2], h0v[3], h1v[0], h1v[1], h1v[2], h1v[3]};
@@ -881,14 +877,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
                     }
                 }
             }
-#endif
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
+#ifndef WSF_ABL_NOBAR
             __syncthreads();
+#endif
+#ifndef WSF_OVERLAP
             if (more) {
-                WSF_XSTORE(h0 + TRS + 1) WSF_GSTORE()
+#ifndef WSF_ABL_NOSTAGE
+                WSF_XSTORE(h0 + TRS + 1) WSF_GSTORE(0)
+#endif
+#ifndef WSF_ABL_NOBAR
                 __syncthreads();
+#endif
             }
+#else
+            gb ^= 1;
+#endif
         }
     }
 #undef WSF_IMAGE
