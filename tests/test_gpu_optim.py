@@ -82,8 +82,8 @@ def test_second_backward_without_step_is_refused():
 
 
 def test_derived_weight_caches_follow_the_parameters():
-    """The padded head matrix / stacked GRU operands are cached between steps; an optimiser step (raw-pointer update),
-    an in-place torch update and load_state_dict must each invalidate them."""
+    """The padded head matrix / stacked GRU operands and (round 3) the split-f16 packs of the conv weights are cached between
+    steps; an optimiser step (raw-pointer update), an in-place torch update and load_state_dict must each invalidate them."""
     from sound_event_detection_dcase2017_task4_amd import ops
     from sound_event_detection_dcase2017_task4_amd.optim import FusedAdamAmsgrad
     from sound_event_detection_dcase2017_task4_amd.pytorch.losses import clip_bce
@@ -105,6 +105,8 @@ def test_derived_weight_caches_follow_the_parameters():
     with torch.no_grad():
         m.att_block.cla.weight.mul_(1.5)                              # in-place torch update bumps _version
         m.gru.weight_ih_l0.add_(0.01)
+        m.conv_block3.conv2.weight.mul_(1.7)                          # a cached split-f16 pack (eval mode: forward layout)
+        m.conv_block2.conv1.weight.add_(0.02)
     b = clip()
     assert (b.cpu() - oracle()).abs().max().item() < 1e-4 and (a - b).abs().max().item() > 1e-4
     sd = om.recipe_state(mt, 9)
