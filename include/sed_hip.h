@@ -260,6 +260,8 @@ int sed_reduce_rows(const float* parts, long n, int K, long ld, float* out, int 
                     sed_stream_t stream);
 int sed_transpose(const float* x, int batch, int rows, int cols, float* out, sed_stream_t stream);
 int sed_axpy(float* out, const float* a, long n, sed_stream_t stream);
+/* out[i] = x[i] * scalar_dev[0] (the chain rule through the 0-dim loss of losses.py:5-12: d loss / d p times the upstream gradient). */
+int sed_scale_by_scalar(const float* x, const float* scalar_dev, long n, float* out, sed_stream_t stream);
 
 /* ---- heads -----------------------------------------------------------------------------------------------
  * FrameAvg (models.py:306-312) / FrameMax (:221-227): logits [B][T][ldn] = feat x Wfc^T by sed_gemm_nt, then

@@ -101,7 +101,11 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
     constexpr int BPLANE = 3 * BN * 32, BSTAGE = 2 * BPLANE;
     constexpr int NI = MW == 2 ? 4 : 6;                // staging items per thread
     constexpr int NDMA = 6 * RB / 4;                   // LDS-DMA instructions per wave and stage
+#ifdef SF_ABL_OCC2        // timing experiment: pad the LDS footprint so that only TWO workgroups fit a CU (2 waves per SIMD)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * APLANE + 2 * BSTAGE + (MW == 4 ? 28 * 1024 : 0)];
+#else
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * APLANE + 2 * BSTAGE];
+#endif
     unsigned char* const As = smem;
     unsigned char* const Bs = smem + 2 * APLANE;
 

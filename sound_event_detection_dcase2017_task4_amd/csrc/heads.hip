@@ -457,6 +457,20 @@ SED_API int sed_gru_gate_bwd(const float* g_out0, const float* g_out1, long ld_g
     return 0;
 }
 
+// out[i] = x[i] * s[0], s a DEVICE scalar (the upstream gradient of a 0-dim loss: clip_bce's backward)
+__global__ __launch_bounds__(256) void scale_by_dev_scalar_kernel(const float* __restrict__ x, const float* __restrict__ s, long n,
+                                                                  float* __restrict__ out) {
+    const float k = s[0];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = x[i] * k;
+}
+
+SED_API int sed_scale_by_scalar(const float* x, const float* scalar_dev, long n, float* out, hipStream_t stream) {
+    if (!x || !scalar_dev || !out || n <= 0) return SED_EINVAL;
+    hipLaunchKernelGGL(scale_by_dev_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, scalar_dev, n, out);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
 SED_API int sed_axpy(float* out, const float* a, long n, hipStream_t stream) {
     if (n <= 0) return SED_EINVAL;
     hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, stream, out, a, n);

@@ -1408,7 +1408,12 @@ class ClipBceFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        return grad * g, None
+        g = _f32c(g)
+        if g.numel() != 1 or not g.is_cuda:
+            return grad * g, None
+        out = torch.empty_like(grad)
+        _call("sed_scale_by_scalar", _ptr(grad), _ptr(g), grad.numel(), _ptr(out), _stream())
+        return out, None
 
 
 def mixup_rows(x, lam):

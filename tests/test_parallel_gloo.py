@@ -213,3 +213,36 @@ def test_bench_roofline_traffic_lookup_matches_the_kernels_that_exist():
     assert tr and tr > 786e6 and src.startswith("profiles/r"), (tr, src)       # >= the algorithmic 786.6 MB per launch
     tr, _ = bench.pmc_traffic(bench.FAMILY_KERNELS["conv3x3_sf16_mfma(fwd+dgrad)"])      # the default convolution path
     assert tr and tr > 1e9
+
+
+def test_bucket_refuses_to_fire_before_its_side_stream_gradients_are_joined():
+    """Ordering contract of the bucketed all-reduce (one process, no backend needed): a bucket is handed to the backend only
+    behind the MAIN stream, so a weight gradient still running on the side stream must have been joined first.
+    GradBuckets asks its owner right before firing (`pre_fire_check`); FusedAdamAmsgrad answers from ops._PENDING."""
+    from sound_event_detection_dcase2017_task4_amd import ops, parallel
+    flat = torch.zeros(100)
+    gb = parallel.GradBuckets(flat, offsets=[0, 40, 70], numels=[40, 30, 30], cuts=[70])
+    seen = []
+
+    class FakeSink(object):
+        def __init__(self, index):
+            self.index, self.opt = index, "opt"
+
+    def check(bucket, indices):
+        seen.append((bucket, list(indices)))
+        late = ops.pending_sink_indices("opt").intersection(indices)
+        if late:
+            raise RuntimeError("bucket %d fired before parameters %s were joined" % (bucket, sorted(late)))
+
+    gb.pre_fire_check = check
+    for i in range(3):
+        gb.expect(i)
+    gb.ready(2)                                       # bucket 1 = {param 2}: complete, fires, nothing pending
+    assert seen == [(1, [2])] and gb.issue_order == [1]
+    ops._PENDING.append((None, FakeSink(1), []))      # parameter 1's weight gradient is still on the side stream
+    try:
+        gb.ready(0)
+        with pytest.raises(RuntimeError, match="before parameters \\[1\\] were joined"):
+            gb.ready(1)                               # would complete bucket 0 = {0, 1} and fire it
+    finally:
+        del ops._PENDING[:]
