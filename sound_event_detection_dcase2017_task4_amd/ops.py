@@ -97,6 +97,13 @@ def _fork_wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, gy_amax=None, 
     global _STREAM_OVERRIDE
     main = torch.cuda.current_stream()
     side = _side_stream(x.device)
+    if _wgrad_algo(H, W, Cin, Cout) == 3:
+        # operand amaxes the caller did not bring are taken HERE, on the main stream: their zeroed pool rows (a fill on
+        # torch's current stream) must not be handed to a kernel of the side stream that is not ordered behind the fill
+        if gy_amax is None:
+            gy_amax = amax_of(gy)
+        if x_amax is None:
+            x_amax = act_amax_full(x, in_st) if in_st is not None else amax_of(x)
     side.wait_stream(main)
     keep = [x, gy, in_st, gy_amax, x_amax]
     _STREAM_OVERRIDE = side
