@@ -125,3 +125,34 @@ def test_evaluator_end_to_end_through_the_hip_model(tmp_path):
     assert abs(got["overall"]["error_rate"]["error_rate"] - want["overall"]["error_rate"]["error_rate"]) < 1e-9
     assert abs(got["overall"]["f_measure"]["f_measure"] - want["overall"]["f_measure"]["f_measure"]) < 1e-9
     assert got["overall"]["count"]["Nref"] == want["overall"]["count"]["Nref"] > 0
+
+
+def test_train_cli_survives_a_non_finite_batch(tmp_path, monkeypatch, caplog):
+    """A batch whose log-mel holds a NaN (diverged input): the Adam kernel refuses the poisoned update(s) on the device, the
+    train loop gets ops.NonFiniteOperand at a later poll, logs it, switches to the fp32 MFMA kernels and re-runs the batch it
+    is at -- the run finishes with finite parameters (the reference would have trained on with NaN weights)."""
+    import logging
+    from sound_event_detection_dcase2017_task4_amd import ops
+    from sound_event_detection_dcase2017_task4_amd.pytorch import main as cli
+    real = ops.logmel
+    calls = {"n": 0}
+
+    def poisoned(wave, tables, amin=1e-10):
+        out = real(wave, tables, amin)
+        calls["n"] += 1
+        if calls["n"] == 2:
+            out[0, 3, 5] = float("nan")
+        return out
+
+    monkeypatch.setattr(ops, "logmel", poisoned)
+    monkeypatch.setattr(ops, "USE_SF16", True)
+    ws = str(tmp_path)
+    args = ["train", "--dataset_dir", ws, "--workspace", ws, "--holdout_fold", "1", "--model_type", "Cnn_9layers_FrameAvg",
+            "--loss_type", "clip_bce", "--augmentation", "mixup", "--batch_size", "4", "--cuda", "--synthetic", "12",
+            "--learning_rate", "1e-3", "--resume_iteration", "0", "--stop_iteration", "5", "--print_every", "1"]
+    with caplog.at_level(logging.WARNING):
+        cli.main(args)
+    assert calls["n"] >= 6
+    assert ops.USE_SF16 is False                                       # the loop switched to the fp32 kernels ...
+    assert any("optimiser step(s) were refused" in r.getMessage() for r in caplog.records)      # ... and said so
+    ops.check_device_errors(synchronize=True)                          # nothing left pending
