@@ -109,3 +109,22 @@ def test_specaug_draw_order_and_ranges(golden_dir):
     y = ofe.apply_specaug(x, s)
     assert y[0, 0, s[0, 0]:s[0, 0] + s[0, 1]].sum() == 0
     assert y[1, 0, :, s[1, 4]:s[1, 4] + s[1, 5]].sum() == 0
+
+
+def test_power_spectrogram_vs_numpy_fft_in_float64():
+    """A third, independent evaluation of F1 (torchlibrosa Spectrogram as called at models.py:251-253): plain numpy in
+    float64 -- np.pad(mode='reflect') by n_fft/2, frames at hop 320, periodic Hann, np.fft.rfft, |.|^2 -- against the oracle's
+    conv1d formulation on noise (the reference's own layout: power (B, 1, T, 513))."""
+    L = 32000
+    x = waves(77, 2, L)
+    got = ofe.power_spectrogram(torch.from_numpy(x)).numpy()
+    n_fft, hop = 1024, 320
+    win = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n_fft) / n_fft)
+    T = L // hop + 1
+    assert got.shape == (2, 1, T, 513)
+    for b in range(2):
+        xp = np.pad(x[b].astype(np.float64), n_fft // 2, mode="reflect")
+        frames = np.stack([xp[t * hop:t * hop + n_fft] * win for t in range(T)])
+        want = np.abs(np.fft.rfft(frames, axis=1)) ** 2
+        err = np.abs(got[b, 0] - want).max() / want.max()
+        assert err < 2e-6, err
