@@ -633,7 +633,8 @@ SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale
 // MFMA lane wants 8 consecutive k (pixels) of ONE channel: the tiles are staged as they come ([pixel][16 channels], 32 B
 // per pixel and 16-channel plane, hi and lo planes) and read with ds_read_b64_tr_b16, the LDS transpose read -- a 16-lane
 // group hands in the four 8-byte pieces of four pixels' 16 channels and lane c gets channel c of the four pixels.
-// Planes of neighbouring channel blocks lie 128 B (mod 256) apart, so the two blocks a half-wave reads never share a bank.
+// LDS images: one 64-byte row per pixel for x (its two channel blocks side by side), one 128-byte row for gy (four blocks,
+// block index XOR (pixel & 2)): stores and transpose reads are both bank-conflict free (see the kernel).
 //
 // Workgroup = 64 co x 32 ci x all 9 taps; waves = 2 co halves x 2 k halves (each wave: 32 x 32 x 9 taps = 9 accumulators,
 // the k halves are separate partial slices).  A stage = 64 pixels (64/W image rows): their gy rows are staged afresh, the
@@ -643,8 +644,9 @@ SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale
 // (Splitting the TAPS over six waves -- 2 co halves x 3 kernel rows, 3 accumulators and 120-160 VGPRs per wave, three to four
 // waves per SIMD -- measured 300-320 TFLOP/s against 335-360 for this layout: the gy fragments are then read three times.
 // Double-buffering gy and enlarging the ring to 2*64/W + 2 rows so that a stage needs ONE barrier instead of two measured
-// +-4 % layer by layer, no net gain.  A 64 co x 64 ci variant for the 64-input-channel layers was tried: 256 VGPRs with 10-119 spilled registers and no gain
-// where it did not spill; those two layers keep the Winograd-domain kernel.)
+// +-4 % layer by layer, no net gain (round 3 rebuilt it with the staging moved between the two k-steps: -DWSF_OVERLAP, 0 %).  A 64 co x
+// 64 ci variant for the 64-input-channel layers was tried: 256 VGPRs with 10-119 spilled registers and no gain where it did
+// not spill.  Since round 3 this kernel serves ALL seven layers, the two 64-input-channel ones included.)
 namespace {
 
 typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
