@@ -348,11 +348,12 @@ int sed_drop_relu_bwd(const float* g_y, const float* y, const unsigned char* kee
  *   skip_flag (nullable, device int[2]) = found-non-finite guard: the gradient is first scanned for NaN / inf (which
  *   raises skip_flag[0] and the nullable host-mapped err_host); when skip_flag[0] != 0 -- from that scan or because a
  *   split-f16 kernel of this step met a non-finite operand (their err_dev word) -- parameters and moments are left
- *   untouched and skip_flag[1] counts the refused step.  g must be 16-byte aligned when the guard is used. */
+ *   untouched and the refused step is counted in *skipped (nullable device int, one per optimiser; null: in skip_flag[1]).
+ *   g must be 16-byte aligned when the guard is used. */
 int sed_clip_bce(const float* p, const float* y, long n, float* loss, float* grad, sed_stream_t stream);
 int sed_mixup_rows(const float* x, const float* lam, long B2, long D, float* out, sed_stream_t stream);
 int sed_adam_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, long n, int step, float lr,
-                     float beta1, float beta2, float eps, float grad_scale, int* skip_flag, int* err_host,
+                     float beta1, float beta2, float eps, float grad_scale, int* skip_flag, int* skipped, int* err_host,
                      sed_stream_t stream);
 
 #ifdef __cplusplus

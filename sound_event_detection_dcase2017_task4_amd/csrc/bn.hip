@@ -300,7 +300,11 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __re
         float4 o = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
         if (MODE == 1) o = mx;
         if (MODE == 2) { o.x += mx.x; o.y += mx.y; o.z += mx.z; o.w += mx.w; }
+#ifndef SED_NO_NT_POOLFWD
+        store_nt4(out, i, o);
+#else
         reinterpret_cast<float4*>(out)[i] = o;
+#endif
         amax = fmaxf(fmaxf(amax, fmaxf(o.x, o.y)), fmaxf(o.z, o.w));          // o >= 0
         if (CNT) cnt4[i] = n4;
     }
@@ -432,7 +436,11 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const float* __re
             float4 o;
             o.x = fmaf(ca.x, dy.x, fmaf(cb.x, v.x, cc.x)); o.y = fmaf(ca.y, dy.y, fmaf(cb.y, v.y, cc.y));
             o.z = fmaf(ca.z, dy.z, fmaf(cb.z, v.z, cc.z)); o.w = fmaf(ca.w, dy.w, fmaf(cb.w, v.w, cc.w));
+#ifndef SED_NO_NT_POOLBWD
+            store_nt4(gy, r * c4n + c4, o);
+#else
             reinterpret_cast<float4*>(gy)[r * c4n + c4] = o;
+#endif
             amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
     }
@@ -517,7 +525,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ d
         float4 o;
         o.x = fmaf(ca.x, d.x, fmaf(cb.x, v.x, cc.x)); o.y = fmaf(ca.y, d.y, fmaf(cb.y, v.y, cc.y));
         o.z = fmaf(ca.z, d.z, fmaf(cb.z, v.z, cc.z)); o.w = fmaf(ca.w, d.w, fmaf(cb.w, v.w, cc.w));
+#ifndef SED_NO_NT_BNAPPLY
+        store_nt4(dy, i, o);
+#else
         reinterpret_cast<float4*>(dy)[i] = o;
+#endif
         amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
     if (amax_out) {

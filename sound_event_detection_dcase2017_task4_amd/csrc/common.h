@@ -56,6 +56,13 @@ static inline hipError_t sed_amax_clear(float* amax_out, hipStream_t stream) {
     return (amax_out && !sed_amax_prezeroed__) ? hipMemsetAsync(amax_out, 0, SED_AMAX_SLOTS * sizeof(float), stream) : hipSuccess;
 }
 
+// Streaming 16-byte store of a tensor that is written once and read by a LATER kernel after everything else has passed through the
+// caches: non-temporal (conv1_fwd writes its 4.2 GB at 4.5 instead of 3.4 TB/s with it: profiles/r03).
+__device__ __forceinline__ void store_nt4(float* base, long idx4, float4 v) {
+    const floatx4 ov = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(ov, reinterpret_cast<floatx4*>(base) + idx4);
+}
+
 // The ONE expression used everywhere for "BatchNorm (folded to scale/shift) then ReLU", so the
 // forward value and every recomputed backward mask agree bit for bit.
 __device__ __forceinline__ float bn_relu(float y, float scale, float shift) {

@@ -560,7 +560,11 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = fmaf(xs[t], wr[t][k], o[k]);
+#ifndef SED_NO_NT_CONV1     // non-temporal: 0.93 instead of 1.24 ms for the 4.2 GB of y at B = 256
+        store_nt4(y, pm * 16 + c4, make_float4(o[0], o[1], o[2], o[3]));
+#else
         reinterpret_cast<float4*>(y)[pm * 16 + c4] = make_float4(o[0], o[1], o[2], o[3]);
+#endif
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float d = o[k] - piv[k]; s[k] += d; q[k] = fmaf(d, d, q[k]);

@@ -441,7 +441,11 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
                     vmn = fminf(vmn, ok ? v : __builtin_inff());
                 }
                 acc[mb][nk][r] = v;
+#ifdef SF_NT_STORE          // experiment: non-temporal output stores (aux = 2)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, yoff[mb][r], nk * 128, 2);
+#else
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, yoff[mb][r], nk * 128, 0);
+#endif
             }
         }
         if (EPI != 2 && p.mm) {      // range of this wave's 64 pixels per channel: the consumer's operand amax comes from it

@@ -226,11 +226,12 @@ __global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p
                                                            float* __restrict__ m, float* __restrict__ v,
                                                            float* __restrict__ vmax, long n, float lr, float beta1,
                                                            float beta2, float eps, float bc1, float bc2_sqrt,
-                                                           float grad_scale, int* __restrict__ skip_flag) {
+                                                           float grad_scale, int* __restrict__ skip_flag,
+                                                           int* __restrict__ skipped) {
     // found-non-finite skip: a kernel of this step met a NaN / inf operand (skip_flag[0] != 0): leave parameters and
-    // moments untouched and count the refused step in skip_flag[1] -- the host learns about it without synchronising
+    // moments untouched and count the refused step -- the host learns about it without synchronising
     if (skip_flag && __hip_atomic_load(skip_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skip_flag + 1, 1);
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped ? skipped : skip_flag + 1, 1);
         return;
     }
     const float step_size = lr / bc1;
@@ -415,8 +416,8 @@ SED_API int sed_mixup_rows(const float* x, const float* lam, long B2, long D, fl
 
 // One Adam-amsgrad step (step >= 1) over flat buffers; grad_scale multiplies the gradient first (1/world_size).
 SED_API int sed_adam_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, long n, int step, float lr,
-                             float beta1, float beta2, float eps, float grad_scale, int* skip_flag, int* err_host,
-                             hipStream_t stream) {
+                             float beta1, float beta2, float eps, float grad_scale, int* skip_flag, int* skipped,
+                             int* err_host, hipStream_t stream) {
     if (n <= 0 || step < 1) return SED_EINVAL;
     if ((reinterpret_cast<uintptr_t>(g) & 15) != 0 && skip_flag) return SED_EINVAL;
     if (skip_flag) {
@@ -427,7 +428,7 @@ SED_API int sed_adam_amsgrad(float* p, const float* g, float* m, float* v, float
     double bc1 = 1.0 - pow((double)beta1, (double)step);
     double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_amsgrad_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, m, v, vmax, n, lr, beta1, beta2, eps,
-                       (float)bc1, (float)sqrt(bc2), grad_scale, skip_flag);
+                       (float)bc1, (float)sqrt(bc2), grad_scale, skip_flag, skipped);
     SED_LAUNCH_CHECK();
     return 0;
 }

@@ -207,6 +207,7 @@ def _call(name, *args):
 
 _ERR_FLAG = None
 _ERR_DEV = {}
+_GUARDED = weakref.WeakSet()      # optimisers whose Adam kernel counts refused steps in their own device word (`_skipped`)
 
 
 class NonFiniteOperand(RuntimeError):
@@ -259,8 +260,15 @@ def check_device_errors(synchronize=False):
     if int(_ERR_FLAG[1]):
         torch.cuda.synchronize()                      # rare path: settle, then read how many steps the Adam kernel refused
         skipped = 0
+        for opt in list(_GUARDED):                    # every guarded optimiser takes ITS refused steps back, whoever polls
+            k = int(opt._skipped.item())
+            if k:
+                opt._skipped.zero_()
+                opt.step_count = max(0, opt.step_count - k)
+                opt.skipped_steps += k
+                skipped = max(skipped, k)
         for t in _ERR_DEV.values():
-            skipped = max(skipped, int(t[1].item()))
+            skipped = max(skipped, int(t[1].item()))  # raw users of adam_amsgrad_ (no optimiser object)
             t.zero_()
         torch.cuda.synchronize()
         _ERR_FLAG[1] = 0
@@ -1438,7 +1446,7 @@ def mixup_rows(x, lam):
     return out
 
 
-def adam_amsgrad_(p, g, m, v, vmax, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, guard=None):
+def adam_amsgrad_(p, g, m, v, vmax, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, guard=None, skipped=None):
     """guard (default: on while the split-f16 kernels are in use): found-non-finite skip -- the update is refused when a
     split-f16 kernel of this step met a NaN / inf operand or the (all-reduced) gradient holds one; see NonFiniteOperand.
     With ops.USE_SF16 = False the step behaves exactly like torch.optim.Adam (NaN gradients make NaN parameters)."""
@@ -1447,4 +1455,5 @@ def adam_amsgrad_(p, g, m, v, vmax, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, 
         guard = USE_SF16
     invalidate_weight_caches()                     # parameters change through raw pointers: `_version` does not see it
     _call("sed_adam_amsgrad", _ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vmax), p.numel(), step, lr, beta1, beta2, eps,
-          grad_scale, _sf16_err_dev_ptr(p.device) if guard else None, _sf16_err_ptr() if guard else None, _stream())
+          grad_scale, _sf16_err_dev_ptr(p.device) if guard else None, _ptr(skipped) if guard else None,
+          _sf16_err_ptr() if guard else None, _stream())

@@ -99,6 +99,8 @@ class FusedAdamAmsgrad(object):
             p._sed_sink = GradSink(self, i, p.grad) if self.direct_grads else None
         self.step_count = 0
         self.skipped_steps = 0             # optimiser steps the Adam kernel refused (device error word set, see step())
+        self._skipped = torch.zeros((1,), dtype=torch.int32, device=dev)    # ... counted here by the kernel itself
+        ops._GUARDED.add(self)             # ops.check_device_errors() books them back, whoever happens to poll
         ops.invalidate_weight_caches()     # parameters moved into the flat buffer: operands derived from them are stale
 
     def _assert_joined(self, bucket, indices):
@@ -155,19 +157,15 @@ class FusedAdamAmsgrad(object):
     def step(self):
         """One Adam-amsgrad update.  Found-non-finite guard: the kernel reads the device error word of the split-f16
         convolutions and leaves parameters and moments untouched when a kernel of this step met a NaN / inf operand; the
-        host learns about it (no synchronisation: host-mapped flag) at this or a later call and raises
-        ops.NonFiniteOperand after taking the refused steps back out of `step_count`."""
+        host learns about it (no synchronisation: host-mapped flag) at this or a later poll -- here or anywhere else
+        ops.check_device_errors() is called -- which raises ops.NonFiniteOperand after taking the refused steps back out
+        of `step_count`."""
         self.reduce_gradients()
         self.buckets.begin_step()
         self.step_count += 1
         ops.adam_amsgrad_(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq, self.step_count,
-                          self.lr, self.betas[0], self.betas[1], self.eps, 1.0 / float(self.world_size))
-        try:
-            ops.check_device_errors()
-        except ops.NonFiniteOperand as e:
-            self.step_count -= e.skipped_steps
-            self.skipped_steps += e.skipped_steps
-            raise
+                          self.lr, self.betas[0], self.betas[1], self.eps, 1.0 / float(self.world_size), skipped=self._skipped)
+        ops.check_device_errors()          # NonFiniteOperand: step_count / skipped_steps were already corrected there
 
     def state_dict(self):
         return {"step": self.step_count, "lr": self.lr, "betas": self.betas, "eps": self.eps,

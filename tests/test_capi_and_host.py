@@ -49,7 +49,7 @@ def test_argument_errors_are_reported_not_crashes():
     assert h.sed_logmel_f32(None, 1, 100, None, None, None, 105, None, 4, None, 866, 1e-10, None, None) == -22     # L <= 512
     assert h.sed_gru_seq_fwd(None, None, None, None, None, 4, 5, 128, None, None, None, None, None, None) == -22        # hidden size != 256
     assert h.sed_mixup_rows(None, None, 3, 17, None, None) == -22
-    assert h.sed_adam_amsgrad(None, None, None, None, None, 10, 0, 1e-3, 0.9, 0.999, 1e-8, 1.0, None, None, None) == -22
+    assert h.sed_adam_amsgrad(None, None, None, None, None, 10, 0, 1e-3, 0.9, 0.999, 1e-8, 1.0, None, None, None, None) == -22
     assert h.sed_act_amax(None, 4, 64, None, None, None, None) == -22
 
 

@@ -50,8 +50,15 @@ def main():
             ("pool_bwd_apply   ", 2 * S + Sp, lambda: ops._call("sed_bn_relu_pool_bwd_apply", ops._ptr(y), ops._ptr(gp), B, H, W, C, ph, pw,
                                                                  ops._ptr(sc), ops._ptr(sh), ops._ptr(coef), ops._ptr(gy), None, s)),
             ("pool_fwd_cnt     ", S + 1.25 * Sp, lambda: ops._call("sed_bn_relu_pool_fwd_cnt", ops._ptr(y), B, H, W, C, ph, pw, ops._ptr(sc),
-                                                                   ops._ptr(sh), ops._ptr(out), ops._ptr(cnt), s)),
+                                                                   ops._ptr(sh), ops._ptr(out), ops._ptr(cnt), None, s)),
         ]
+        if C == 64:                                      # block 1's first convolution (Cin = 1): writes y, 16.4 MB per clip
+            x0 = torch.randn(B, H, W, 1, device="cuda")
+            w1 = torch.randn(64, 1, 3, 3, device="cuda") * 0.3
+            rpp = ops._lib.lib().sed_conv1_rows_per_part()
+            part = torch.empty(((M + rpp - 1) // rpp, 2, 64), device="cuda")
+            runs.append(("conv1_fwd        ", S, lambda: ops._call("sed_conv1_fwd", ops._ptr(x0), ops._ptr(w1), ops._ptr(gy), B, H, W,
+                                                                   ops._ptr(part), None, s)))
         for name, gb, fn in runs:
             ms = timeit(fn, args.reps)
             tot[name] = tot.get(name, 0.0) + ms
