@@ -400,7 +400,11 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const float* __re
         int h = (int)(q % H);
         int b = (int)(q / H);
         int ho = h / ph, wo = w / pw;
+#ifndef SED_NO_NT_LOADS       // streamed once: non-temporal (-3.6 % on the pass-2 kernel; nothing on bn_bwd_apply)
+        float4 v = load_nt4(y, r * c4n + c4);
+#else
         float4 v = reinterpret_cast<const float4*>(y)[r * c4n + c4];
+#endif
         float4 g = make_float4(0, 0, 0, 0);
         if (ho < Ho && wo < Wo) g = reinterpret_cast<const float4*>(gout)[(((long)b * Ho + ho) * Wo + wo) * c4n + c4];
         float4 wgt = make_float4(inv, inv, inv, inv);       // share of the pooled gradient this element receives
@@ -521,7 +525,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ d
         int c4 = (int)(i % c4n);
         float4 ca = reinterpret_cast<const float4*>(coef)[c4], cb = reinterpret_cast<const float4*>(coef)[c4n + c4],
                cc = reinterpret_cast<const float4*>(coef)[2 * c4n + c4];
+#ifdef SED_NT_LOADS          // experiment: non-temporal loads of the two streamed operands
+        float4 d = load_nt4(dy, i), v = load_nt4(y, i);
+#else
         float4 d = reinterpret_cast<float4*>(dy)[i], v = reinterpret_cast<const float4*>(y)[i];
+#endif
         float4 o;
         o.x = fmaf(ca.x, d.x, fmaf(cb.x, v.x, cc.x)); o.y = fmaf(ca.y, d.y, fmaf(cb.y, v.y, cc.y));
         o.z = fmaf(ca.z, d.z, fmaf(cb.z, v.z, cc.z)); o.w = fmaf(ca.w, d.w, fmaf(cb.w, v.w, cc.w));

@@ -63,6 +63,11 @@ __device__ __forceinline__ void store_nt4(float* base, long idx4, float4 v) {
     __builtin_nontemporal_store(ov, reinterpret_cast<floatx4*>(base) + idx4);
 }
 
+__device__ __forceinline__ float4 load_nt4(const float* base, long idx4) {
+    const floatx4 v = __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(base) + idx4);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // The ONE expression used everywhere for "BatchNorm (folded to scale/shift) then ReLU", so the
 // forward value and every recomputed backward mask agree bit for bit.
 __device__ __forceinline__ float bn_relu(float y, float scale, float shift) {
