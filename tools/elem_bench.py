@@ -59,6 +59,16 @@ def main():
             part = torch.empty(((M + rpp - 1) // rpp, 2, 64), device="cuda")
             runs.append(("conv1_fwd        ", S, lambda: ops._call("sed_conv1_fwd", ops._ptr(x0), ops._ptr(w1), ops._ptr(gy), B, H, W,
                                                                    ops._ptr(part), None, s)))
+        if C == 64:                                      # ... and its backward (BN1 backward applied on load, dW partials, dX taps)
+            coef1 = torch.randn(3, 64, device="cuda")
+            nblk = (M + 1023) // 1024
+            dwp = torch.empty((nblk, 576), device="cuda")
+            dw1 = torch.empty((64, 1, 3, 3), device="cuda")
+            tbuf = torch.empty((M, 9), device="cuda")
+            gx = torch.empty((B, H, W, 1), device="cuda")
+            runs.append(("conv1_bwd        ", 2 * S + M * 9 * 4 / 1e9, lambda: ops._call(
+                "sed_conv1_bwd", ops._ptr(x0), ops._ptr(w1), ops._ptr(d), ops._ptr(y), ops._ptr(coef1), B, H, W, ops._ptr(dw1),
+                ops._ptr(gx), ops._ptr(dwp), ops._ptr(tbuf), s)))
         for name, gb, fn in runs:
             ms = timeit(fn, args.reps)
             tot[name] = tot.get(name, 0.0) + ms
