@@ -422,7 +422,11 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
             if (EPI == 2) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
+#ifdef SF_NT_YPREV         // experiment: non-temporal loads of the previous activations in the dgrad epilogue
+                    yp[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, yoff[mb][r], nk * 128, 2));
+#else
                     yp[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, yoff[mb][r], nk * 128, 0));
+#endif
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
