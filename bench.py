@@ -28,6 +28,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 from sound_event_detection_dcase2017_task4_amd import ops, parallel
+from sound_event_detection_dcase2017_task4_amd.graph import GraphedTrainStep
 from sound_event_detection_dcase2017_task4_amd.optim import FusedAdamAmsgrad
 from sound_event_detection_dcase2017_task4_amd.pytorch import models
 from sound_event_detection_dcase2017_task4_amd.pytorch.losses import get_loss_func
@@ -206,8 +207,9 @@ def kernel_report(timing, steps, B2, default_workload, by_shape=False, frames=10
 class Workload(object):
     """One configuration of the hot path on this rank: model + optimiser + a resident pool of synthetic batches."""
 
-    def __init__(self, model_type, B, mix, rank, world, dev, seconds=10, inference=False, int16=False, h2d=False):
+    def __init__(self, model_type, B, mix, rank, world, dev, seconds=10, inference=False, int16=False, h2d=False, hip_graph=False):
         self.mt, self.B, self.mix, self.inference, self.h2d = model_type, B, mix, inference, h2d
+        self.graphed, self.hip_graph_error = None, None
         self.rank, self.world, self.dev = rank, world, dev
         self.B2 = 2 * B if (mix and not inference) else B
         L = 32000 * seconds
@@ -230,6 +232,10 @@ class Workload(object):
             self.upload(0)
         if inference:
             self.model.eval()
+        elif hip_graph and not h2d:
+            # forward + loss + backward replayed as ONE hipGraphLaunch after `hip_graph` eager steps (graph.GraphedTrainStep); the
+            # batch is copied into the graph's static input buffers every step (inside the timed region)
+            self.graphed = GraphedTrainStep(self.model, self.opt, self.loss_func, mixup=mix, eager_steps=hip_graph)
 
     def upload(self, i):
         self.copy_stream.wait_stream(torch.cuda.current_stream())     # the buffer's previous reader (step i-2) is done
@@ -247,6 +253,14 @@ class Workload(object):
             with torch.no_grad():
                 out = self.model(wave, None)
             return out["clipwise_output"].sum()
+        if self.graphed is not None:
+            try:
+                return self.graphed(wave, target, self.mixup.get_lambda(self.B2) if self.mix else None)
+            except ops.NonFiniteOperand:
+                raise
+            except Exception as e:             # capture refused (never seen; a side feature must not lose the line): eager from here on
+                self.hip_graph_error, self.graphed = repr(e), None
+                torch.cuda.synchronize()
         if self.mix:
             lam = ops.upload_small(self.mixup.get_lambda(self.B2), self.dev, torch.float32)   # pinned staging, async
             out = self.model(wave, lam)
@@ -259,6 +273,13 @@ class Workload(object):
         loss.backward()                  # gradient buckets go to RCCL as they complete (parallel.GradBuckets)
         self.opt.step()                  # waits for the buckets, then ONE Adam kernel over the flat buffer (1/world folded in)
         return loss
+
+    def graph_info(self):
+        if self.graphed is None:
+            return {"hip_graph": False, "hip_graph_error": self.hip_graph_error} if self.hip_graph_error else {"hip_graph": False}
+        return {"hip_graph": self.graphed.replays > 0, "hip_graph_replays": self.graphed.replays,
+                "hip_graph_note": "forward + loss + backward = one hipGraphLaunch per step (graph.GraphedTrainStep); inputs are "
+                                  "copied into its static buffers and the Adam kernel is launched behind it, both inside the timed region"}
 
     def sync(self):
         if self.world > 1:
@@ -275,6 +296,7 @@ class Workload(object):
         t0 = time.time()
         for i in range(steps):
             loss = self.step(warmup + i)
+        self.host_ms_per_step = (time.time() - t0) / steps * 1e3      # host time to ENQUEUE a step (it runs ahead of the GPU)
         self.sync()
         dt = time.time() - t0
         tm, ops.TIMING = ops.TIMING, None
@@ -292,7 +314,16 @@ class Workload(object):
             "eval-mode forward only" if self.inference else "SpecAugment on, clip_bce, Adam-amsgrad")
 
 
-def extra_configs(rank, world, dev, steps=5, warmup=2):
+def graph_eager_steps(mode, B, world, warmup, inference=False, h2d=False):
+    """Eager steps before the HIP-graph capture (0 = no graph).  auto: the launch-bound small batches on one rank; the capture
+    must fall inside the warm-up (it takes a few hundred ms) behind at least one eager step (lazily built tables)."""
+    on = mode == "on" or (mode == "auto" and B <= 64)
+    if not on or world > 1 or inference or h2d or warmup < 2:
+        return 0
+    return min(3, warmup - 1)
+
+
+def extra_configs(rank, world, dev, steps=5, warmup=2, hip_graph="auto"):
     """The other BASELINE.json configurations, a few steps each (single GPU, same process, after the headline run).  The
     metric's own batch size (bs=32, reference README) carries its own `roofline` + `kernels`."""
     out = []
@@ -303,12 +334,19 @@ def extra_configs(rank, world, dev, steps=5, warmup=2):
             ("configs[0] shape on the GPU: Cnn_9layers_FrameAvg B=32 no mixup", "Cnn_9layers_FrameAvg", 32, False, False, False),
             ("inference (eval-mode forward) Cnn_9layers_FrameAvg 256 clips/step", "Cnn_9layers_FrameAvg", 256, False, True, False)):
         try:
-            w = Workload(mt, B, mix, rank, world, dev, inference=inf)
+            w = Workload(mt, B, mix, rank, world, dev, inference=inf, hip_graph=graph_eager_steps(hip_graph, B, world, warmup, inf))
             k = steps * (8 if B <= 32 else 1)
             dt, loss, _ = w.run(k, warmup)
             row = {"config": tag, "workload": w.describe(), "value": round(B * k / dt, 2), "unit": "clips/s", "steps": k,
                    "warmup": warmup, "ms_per_step": round(dt / k * 1e3, 3),
                    "metric": "inference clips/sec" if inf else "training clips/sec", "loss": round(loss, 5)}
+            row.update(w.graph_info())
+            row["host_enqueue_ms_per_step"] = round(w.host_ms_per_step, 3)
+            if w.graphed is not None:          # the same steps launched kernel by kernel, for comparison (and for the event pass below)
+                w.graphed.enabled = False
+                dte, _, _ = w.run(k, 1)
+                row["eager_ms_per_step"] = round(dte / k * 1e3, 3)
+                row["eager_host_enqueue_ms_per_step"] = round(w.host_ms_per_step, 3)
             if detail:
                 # a second pass with a HIP event pair around every MFMA kernel launch (each pair costs the stream ~6 us:
                 # 0.25 ms per step, 2.7 % at this batch size -- `value` above is measured without them)
@@ -359,6 +397,8 @@ def main():
     ap.add_argument("--by_shape", action="store_true", help="print a per-layer MFMA kernel table to stderr")
     ap.add_argument("--no_kernel_events", action="store_true",
                     help="diagnostic: no HIP event pairs around the MFMA kernel launches in the timed region (roofline = null)")
+    ap.add_argument("--hip_graph", type=str, default="auto", choices=("auto", "on", "off"),
+                    help="replay forward+backward as one HIP graph per step (auto: per-GPU batch <= 64 on one rank)")
     ap.add_argument("--cpu_threads", type=int, default=0)
     ap.add_argument("--inference", action="store_true",
                     help="secondary metric (SURVEY.md 8d): eval-mode forward only, clips/s over --batch_size waveforms per step")
@@ -382,11 +422,23 @@ def main():
 
     B = args.batch_size
     mix = not args.no_mixup
+    ge = graph_eager_steps(args.hip_graph, B, world, args.warmup, args.inference, args.h2d)
     wl = Workload(args.model_type, B, mix, rank, world, dev, seconds=args.seconds, inference=args.inference, int16=args.int16,
-                  h2d=args.h2d)
+                  h2d=args.h2d, hip_graph=ge)
     B2 = wl.B2
     wl.opt.buckets.wait_events = []   # HIP events around the compute stream's wait for the gradient all-reduces
-    dt, loss, timing = wl.run(args.steps, args.warmup, timing=not args.no_kernel_events)
+    if ge:                            # graph replays carry no per-kernel events: `value` from the graphed steps, the kernel table
+        dt, loss, timing = wl.run(args.steps, args.warmup)                   # from a second, eager pass of the same workload
+        graph_info = wl.graph_info()
+        graph_info["host_enqueue_ms_per_step"] = round(wl.host_ms_per_step, 3)
+        if wl.graphed is not None and not args.no_kernel_events:
+            wl.graphed.enabled = False
+            dte, _, timing = wl.run(args.steps, 1, timing=True)
+            graph_info["eager_ms_per_step_with_kernel_events"] = round(dte / args.steps * 1e3, 3)
+    else:
+        dt, loss, timing = wl.run(args.steps, args.warmup, timing=not args.no_kernel_events)
+        graph_info = wl.graph_info()
+        graph_info["host_enqueue_ms_per_step"] = round(wl.host_ms_per_step, 3)
     bucket_order = list(wl.opt.buckets.last_issue_order)
     waits = wl.opt.buckets.wait_events[-args.steps:]
     dist_info = {"backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
@@ -431,6 +483,7 @@ def main():
         "waveforms_per_s": round(B2 * world * args.steps / dt, 2),
         "loss": round(loss, 5),
         "dist": dist_info,
+        "hip_graph": graph_info,
         "roofline": roofline,
         "roofline_frontend": frontend,
         "kernels": kern,
@@ -442,7 +495,7 @@ def main():
     if world == 1 and default_workload and not args.no_extra:
         if ops.USE_SF16:
             line["strict_fp32"] = strict_fp32(args.model_type, B, mix, rank, world, dev)
-        line["extra_configs"] = extra_configs(rank, world, dev)
+        line["extra_configs"] = extra_configs(rank, world, dev, hip_graph=args.hip_graph)
     if world == 1 and not args.no_cpu_baseline:
         try:
             line["cpu_baseline"] = cpu_baseline(threads=args.cpu_threads)

@@ -753,6 +753,13 @@ def _amax_buf(device, n=AMAX_SLOTS):
     return v
 
 
+def reset_amax_pool():
+    """The next _amax_buf() starts a fresh pool.  graph.GraphedTrainStep brackets its capture with this: rows handed out
+    inside a captured region must come from a pool whose zero fill is PART of that region (a replay re-zeroes them), and
+    eager code must never be handed rows of a pool a graph owns."""
+    _AMAX_POOL.clear()
+
+
 def amax_value(a):
     """Host float of a device amax vector (tests / debugging; synchronises)."""
     return float(a.max())

@@ -162,6 +162,7 @@ class GradBuckets(object):
         self.issue_order = []          # bucket indices in the order they were handed to the backend (for tests / logs)
         self.pre_fire_check = None     # callable(bucket index, param indices) run before a bucket goes to the backend
         self.wait_events = None        # bench: list that receives (start, end) CUDA event pairs around the waits of finish()
+        self.deferred = False          # True: ready() never fires a bucket, finish() issues them all (graph.GraphedTrainStep)
         self.begin_step()
         self.last_issue_order = []
 
@@ -196,7 +197,7 @@ class GradBuckets(object):
         pend = self.pending[b]
         if i in pend:
             pend.discard(i)
-            if not pend and not self.fired[b]:
+            if not pend and not self.fired[b] and not self.deferred:
                 self._fire(b)
 
     def _fire(self, b):

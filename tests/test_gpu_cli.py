@@ -156,3 +156,21 @@ def test_train_cli_survives_a_non_finite_batch(tmp_path, monkeypatch, caplog):
     assert ops.USE_SF16 is False                                       # the loop switched to the fp32 kernels ...
     assert any("optimiser step(s) were refused" in r.getMessage() for r in caplog.records)      # ... and said so
     ops.check_device_errors(synchronize=True)                          # nothing left pending
+
+
+def test_train_cli_with_hip_graph_prints_the_same_losses(tmp_path, capsys):
+    """`train --hip_graph`: three eager iterations, then forward + loss + backward replayed as one HIP graph per iteration;
+    the loss series is the eager run's."""
+    from sound_event_detection_dcase2017_task4_amd.pytorch import main as cli
+    series = []
+    for extra in ([], ["--hip_graph"]):
+        ws = str(tmp_path / ("g" if extra else "e"))
+        os.makedirs(ws)
+        torch.manual_seed(4321)
+        cli.main(["train", "--dataset_dir", ws, "--workspace", ws, "--holdout_fold", "1", "--model_type", "Cnn_9layers_FrameAvg",
+                  "--loss_type", "clip_bce", "--augmentation", "mixup", "--batch_size", "4", "--cuda", "--synthetic", "12",
+                  "--learning_rate", "1e-3", "--resume_iteration", "0", "--stop_iteration", "7", "--print_every", "1"] + extra)
+        out = capsys.readouterr().out
+        series.append([float(l.split()[1]) for l in out.splitlines() if len(l.split()) == 2 and l.split()[0].isdigit()])
+    assert len(series[0]) == len(series[1]) == 8
+    np.testing.assert_allclose(series[1], series[0], rtol=5e-6, atol=0)
