@@ -216,6 +216,11 @@ int sed_amax_caller_zeroes(int on);
 int sed_amax(const float* x, long n, float* amax_out, sed_stream_t stream);
 int sed_pack_conv_weights_sf16(const float* w_oihw, int Cout, int Cin, int dgrad, float* wscale, void* wp,
                                sed_stream_t stream);
+/* The same for n <= 16 weights in TWO launches (one amax pass + one pack pass over all of them): HOST arrays of n device
+ * pointers / shapes; dgrad[i] = 0 (forward layout), 1 (dgrad layout) or 4 (both, wp[i] = forward pack then dgrad pack).
+ * Every ConvBlock weight of reference models.py:77-85 is packed once per optimiser step this way. */
+int sed_pack_conv_weights_sf16_multi(int n, const float* const* w_oihw, const int* Cout, const int* Cin, const int* dgrad,
+                                     float* const* wscale, void* const* wp, sed_stream_t stream);
 int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale, float* y, int B, int H, int W, int Cin,
                      int Cout, const float* in_scale, const float* in_shift, int epi, float* partials,
                      const float* yprev, const float* p_scale, const float* p_shift, const float* p_mean,

@@ -539,6 +539,45 @@ __global__ __launch_bounds__(256) void pack_sf16_kernel(const float* __restrict_
     }
 }
 
+// ---- all conv weights of a model in TWO launches (one amax pass, one pack pass) instead of two per weight: 14 -> 2 tiny
+// launches per optimiser step, each of which costs the stream its ~6 us dependent-launch gap on top of its run time
+constexpr int SF_MULTI_MAX = 16;
+struct SfMultiP {
+    const float* w[SF_MULTI_MAX];
+    float* wscale[SF_MULTI_MAX];
+    _Float16* wp[SF_MULTI_MAX];
+    int cout[SF_MULTI_MAX], cin[SF_MULTI_MAX], mode[SF_MULTI_MAX];
+};
+
+__global__ __launch_bounds__(256) void amax_multi_kernel(SfMultiP p) {
+    const int t = blockIdx.y;
+    const float* __restrict__ x = p.w[t];
+    const long n = 9L * p.cout[t] * p.cin[t];
+    float m = 0.f;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[e]));
+    amax_publish_block(p.wscale[t], m);
+}
+
+__global__ __launch_bounds__(256) void pack_sf16_multi_kernel(SfMultiP p) {
+    const int t = blockIdx.y;
+    const float* __restrict__ w = p.w[t];
+    float* __restrict__ wscale = p.wscale[t];
+    _Float16* __restrict__ wp = p.wp[t];
+    const int Cout = p.cout[t], Cin = p.cin[t], mode = p.mode[t];
+    const float sw = sf_scale_of(amax_read(wscale));
+    if (blockIdx.x == 0 && threadIdx.x == 0) wscale[SED_AMAX_SLOTS] = sw;
+    const long total = 9L * Cout * Cin;
+    const long n = mode == 2 ? 2 * total : total;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        if (mode == 2) {
+            if (e < total) pack_sf16_one(w, Cout, Cin, 0, sw, e, wp);
+            else pack_sf16_one(w, Cout, Cin, 1, sw, e - total, wp + 2 * total);
+        } else {
+            pack_sf16_one(w, Cout, Cin, mode, sw, e, wp);
+        }
+    }
+}
+
 static int sf_log2w(int W) { return W == 64 ? 6 : W == 32 ? 5 : W == 16 ? 4 : 3; }
 // tile choice: 256 px x 64 co (MW = 4: 50 KB LDS, <= 160 VGPRs, THREE workgroups per CU) for every layer -- 5 % faster than
 // 128 px x 128 co (MW = 2: 66 KB, two per CU) on the >= 128-channel layers although it converts each patch twice as
@@ -588,6 +627,33 @@ SED_API int sed_pack_conv_weights_sf16(const float* w_oihw, int Cout, int Cin, i
     const long nb = ((both ? 2 : 1) * total + 255) / 256;
     hipLaunchKernelGGL(pack_sf16_kernel, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, (hipStream_t)stream, w_oihw,
                        Cout, Cin, both ? 2 : dg, wscale, (_Float16*)wp);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+SED_API int sed_pack_conv_weights_sf16_multi(int n, const float* const* w_oihw, const int* Cout, const int* Cin, const int* dgrad,
+                                             float* const* wscale, void* const* wp, sed_stream_t stream) {
+    if (n <= 0 || n > SF_MULTI_MAX || !w_oihw || !Cout || !Cin || !dgrad || !wscale || !wp) return SED_EINVAL;
+    SfMultiP p;
+    long most = 0;
+    for (int t = 0; t < SF_MULTI_MAX; ++t) {
+        const int s = t < n ? t : 0;                   // unused entries repeat the first one (never read: gridDim.y = n)
+        const int both = dgrad[s] & 4, dg = dgrad[s] & 1;
+        if (!w_oihw[s] || !wscale[s] || !wp[s] || Cout[s] <= 0 || Cin[s] <= 0 || (dgrad[s] & ~5) || (both && dg)) return SED_EINVAL;
+        if (((both || !dg) && Cin[s] % 16) || ((both || dg) && Cout[s] % 16)) return SED_EINVAL;
+        p.w[t] = w_oihw[s]; p.wscale[t] = wscale[s]; p.wp[t] = (_Float16*)wp[s];
+        p.cout[t] = Cout[s]; p.cin[t] = Cin[s]; p.mode[t] = both ? 2 : dg;
+        const long tot = (both ? 2 : 1) * 9L * Cout[s] * Cin[s];
+        if (t < n && tot > most) most = tot;
+        if (t < n) {
+            hipError_t e = sed_amax_clear(wscale[s], (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    const long nb_a = (most / 2 + 1023) / 1024, nb_p = (most + 255) / 256;
+    hipLaunchKernelGGL(amax_multi_kernel, dim3((unsigned)(nb_a > 64 ? 64 : (nb_a < 1 ? 1 : nb_a)), n), dim3(256), 0,
+                       (hipStream_t)stream, p);
+    hipLaunchKernelGGL(pack_sf16_multi_kernel, dim3((unsigned)(nb_p > 1024 ? 1024 : nb_p), n), dim3(256), 0, (hipStream_t)stream, p);
     SED_LAUNCH_CHECK();
     return 0;
 }

@@ -342,6 +342,21 @@ def invalidate_weight_caches():
     PARAM_GENERATION += 1
 
 
+def _cache_stamp(srcs):
+    return (PARAM_GENERATION,) + tuple((t.data_ptr(), t._version) for t in srcs)
+
+
+def _cache_fresh(kind, srcs):
+    hit = _WCACHE.get((kind,) + tuple(id(t) for t in srcs))
+    return hit is not None and hit[0] == _cache_stamp(srcs) and all(r() is t for r, t in zip(hit[2], srcs))
+
+
+def _cache_put(kind, srcs, val):
+    if len(_WCACHE) > 64:
+        _WCACHE.clear()
+    _WCACHE[(kind,) + tuple(id(t) for t in srcs)] = (_cache_stamp(srcs), val, [weakref.ref(t) for t in srcs])
+
+
 def _cached(kind, srcs, build):
     """The entry belongs to these very tensor OBJECTS (weak references: the allocator recycles addresses and Python
     recycles ids, so neither identifies a parameter) in this very state (storage address, torch version counter,
@@ -797,6 +812,32 @@ def sf16_packs(w, want_dgrad):
     return ent[0], ent[1]
 
 
+def prepack_sf16(weights, want_dgrad):
+    """The split-f16 operands of ALL the conv weights of a model whose cached packs are stale, in two launches
+    (sed_pack_conv_weights_sf16_multi) instead of two per weight; leaves the same cache entries sf16_packs() builds, so
+    the convolutions that follow find them.  Called by the models' trunk once per forward pass (a no-op while the
+    parameters have not changed: inference, or a second forward pass before the optimiser step)."""
+    todo = [w for w in weights if not _cache_fresh("sf16_packs", (w,))]
+    if not todo:
+        return 0
+    L = _lib.lib()
+    for i in range(0, len(todo), 16):
+        grp = todo[i:i + 16]
+        n = len(grp)
+        both = [bool(want_dgrad) and w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0 for w in grp]
+        halfs = [int(L.sed_conv_sf16_pack_halfs(w.shape[1], w.shape[0])) for w in grp]
+        wps = [torch.empty((2 * h if b else h,), dtype=torch.float16, device=w.device) for w, h, b in zip(grp, halfs, both)]
+        wss = [_amax_buf(w.device, AMAX_SLOTS + 1) for w in grp]
+        srcs = [_f32c(w) for w in grp]
+        _call("sed_pack_conv_weights_sf16_multi", n, (ctypes.c_void_p * n)(*[t.data_ptr() for t in srcs]),
+              (ctypes.c_int * n)(*[w.shape[0] for w in grp]), (ctypes.c_int * n)(*[w.shape[1] for w in grp]),
+              (ctypes.c_int * n)(*[4 if b else 0 for b in both]), (ctypes.c_void_p * n)(*[t.data_ptr() for t in wss]),
+              (ctypes.c_void_p * n)(*[t.data_ptr() for t in wps]), _stream())
+        for w, wp, ws, h, b in zip(grp, wps, wss, halfs, both):
+            _cache_put("sf16_packs", (w,), [(wp[:h], ws), (wp[h:], ws)] if b else [(wp, ws), None])
+    return len(todo)
+
+
 def amax_of(x):
     """max |x| as a device amax vector (one pass)."""
     out = _amax_buf(x.device)
@@ -904,6 +945,7 @@ class ConvBlockFn(torch.autograd.Function):
         """Returns (out, out_amax): out_amax = device amax vector of `out` for the next block's split-f16 scale (x_amax
         there).  pool_mode: 0 = 'avg' (every model), 1 = 'max', 2 = 'avg+max' (models.py:104-111)."""
         _chk_dev(x, w1, w2)
+        ctx.set_materialize_grads(False)     # out_amax takes no gradient: spare autograd its zero tensor (a fill launch per block)
         x = _f32c(x)
         B, H, W, Cin = x.shape
         Cout = w1.shape[0]

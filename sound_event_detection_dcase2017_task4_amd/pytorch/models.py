@@ -298,6 +298,10 @@ class _Cnn9Base(nn.Module):
             torch._foreach_add_([self.bn0.num_batches_tracked] + [bn.num_batches_tracked for blk in (
                 self.conv_block1, self.conv_block2, self.conv_block3, self.conv_block4) for bn in (blk.bn1, blk.bn2)], 1)
         x = x.view(x.shape[0], T, M, 1)                                  # NHWC, C = 1
+        if ops.USE_SF16:                 # split-f16 operands of all seven MFMA conv weights: two launches per optimiser step
+            blks = (self.conv_block1, self.conv_block2, self.conv_block3, self.conv_block4)
+            ops.prepack_sf16([b.conv1.weight for b in blks[1:]] + [b.conv2.weight for b in blks],
+                             self.training and torch.is_grad_enabled())
         x = self.conv_block1(x, pool_size=(2, 2), pool_type='avg')
         x = self.conv_block2(x, pool_size=(2, 2), pool_type='avg')
         x = self.conv_block3(x, pool_size=(2, 2), pool_type='avg')

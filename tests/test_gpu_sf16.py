@@ -265,3 +265,25 @@ def test_sf16_nonfinite_operand_is_reported_and_adam_refuses_the_step():
     ops.adam_amsgrad_(p, gbad, m, v, vm, 2, 1e-3, guard=False)         # guard off = torch.optim.Adam: NaN in, NaN out
     torch.cuda.synchronize()
     assert torch.isnan(p[777]) and not torch.isnan(p[0])
+
+
+def test_multi_tensor_pack_equals_the_single_packs():
+    """sed_pack_conv_weights_sf16_multi (all conv weights of a model in two launches) writes bit-identical operands, scales
+    and amax slots to one sed_pack_conv_weights_sf16 call per weight, and leaves cache entries sf16_packs() finds."""
+    from sound_event_detection_dcase2017_task4_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    shapes = [(128, 64), (256, 128), (512, 256), (64, 64), (128, 128), (256, 256), (512, 512)]
+    ws = [torch.randn((co, ci, 3, 3), device="cuda", generator=g) * (10.0 ** (i - 3)) for i, (co, ci) in enumerate(shapes)]
+    ops.invalidate_weight_caches()
+    assert ops.prepack_sf16(ws, True) == 7
+    assert ops.prepack_sf16(ws, True) == 0                       # fresh: nothing to do
+    for w in ws:
+        (f_m, s_m), (d_m, _) = ops.sf16_packs(w, True)           # cache hit: the multi-tensor result
+        (f_1, s_1), (d_1, _) = ops.pack_sf16(w, both=True)
+        assert torch.equal(f_m, f_1) and torch.equal(d_m, d_1)
+        assert float(s_m[64]) == float(s_1[64]) and float(s_m[:64].max()) == float(s_1[:64].max()) == float(w.abs().max())
+    # forward-only packs (inference) and a stale entry after the parameters moved
+    ops.invalidate_weight_caches()
+    assert ops.prepack_sf16(ws[:2], False) == 2
+    f_m, d_m = ops.sf16_packs(ws[0], False)
+    assert d_m is None and torch.equal(f_m[0], ops.pack_sf16(ws[0])[0])
