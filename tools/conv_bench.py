@@ -26,12 +26,26 @@ def timeit(fn, reps):
     return a.elapsed_time(b) / reps
 
 
+def presplit(t):
+    """fp32 [..., C] -> the same bytes holding, per 4 channels, (h0 h1 h2 h3 l0 l1 l2 l3) f16 of t * 2^k, amax -> [2^13, 2^14)"""
+    import math
+    s = 2.0 ** (14 - math.frexp(float(t.abs().max()))[1])
+    v = t * s
+    hi = v.half()
+    lo = (v - hi.float()).half()
+    C = t.shape[-1]
+    both = torch.cat([hi.view(-1, C // 4, 4), lo.view(-1, C // 4, 4)], -1).contiguous()
+    return both.view(torch.float32).view(t.shape)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--layers", type=str, default="", help="comma-separated indices into LAYERS (default: all)")
+    ap.add_argument("--presplit", action="store_true", help="experiment (-DSF_EMU_PRESPLIT builds): hand the split-f16 kernels "
+                    "operands that are already (hi, lo) f16 pairs, 16 bytes per 4 channels")
     args = ap.parse_args()
     B = args.batch
     tot_ms, tot_fl = {}, {}
@@ -73,19 +87,21 @@ def main():
         if args.only in ("", "wino2", "sf16") and L.sed_conv3x3_sf16_supported(H, W, ci, co):
             wps, wpsd = ops.pack_sf16(w), ops.pack_sf16(w, dgrad=True)
             xam, xamT, gam0 = ops.amax_of(x), ops.act_amax_full(x, st), ops.amax_of(gy)
+            xs, gys = (presplit(x), presplit(gy)) if args.presplit else (x, gy)
             Ps = int(L.sed_conv_sf16_num_parts(B, H, W, co))
             ps1 = torch.empty((Ps * 2 * co + Ps,), device="cuda")
             mm1 = torch.empty((Ps, 2, co), device="cuda")
             psb = torch.empty((int(L.sed_conv_sf16_num_parts(B, H, W, ci)) * 2 * ci,), device="cuda")
-            runs += [("sf16  fwd epi0    ", lambda: ops.conv3x3_sf16(x, wps, B, H, W, ci, co, x_amax=xam)),
+            runs += [("sf16  fwd epi0    ", lambda: ops.conv3x3_sf16(xs, wps, B, H, W, ci, co, x_amax=xam)),
                      ("sf16  fwd epi0+inT", lambda: ops.conv3x3_sf16(x, wps, B, H, W, ci, co, in_st=st, x_amax=xamT)),
                      ("sf16  fwd epi1+inT", lambda: ops.conv3x3_sf16(x, wps, B, H, W, ci, co, in_st=st, x_amax=xamT, epi=1, partials=ps1)),
-                     ("sf16  fwd epi1+mm ", lambda: ops.conv3x3_sf16(x, wps, B, H, W, ci, co, x_amax=xam, epi=1, partials=ps1, minmax=mm1)),
-                     ("sf16  dgrad epi2  ", lambda: ops.conv3x3_sf16(gy, wpsd, B, H, W, co, ci, x_amax=gam0, epi=2, partials=psb, yprev=x, p_st=sto))]
+                     ("sf16  fwd epi1+mm ", lambda: ops.conv3x3_sf16(xs, wps, B, H, W, ci, co, x_amax=xam, epi=1, partials=ps1, minmax=mm1)),
+                     ("sf16  dgrad epi2  ", lambda: ops.conv3x3_sf16(gys, wpsd, B, H, W, co, ci, x_amax=gam0, epi=2, partials=psb, yprev=x, p_st=sto))]
         if args.only in ("", "wgrad", "sf16w") and L.sed_wgrad_sf16_supported(H, W, ci, co):
             gam, xam2, xamT2 = ops.amax_of(gy), ops.amax_of(x), ops.act_amax_full(x, st)
-            runs += [("wgrad sf16 +inT   ", lambda: ops._wgrad_sf16(x, gy, B, H, W, ci, co, in_st=st, gy_amax=gam, x_amax=xamT2)),
-                     ("wgrad sf16        ", lambda: ops._wgrad_sf16(x, gy, B, H, W, ci, co, gy_amax=gam, x_amax=xam2))]
+            xs2, gys2 = (presplit(x), presplit(gy)) if args.presplit else (x, gy)
+            runs += [("wgrad sf16 +inT   ", lambda: ops._wgrad_sf16(x, gys2, B, H, W, ci, co, in_st=st, gy_amax=gam, x_amax=xamT2)),
+                     ("wgrad sf16        ", lambda: ops._wgrad_sf16(xs2, gys2, B, H, W, ci, co, gy_amax=gam, x_amax=xam2))]
         if args.only in ("", "wgrad"):
             runs += [("wgrad +inT        ", lambda: ops._wgrad_direct(x, gy, B, H, W, ci, co, in_st=st)),
                      ("wgrad             ", lambda: ops._wgrad_direct(x, gy, B, H, W, ci, co)),

@@ -1,0 +1,73 @@
+p='/root/repo/sound_event_detection_dcase2017_task4_amd/csrc/conv_sf16.hip'
+s=open(p).read()
+def rep(a,b,cnt=1):
+    global s
+    assert s.count(a)==cnt,(a[:60],s.count(a))
+    s=s.replace(a,b)
+# conv: non-INT staging = plain copy of pre-split (h01,h23,l01,l23) words
+rep("""#define SF_ASTORE(i)                                                                                            \\
+    if (i < NI && (INT ? sok##i : val##i)) {   /* INT: rows outside the image were zeroed once and are never written */ \\
+        float4 v = areg##i;                                                                                     \\""",
+"""#ifdef SF_EMU_PRESPLIT
+#define SF_PRESPLIT_COPY(i)                                                                                     \\
+    if (!INT && i < NI && val##i) {                                                                             \\
+        const uint4 u = __builtin_bit_cast(uint4, areg##i);                                                     \\
+        *reinterpret_cast<uint2*>(As + lso##i) = make_uint2(u.x, u.y);                                          \\
+        *reinterpret_cast<uint2*>(As + APLANE + lso##i) = make_uint2(u.z, u.w);                                 \\
+    } else
+#else
+#define SF_PRESPLIT_COPY(i)
+#endif
+#define SF_ASTORE(i)                                                                                            \\
+    SF_PRESPLIT_COPY(i)                                                                                         \\
+    if (i < NI && (INT ? sok##i : val##i)) {   /* INT: rows outside the image were zeroed once and are never written */ \\
+        float4 v = areg##i;                                                                                     \\""")
+rep("""#define WSF_GSTORE(GB)                                                                                          \\
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                             \\
+        float4 v = greg[i];                                                                                     \\""",
+"""#define WSF_GSTORE_CVT(GB)                                                                                      \\
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                             \\
+        float4 v = greg[i];                                                                                     \\""")
+rep("""        *reinterpret_cast<uint2*>(Gs + (GB) + GPL + gls[i]) = make_uint2(l01, l23);                             \\
+    }
+
+    // halo columns of every ring row""","""        *reinterpret_cast<uint2*>(Gs + (GB) + GPL + gls[i]) = make_uint2(l01, l23);                             \\
+    }
+#ifdef SF_EMU_PRESPLIT
+#define WSF_GSTORE(GB)                                                                                          \\
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                             \\
+        const uint4 u = __builtin_bit_cast(uint4, greg[i]);                                                     \\
+        *reinterpret_cast<uint2*>(Gs + (GB) + gls[i]) = make_uint2(u.x, u.y);                                   \\
+        *reinterpret_cast<uint2*>(Gs + (GB) + GPL + gls[i]) = make_uint2(u.z, u.w);                             \\
+    }
+#else
+#define WSF_GSTORE(GB) WSF_GSTORE_CVT(GB)
+#endif
+
+    // halo columns of every ring row""")
+# wgrad x operand (non-INT): plain copy
+rep("""#define WSF_XSTORE(ROW0)                                                                                        \\
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                             \\
+        float4 v = xreg[i];                                                                                     \\""",
+"""#define WSF_XSTORE(ROW0)                                                                                        \\
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                             \\
+        WSF_X_PRESPLIT(ROW0)                                                                                    \\
+        float4 v = xreg[i];                                                                                     \\""")
+rep("""    __amdgpu_buffer_rsrc_t xrs, grs;
+#define WSF_IMAGE(BB)""","""#ifdef SF_EMU_PRESPLIT
+#define WSF_X_PRESPLIT(ROW0)                                                                                    \\
+        if (!INT) {                                                                                             \\
+            const uint4 u = __builtin_bit_cast(uint4, xreg[i]);                                                 \\
+            const int slot_ = ((ROW0) + xrr[i] + 1) & (RING - 1);                                               \\
+            const int o_ = (slot_ * WP + xcc[i] + 1) * 64 + xq * 8;                                             \\
+            *reinterpret_cast<uint2*>(Xs + o_) = make_uint2(u.x, u.y);                                          \\
+            *reinterpret_cast<uint2*>(Xs + XPL + o_) = make_uint2(u.z, u.w);                                    \\
+            continue;                                                                                           \\
+        }
+#else
+#define WSF_X_PRESPLIT(ROW0)
+#endif
+    __amdgpu_buffer_rsrc_t xrs, grs;
+#define WSF_IMAGE(BB)""")
+open(p,'w').write(s)
+print("ok")
