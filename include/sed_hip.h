@@ -193,8 +193,8 @@ int sed_conv3x3_wgrad_wino2(const float* x, const float* gy, float* dw_oihw, flo
 /* 3x3 convolution (forward / dgrad) on the f16 MFMA pipe with SPLIT operands: x = (hi + lo)/s with hi, lo f16 and s a
  * power of two per tensor, three f16 MFMAs (hi*hi + hi*lo + lo*hi, exact products, fp32 accumulation) per product slab --
  * the error of a direct fp32 convolution at 3/16 of its MFMA issue time (csrc/conv_sf16.hip).  Same contract as
- * sed_conv3x3_wino2 (in_scale/in_shift operand transform, epi 0/1/2, partials = sed_conv_sf16_num_parts(...) parts with the
- * pixel counts appended for epi 1).  wp: sed_conv_sf16_pack_halfs(...) f16 values and wscale[65] (64 amax slots, scale) written by
+ * sed_conv3x3_wino2 (in_scale/in_shift operand transform, epi 0/1/2, partials = sed_conv_sf16_num_parts(...) parts -- one per
+ * workgroup tile of 256 pixels x 64 channels -- with the pixel counts appended for epi 1).  wp: sed_conv_sf16_pack_halfs(...) f16 values and wscale[65] (64 amax slots, scale) written by
  * sed_pack_conv_weights_sf16 (dgrad = 1: operand of the transposed convolution).  Operand scale: x_amax = device pointer
  * to the amax of the operand as the MFMAs see it (of relu(in_scale*x + in_shift) when that transform is fused: sed_act_amax;
  * of x otherwise: sed_amax or the producer kernels' amax_out) -- the power of two that brings it to [2^13, 2^14) is

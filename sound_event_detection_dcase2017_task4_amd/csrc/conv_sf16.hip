@@ -21,8 +21,9 @@
 // taps (one kernel row) per stage, double-buffered.  16-byte chunk index XOR ((row >> 3) & 1) keeps every ds_read_b128
 // conflict-free (consecutive pixels = consecutive rows, for any tap shift).
 //
-// Fusions as in conv_wino2.hip: input relu(scale*x+shift); epilogue 1 = BN statistics (sum, M2) per wave (64 pixels) +
-// the per-part pixel count; epilogue 2 = ReLU mask of the previous activation + BN-backward sums.
+// Fusions as in conv_wino2.hip: input relu(scale*x+shift); epilogue 1 = BN statistics (sum, M2) per WORKGROUP tile (the
+// waves' 64-pixel statistics merged through LDS, Chan's formula) + the per-part pixel count; epilogue 2 = ReLU mask of the
+// previous activation + BN-backward sums.
 #include "common.h"
 #include "sed_hip.h"
 #include <stdlib.h>
@@ -40,7 +41,7 @@ struct Sf16P {
     float* y;                  // [B][H][W][N]
     const float* in_scale;
     const float* in_shift;
-    float* partials;           // EPI 1: [nparts][2][N] + [nparts] counts; EPI 2: [nparts][2][N]; nparts = B*ntile*MW
+    float* partials;           // EPI 1: [nparts][2][N] + [nparts] counts; EPI 2: [nparts][2][N]; nparts = B*ntile
     const float* yprev;
     const float* p_scale;
     const float* p_shift;
@@ -400,7 +401,18 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
     const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(EPI == 2 ? p.yprev + (long)b * p.H * W * p.N : p.x), 0, (int)y_img_bytes, 0x00020000);
     const int colb = n0 + 64 * wn + (lane & 31);       // + 32*nk
-    const long part = ((long)b * p.ntile + tile) * MW + wm;
+    const long part = (long)b * p.ntile + tile;        // ONE part per workgroup: the MW waves' sums are merged below
+    // per-wave (sum, M2 | second sum, max, min) of its 64 pixels per channel -> LDS (the staging buffers are free behind the
+    // loop's last barrier) -> merged by wave wm = 0 of every channel half: a quarter of the partial rows in memory and in the
+    // BatchNorm merge kernels (131 -> 33 MB of partials per launch on block 1 at B = 256; step time unchanged: measured)
+    float* const red = reinterpret_cast<float*>(smem);             // [wave][nk][32 columns][4]
+    // valid pixels of wave w's 64 (whole rows of W <= 64 pixels)
+    auto wave_count = [&](int w) -> float {
+        const int rows_w = 64 >> logW;
+        int nv = p.H - (h0 + ((64 * w) >> logW));
+        nv = nv < 0 ? 0 : (nv > rows_w ? rows_w : nv);
+        return (float)(nv * W);
+    };
     int yoff[2][16];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
@@ -452,20 +464,14 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
 #endif
             }
         }
+        float* const mine = red + ((wvu * 2 + nk) * 32 + (lane & 31)) * 4;
         if (EPI != 2 && p.mm) {      // range of this wave's 64 pixels per channel: the consumer's operand amax comes from it
             vmx = fmaxf(vmx, __shfl_xor(vmx, 32, 64));
             vmn = fminf(vmn, __shfl_xor(vmn, 32, 64));
-            if (kh == 0) {
-                p.mm[(part * 2 + 0) * p.N + col] = vmx;
-                p.mm[(part * 2 + 1) * p.N + col] = vmn;
-            }
+            if (kh == 0) { mine[2] = vmx; mine[3] = vmn; }
         }
         if (EPI == 1) {
-            // valid pixels of this wave's 64 (scalar): whole rows of W <= 64 pixels
-            const int rows_w = 64 >> logW;
-            int nv = p.H - (h0 + ((64 * wm) >> logW));
-            nv = nv < 0 ? 0 : (nv > rows_w ? rows_w : nv);
-            const float cnt = (float)(nv * W);
+            const float cnt = wave_count(wm);
             s1 += __shfl_xor(s1, 32, 64);
             const float mean = cnt > 0.f ? s1 / cnt : 0.f;
 #pragma unroll
@@ -477,19 +483,50 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
                     s2 = fmaf(d, d, s2);
                 }
             s2 += __shfl_xor(s2, 32, 64);
-            if (kh == 0) {
-                p.partials[(part * 2 + 0) * p.N + col] = s1;
-                p.partials[(part * 2 + 1) * p.N + col] = s2;
-            }
-            if (nk == 0 && wn == 0 && n0 == 0 && lane == 0) p.partials[(long)p.B * p.ntile * MW * 2 * p.N + part] = cnt;
+            if (kh == 0) { mine[0] = s1; mine[1] = s2; }
         }
         if (EPI == 2) {
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
-            if (kh == 0) {
-                p.partials[(part * 2 + 0) * p.N + col] = s1;
-                p.partials[(part * 2 + 1) * p.N + col] = s2;
+            if (kh == 0) { mine[0] = s1; mine[1] = s2; }
+        }
+    }
+    if (EPI == 0 && !p.mm) return;
+    __syncthreads();
+    if (wm != 0) return;
+    {
+        const int nk = lane >> 5, col = colb + 32 * nk;            // lane -> one of this wave's 64 columns
+        const float* const theirs = red + (((wn * MW) * 2 + nk) * 32 + (lane & 31)) * 4;       // + w * 256: wave (w, wn)
+        if (EPI != 2 && p.mm) {
+            float vmx = theirs[2], vmn = theirs[3];
+#pragma unroll
+            for (int w = 1; w < MW; ++w) { vmx = fmaxf(vmx, theirs[w * 256 + 2]); vmn = fminf(vmn, theirs[w * 256 + 3]); }
+            p.mm[(part * 2 + 0) * p.N + col] = vmx;
+            p.mm[(part * 2 + 1) * p.N + col] = vmn;
+        }
+        if (EPI == 1) {
+            // Chan's merge of the waves' (count, sum, M2): M2 = sum_w M2_w + n_w (mean_w - mean)^2
+            float S = 0.f, Nn = 0.f;
+#pragma unroll
+            for (int w = 0; w < MW; ++w) { S += theirs[w * 256]; Nn += wave_count(w); }
+            const float mean = Nn > 0.f ? S / Nn : 0.f;
+            float M2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < MW; ++w) {
+                const float nw = wave_count(w);
+                const float d = nw > 0.f ? theirs[w * 256] / nw - mean : 0.f;
+                M2 += theirs[w * 256 + 1] + nw * d * d;
             }
+            p.partials[(part * 2 + 0) * p.N + col] = S;
+            p.partials[(part * 2 + 1) * p.N + col] = M2;
+            if (wn == 0 && n0 == 0 && lane == 0) p.partials[(long)p.B * p.ntile * 2 * p.N + part] = Nn;
+        }
+        if (EPI == 2) {
+            float a = 0.f, c = 0.f;
+#pragma unroll
+            for (int w = 0; w < MW; ++w) { a += theirs[w * 256]; c += theirs[w * 256 + 1]; }
+            p.partials[(part * 2 + 0) * p.N + col] = a;
+            p.partials[(part * 2 + 1) * p.N + col] = c;
         }
     }
 }
@@ -599,7 +636,7 @@ SED_API long sed_conv_sf16_pack_halfs(int Cin, int Cout) { return 18L * Cin * Co
 SED_API long sed_conv_sf16_num_parts(int B, int H, int W, int Cout) {
     if (!(W == 8 || W == 16 || W == 32 || W == 64) || Cout % 64) return 0;
     const int mw = sf_mw(Cout), tr = (64 * mw) >> sf_log2w(W);
-    return (long)B * ((H + tr - 1) / tr) * mw;
+    return (long)B * ((H + tr - 1) / tr);
 }
 
 SED_API int sed_amax(const float* x, long n, float* amax_out, sed_stream_t stream) {
