@@ -619,6 +619,10 @@ static int sf_log2w(int W) { return W == 64 ? 6 : W == 32 ? 5 : W == 16 ? 4 : 3;
 // tile choice: 256 px x 64 co (MW = 4: 50 KB LDS, <= 160 VGPRs, THREE workgroups per CU) for every layer -- 5 % faster than
 // 128 px x 128 co (MW = 2: 66 KB, two per CU) on the >= 128-channel layers although it converts each patch twice as
 // often: the third wave per SIMD hides more than the reuse saves.  SED_SF16_MW2=1 selects MW = 2 where Cout % 128 == 0.
+// (Round 3 also built 192 px x 128 co with SIX waves -- three per SIMD AND the 128-channel reuse, 69 KB, two workgroups per CU;
+// parity-green: 323-339 TFLOP/s against 408-420 for MW = 4 and 384-390 for MW = 2 over the six >= 128-channel layers,
+// profiles/r03/experiment_tile_192x128_six_waves.txt -- six waves do not spread evenly over four SIMDs and only two barrier
+// domains share a CU.  Removed again.)
 static int sf_mw(int Cout) {
     static int mw2 = -1;
     if (mw2 < 0) { const char* e = getenv("SED_SF16_MW2"); mw2 = (e && e[0] == '1') ? 1 : 0; }
