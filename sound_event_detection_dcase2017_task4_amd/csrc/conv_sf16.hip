@@ -622,7 +622,8 @@ static int sf_log2w(int W) { return W == 64 ? 6 : W == 32 ? 5 : W == 16 ? 4 : 3;
 // (Round 3 also built 192 px x 128 co with SIX waves -- three per SIMD AND the 128-channel reuse, 69 KB, two workgroups per CU;
 // parity-green: 323-339 TFLOP/s against 408-420 for MW = 4 and 384-390 for MW = 2 over the six >= 128-channel layers,
 // profiles/r03/experiment_tile_192x128_six_waves.txt -- six waves do not spread evenly over four SIMDs and only two barrier
-// domains share a CU.  Removed again.)
+// domains share a CU.  And 256 px x 128 co with EIGHT waves at four waves per SIMD (128 VGPRs: 9-41 spilled registers): the
+// dgrad variant (11 spills) +0.7 %, the fused-input variants -10 %, experiment_tile_256x128_eight_waves.txt.  Removed again.)
 static int sf_mw(int Cout) {
     static int mw2 = -1;
     if (mw2 < 0) { const char* e = getenv("SED_SF16_MW2"); mw2 = (e && e[0] == '1') ? 1 : 0; }
