@@ -283,6 +283,36 @@ def test_full_size_train_step_properties():
     y2 = ops._conv_igemm(x, wf, 256, 1001, 64, 64, 64)
     assert (y2 - 2.0 * y1).abs().max().item() <= 1e-5 * y1.abs().max().item()
     del x, y1, y2
+    # the same layer on the split-f16 kernel: the operand scale is a power of two taken from the device amax, so doubling the
+    # input halves the scale, the (hi, lo) operands are the same bits and the result is EXACTLY twice the first one
+    x = torch.randn((256, 1001, 64, 64), generator=g, device="cuda")
+    pk = ops.pack_sf16(m.conv_block1.conv2.weight.detach())
+    y1 = ops.conv3x3_sf16(x, pk, 256, 1001, 64, 64, 64, x_amax=ops.amax_of(x))
+    x.mul_(2.0)
+    y2 = ops.conv3x3_sf16(x, pk, 256, 1001, 64, 64, 64, x_amax=ops.amax_of(x))
+    assert torch.equal(y2, 2.0 * y1)
+    del x, y1, y2
+
+
+def test_full_size_eval_batch_is_row_consistent():
+    """Eval-mode forward of 256 ten-second clips = 8 copies of 32 distinct ones: every copy's outputs are bit-identical to the
+    32-clip run (nothing depends on the batch position or on the workgroup a clip lands in), and the gradient of a sum loss
+    over the 256 rows w.r.t. the conv weights is 8x the 32-row one (eval-mode BatchNorm does not couple rows)."""
+    mt = "Cnn_9layers_FrameAvg"
+    m = build(mt).eval()
+    x32 = torch.from_numpy(waves(5, 32, 320000)).cuda()
+    x256 = x32.repeat(8, 1)
+    with torch.no_grad():
+        a = m(x32)["clipwise_output"]
+        b = m(x256)["clipwise_output"]
+    assert torch.equal(b.view(8, 32, 17), a.unsqueeze(0).expand(8, 32, 17))
+    grads = []
+    for x in (x32[:8], x32[:8].repeat(4, 1)):
+        m.zero_grad()
+        m(x)["clipwise_output"].sum().backward()
+        grads.append([p.grad.double().clone() for p in (m.conv_block2.conv1.weight, m.conv_block4.conv2.weight, m.fc.weight)])
+    for g8, g32 in zip(*grads):
+        assert (g32 - 4.0 * g8).abs().max().item() <= 2e-5 * g8.abs().max().item() * 4.0
 
 
 def test_int16_waveforms_end_to_end():
