@@ -221,6 +221,15 @@ int sed_pack_conv_weights_sf16(const float* w_oihw, int Cout, int Cin, int dgrad
  * Every ConvBlock weight of reference models.py:77-85 is packed once per optimiser step this way. */
 int sed_pack_conv_weights_sf16_multi(int n, const float* const* w_oihw, const int* Cout, const int* Cin, const int* dgrad,
                                      float* const* wscale, void* const* wp, sed_stream_t stream);
+/* Inference form of the second convolution of a ConvBlock (reference models.py:99-113 in eval mode):
+ * out = avg_pool(relu(o_scale * conv(relu(in_scale * x + in_shift)) + o_shift)) with the eval-mode BatchNorm folded into
+ * o_scale / o_shift (sed_bn_eval_affine) -- the full-resolution convolution output is never written.  Pooling (2, 2) for
+ * W in {16, 32, 64} or (1, W) for W = 8; out = [B][H/ph][W/pw][Cout]; out_amax (nullable) receives the amax slots of out. */
+int sed_conv3x3_sf16_eval_pool_supported(int H, int W, int Cin, int Cout, int ph, int pw);
+int sed_conv3x3_sf16_eval_pool(const float* x, const void* wp, const float* wscale, float* out, int B, int H, int W,
+                               int Cin, int Cout, const float* in_scale, const float* in_shift, const float* o_scale,
+                               const float* o_shift, int ph, int pw, const float* x_amax, float* out_amax,
+                               int* err_host, int* err_dev, sed_stream_t stream);
 int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale, float* y, int B, int H, int W, int Cin,
                      int Cout, const float* in_scale, const float* in_shift, int epi, float* partials,
                      const float* yprev, const float* p_scale, const float* p_shift, const float* p_mean,

@@ -21,6 +21,8 @@
 // taps (one kernel row) per stage, double-buffered.  16-byte chunk index XOR ((row >> 3) & 1) keeps every ds_read_b128
 // conflict-free (consecutive pixels = consecutive rows, for any tap shift).
 //
+// Epilogue 3 (inference): eval-mode BatchNorm (folded to scale / shift) + ReLU + average pooling in
+// registers -- the full-resolution conv output is never written; the pooled tensor and its amax are.
 // Fusions as in conv_wino2.hip: input relu(scale*x+shift); epilogue 1 = BN statistics (sum, M2) per WORKGROUP tile (the
 // waves' 64-pixel statistics merged through LDS, Chan's formula) + the per-part pixel count; epilogue 2 = ReLU mask of the
 // previous activation + BN-backward sums.
@@ -52,6 +54,8 @@ struct Sf16P {
     float* mm;                 // nullable: per-part (max, min) of the outputs per channel, [nparts][2][N] (EPI 0 / 1)
     int* err_host;             // nullable, host-mapped: set to 1 when an operand is not finite
     int* err_dev;              // nullable, device: same (read by sed_adam_amsgrad)
+    float* pool_amax;          // EPI 3: amax slots of the pooled output
+    int ph, pw;                // EPI 3: pooling window, (2, 2) or (1, W)
 };
 
 __device__ __forceinline__ int sf_sw(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 3) & 1)) << 4); }
@@ -233,7 +237,11 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
         const int pix = 64 * wm + 32 * mb + (lane & 31);
-        const int r = pix >> logW, c = pix & (W - 1);
+        int r = pix >> logW, c = pix & (W - 1);
+        if (EPI == 3 && logW == 6) {       // pooling epilogue at W = 64: a wave owns 2 rows x 32 columns (whole 2x2 windows)
+            r = 2 * (wm >> 1) + mb;
+            c = 32 * (wm & 1) + (lane & 31);
+        }
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) aoffs[mb][tp] = sf_swA(r + tp / 3, (r + tp / 3) * WP + c + tp % 3, kh, rowkey);
     }
@@ -394,6 +402,72 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
         if (p.err_dev) __hip_atomic_store(p.err_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
+    if (EPI == 3) {
+        // ---- inference epilogue: relu(scale * y + shift) -> average pool -> store (accumulator register r of a 32-pixel block
+        // holds pixel i = (r & 3) + 4 * kh + 8 * (r >> 2) of it, channel = lane & 31)
+        const int Hp = p.H / p.ph, Wq = W / p.pw;
+        float* const outb = p.y + (long)b * Hp * Wq * p.N;
+        float amax = 0.f;
+#pragma unroll
+        for (int nk = 0; nk < 2; ++nk) {
+            const int col = n0 + 64 * wn + (lane & 31) + 32 * nk;
+            const float sc = p.p_scale[col], sh = p.p_shift[col];
+            float a[2][16];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a[mb][r] = bn_relu(acc[mb][nk][r] * inv, sc, sh);
+            if (p.pw == 2) {
+                if (logW >= 5) {            // W = 64 (remapped above) / 32: block mb = one image row, 32 columns
+                    const int prow = (h0 >> 1) + (logW == 6 ? (wm >> 1) : wm);
+                    const int pc0 = logW == 6 ? 16 * (wm & 1) : 0;
+                    if (prow < Hp) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const float v = 0.25f * ((a[0][4 * q + 2 * j] + a[0][4 * q + 2 * j + 1]) +
+                                                         (a[1][4 * q + 2 * j] + a[1][4 * q + 2 * j + 1]));
+                                outb[((long)prow * Wq + pc0 + j + 4 * q + 2 * kh) * p.N + col] = v;
+                                amax = fmaxf(amax, v);
+                            }
+                    }
+                } else {                    // W = 16: block mb = image rows (2 mb, 2 mb + 1) of the wave's four
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) {
+                        const int prow = (h0 >> 1) + 2 * wm + mb;
+                        if (prow < Hp) {
+#pragma unroll
+                            for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                                for (int j = 0; j < 2; ++j) {
+                                    const int r0 = 4 * qq + 2 * j;
+                                    const float v = 0.25f * ((a[mb][r0] + a[mb][r0 + 1]) + (a[mb][r0 + 8] + a[mb][r0 + 9]));
+                                    outb[((long)prow * Wq + j + 2 * kh + 4 * qq) * p.N + col] = v;
+                                    amax = fmaxf(amax, v);
+                                }
+                        }
+                    }
+                }
+            } else {                        // (1, W) average at W = 8: block = four image rows of eight columns
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float sm = (a[mb][4 * q] + a[mb][4 * q + 1]) + (a[mb][4 * q + 2] + a[mb][4 * q + 3]);
+                        sm += __shfl_xor(sm, 32, 64);
+                        const int prow = h0 + 8 * wm + 4 * mb + q;
+                        const float v = sm * 0.125f;
+                        if (kh == 0 && prow < Hp) {
+                            outb[(long)prow * p.N + col] = v;
+                            amax = fmaxf(amax, v);
+                        }
+                    }
+            }
+        }
+        if (p.pool_amax) amax_publish_block(p.pool_amax, amax);
+        return;
+    }
     // ---- epilogue: unscale, (mask,) statistics, store (rows past the image fall outside the descriptor and are dropped)
     const unsigned y_img_bytes = (unsigned)p.H * W * p.N * 4u;
     const __amdgpu_buffer_rsrc_t yrs =
@@ -700,6 +774,41 @@ SED_API int sed_pack_conv_weights_sf16_multi(int n, const float* const* w_oihw, 
     return 0;
 }
 
+SED_API int sed_conv3x3_sf16_eval_pool_supported(int H, int W, int Cin, int Cout, int ph, int pw) {
+    if (!sed_conv3x3_sf16_supported(H, W, Cin, Cout) || sf_mw(Cout) != 4) return 0;
+    return ((ph == 2 && pw == 2 && W >= 16 && H >= 2) || (ph == 1 && pw == W && W == 8)) ? 1 : 0;
+}
+
+SED_API int sed_conv3x3_sf16_eval_pool(const float* x, const void* wp, const float* wscale, float* out, int B, int H, int W,
+                                       int Cin, int Cout, const float* in_scale, const float* in_shift, const float* o_scale,
+                                       const float* o_shift, int ph, int pw, const float* x_amax, float* out_amax,
+                                       int* err_host, int* err_dev, sed_stream_t stream) {
+    if (!x || !wp || !wscale || !out || !x_amax || !o_scale || !o_shift || B <= 0 ||
+        !sed_conv3x3_sf16_eval_pool_supported(H, W, Cin, Cout, ph, pw))
+        return SED_EINVAL;
+    if ((in_scale == nullptr) != (in_shift == nullptr)) return SED_EINVAL;
+    if (out_amax) {
+        hipError_t e = sed_amax_clear(out_amax, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    Sf16P p;
+    p.x = x; p.wp = (const _Float16*)wp; p.wscale = wscale; p.x_amax = x_amax; p.y = out;
+    p.in_scale = in_scale; p.in_shift = in_shift; p.partials = nullptr; p.yprev = nullptr;
+    p.p_scale = o_scale; p.p_shift = o_shift; p.p_mean = nullptr; p.p_invstd = nullptr;
+    p.B = B; p.H = H; p.W = W; p.K = Cin; p.N = Cout;
+    p.logW = sf_log2w(W);
+    p.TR = 256 >> p.logW;
+    p.ntile = (H + p.TR - 1) / p.TR;
+    p.mm = nullptr; p.err_host = err_host; p.err_dev = err_dev;
+    p.pool_amax = out_amax; p.ph = ph; p.pw = pw;
+    const long nblk = (long)B * p.ntile * (Cout / 64);
+    if (nblk > 0x7fffffffL) return SED_EINVAL;
+    if (in_scale) hipLaunchKernelGGL((conv_sf16_kernel<4, true, 3>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((conv_sf16_kernel<4, false, 3>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
 SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale, float* y, int B, int H, int W, int Cin,
                              int Cout, const float* in_scale, const float* in_shift, int epi, float* partials,
                              const float* yprev, const float* p_scale, const float* p_shift, const float* p_mean,
@@ -722,6 +831,7 @@ SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale
     p.TR = (64 * mw) >> p.logW;
     p.ntile = (H + p.TR - 1) / p.TR;
     p.mm = minmax; p.err_host = err_host; p.err_dev = err_dev;
+    p.pool_amax = nullptr; p.ph = p.pw = 1;
     const long nblk = (long)B * p.ntile * (Cout / (mw == 2 ? 128 : 64));
     if (nblk > 0x7fffffffL) return SED_EINVAL;
     const dim3 g((unsigned)nblk), blk(256);

@@ -35,6 +35,7 @@ USE_FUSED_GRU = True        # False: per-step GEMM + gate launches (any hidden s
 # kernels only get the slots its workgroups free as they retire: the step gains 1.0-1.6 % (A/B on one box), not the 5 % a
 # perfect overlap would give.  SED_WGRAD_SIDE_STREAM=0 turns it off (A/B runs).
 WGRAD_SIDE_STREAM = os.environ.get("SED_WGRAD_SIDE_STREAM", "1") != "0"
+EVAL_POOL_FUSION = os.environ.get("SED_EVAL_POOL_FUSION", "1") != "0"     # inference: pool inside the conv2 epilogue (csrc/conv_sf16.hip)
 _SIDE = {}
 _PENDING = []            # [(event recorded on the side stream, sink or None)] of weight gradients not yet joined
 
@@ -941,9 +942,11 @@ class ConvBlockFn(torch.autograd.Function):
     on the fly by the consumers."""
 
     @staticmethod
-    def forward(ctx, x, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, training, ph, pw, x_amax=None, pool_mode=0):
+    def forward(ctx, x, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, training, ph, pw, x_amax=None, pool_mode=0, no_backward=False):
         """Returns (out, out_amax): out_amax = device amax vector of `out` for the next block's split-f16 scale (x_amax
-        there).  pool_mode: 0 = 'avg' (every model), 1 = 'max', 2 = 'avg+max' (models.py:104-111)."""
+        there).  pool_mode: 0 = 'avg' (every model), 1 = 'max', 2 = 'avg+max' (models.py:104-111).  no_backward: the caller
+        runs under torch.no_grad() (the Function cannot see that itself): nothing is kept for a backward pass and the
+        inference epilogue may be used."""
         _chk_dev(x, w1, w2)
         ctx.set_materialize_grads(False)     # out_amax takes no gradient: spare autograd its zero tensor (a fill launch per block)
         x = _f32c(x)
@@ -986,6 +989,18 @@ class ConvBlockFn(torch.autograd.Function):
         if need_a1:
             a1 = act_amax(mm1, np1, Cout, st1) if mm1 is not None else act_amax_full(y1, st1)
         del mm1
+        if (EVAL_POOL_FUSION and no_backward and not training and pool_mode == 0 and pk2 is not None
+                and L.sed_conv3x3_sf16_eval_pool_supported(H, W, Cout, Cout, ph, pw)):
+            # inference: conv2 + eval-mode BatchNorm + ReLU + average pool in ONE kernel -- the
+            # full-resolution y2 is never written, the pool pass never runs
+            st2 = bn_eval_affine(g2, b2, rm2, rv2)
+            out = torch.empty((B, H // ph, W // pw, Cout), dtype=torch.float32, device=dev)
+            out_amax = _amax_buf(dev)
+            _call("sed_conv3x3_sf16_eval_pool", _ptr(y1), _ptr(pk2[0][0]), _ptr(pk2[0][1]), _ptr(out), B, H, W, Cout, Cout,
+                  _ptr(st1.scale), _ptr(st1.shift), _ptr(st2.scale), _ptr(st2.shift), ph, pw, _ptr(a1), _ptr(out_amax),
+                  _sf16_err_ptr(), _sf16_err_dev_ptr(dev), _stream())
+            ctx.mark_non_differentiable(out_amax)
+            return out, out_amax
         # conv2 over relu(bn1(y1)) computed on the fly (+ statistics)
         np2, rpp2, nf2 = _conv_parts(B, H, W, Cout, Cout)
         part2 = torch.empty((nf2,), dtype=torch.float32, device=dev) if training else None
@@ -1092,7 +1107,7 @@ class ConvBlockFn(torch.autograd.Function):
                 dw1 = _fork_wgrad(x, gy1, B, H, W, Cin, Cout, sink=sk[0], gy_amax=amax1, x_amax=ctx.xa)
             else:
                 dw1 = _wgrad(x, gy1, B, H, W, Cin, Cout, sink=sk[0], gy_amax=amax1, x_amax=ctx.xa)
-        return gx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, None, None, None, None, None
+        return gx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------------------

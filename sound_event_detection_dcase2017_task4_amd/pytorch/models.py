@@ -160,7 +160,7 @@ class ConvBlock(nn.Module):
                                               self.bn1.running_mean, self.bn1.running_var, self.conv2.weight,
                                               self.bn2.weight, self.bn2.bias, self.bn2.running_mean, self.bn2.running_var,
                                               self.training, pool_size[0], pool_size[1], getattr(input, '_sed_amax', None),
-                                              self.POOL_MODES[pool_type])
+                                              self.POOL_MODES[pool_type], not torch.is_grad_enabled())
         out._sed_amax = out_amax
         if self.training and not getattr(self, '_defer_counters', False):
             self.bn1.num_batches_tracked += 1

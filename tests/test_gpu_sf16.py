@@ -287,3 +287,43 @@ def test_multi_tensor_pack_equals_the_single_packs():
     assert ops.prepack_sf16(ws[:2], False) == 2
     f_m, d_m = ops.sf16_packs(ws[0], False)
     assert d_m is None and torch.equal(f_m[0], ops.pack_sf16(ws[0])[0])
+
+
+@pytest.mark.parametrize("B,H,W,C,ph,pw", [(2, 37, 64, 64, 2, 2), (3, 21, 32, 128, 2, 2), (2, 50, 16, 256, 2, 2), (3, 13, 8, 512, 1, 8),
+                                          (1, 1001, 64, 64, 2, 2), (2, 125, 8, 512, 1, 8), (1, 2, 16, 64, 2, 2)])
+def test_sf16_eval_pool_epilogue(B, H, W, C, ph, pw):
+    """Inference epilogue: avg_pool(relu(bn2(conv(relu(bn1(y1)))))) in one kernel equals the conv + pool kernels of the training
+    path and a float64 evaluation; the amax it leaves is the maximum of the pooled tensor."""
+    from sound_event_detection_dcase2017_task4_amd import ops, _lib
+    g = torch.Generator().manual_seed(5 + H)
+    y1 = torch.randn((B, H, W, C), generator=g)
+    w = (torch.rand((C, C, 3, 3), generator=g) * 2 - 1) * 0.05
+    st1, st2 = ops.BnStats(C, "cuda"), ops.BnStats(C, "cuda")
+    s1, h1 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    s2, h2 = torch.rand(C, generator=g) * 2 - 1, torch.randn(C, generator=g) * 0.3          # both signs
+    st1.scale.copy_(s1); st1.shift.copy_(h1); st2.scale.copy_(s2); st2.shift.copy_(h2)
+    assert _lib.lib().sed_conv3x3_sf16_eval_pool_supported(H, W, C, C, ph, pw) == 1
+    y1c = y1.cuda()
+    pk = ops.pack_sf16(w.cuda())
+    a1 = ops.act_amax_full(y1c, st1)
+    out = torch.full((B, H // ph, W // pw, C), float("nan"), device="cuda")
+    oa = ops._amax_buf("cuda")
+    ops._call("sed_conv3x3_sf16_eval_pool", ops._ptr(y1c), ops._ptr(pk[0]), ops._ptr(pk[1]), ops._ptr(out), B, H, W, C, C,
+              ops._ptr(st1.scale), ops._ptr(st1.shift), ops._ptr(st2.scale), ops._ptr(st2.shift), ph, pw, ops._ptr(a1), ops._ptr(oa),
+              None, None, ops._stream())
+    # the two-kernel path
+    y2 = ops.conv3x3_sf16(y1c, pk, B, H, W, C, C, in_st=st1, x_amax=a1)
+    ref2 = torch.empty_like(out)
+    oa2 = ops._amax_buf("cuda")
+    ops._call("sed_bn_relu_pool_fwd", ops._ptr(y2), B, H, W, C, ph, pw, ops._ptr(st2.scale), ops._ptr(st2.shift), ops._ptr(ref2),
+              ops._ptr(oa2), ops._stream())
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    assert float((out - ref2).abs().max()) <= 1e-6 * max(1.0, float(ref2.abs().max()))
+    assert ops.amax_value(oa) == float(out.max()) and abs(ops.amax_value(oa) - ops.amax_value(oa2)) <= 1e-6 * ops.amax_value(oa2)
+    # float64
+    a = torch.relu(y1.double() * s1.double() + h1.double()).permute(0, 3, 1, 2)
+    z = F.conv2d(a, w.double(), padding=1)
+    z = torch.relu(z * s2.double()[None, :, None, None] + h2.double()[None, :, None, None])
+    want = F.avg_pool2d(z, kernel_size=(ph, pw)).permute(0, 2, 3, 1)
+    assert float((out.cpu().double() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
