@@ -315,15 +315,16 @@ class Workload(object):
 
 
 def graph_eager_steps(mode, B, world, warmup, inference=False, h2d=False):
-    """Eager steps before the HIP-graph capture (0 = no graph).  auto: the launch-bound small batches on one rank; the capture
-    must fall inside the warm-up (it takes a few hundred ms) behind at least one eager step (lazily built tables)."""
-    on = mode == "on" or (mode == "auto" and B <= 64)
+    """Eager steps before the HIP-graph capture (0 = no graph; the default: on this runtime a replay is as expensive for the host
+    as the 124 launches and measured 0.5 % faster on one box, 8 % SLOWER on another).  The capture must fall inside the warm-up
+    (it takes a few hundred ms) behind at least one eager step (lazily built tables)."""
+    on = mode == "on"
     if not on or world > 1 or inference or h2d or warmup < 2:
         return 0
     return min(3, warmup - 1)
 
 
-def extra_configs(rank, world, dev, steps=5, warmup=2, hip_graph="auto"):
+def extra_configs(rank, world, dev, steps=5, warmup=2, hip_graph="off"):
     """The other BASELINE.json configurations, a few steps each (single GPU, same process, after the headline run).  The
     metric's own batch size (bs=32, reference README) carries its own `roofline` + `kernels`."""
     out = []
@@ -397,8 +398,8 @@ def main():
     ap.add_argument("--by_shape", action="store_true", help="print a per-layer MFMA kernel table to stderr")
     ap.add_argument("--no_kernel_events", action="store_true",
                     help="diagnostic: no HIP event pairs around the MFMA kernel launches in the timed region (roofline = null)")
-    ap.add_argument("--hip_graph", type=str, default="auto", choices=("auto", "on", "off"),
-                    help="replay forward+backward as one HIP graph per step (auto: per-GPU batch <= 64 on one rank)")
+    ap.add_argument("--hip_graph", type=str, default="off", choices=("on", "off"),
+                    help="replay forward+backward as one HIP graph per step (graph.GraphedTrainStep; one rank only)")
     ap.add_argument("--cpu_threads", type=int, default=0)
     ap.add_argument("--inference", action="store_true",
                     help="secondary metric (SURVEY.md 8d): eval-mode forward only, clips/s over --batch_size waveforms per step")

@@ -10,7 +10,7 @@ R=$PWD
 OUT=$R/gpurun_out/prof_$ROUND
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-B="python $R/bench.py --no_cpu_baseline --no_extra --hip_graph off"
+B="python $R/bench.py --no_cpu_baseline --no_extra"
 # Pass 1: the default command (weight gradients on the side stream).  Two kernels then run at once and each one's duration
 # includes the time it waited for CU slots, so kernel-time sums no longer add up to the step; the conv_wino2 kernels (the
 # roofline's dominant family) never run beside another kernel and are unaffected.
