@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 tools/mfma_f16_ubench.hip -o /tmp/mfma_f16_ubench && /tmp/mfma_f16_ubench
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
@@ -53,8 +54,29 @@ void run(const char* name, float* out, int blocks_per_cu) {
            100 * tf / 2516.6, 2.4e9 * ms * 1e-3 / (mfmas / 1024.0));
 }
 
-int main() {
+// sustained mode: `mfma_f16_ubench smooth|random <seconds>` keeps the pipe busy so that rocm-smi can be sampled beside it
+template <bool RANDOM>
+static void sustain(float* out, double seconds) {
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    double done_ms = 0.0, tf = 0.0;
+    long launches = 0;
+    while (done_ms < seconds * 1e3) {
+        (void)hipEventRecord(a);
+        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k<4, RANDOM>), dim3(256 * 2), dim3(256), 0, 0, out, 20000);
+        (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+        float ms; (void)hipEventElapsedTime(&ms, a, b);
+        done_ms += ms; launches += 20;
+        tf = 20.0 * (256.0 * 2 * 4 * 20000 * 36) * 32768.0 / (ms * 1e-3) / 1e12;
+    }
+    printf("%s operands sustained %.1f s: last window %.1f TFLOP/s (%ld launches)\n", RANDOM ? "RANDOM" : "smooth", done_ms * 1e-3, tf, launches);
+}
+
+int main(int argc, char** argv) {
     float* out; (void)hipMalloc(&out, 256 * 3 * 256 * sizeof(float));
+    if (argc >= 3) {
+        if (argv[1][0] == 'r') sustain<true>(out, atof(argv[2])); else sustain<false>(out, atof(argv[2]));
+        return 0;
+    }
     run<4>("32x32x16 f16, 4 accumulators", out, 1); run<4>("32x32x16 f16, 4 accumulators", out, 2);
     run<9>("32x32x16 f16, 9 accumulators", out, 1); run<9>("32x32x16 f16, 9 accumulators", out, 2);
     run<4>("32x32x16 f16, 4 accumulators (again, warm)", out, 2);
