@@ -1,17 +1,20 @@
 #!/usr/bin/env python
-"""Headline benchmark: training clips/s (10 s @ 32 kHz) of Cnn_9layers_FrameAvg on MI355X, synthetic data.
+"""Headline benchmark: training clips/s (10 s @ 32 kHz) of Cnn_9layers_FrameAvg bs=32 on MI355X, synthetic data.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" = one pass of the hot path over one batch: log-mel -> bn0+SpecAugment+mixup -> 4 ConvBlocks -> head ->
 clip_bce -> backward (the RCCL all-reduce of the flat gradient runs in buckets beside it) -> Adam-amsgrad, with the
-waveforms already resident in HBM.  Workload at N=1 = BASELINE.json configs[1] (B=256 post-mixup clips = 512 waveforms
-per step, mixup on); weak scaling (B per GPU fixed).  `--gpus N` started WITHOUT a launcher (no WORLD_SIZE in the
-environment) re-executes itself as N ranks under torch.distributed.run and refuses to run if the node has fewer than
-N GPUs.  Prints ONE JSON line on rank 0 carrying `roofline` (dominant kernel, HIP-event timed inside the timed
-region), `cpu_baseline` (the CPU oracle timed on this host's cores, config 0) and, at N=1, `extra_configs`: the other
-BASELINE.json configurations timed for a few steps each in the same process.
+waveforms already resident in HBM.  Workload = the configuration BASELINE.json's metric is quoted on: Cnn_9layers_FrameAvg,
+batch_size 32 (post-mixup clips per GPU = 64 waveforms per step, mixup + SpecAugment on: the reference README's training
+command); weak scaling (batch per GPU fixed).  `--gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment)
+re-executes itself as N ranks under torch.distributed.run and refuses to run if the node has fewer than N GPUs.  Prints ONE
+JSON line on rank 0 carrying `roofline` (the dominant kernel family, HIP-event timed INSIDE the timed region), `kernels`
+(every MFMA family, from a second pass with the weight gradients on the main stream so that no duration includes waiting
+beside another kernel), `cpu_baseline` (the CPU oracle timed on this host's cores, config 0) and, at N=1, `extra_configs`:
+BASELINE.json configs[1] (B=256, with its own roofline / front-end / traffic objects) first, then the other configurations, a
+few steps each in the same process.
 """
 import argparse
 import gc
@@ -95,11 +98,12 @@ def latest_profile(name):
     return cands[-1] if cands else None
 
 
-def pmc_traffic(substrings):
+def pmc_traffic(substrings, name="pmc_traffic.json"):
     """HBM bytes per launch of a timed kernel family, from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
     gfx950 correction + WRITE_SIZE; tools/pmc_digest.py).  PMC collection needs rocprofv3 around the process, so it cannot
-    be sampled live: the figure is valid for the default workload only, otherwise null."""
-    path = latest_profile("pmc_traffic.json")
+    be sampled live: the figure is valid for the workload the file was collected on (pmc_traffic_b32.json: the headline
+    bs=32; pmc_traffic.json: configs[1], B=256), otherwise null."""
+    path = latest_profile(name)
     if not substrings or path is None:
         return None, None
     tot, n = 0.0, 0
@@ -125,7 +129,7 @@ NOTES = {"conv3x3_wino_mfma(fwd+dgrad)": ("fused 1-D Winograd F(2,3) implicit GE
                                           "accumulation: the error of a direct fp32 convolution) on the f16 MFMA pipe", 3.0, F16_MFMA_PEAK_TFLOPS)}
 
 
-def kernel_report(timing, steps, B2, default_workload, by_shape=False, frames=1001):
+def kernel_report(timing, steps, B2, default_workload, by_shape=False, frames=1001, pmc_file="pmc_traffic.json"):
     """(per-family MFMA kernel table, `roofline` of the dominant family, `roofline_frontend`) from the HIP events ops.TIMING
     collected inside a timed region.  'achieved' always counts the ALGORITHMIC direct-convolution flops:
     Winograd kernels execute fewer MACs than that on the fp32 MFMA pipe, the split-f16 kernels THREE f16 MACs per
@@ -150,7 +154,7 @@ def kernel_report(timing, steps, B2, default_workload, by_shape=False, frames=10
     if fe:
         ms = sum(a.elapsed_time(b) for a, b, _ in fe)
         gbps = sum(nb for _, _, nb in fe) / (ms * 1e-3) / 1e9
-        tr, src = pmc_traffic(["logmel32_kernel"]) if default_workload else (None, None)
+        tr, src = pmc_traffic(["logmel32_kernel"], pmc_file) if default_workload else (None, None)
         # what bounds it: the FFT runs on the vector ALU + LDS (4450 cycles per frame pair against a
         # VALU-only floor of 2300 = 0.25 ms per 512 waveforms, tools/valu_ubench.hip); HBM traffic is 1.06x algorithmic
         valu_floor_ms = 0.25 * (B2 * frames) / (512.0 * 1001.0)
@@ -185,7 +189,7 @@ def kernel_report(timing, steps, B2, default_workload, by_shape=False, frames=10
                                           "(power-limited clock; 2.04-2.17 PF with smooth operands): profiles/r03/mfma_f16_ubench.txt, "
                                           "tools/mfma_f16_ubench.hip -- `frac` / `executed_frac` stay relative to the 2.5 PF datasheet peak")
         if default_workload:
-            roofline["traffic"], src = pmc_traffic(FAMILY_KERNELS.get(dom))
+            roofline["traffic"], src = pmc_traffic(FAMILY_KERNELS.get(dom), pmc_file)
             if src:
                 roofline["traffic_source"] = src
         busy = latest_profile("pmc_mfma_busy.json")
@@ -286,26 +290,52 @@ class Workload(object):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def run(self, steps, warmup, timing=False):
+    def run(self, steps, warmup, timing=False, timing_only=None):
         """W untimed steps, then exactly K timed ones bracketed by barrier + synchronize; MAX over ranks."""
         for i in range(warmup):
             self.step(i)
         self.sync()
         if timing:
-            ops.TIMING = {}
+            ops.TIMING, ops.TIMING_ONLY = {}, timing_only
         t0 = time.time()
         for i in range(steps):
             loss = self.step(warmup + i)
-        self.host_ms_per_step = (time.time() - t0) / steps * 1e3      # host time to ENQUEUE a step (it runs ahead of the GPU)
         self.sync()
         dt = time.time() - t0
-        tm, ops.TIMING = ops.TIMING, None
+        tm, ops.TIMING, ops.TIMING_ONLY = ops.TIMING, None, None
         ops.check_device_errors()
         if self.world > 1:
             t = torch.tensor([dt], device=self.dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = float(t.item())
         return dt, float(loss.item()), tm
+
+    def host_enqueue_ms(self, steps=5):
+        """Host time to ENQUEUE one step, un-throttled: `steps` <= 5 steps issued from a drained device -- fewer than the 8
+        slots of the pinned upload ring (ops.upload_small waits for the copy of 8 uploads ago) and nothing else blocks, so
+        the host never waits for the GPU inside the bracket.  (Round 3 reported the average over the whole timed region,
+        where the ring throttles the host to the GPU's pace: that number followed the step count, not the launch cost.)"""
+        steps = min(int(steps), 5)
+        self.sync()
+        t0 = time.time()
+        for i in range(steps):
+            self.step(i)
+        ms = (time.time() - t0) / steps * 1e3
+        self.sync()
+        return round(ms, 3)
+
+    def kernel_table(self, steps, default_workload, pmc_file, by_shape=False, frames=1001):
+        """Every MFMA kernel family from a pass with ALL kernels on one stream (weight gradients not on the side stream): a
+        duration measured beside another kernel includes the time spent waiting for CU slots (round 3's driver line
+        showed 24.4 ms of weight gradients where the one-stream profile has 17.3).  Returns (kernels, roofline, frontend,
+        ms_per_step of that pass)."""
+        prev, ops.WGRAD_SIDE_STREAM = ops.WGRAD_SIDE_STREAM, False
+        try:
+            dt, _, tm = self.run(steps, 1, timing=True)
+        finally:
+            ops.WGRAD_SIDE_STREAM = prev
+        kern, roof, fe = kernel_report(tm, steps, self.B2, default_workload, by_shape=by_shape, frames=frames, pmc_file=pmc_file)
+        return kern, roof, fe, dt / steps * 1e3
 
     def describe(self, seconds=10, int16=False):
         return "%s, batch_size=%d per GPU%s, %d s @ 32 kHz %s waveforms resident in HBM, %s" % (
@@ -315,25 +345,65 @@ class Workload(object):
 
 
 def graph_eager_steps(mode, B, world, warmup, inference=False, h2d=False):
-    """Eager steps before the HIP-graph capture (0 = no graph; the default: on this runtime a replay is as expensive for the host
-    as the 124 launches and measured 0.5 % faster on one box, 8 % SLOWER on another).  The capture must fall inside the warm-up
-    (it takes a few hundred ms) behind at least one eager step (lazily built tables)."""
+    """Eager steps before the HIP-graph capture (0 = no graph).  The capture must fall inside the warm-up (it takes a few
+    hundred ms) behind at least one eager step (lazily built tables)."""
     on = mode == "on"
     if not on or world > 1 or inference or h2d or warmup < 2:
         return 0
     return min(3, warmup - 1)
 
 
+DOMINANT = ("conv3x3_sf16_mfma(fwd+dgrad)", "conv3x3_wino2d_mfma(fwd+dgrad)", "conv3x3_wino_mfma(fwd+dgrad)",
+            "conv3x3_igemm_mfma(fwd+dgrad)", "logmel_frontend")     # families bracketed by HIP events inside the headline region
+
+
+def measure(w, steps, warmup, default_workload, pmc_file, by_shape=False, frames=1001, events_in_region=True):
+    """The full set of numbers of one training workload: (row dict).  `value` comes from the timed region on the default
+    schedule, WITH HIP-event pairs around the forward / dgrad convolutions and the log-mel kernel (the `roofline` /
+    `roofline_frontend` objects are measured live over that very region; those kernels never run beside another one, so the
+    side-stream weight gradients do not distort them); `kernels` from a second, one-stream pass."""
+    dt, loss, tm = w.run(steps, warmup, timing=events_in_region, timing_only=DOMINANT)
+    _, roof, fe = kernel_report(tm, steps, w.B2, default_workload, frames=frames, pmc_file=pmc_file)
+    row = {"value": round(w.B * w.world * steps / dt, 2), "unit": "clips/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(dt / steps * 1e3, 3), "loss": round(loss, 5), "roofline": roof, "roofline_frontend": fe}
+    row.update(w.graph_info())
+    if w.world == 1:
+        ksteps = max(2, min(steps, 10))
+        kern, roof2, _, ms2 = w.kernel_table(ksteps, default_workload, pmc_file, by_shape=by_shape, frames=frames)
+        row["kernels"] = kern
+        row["kernels_pass"] = {"ms_per_step": round(ms2, 3), "steps": ksteps,
+                               "note": "every MFMA family HIP-event-timed with the weight gradients on the MAIN stream (no "
+                                       "kernel runs beside another: clean durations); an event pair costs the stream ~6 us"}
+        row["mfma_kernels_share_of_step"] = round(sum(v["ms_total"] for v in kern.values()) / (ms2 * ksteps), 4)
+        dt3, _, _ = w.run(steps, 1)
+        row["ms_per_step_without_kernel_events"] = round(dt3 / steps * 1e3, 3)
+        row["value_without_kernel_events"] = round(w.B * steps / dt3, 2)
+        row["host_enqueue_ms_per_step"] = w.host_enqueue_ms()
+    return row, dt
+
+
 def extra_configs(rank, world, dev, steps=5, warmup=2, hip_graph="off"):
-    """The other BASELINE.json configurations, a few steps each (single GPU, same process, after the headline run).  The
-    metric's own batch size (bs=32, reference README) carries its own `roofline` + `kernels`."""
+    """The other BASELINE.json configurations, a few steps each (single GPU, same process, after the headline run):
+    configs[1] (B=256, the batch north_star's targets are quoted at) first, with its full roofline / front-end / traffic /
+    kernel objects."""
     out = []
-    for tag, mt, B, mix, inf, detail in (
-            ("configs[2] Cnn_9layers_FrameAtt B=256 mixup", "Cnn_9layers_FrameAtt", 256, True, False, False),
-            ("configs[3] Cnn_9layers_Gru_FrameAtt B=256 mixup", "Cnn_9layers_Gru_FrameAtt", 256, True, False, False),
-            ("metric batch size: Cnn_9layers_FrameAvg B=32 mixup (reference README)", "Cnn_9layers_FrameAvg", 32, True, False, True),
-            ("configs[0] shape on the GPU: Cnn_9layers_FrameAvg B=32 no mixup", "Cnn_9layers_FrameAvg", 32, False, False, False),
-            ("inference (eval-mode forward) Cnn_9layers_FrameAvg 256 clips/step", "Cnn_9layers_FrameAvg", 256, False, True, False)):
+    try:
+        w = Workload("Cnn_9layers_FrameAvg", 256, True, rank, world, dev)
+        row, _ = measure(w, 2 * steps, warmup + 1, True, "pmc_traffic.json")
+        row = dict({"config": "configs[1] Cnn_9layers_FrameAvg B=256 mixup", "workload": w.describe() + "; BASELINE.json configs[1]",
+                    "metric": "training clips/sec"}, **row)
+        out.append(row)
+        del w
+    except Exception as e:
+        out.append({"config": "configs[1] Cnn_9layers_FrameAvg B=256 mixup", "value": None, "error": repr(e)})
+    gc.collect()
+    torch.cuda.empty_cache()
+    for tag, mt, B, mix, inf in (
+            ("configs[2] Cnn_9layers_FrameAtt B=256 mixup", "Cnn_9layers_FrameAtt", 256, True, False),
+            ("configs[3] Cnn_9layers_Gru_FrameAtt B=256 mixup", "Cnn_9layers_Gru_FrameAtt", 256, True, False),
+            ("configs[0] shape on the GPU: Cnn_9layers_FrameAvg B=32 no mixup", "Cnn_9layers_FrameAvg", 32, False, False),
+            ("small per-GPU batch (--batch_size 32 over 8 GPUs in the CLI): Cnn_9layers_FrameAvg B=4 mixup", "Cnn_9layers_FrameAvg", 4, True, False),
+            ("inference (eval-mode forward) Cnn_9layers_FrameAvg 256 clips/step", "Cnn_9layers_FrameAvg", 256, False, True)):
         try:
             w = Workload(mt, B, mix, rank, world, dev, inference=inf, hip_graph=graph_eager_steps(hip_graph, B, world, warmup, inf))
             k = steps * (8 if B <= 32 else 1)
@@ -342,19 +412,12 @@ def extra_configs(rank, world, dev, steps=5, warmup=2, hip_graph="off"):
                    "warmup": warmup, "ms_per_step": round(dt / k * 1e3, 3),
                    "metric": "inference clips/sec" if inf else "training clips/sec", "loss": round(loss, 5)}
             row.update(w.graph_info())
-            row["host_enqueue_ms_per_step"] = round(w.host_ms_per_step, 3)
-            if w.graphed is not None:          # the same steps launched kernel by kernel, for comparison (and for the event pass below)
+            row["host_enqueue_ms_per_step"] = w.host_enqueue_ms()
+            if w.graphed is not None:          # the same steps launched kernel by kernel, for comparison
                 w.graphed.enabled = False
                 dte, _, _ = w.run(k, 1)
                 row["eager_ms_per_step"] = round(dte / k * 1e3, 3)
-                row["eager_host_enqueue_ms_per_step"] = round(w.host_ms_per_step, 3)
-            if detail:
-                # a second pass with a HIP event pair around every MFMA kernel launch (each pair costs the stream ~6 us:
-                # 0.25 ms per step, 2.7 % at this batch size -- `value` above is measured without them)
-                dt2, _, tm = w.run(k, 1, timing=True)
-                kern, roof, fe = kernel_report(tm, k, w.B2, False)
-                row.update({"roofline": roof, "roofline_frontend": fe, "kernels": kern, "ms_per_step_with_kernel_events": round(dt2 / k * 1e3, 3),
-                            "mfma_kernels_share_of_step": round(sum(v["ms_total"] for v in kern.values()) / (dt2 * 1e3), 4)})
+                row["eager_host_enqueue_ms_per_step"] = w.host_enqueue_ms()
             out.append(row)
             del w
         except Exception as e:                 # a side number must never lose the headline line
@@ -385,11 +448,12 @@ def strict_fp32(mt, B, mix, rank, world, dev, steps=5, warmup=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model_type", type=str, default="Cnn_9layers_FrameAvg",
-                    help="Cnn_9layers_Gru_FrameAtt = BASELINE.json configs[3] / [4] (with --gpus 8)")
-    ap.add_argument("--batch_size", type=int, default=256, help="post-mixup clips per GPU per step")
+                    help="Cnn_9layers_Gru_FrameAtt = BASELINE.json configs[3] / [4] (with --gpus 8 --batch_size 256)")
+    ap.add_argument("--batch_size", type=int, default=32,
+                    help="post-mixup clips per GPU per step (32 = the configuration BASELINE.json's metric is quoted on; 256 = configs[1])")
     ap.add_argument("--no_mixup", action="store_true")
     ap.add_argument("--seconds", type=int, default=10)
     ap.add_argument("--no_cpu_baseline", action="store_true")
@@ -397,7 +461,7 @@ def main():
     ap.add_argument("--int16", action="store_true", help="feed int16 waveforms (the HDF5 storage dtype)")
     ap.add_argument("--by_shape", action="store_true", help="print a per-layer MFMA kernel table to stderr")
     ap.add_argument("--no_kernel_events", action="store_true",
-                    help="diagnostic: no HIP event pairs around the MFMA kernel launches in the timed region (roofline = null)")
+                    help="diagnostic: no HIP event pairs inside the timed region (roofline = null)")
     ap.add_argument("--hip_graph", type=str, default="off", choices=("on", "off"),
                     help="replay forward+backward as one HIP graph per step (graph.GraphedTrainStep; one rank only)")
     ap.add_argument("--cpu_threads", type=int, default=0)
@@ -427,46 +491,51 @@ def main():
     wl = Workload(args.model_type, B, mix, rank, world, dev, seconds=args.seconds, inference=args.inference, int16=args.int16,
                   h2d=args.h2d, hip_graph=ge)
     B2 = wl.B2
+    plain = (mix and args.model_type == "Cnn_9layers_FrameAvg" and not args.inference and not args.h2d and not args.int16
+             and args.seconds == 10)
+    default_workload = plain and B == 32                   # the configuration the metric is quoted on
+    pmc_file = "pmc_traffic_b32.json" if B == 32 else "pmc_traffic.json"
+    has_pmc = plain and B in (32, 256)
     wl.opt.buckets.wait_events = []   # HIP events around the compute stream's wait for the gradient all-reduces
-    if ge:                            # graph replays carry no per-kernel events: `value` from the graphed steps, the kernel table
-        dt, loss, timing = wl.run(args.steps, args.warmup)                   # from a second, eager pass of the same workload
-        graph_info = wl.graph_info()
-        graph_info["host_enqueue_ms_per_step"] = round(wl.host_ms_per_step, 3)
-        if wl.graphed is not None and not args.no_kernel_events:
-            wl.graphed.enabled = False
-            dte, _, timing = wl.run(args.steps, 1, timing=True)
-            graph_info["eager_ms_per_step_with_kernel_events"] = round(dte / args.steps * 1e3, 3)
+    frames = 32000 * args.seconds // 320 + 1
+    if args.inference or ge:
+        # no per-kernel events: graph replays cannot carry them, and the inference metric is a secondary one
+        dt, loss, _ = wl.run(args.steps, args.warmup)
+        row = {"roofline": None, "roofline_frontend": None, "kernels": {}}
+        row.update(wl.graph_info())
+        if world == 1:
+            row["host_enqueue_ms_per_step"] = wl.host_enqueue_ms()
+            if wl.graphed is not None and not args.no_kernel_events:
+                wl.graphed.enabled = False
+                kern, roof, fe, ms2 = wl.kernel_table(min(args.steps, 10), has_pmc, pmc_file, by_shape=args.by_shape, frames=frames)
+                row.update({"roofline": roof, "roofline_frontend": fe, "kernels": kern, "eager_ms_per_step_with_kernel_events": round(ms2, 3)})
     else:
-        dt, loss, timing = wl.run(args.steps, args.warmup, timing=not args.no_kernel_events)
-        graph_info = wl.graph_info()
-        graph_info["host_enqueue_ms_per_step"] = round(wl.host_ms_per_step, 3)
+        row, dt = measure(wl, args.steps, args.warmup, has_pmc, pmc_file, by_shape=args.by_shape, frames=frames,
+                          events_in_region=not args.no_kernel_events)
+        loss = row["loss"]
     bucket_order = list(wl.opt.buckets.last_issue_order)
-    waits = wl.opt.buckets.wait_events[-args.steps:]
+    waits = wl.opt.buckets.wait_events[:args.steps]
     dist_info = {"backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
                  "world_size": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
                  # time the compute stream sat behind the bucketed all-reduces in optimizer.step() = the EXPOSED part of the
                  # gradient exchange (the rest ran beside the backward pass); null at 1 rank
                  "allreduce_exposed_ms_per_step": (round(sum(a.elapsed_time(b) for a, b in waits) / max(len(waits), 1), 4)
                                                    if waits else None),
+                 # SED_ALLREDUCE_OVERLAP=0: every bucket goes out behind the backward pass instead of from inside it
+                 "allreduce_overlap": not wl.opt.buckets.deferred,
+                 "nonfinite_poll_lag_steps": wl.opt.poll_lag,
                  "flat_gradient_bytes": int(wl.opt.flat_grad.numel() * 4)}
     wl.opt.buckets.wait_events = None
     parallel.shutdown()               # all ranks: barrier + destroy the process group; rank 0 then reports alone
     if rank != 0:
         return
     bucket_ranges = [[lo, hi] for lo, hi in wl.opt.buckets.ranges]
-    default_workload = (B == 256 and mix and args.model_type == "Cnn_9layers_FrameAvg" and not args.inference
-                        and not args.h2d and not args.int16 and args.seconds == 10)
-
-    kern, roofline, frontend = kernel_report(timing, args.steps, B2, default_workload, by_shape=args.by_shape,
-                                             frames=32000 * args.seconds // 320 + 1)
-    conv_ms = sum(v["ms_total"] for v in kern.values())
     clips_per_s = B * world * args.steps / dt
     line = {
-        # BASELINE.json: "training clips/sec (10s@32kHz) Cnn_9layers_FrameAvg bs=32 at 1/2/4/8 GPU"; the headline workload is
-        # configs[1] (bs=256 per GPU, mixup), the metric's own bs=32 run is extra_configs["metric batch size ..."]
+        # BASELINE.json: "training clips/sec (10s@32kHz) Cnn_9layers_FrameAvg bs=32 at 1/2/4/8 GPU"
         "metric": ("inference clips/sec (10s@32kHz, eval mode) %s bs=%d per GPU at %d GPU" % (args.model_type, B, world))
                   if args.inference else
-                  ("training clips/sec (10s@32kHz) %s bs=%d per GPU at %d GPU" % (args.model_type, B, world)),
+                  ("training clips/sec (10s@32kHz) %s bs=%d at %d GPU" % (args.model_type, B, world)),
         "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -475,27 +544,29 @@ def main():
                        "rounding error of a direct fp32 convolution at any magnitude (tests/test_gpu_sf16.py vs float64); "
                        "`strict_fp32` = the same workload on the fp32 MFMA pipe")
                       if ops.USE_SF16 else "fp32 throughout (fp32 MFMA, Winograd F(2x2,3x3))",
-        "config": {"workload": wl.describe(args.seconds, args.int16) + ("; BASELINE.json configs[1]" if default_workload else
-                                                                         " (modified by flags)"),
+        "config": {"workload": wl.describe(args.seconds, args.int16) + ("; the configuration BASELINE.json's metric is quoted on "
+                                                                         "(bs=32 per GPU, weak scaling)" if default_workload else
+                                                                         ("; BASELINE.json configs[1]" if (plain and B == 256) else " (modified by flags)")),
                    "global_batch": B * world, "waveforms_per_step": B2 * world,
                    "parallelism": "dp%d" % world + (" (TEST MODE: ranks share one GPU over gloo)" if share_gpu else ""),
-                   "grad_allreduce": "%d buckets of the flat fp32 gradient (elements %s), issued from inside backward in the "
-                                     "order %s" % (len(bucket_ranges), bucket_ranges, bucket_order)},
+                   "grad_allreduce": "%d buckets of the flat fp32 gradient (elements %s), issued %s in the "
+                                     "order %s" % (len(bucket_ranges), bucket_ranges,
+                                                   "behind the backward pass" if wl.opt.buckets.deferred else "from inside backward",
+                                                   bucket_order)},
         "waveforms_per_s": round(B2 * world * args.steps / dt, 2),
-        "loss": round(loss, 5),
+        "loss": round(float(loss), 5),
         "dist": dist_info,
-        "hip_graph": graph_info,
-        "roofline": roofline,
-        "roofline_frontend": frontend,
-        "kernels": kern,
-        "mfma_kernels_share_of_step": round(conv_ms / (dt * 1e3), 4),
     }
+    for k, v in row.items():
+        if k not in ("value", "unit", "steps", "warmup", "ms_per_step", "loss"):
+            line[k] = v
+    line.setdefault("hip_graph", False)
     del wl
     gc.collect()
     torch.cuda.empty_cache()
     if world == 1 and default_workload and not args.no_extra:
         if ops.USE_SF16:
-            line["strict_fp32"] = strict_fp32(args.model_type, B, mix, rank, world, dev)
+            line["strict_fp32"] = strict_fp32(args.model_type, B, mix, rank, world, dev, steps=20, warmup=3)
         line["extra_configs"] = extra_configs(rank, world, dev, hip_graph=args.hip_graph)
     if world == 1 and not args.no_cpu_baseline:
         try:

@@ -53,13 +53,15 @@ int sed_logmel_i16(const short* wave, int B2, int L, const float* window, const 
  * sed_conv3x3_igemm epi 1) into mean / invstd / folded scale = gamma*invstd, shift = beta - mean*scale and
  * updates the running statistics (unbiased variance).  ws: >= 2048*C doubles.  rows_per_part = -1: the parts hold
  * varying row counts, given as nparts floats appended after the [nparts][2][C] partials (sed_conv3x3_wino2).
+ * guard_dev / guard_host (nullable; the found-non-finite words of the split-f16 path, see sed_adam_amsgrad): batch
+ * statistics that are NaN / inf raise them and leave running_mean / running_var untouched; null = torch semantics.
  * sed_bn_eval_affine: eval mode, fold the running statistics instead. */
 int sed_chan_stats(const float* x, long N, int C, float* partials, sed_stream_t stream);
 int sed_stats_rows_per_part(void);
 int sed_bn_finalize(const float* partials, int nparts, int rows_per_part, long N, int C, const float* gamma,
                     const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                     float* mean_out, float* invstd_out, float* scale_out, float* shift_out, double* ws,
-                    sed_stream_t stream);
+                    int* guard_dev, int* guard_host, sed_stream_t stream);
 int sed_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* mean_out, float* invstd_out, float* scale_out,
                        float* shift_out, sed_stream_t stream);
@@ -209,10 +211,11 @@ long sed_conv_sf16_num_parts(int B, int H, int W, int Cout);
 /* Device-resident amax values are float[sed_amax_slots()] (= 64), NOT one float: producers publish one atomic per block
  * into slot (block id mod 64) -- thousands of atomics on one word serialise in the L2 -- and consumers take the maximum over
  * the slots.  Every `amax_out` / `*_amax` pointer of this header is such a vector.  The entry points zero amax_out
- * themselves unless sed_amax_caller_zeroes(1) was called (the caller then hands in zeroed buffers, e.g. slices of one
- * zeroed pool: saves the per-launch memsets).  wscale of the weight packs = [64 amax slots][1 power-of-two scale]. */
+ * themselves, except for pointers inside an address range registered with sed_amax_prezeroed_range(base, nfloats, 1)
+ * (slices of a pool the caller zeroes with one fill: saves the per-launch memsets; on = 0 unregisters; <= 64 ranges).
+ * wscale of the weight packs = [64 amax slots][1 power-of-two scale]. */
 int sed_amax_slots(void);
-int sed_amax_caller_zeroes(int on);
+int sed_amax_prezeroed_range(const float* base, long nfloats, int on);
 int sed_amax(const float* x, long n, float* amax_out, sed_stream_t stream);
 int sed_pack_conv_weights_sf16(const float* w_oihw, int Cout, int Cin, int dgrad, float* wscale, void* wp,
                                sed_stream_t stream);
@@ -363,12 +366,20 @@ int sed_drop_relu_bwd(const float* g_y, const float* y, const unsigned char* kee
  *   raises skip_flag[0] and the nullable host-mapped err_host); when skip_flag[0] != 0 -- from that scan or because a
  *   split-f16 kernel of this step met a non-finite operand (their err_dev word) -- parameters and moments are left
  *   untouched and the refused step is counted in *skipped (nullable device int, one per optimiser; null: in skip_flag[1]).
- *   g must be 16-byte aligned when the guard is used. */
+ *   status_host (nullable, host-mapped int): receives the CUMULATIVE refused-step count as of this step (system-scope
+ *   store by the kernel): a host that waits for an event behind step i reads whether step i was refused -- the
+ *   deterministic, rank-consistent poll of optim.FusedAdamAmsgrad.  rank_flag: see sed_guard_publish.  g must be 16-byte
+ *   aligned when the guard is used. */
 int sed_clip_bce(const float* p, const float* y, long n, float* loss, float* grad, sed_stream_t stream);
 int sed_mixup_rows(const float* x, const float* lam, long B2, long D, float* out, sed_stream_t stream);
 int sed_adam_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, long n, int step, float lr,
                      float beta1, float beta2, float eps, float grad_scale, int* skip_flag, int* skipped, int* err_host,
-                     sed_stream_t stream);
+                     int* status_host, const float* rank_flag, sed_stream_t stream);
+/* Rank-consistent found-non-finite guard of a data-parallel job (replaces nothing in the reference: main.py:245-258 has no
+ * guard).  sed_guard_publish writes NaN (err_dev[0] != 0) or 0 into flag_out[0]; the caller keeps that word adjacent to
+ * the gradient bucket it all-reduces last and hands it to sed_adam_amsgrad as rank_flag (nullable): a non-zero / NaN word
+ * after the sum means SOME rank met a non-finite operand, and every rank refuses the same step. */
+int sed_guard_publish(const int* err_dev, float* flag_out, sed_stream_t stream);
 
 #ifdef __cplusplus
 }

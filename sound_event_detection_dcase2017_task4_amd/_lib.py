@@ -73,8 +73,27 @@ def lib():
             fn = getattr(h, name)            # AttributeError if the library lacks a declared symbol
             fn.restype = ret
             fn.argtypes = argtypes
+        verify_flags(h)
         _LIB = h
     return _LIB
+
+
+def verify_flags(h):
+    """Refuse a library that was not compiled with the default flags of build.py (sed_version() carries the hash of the flags
+    of every object): a timing-experiment build (-DSF_ABL_..., tools/experiment_*.patch) computes wrong results by design
+    and must never be picked up by accident.  SED_ALLOW_EXPERIMENT=1 lets the experiment tooling load it."""
+    from . import build
+    fn = h.sed_version
+    fn.restype = ctypes.c_char_p
+    ver = fn().decode()
+    want = build.flags_hash(build.BASE_FLAGS)
+    got = ver.split("flags:")[-1] if "flags:" in ver else "none"
+    if got != want and os.environ.get("SED_ALLOW_EXPERIMENT") != "1":
+        raise RuntimeError(
+            "libsed_hip.so was built with non-default hipcc flags (%r, default build = %s): an experiment build is refused.  "
+            "Rebuild with `python -m sound_event_detection_dcase2017_task4_amd.build --force` (SED_HIPCC_FLAGS unset), or set "
+            "SED_ALLOW_EXPERIMENT=1 to load it on purpose." % (ver, want))
+    return ver
 
 
 class SedHipError(RuntimeError):

@@ -3,6 +3,7 @@
 Cross-compiles without a GPU.  The .so is built IN-TREE (next to this file) so it travels with the repo
 snapshot to the GPU box; it is git-ignored.
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -13,7 +14,27 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsed_hip.so")
 SOURCES = ["logmel.hip", "bn.hip", "conv.hip", "conv_wino.hip", "conv_wino2.hip", "conv_sf16.hip", "heads.hip", "attention.hip", "gru.hip"]
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-I", INCLUDE] + os.environ.get("SED_HIPCC_FLAGS", "").split()   # SED_HIPCC_FLAGS: kernel experiments (-DSF_ABL_*, ...)
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-I", INCLUDE]
+# SED_HIPCC_FLAGS: extra flags for kernel experiments (tools/ablate.sh, tools/experiment_*.patch).  A library built with them
+# carries a different flags hash in sed_version(), and _lib.lib() refuses it unless SED_ALLOW_EXPERIMENT=1.
+FLAGS = BASE_FLAGS + os.environ.get("SED_HIPCC_FLAGS", "").split()
+
+
+def flags_hash(flags=None):
+    """Identity of a set of hipcc flags (the include PATH is machine-specific and left out)."""
+    flags = list(BASE_FLAGS if flags is None else flags)
+    keep, skip = [], False
+    for f in flags:
+        if skip:
+            skip = False
+            continue
+        if f == "-I":
+            skip = True
+            continue
+        if f.startswith("-DSED_BUILD_FLAGS_HASH"):
+            continue
+        keep.append(f)
+    return hashlib.sha1(" ".join(keep).encode()).hexdigest()[:12]
 
 
 def _stale(target, deps):
@@ -23,17 +44,26 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def compile_cmd(src, obj, flags=None):
+    flags = list(FLAGS if flags is None else flags)
+    return [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + flags + ['-DSED_BUILD_FLAGS_HASH="%s"' % flags_hash(flags), "-c", src, "-o", obj]
+
+
 def build(force=False, verbose=False):
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "sed_hip.h")]
+    # objects compiled with other flags (an experiment build) are never mixed with these: the stamp forces a full rebuild
+    stamp = os.path.join(objdir, "flags.stamp")
+    want = flags_hash(FLAGS)
+    if not os.path.exists(stamp) or open(stamp).read().strip() != want:
+        force = True
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append(compile_cmd(src, obj))
 
     def run(cmd):
         if verbose:
@@ -45,6 +75,8 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
+    with open(stamp, "w") as f:
+        f.write(want)
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
         # Link with the host C++ driver and NO DT_NEEDED on libamdhip64: the hip* symbols (and the fat-binary

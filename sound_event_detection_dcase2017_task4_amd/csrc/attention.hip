@@ -10,6 +10,7 @@
 // stats [B][8][T][4] = (row max m, row sum l, D, unused).
 #include "common.h"
 #include "sed_hip.h"
+SED_OBJECT_FLAGS(attention)
 
 namespace {
 

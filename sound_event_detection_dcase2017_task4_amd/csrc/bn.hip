@@ -8,7 +8,9 @@
 // Statistics are carried as per-tile partials (sum, M2 = sum((x - tile_mean)^2)) in fp32 and merged in fp64
 // (raw moments S1, S2 = M2 + sum^2/n), so var = S2/N - mean^2 is immune to cancellation.
 #include "common.h"
+#include <mutex>
 #include "sed_hip.h"
+SED_OBJECT_FLAGS(bn)
 
 namespace {
 
@@ -98,7 +100,8 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, int nchunks, i
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                   float* __restrict__ scale_out, float* __restrict__ shift_out) {
+                                   float* __restrict__ scale_out, float* __restrict__ shift_out,
+                                   int* __restrict__ guard_dev, int* __restrict__ guard_host) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), sub = threadIdx.x & 63;    // 256 threads = 4 channels x one wave
     if (c >= C) return;
     double s1, s2;
@@ -112,6 +115,14 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, int nchunks, i
     float sc = gamma[c] * invf;
     mean_out[c] = meanf; invstd_out[c] = invf;
     scale_out[c] = sc; shift_out[c] = fmaf(-meanf, sc, beta[c]);
+    if (guard_dev && !(fabs(mean) < 1e300 && var < 1e300)) {
+        // found-non-finite guard (the split-f16 path): batch statistics that are NaN / inf raise the error words -- the Adam
+        // kernel of this step refuses its update -- and are NOT blended into the running statistics: a refused step leaves
+        // the BatchNorm buffers as intact as the parameters.  (guard_dev null: torch semantics, NaN flows into the buffers.)
+        __hip_atomic_store(guard_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (guard_host) __hip_atomic_store(guard_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     if (running_mean) {
         double unbiased = (N > 1) ? var * (double)N / (double)(N - 1) : var;
         running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
@@ -300,11 +311,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __re
         float4 o = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
         if (MODE == 1) o = mx;
         if (MODE == 2) { o.x += mx.x; o.y += mx.y; o.z += mx.z; o.w += mx.w; }
-#ifndef SED_NO_NT_POOLFWD
         store_nt4(out, i, o);
-#else
-        reinterpret_cast<float4*>(out)[i] = o;
-#endif
         amax = fmaxf(fmaxf(amax, fmaxf(o.x, o.y)), fmaxf(o.z, o.w));          // o >= 0
         if (CNT) cnt4[i] = n4;
     }
@@ -400,11 +407,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const float* __re
         int h = (int)(q % H);
         int b = (int)(q / H);
         int ho = h / ph, wo = w / pw;
-#ifndef SED_NO_NT_LOADS       // streamed once: non-temporal (-3.6 % on the pass-2 kernel; nothing on bn_bwd_apply)
         float4 v = load_nt4(y, r * c4n + c4);
-#else
-        float4 v = reinterpret_cast<const float4*>(y)[r * c4n + c4];
-#endif
         float4 g = make_float4(0, 0, 0, 0);
         if (ho < Ho && wo < Wo) g = reinterpret_cast<const float4*>(gout)[(((long)b * Ho + ho) * Wo + wo) * c4n + c4];
         float4 wgt = make_float4(inv, inv, inv, inv);       // share of the pooled gradient this element receives
@@ -440,11 +443,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const float* __re
             float4 o;
             o.x = fmaf(ca.x, dy.x, fmaf(cb.x, v.x, cc.x)); o.y = fmaf(ca.y, dy.y, fmaf(cb.y, v.y, cc.y));
             o.z = fmaf(ca.z, dy.z, fmaf(cb.z, v.z, cc.z)); o.w = fmaf(ca.w, dy.w, fmaf(cb.w, v.w, cc.w));
-#ifndef SED_NO_NT_POOLBWD
             store_nt4(gy, r * c4n + c4, o);
-#else
-            reinterpret_cast<float4*>(gy)[r * c4n + c4] = o;
-#endif
             amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
     }
@@ -525,19 +524,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ d
         int c4 = (int)(i % c4n);
         float4 ca = reinterpret_cast<const float4*>(coef)[c4], cb = reinterpret_cast<const float4*>(coef)[c4n + c4],
                cc = reinterpret_cast<const float4*>(coef)[2 * c4n + c4];
-#ifdef SED_NT_LOADS          // experiment: non-temporal loads of the two streamed operands
-        float4 d = load_nt4(dy, i), v = load_nt4(y, i);
-#else
         float4 d = reinterpret_cast<float4*>(dy)[i], v = reinterpret_cast<const float4*>(y)[i];
-#endif
         float4 o;
         o.x = fmaf(ca.x, d.x, fmaf(cb.x, v.x, cc.x)); o.y = fmaf(ca.y, d.y, fmaf(cb.y, v.y, cc.y));
         o.z = fmaf(ca.z, d.z, fmaf(cb.z, v.z, cc.z)); o.w = fmaf(ca.w, d.w, fmaf(cb.w, v.w, cc.w));
-#ifndef SED_NO_NT_BNAPPLY
         store_nt4(dy, i, o);
-#else
-        reinterpret_cast<float4*>(dy)[i] = o;
-#endif
         amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
     if (amax_out) {
@@ -547,10 +538,37 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ d
 
 }  // namespace
 
-int sed_amax_prezeroed__ = 0;
-// The caller promises that every amax_out buffer it hands in is already zero (e.g. slices of one zeroed pool): the entry
-// points then skip their 256-byte memset launches (33 per training step).
-SED_API int sed_amax_caller_zeroes(int on) { sed_amax_prezeroed__ = on ? 1 : 0; return 0; }
+// Address ranges whose amax buffers arrive zeroed (slices of a pool the caller zeroes with one fill): the entry points skip
+// their 256-byte memset launches (33 per training step) for pointers inside such a range ONLY -- a per-buffer property, not a
+// process-wide mode: every other caller of the library in the same process keeps the self-zeroing contract.
+namespace {
+struct PrezeroRange { const float* lo; const float* hi; };
+constexpr int SED_MAX_PREZERO = 64;
+PrezeroRange prezero_ranges__[SED_MAX_PREZERO];
+int n_prezero__ = 0;
+std::mutex prezero_mu__;
+}  // namespace
+bool sed_amax_is_prezeroed__(const float* p) {
+    if (n_prezero__ == 0) return false;
+    std::lock_guard<std::mutex> g(prezero_mu__);
+    for (int i = 0; i < n_prezero__; ++i)
+        if (p >= prezero_ranges__[i].lo && p < prezero_ranges__[i].hi) return true;
+    return false;
+}
+SED_API int sed_amax_prezeroed_range(const float* base, long nfloats, int on) {
+    if (!base || nfloats <= 0) return SED_EINVAL;
+    std::lock_guard<std::mutex> g(prezero_mu__);
+    for (int i = 0; i < n_prezero__; ++i)
+        if (prezero_ranges__[i].lo == base) {              // re-register / unregister
+            prezero_ranges__[i] = prezero_ranges__[--n_prezero__];
+            break;
+        }
+    if (on) {
+        if (n_prezero__ == SED_MAX_PREZERO) return SED_EINVAL;
+        prezero_ranges__[n_prezero__++] = PrezeroRange{base, base + nfloats};
+    }
+    return 0;
+}
 SED_API int sed_amax_slots(void) { return SED_AMAX_SLOTS; }
 
 namespace {
@@ -586,13 +604,13 @@ SED_API int sed_stats_rows_per_part(void) { return 1024; }
 SED_API int sed_bn_finalize(const float* partials, int nparts, int rows_per_part, long N, int C, const float* gamma,
                             const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                             float* mean_out, float* invstd_out, float* scale_out, float* shift_out, double* ws,
-                            hipStream_t stream) {
+                            int* guard_dev, int* guard_host, hipStream_t stream) {
     if (nparts <= 0 || C <= 0 || N <= 0) return SED_EINVAL;
     int ppc = reduce_chunks(nparts), nchunks = sed_cdiv(nparts, ppc), K = 2 * C;
     hipLaunchKernelGGL(reduce_parts_kernel<1>, dim3(nchunks, sed_cdiv(K, 256)), dim3(256), 0, stream, partials, nparts, K,
                        ppc, N, rows_per_part, ws);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(sed_cdiv(C, 4)), dim3(256), 0, stream, ws, nchunks, C, N, gamma, beta, eps,
-                       momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out);
+                       momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out, guard_dev, guard_host);
     SED_LAUNCH_CHECK();
     return 0;
 }

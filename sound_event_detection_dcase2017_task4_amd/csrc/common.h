@@ -13,6 +13,14 @@
         if (e__ != hipSuccess) return (int)e__;    \
     } while (0)
 
+// Every object of the library records the hash of the hipcc flags it was compiled with (build.py defines it); sed_version()
+// reports it, "mixed" when the objects disagree, and the Python loader refuses anything but the default flags unless
+// SED_ALLOW_EXPERIMENT=1 -- a library built with a timing-experiment -D can no longer be picked up silently.
+#ifndef SED_BUILD_FLAGS_HASH
+#define SED_BUILD_FLAGS_HASH "unknown"
+#endif
+#define SED_OBJECT_FLAGS(name) extern "C" __attribute__((visibility("hidden"))) const char sed_objflags_##name[] = SED_BUILD_FLAGS_HASH;
+
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
@@ -51,9 +59,12 @@ __device__ __forceinline__ void amax_publish_block(float* __restrict__ out, floa
     }
 }
 __device__ __forceinline__ float amax_read(const float* __restrict__ p) { return wave_max(p[threadIdx.x & (SED_AMAX_SLOTS - 1)]); }
-extern int sed_amax_prezeroed__;      // host flag: the caller hands in zeroed amax buffers (sed_amax_caller_zeroes)
+// Callers that hand in amax buffers carved out of a pool they zero themselves register the pool's address range
+// (sed_amax_prezeroed_range); only pointers inside a registered range skip the memset -- any other buffer is zeroed here.
+bool sed_amax_is_prezeroed__(const float* p);
 static inline hipError_t sed_amax_clear(float* amax_out, hipStream_t stream) {
-    return (amax_out && !sed_amax_prezeroed__) ? hipMemsetAsync(amax_out, 0, SED_AMAX_SLOTS * sizeof(float), stream) : hipSuccess;
+    return (amax_out && !sed_amax_is_prezeroed__(amax_out)) ? hipMemsetAsync(amax_out, 0, SED_AMAX_SLOTS * sizeof(float), stream)
+                                                            : hipSuccess;
 }
 
 // Streaming 16-byte store of a tensor that is written once and read by a LATER kernel after everything else has passed through the

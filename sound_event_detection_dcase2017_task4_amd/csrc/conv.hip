@@ -12,6 +12,7 @@
 #include "common.h"
 #include "sed_hip.h"
 #include <stdlib.h>
+SED_OBJECT_FLAGS(conv)
 
 namespace {
 
@@ -560,11 +561,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = fmaf(xs[t], wr[t][k], o[k]);
-#ifndef SED_NO_NT_CONV1     // non-temporal: 0.93 instead of 1.24 ms for the 4.2 GB of y at B = 256
         store_nt4(y, pm * 16 + c4, make_float4(o[0], o[1], o[2], o[3]));
-#else
-        reinterpret_cast<float4*>(y)[pm * 16 + c4] = make_float4(o[0], o[1], o[2], o[3]);
-#endif
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float d = o[k] - piv[k]; s[k] += d; q[k] = fmaf(d, d, q[k]);
@@ -650,17 +647,9 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
     C1Walk pos(base + pl, H, W);
     for (int r = pl; r < nrows; r += 16, pos.advance(16, H, W)) {
         long pm = base + r;
-#ifndef SED_NO_NT_C1BWD    // the two streamed tensors: non-temporal loads (2.08 -> 1.95 ms)
         float4 g = load_nt4(gy, pm * 16 + c4);
-#else
-        float4 g = reinterpret_cast<const float4*>(gy)[pm * 16 + c4];
-#endif
         if (AFF) {
-#ifndef SED_NO_NT_C1BWD
             const float4 v = load_nt4(yraw, pm * 16 + c4);
-#else
-            const float4 v = reinterpret_cast<const float4*>(yraw)[pm * 16 + c4];
-#endif
             g.x = fmaf(ca.x, g.x, fmaf(cb.x, v.x, cc.x)); g.y = fmaf(ca.y, g.y, fmaf(cb.y, v.y, cc.y));
             g.z = fmaf(ca.z, g.z, fmaf(cb.z, v.z, cc.z)); g.w = fmaf(ca.w, g.w, fmaf(cb.w, v.w, cc.w));
         }
@@ -680,11 +669,7 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
                 float v = tp[0];
 #pragma unroll
                 for (int t = 1; t < 9; ++t) v = (c4 == t) ? tp[t] : v;
-#ifdef SED_NT_C1TBUF
-                __builtin_nontemporal_store(v, tbuf + pm * 9 + c4);
-#else
                 tbuf[pm * 9 + c4] = v;
-#endif
             }
         }
     }

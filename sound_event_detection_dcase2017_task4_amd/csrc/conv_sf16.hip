@@ -29,6 +29,7 @@
 #include "common.h"
 #include "sed_hip.h"
 #include <stdlib.h>
+SED_OBJECT_FLAGS(conv_sf16)
 
 namespace {
 
@@ -106,11 +107,7 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
     constexpr int BPLANE = 3 * BN * 32, BSTAGE = 2 * BPLANE;
     constexpr int NI = MW == 2 ? 4 : 6;                // staging items per thread
     constexpr int NDMA = 6 * RB / 4;                   // LDS-DMA instructions per wave and stage
-#ifdef SF_ABL_OCC2        // timing experiment: pad the LDS footprint so that only TWO workgroups fit a CU (2 waves per SIMD)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * APLANE + 2 * BSTAGE + (MW == 4 ? 28 * 1024 : 0)];
-#else
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * APLANE + 2 * BSTAGE];
-#endif
     unsigned char* const As = smem;
     unsigned char* const Bs = smem + 2 * APLANE;
 
@@ -266,84 +263,18 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy, ++step) {
             const int st = step & 1;
-#ifndef SF_ABL_NODMA       // timing experiment: no weight DMA after the first stage (results wrong)
             if (step + 1 < nsteps) {
                 if (st) { sf_bdma(step + 1, 0) } else { sf_bdma(step + 1, 1) }
             }
-#endif
-#ifndef SF_ABL_NOALOAD
             if (dy == 0 && ks + 1 < KT) sf_aload(ks + 1);
-#endif
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
             const unsigned char* const Bst = Bs + st * BSTAGE;
             // (requesting the fragments of tap dx+1 before the MFMAs of tap dx -- two register sets -- measured +-1 %: the
             // second wave of the SIMD already hides the LDS latency; one set keeps the kernel at 3 waves per SIMD for MW = 4)
-#ifdef SF_PIPE  // experiment kept for the record (round 3): 8.62 ms vs 8.62 ms over the seven layers at B = 128 -- NO gain: with
-            // three waves per SIMD the co-resident waves already cover a wave's LDS latency (and the fused-input variants spill
-            // 18 registers at the 168-VGPR budget).  PMC: the MFMA pipe is busy 72-77 % of the cycles at the ~1.75 GHz the
-            // part sustains under this load; what is left is barrier / staging / tail time, not fragment latency.
-            // Software-pipelined fragment reads within a stage (3 taps): every operand is requested one MFMA phase (4 MFMAs
-            // = 128 pipe cycles) before its first use, into the registers its predecessor has just vacated -- al after
-            // phase 1, bl (and the next bh, the one double-buffered operand) after phase 2, ah after phase 3 -- so only the
-            // first tap of a stage waits for LDS with nothing to issue.
-            {
-#define SF_LD_A(dst, plane, DX) _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) dst[mb] = *reinterpret_cast<const half8*>(As + (plane) + aoffs[mb][dy * 3 + (DX)]);
-#define SF_LD_B(dst, plane, DX) _Pragma("unroll") for (int nk = 0; nk < 2; ++nk) dst[nk] = *reinterpret_cast<const half8*>(Bst + (plane) + boffs[nk][(DX)]);
-#define SF_MM(A, B) _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) _Pragma("unroll") for (int nk = 0; nk < 2; ++nk) \
-                        acc[mb][nk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[mb], B[nk], acc[mb][nk], 0, 0, 0);
-                half8 ah[2], al[2], bl[2], bhA[2], bhB[2];
-                SF_LD_A(al, APLANE, 0) SF_LD_B(bhA, 0, 0) SF_LD_A(ah, 0, 0) SF_LD_B(bl, BPLANE, 0)
-                __builtin_amdgcn_sched_barrier(0);
-                // tap 0
-                SF_MM(al, bhA)
-                __builtin_amdgcn_sched_barrier(0);
-                SF_LD_A(al, APLANE, 1)
-                __builtin_amdgcn_sched_barrier(0);
-                SF_MM(ah, bl)
-                __builtin_amdgcn_sched_barrier(0);
-                SF_LD_B(bhB, 0, 1) SF_LD_B(bl, BPLANE, 1)
-                __builtin_amdgcn_sched_barrier(0);
-                SF_MM(ah, bhA)
-                __builtin_amdgcn_sched_barrier(0);
-                SF_LD_A(ah, 0, 1)
-                __builtin_amdgcn_sched_barrier(0);
-                // tap 1
-                SF_MM(al, bhB)
-                __builtin_amdgcn_sched_barrier(0);
-                SF_LD_A(al, APLANE, 2)
-                __builtin_amdgcn_sched_barrier(0);
-                SF_MM(ah, bl)
-                __builtin_amdgcn_sched_barrier(0);
-                SF_LD_B(bhA, 0, 2) SF_LD_B(bl, BPLANE, 2)
-                __builtin_amdgcn_sched_barrier(0);
-                SF_MM(ah, bhB)
-                __builtin_amdgcn_sched_barrier(0);
-                SF_LD_A(ah, 0, 2)
-                __builtin_amdgcn_sched_barrier(0);
-                // tap 2
-                SF_MM(al, bhA)
-                SF_MM(ah, bl)
-                SF_MM(ah, bhA)
-#undef SF_LD_A
-#undef SF_LD_B
-#undef SF_MM
-            }
-#else
-#ifdef SF_ABL_FRAGONCE     // timing experiment: fragments read for the first tap of a stage only, reused for the other two
-            half8 ah[2], al[2], bh[2], bl[2];   // (results wrong; the MFMAs still consume real data: separates LDS cost from DVFS)
-#endif
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-#ifndef SF_ABL_FRAGONCE
                 half8 ah[2], al[2], bh[2], bl[2];
-#endif
-#ifdef SF_ABL_NOFRAG      // timing experiment: fragments never read (results wrong)
-                if (step < 0)
-#endif
-#ifdef SF_ABL_FRAGONCE
-                if (dx == 0)
-#endif
                 {
 #pragma unroll
                     for (int mb = 0; mb < 2; ++mb) {
@@ -373,20 +304,13 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
                     for (int nk = 0; nk < 2; ++nk)
                         acc[mb][nk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bh[nk], acc[mb][nk], 0, 0, 0);
             }
-#endif
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifndef SF_ABL_NOBAR
             __syncthreads();
-#endif
             if (dy == 2 && ks + 1 < KT) {          // every wave is done with this k-step's patch: replace it
-#ifndef SF_ABL_NOASTORE
                 sf_astore();
-#endif
-#ifndef SF_ABL_NOBAR
                 __syncthreads();
-#endif
             }
         }
     }
@@ -508,11 +432,7 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
             if (EPI == 2) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-#ifdef SF_NT_YPREV         // experiment: non-temporal loads of the previous activations in the dgrad epilogue
-                    yp[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, yoff[mb][r], nk * 128, 2));
-#else
                     yp[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, yoff[mb][r], nk * 128, 0));
-#endif
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -531,11 +451,7 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
                     vmn = fminf(vmn, ok ? v : __builtin_inff());
                 }
                 acc[mb][nk][r] = v;
-#ifdef SF_NT_STORE          // experiment: non-temporal output stores (aux = 2)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, yoff[mb][r], nk * 128, 2);
-#else
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, yoff[mb][r], nk * 128, 0);
-#endif
             }
         }
         float* const mine = red + ((wvu * 2 + nk) * 32 + (lane & 31)) * 4;
@@ -900,14 +816,8 @@ __device__ __forceinline__ half4 sf_tr_read(const unsigned char* p) {
 template <int LOGW, bool INT>
 __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
     constexpr int W = 1 << LOGW, TRS = 64 >> LOGW, WP = W + 2;
-#ifndef WSF_OVERLAP
     constexpr int RING = TRS <= 2 ? 4 : (TRS == 4 ? 8 : 16);
     constexpr int GBUF = 1;
-#else
-    // (experiment) the next stage's rows are stored WHILE this stage is being read: 2 TRS + 2 ring rows, two gy buffers
-    constexpr int RING = TRS == 1 ? 4 : (TRS == 2 ? 8 : (TRS == 4 ? 16 : 32));
-    constexpr int GBUF = 2;
-#endif
     // LDS images (round 3: conflict-free for the STORES too -- the per-channel-block planes of round 2, 128 B (mod 256)
     // apart for the transpose reads, put the 16 lanes of a ds_write_b64 group 2-way (x) / 4-way (gy) on the same banks:
     // 35 % of the LDS cycles were conflicts).  x: one 64-byte row per pixel = its two 16-channel blocks side by side;
@@ -1041,47 +951,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
         if (TRS == 1) { WSF_XLOAD(hs0) WSF_XSTORE(hs0) }
         WSF_XLOAD(hs0 + 1) WSF_GLOAD(hs0)
         WSF_XSTORE(hs0 + 1) WSF_GSTORE(0)
-#ifdef WSF_OVERLAP
-        if (s0 + 1 < s1) { WSF_XLOAD(hs0 + TRS + 1) WSF_GLOAD(hs0 + TRS) }      // the second stage's rows are in flight
-        int gb = 0;                                                              // gy buffer this stage reads
-#endif
         __syncthreads();
         for (int s = s0; s < s1; ++s) {
             const int h0 = s * TRS;
             const bool more = s + 1 < s1;
-#ifndef WSF_OVERLAP
-#ifndef WSF_ABL_NOLOAD     // timing experiments (results wrong): WSF_ABL_NOLOAD / _NOSTAGE / _NOBAR
             if (more) { WSF_XLOAD(h0 + TRS + 1) WSF_GLOAD(h0 + TRS) }
-#endif
-#endif
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int ks = 2 * wk + kk;                // wave-uniform (wk scalar)
-#ifdef WSF_OVERLAP
-                if (kk == 1) {
-                    // EXPERIMENT (-DWSF_OVERLAP, round 3; measured 9.60 vs 9.36-9.43 ms over the seven layers: NO gain, not the
-                    // default).  Between the two k-steps of the stage: convert and store the NEXT stage's rows (into ring slots /
-                    // a second gy buffer nobody reads during this stage) and request the rows of the stage after it -- one
-                    // barrier per stage, the staging VALU beside the partner wave's MFMAs.  The ablation that suggested it
-                    // (no staging: +27-37 %) was a DVFS artefact: without staging the MFMA operands repeat, switching
-                    // activity and power drop and the clock rises -- like every "remove X" experiment on this
-                    // power-limited part (tools/mfma_f16_ubench.hip: 1.63 PF with random operands, 2.1 PF with smooth ones).
-                    __builtin_amdgcn_s_setprio(0);
-#ifndef WSF_ABL_NOSTAGE
-                    if (more) { WSF_XSTORE(h0 + TRS + 1) WSF_GSTORE((gb ^ 1) * 2 * GPL) }
-#endif
-#ifndef WSF_ABL_NOLOAD
-                    if (s + 2 < s1) { WSF_XLOAD(h0 + 2 * TRS + 1) WSF_GLOAD(h0 + 2 * TRS) }
-#endif
-                    __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_setprio(1);
-                }
-                const unsigned char* const Gcur = Gs + gb * 2 * GPL;
-#else
                 const unsigned char* const Gcur = Gs;
-#endif
                 half8 ah, al;
                 {
                     const unsigned char* ap = Gcur + a_base + ks * 2048;
@@ -1111,21 +991,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-#ifndef WSF_ABL_NOBAR
             __syncthreads();
-#endif
-#ifndef WSF_OVERLAP
             if (more) {
-#ifndef WSF_ABL_NOSTAGE
                 WSF_XSTORE(h0 + TRS + 1) WSF_GSTORE(0)
-#endif
-#ifndef WSF_ABL_NOBAR
                 __syncthreads();
-#endif
             }
-#else
-            gb ^= 1;
-#endif
         }
     }
 #undef WSF_IMAGE

@@ -15,6 +15,7 @@
 // ReLU mask + BN-backward sums.  Requirements: W even, W | 128, Cin % 16 == 0, Cout % 64 == 0.
 #include "common.h"
 #include "sed_hip.h"
+SED_OBJECT_FLAGS(conv_wino)
 
 namespace {
 

@@ -21,11 +21,10 @@
 // + the per-part pixel count (tiles past the image edge are not counted); epilogue 2 = ReLU mask + BN-backward sums.
 #include "common.h"
 #include "sed_hip.h"
+SED_OBJECT_FLAGS(conv_wino2)
 
-#ifndef SED_ABL
-#define SED_ABL 0       // timing experiments only (tools/ablate.sh; results become wrong): 1 no output stores, 2 no yprev loads,
-#endif                  // 4 no eta exchange through LDS, 8 no statistics, 16 one K-step only
-// Round-2 measurements with these switches (64->64 @ 1001x64, B = 128): prologue + ONE K-step + epilogue
+// Round-2 measurements with timing switches that have since been removed from this file (no output stores / no yprev loads /
+// no eta exchange / no statistics / one K-step only; tools/experiment_kernel_ablations.patch) (64->64 @ 1001x64, B = 128): prologue + ONE K-step + epilogue
 // = 0.94 ms of the 2.69 ms the 8-step kernel takes, i.e. the per-workgroup fixed cost equals 2.8 K-steps and is NOT hidden
 // by the co-resident workgroup; of it the output stores are 0.17 ms, the eta exchange 0.03 ms, the statistics 0, the
 // previous-activation loads of the dgrad epilogue 0.33 ms.  Delaying half of the first generation of workgroups by 7-14 us
@@ -315,7 +314,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2P p) {
         // (no 128 v_mov per wave, which matters for the 8-step 64-channel layers)
         W2_STEP(0, KT > 1 ? 1 : 0)
         int it = 1;
-        if (SED_ABL & 16) it = KT;
         for (; it + 1 < KT; it += 2) {
             W2_STEP(1, it + 1)
             W2_STEP(0, it + 2 < KT ? it + 2 : it + 1)
@@ -361,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2P p) {
     // everything below works on pairs over the accumulator rows (2rp, 2rp+1), separately for q = 0 and q = 1
     f2 yp0[EPI == 2 ? 8 : 1], yp1[EPI == 2 ? 8 : 1];   // previous-layer activations
 #define SED_YPREV_LOADS \
-    if (EPI == 2 && !(SED_ABL & 2)) { \
+    if (EPI == 2) { \
         e_sc = p.p_scale[col]; e_sh = p.p_shift[col]; e_mu = p.p_mean[col]; e_is = p.p_invstd[col]; \
 _Pragma("unroll") \
         for (int rp = 0; rp < 8; ++rp) { \
@@ -377,7 +375,7 @@ _Pragma("unroll") \
     f2 mine[16];                                       // [row pair rp][q]: accumulator rows 2rp, 2rp+1
 #define SED_AP(a) f2{acc[a][2 * rp], acc[a][2 * rp + 1]}
 #define SED_GIVE(G0, G1)                                                                                        \
-    if (!(SED_ABL & 4)) {                                                                                       \
+    {                                                                                                           \
     xch[(wvu * 32 + 4 * rp + 0) * 64 + lane] = G0.x; xch[(wvu * 32 + 4 * rp + 1) * 64 + lane] = G1.x;           \
     xch[(wvu * 32 + 4 * rp + 2) * 64 + lane] = G0.y; xch[(wvu * 32 + 4 * rp + 3) * 64 + lane] = G1.y; }
     if (eh) {
@@ -405,7 +403,7 @@ _Pragma("unroll") \
 #pragma unroll
     for (int rp = 0; rp < 8; ++rp) {
         f2 y0 = mine[2 * rp], y1 = mine[2 * rp + 1];
-        if (!(SED_ABL & 4)) {
+        {
             y0 += f2{rx[(4 * rp + 0) * 64], rx[(4 * rp + 2) * 64]};      // q = 0 of rows 2rp, 2rp+1
             y1 += f2{rx[(4 * rp + 1) * 64], rx[(4 * rp + 3) * 64]};      // q = 1
         }
@@ -425,7 +423,7 @@ _Pragma("unroll") \
             s1p += y0 + y1;
         }
         yq0[rp] = y0; yq1[rp] = y1;
-        if (!(SED_ABL & 1) || rp == 7) {
+        {
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y0.x), yrs, (int)yoff[2 * rp], 0, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y1.x), yrs, (int)yoff[2 * rp], n4, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y0.y), yrs, (int)yoff[2 * rp + 1], 0, 0);
@@ -459,7 +457,7 @@ _Pragma("unroll") \
         s1 = s1p.x + s1p.y; s2 = s2p.x + s2p.y;
         s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
     }
-    if ((EPI == 1 || EPI == 2) && half == 0 && !(SED_ABL & 8)) {
+    if ((EPI == 1 || EPI == 2) && half == 0) {
         const long part = (long)tblk * 4 + wvu;
         p.partials[(part * 2 + 0) * p.N + col] = s1;
         p.partials[(part * 2 + 1) * p.N + col] = s2;
@@ -595,11 +593,14 @@ __device__ __forceinline__ void wgrad_wino2_transforms(f2 d0, f2 d1, f2 a03, f2 
         "v_pk_add_f32 %5, %11, %15 neg_lo:[0,1] neg_hi:[0,1]\n\t"                           // ca12 = a12 - c12
         "v_pk_fma_f32 %6, %18, %14, %12\n\t"                                                // cb03 = ga*c03 + b03
         "v_pk_fma_f32 %7, %18, %15, %13\n\t"                                                // cb12 = ga*c12 + b12
-        "v_pk_add_f32 %2, %0, %0 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"             // ma = (ea.x+ea.y, ea.x-ea.y)
-        "v_pk_add_f32 %3, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"             // mb
-        "v_pk_add_f32 %4, %4, %5 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" // va03 = (c0-c2, c3-c1)
+        // operand order: wherever the LOW lane reads a HIGH half, that read sits on src0 (op_sel[src0] = 1, op_sel[src1] = 0).
+        // The mirrored form (op_sel = [0,1]) returns wrong values now and then beside f16 MFMAs of another kernel on the CU
+        // (tools/pk_f32_beside_mfma_probe.hip); additions commute, so the results are bit-identical.
+        "v_pk_add_f32 %2, %0, %0 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"             // ma = (ea.y+ea.x, -ea.y+ea.x)
+        "v_pk_add_f32 %3, %1, %1 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"             // mb
+        "v_pk_add_f32 %4, %5, %4 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0] neg_hi:[1,0]\n\t" // va03 = (-c2+c0, -c1+c3)
         "v_pk_add_f32 %5, %5, %5 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"             // va12 = (c2+c1, c2-c1)
-        "v_pk_add_f32 %6, %6, %7 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" // vb03
+        "v_pk_add_f32 %6, %7, %6 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0] neg_hi:[1,0]\n\t" // vb03
         "v_pk_add_f32 %7, %7, %7 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"             // vb12
         "s_nop 1"
         : "=&v"(ea), "=&v"(eb), "=&v"(ma), "=&v"(mb), "=&v"(va03), "=&v"(va12), "=&v"(vb03), "=&v"(vb12)

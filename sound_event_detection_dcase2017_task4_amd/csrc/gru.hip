@@ -19,6 +19,7 @@
 // resident: 128 x 512 threads, 48 KB LDS) gives up after ~1 s and raises the error word instead of hanging the GPU.
 #include "common.h"
 #include "sed_hip.h"
+SED_OBJECT_FLAGS(gru)
 
 namespace {
 

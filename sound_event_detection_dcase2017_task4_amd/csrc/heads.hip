@@ -5,7 +5,10 @@
 // Reference: FrameAvg head models.py:306-312, FrameMax :221-227, AttBlock :135-143, interpolate :58-69,
 // nn.GRU gates :529-530, clip_bce losses.py:5-12, do_mixup pytorch_utils.py:80-93, Adam(amsgrad) main.py:144-145.
 #include "common.h"
+#include <stdio.h>
+#include <string.h>
 #include "sed_hip.h"
+SED_OBJECT_FLAGS(heads)
 
 namespace {
 
@@ -183,7 +186,9 @@ __global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ p, c
     const float inv_n = 1.0f / (float)n;
     for (long i = threadIdx.x; i < n; i += 256) {
         float pi = p[i], yi = y[i];
-        float lp = fmaxf(logf(pi), -100.0f), lq = fmaxf(log1pf(-pi), -100.0f);
+        // double-precision logs (B x 17 values: free): the fp32 library logf / log1pf compile to a packed-fp32 horizontal add
+        // in the fragile operand form of tests/test_isa_audit.py, and the float rounding of an exact log is what torch computes
+        float lp = fmaxf((float)log((double)pi), -100.0f), lq = fmaxf((float)log1p(-(double)pi), -100.0f);
         acc += (double)(-(yi * lp + (1.0f - yi) * lq));
         if (grad) grad[i] = (pi - yi) / fmaxf((1.0f - pi) * pi, 1e-12f) * inv_n;
     }
@@ -206,9 +211,12 @@ __global__ __launch_bounds__(256) void mixup_rows_kernel(const float* __restrict
 // ---- Adam(amsgrad=True, weight_decay=0) over one flat buffer ----------------------------------------------------
 // found-non-finite guard of the optimiser step: any NaN / inf gradient (after the all-reduce, so every rank of a
 // data-parallel job sees what one rank's poisoned step produced) raises the skip flag and the host-mapped error word
+// rank_flag (nullable): the word sed_guard_publish left in front of the gradient before the all-reduce -- non-zero (NaN)
+// when ANY rank's split-f16 kernels met a non-finite operand this step
 __global__ __launch_bounds__(256) void grad_finite_check_kernel(const float* __restrict__ g, long n, int* __restrict__ skip_flag,
-                                                                int* __restrict__ err_host) {
+                                                                int* __restrict__ err_host, const float* __restrict__ rank_flag) {
     bool bad = false;
+    if (rank_flag && blockIdx.x == 0 && threadIdx.x == 0) bad = !(rank_flag[0] == 0.f);
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const float4 v = reinterpret_cast<const float4*>(g)[i];
@@ -227,13 +235,19 @@ __global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p
                                                            float* __restrict__ vmax, long n, float lr, float beta1,
                                                            float beta2, float eps, float bc1, float bc2_sqrt,
                                                            float grad_scale, int* __restrict__ skip_flag,
-                                                           int* __restrict__ skipped) {
+                                                           int* __restrict__ skipped, int* __restrict__ status_host) {
     // found-non-finite skip: a kernel of this step met a NaN / inf operand (skip_flag[0] != 0): leave parameters and
     // moments untouched and count the refused step -- the host learns about it without synchronising
     if (skip_flag && __hip_atomic_load(skip_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped ? skipped : skip_flag + 1, 1);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const int before = atomicAdd(skipped ? skipped : skip_flag + 1, 1);
+            if (status_host) __hip_atomic_store(status_host, before + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         return;
     }
+    if (status_host && skip_flag && blockIdx.x == 0 && threadIdx.x == 0)      // cumulative refused steps as of THIS step
+        __hip_atomic_store(status_host, __hip_atomic_load(skipped ? skipped : skip_flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const float step_size = lr / bc1;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         float gi = g[i] * grad_scale;
@@ -414,21 +428,34 @@ SED_API int sed_mixup_rows(const float* x, const float* lam, long B2, long D, fl
     return 0;
 }
 
+// flag_out[0] = NaN when this rank's found-non-finite word is set, else 0: placed next to the gradient bucket that is
+// all-reduced LAST, it tells every rank of a data-parallel job that one of them met a non-finite operand this step
+__global__ void guard_publish_kernel(const int* __restrict__ err_dev, float* __restrict__ flag_out) {
+    flag_out[0] = __hip_atomic_load(err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? __builtin_nanf("") : 0.f;
+}
+
+SED_API int sed_guard_publish(const int* err_dev, float* flag_out, hipStream_t stream) {
+    if (!err_dev || !flag_out) return SED_EINVAL;
+    hipLaunchKernelGGL(guard_publish_kernel, dim3(1), dim3(1), 0, stream, err_dev, flag_out);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
 // One Adam-amsgrad step (step >= 1) over flat buffers; grad_scale multiplies the gradient first (1/world_size).
 SED_API int sed_adam_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, long n, int step, float lr,
                              float beta1, float beta2, float eps, float grad_scale, int* skip_flag, int* skipped,
-                             int* err_host, hipStream_t stream) {
+                             int* err_host, int* status_host, const float* rank_flag, hipStream_t stream) {
     if (n <= 0 || step < 1) return SED_EINVAL;
     if ((reinterpret_cast<uintptr_t>(g) & 15) != 0 && skip_flag) return SED_EINVAL;
     if (skip_flag) {
         const long nb = (n / 4 + 255) / 256;
         hipLaunchKernelGGL(grad_finite_check_kernel, dim3((unsigned)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb))), dim3(256), 0, stream, g,
-                           n, skip_flag, err_host);
+                           n, skip_flag, err_host, rank_flag);
     }
     double bc1 = 1.0 - pow((double)beta1, (double)step);
     double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_amsgrad_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, m, v, vmax, n, lr, beta1, beta2, eps,
-                       (float)bc1, (float)sqrt(bc2), grad_scale, skip_flag, skipped);
+                       (float)bc1, (float)sqrt(bc2), grad_scale, skip_flag, skipped, status_host);
     SED_LAUNCH_CHECK();
     return 0;
 }
@@ -479,4 +506,26 @@ SED_API int sed_axpy(float* out, const float* a, long n, hipStream_t stream) {
     return 0;
 }
 
-SED_API const char* sed_version(void) { return "sed-hip 0.1 (gfx950)"; }
+// "sed-hip <abi> (gfx950) flags:<hash>": the hash identifies the hipcc flags EVERY object of this library was compiled with
+// ("mixed:..." when they disagree); build.py defines it, the loader refuses a library whose flags are not the default ones
+// unless SED_ALLOW_EXPERIMENT=1.
+#define SED_WEAK_FLAGS(name) extern "C" __attribute__((weak, visibility("hidden"))) const char sed_objflags_##name[];
+SED_WEAK_FLAGS(logmel) SED_WEAK_FLAGS(bn) SED_WEAK_FLAGS(conv) SED_WEAK_FLAGS(conv_wino) SED_WEAK_FLAGS(conv_wino2)
+SED_WEAK_FLAGS(conv_sf16) SED_WEAK_FLAGS(attention) SED_WEAK_FLAGS(gru)
+SED_API const char* sed_version(void) {
+    static char buf[512];
+    if (!buf[0]) {
+        const char* objs[] = {sed_objflags_heads,     sed_objflags_logmel,    sed_objflags_bn,        sed_objflags_conv, sed_objflags_conv_wino,
+                              sed_objflags_conv_wino2, sed_objflags_conv_sf16, sed_objflags_attention, sed_objflags_gru};
+        bool same = true;
+        for (const char* o : objs) same = same && (!o || strcmp(o, objs[0]) == 0);
+        if (same) {
+            snprintf(buf, sizeof buf, "sed-hip 0.4 (gfx950) flags:%s", objs[0]);
+        } else {
+            int n = snprintf(buf, sizeof buf, "sed-hip 0.4 (gfx950) flags:mixed");
+            for (const char* o : objs)
+                if (o && n < (int)sizeof buf - 40) n += snprintf(buf + n, sizeof buf - n, ":%s", o);
+        }
+    }
+    return buf;
+}

@@ -33,6 +33,7 @@
 #include "common.h"
 #include "sed_hip.h"
 #include <math.h>
+SED_OBJECT_FLAGS(logmel)
 
 namespace {
 

@@ -35,6 +35,7 @@ class GraphedTrainStep(object):
         self.enabled = bool(enabled)
         self.graph = None
         self.loss = None
+        self._written = set()
         self.calls = 0
         self.replays = 0
         self._key = None
@@ -90,6 +91,11 @@ class GraphedTrainStep(object):
         if ops.pending_sink_indices():
             raise RuntimeError("GraphedTrainStep: side-stream weight gradients were left un-joined by the captured backward pass")
         self.graph, self.loss = g, loss
+        # which gradients the captured backward pass writes through the sinks: a replay runs no Python, so the buckets'
+        # `written` set must be restored by hand before every optimiser step -- otherwise FusedAdamAmsgrad._gather() would
+        # take a `p.grad is None` parameter (model.zero_grad(set_to_none=True) between replays) for one that received
+        # nothing and ZERO the slice the graph has just filled
+        self._written = set(buckets.written)
 
     def __call__(self, wave, target, lam=None, stripes=None):
         if self.mixup and lam is None:
@@ -109,8 +115,10 @@ class GraphedTrainStep(object):
         else:
             if self.graph is None:
                 self._capture()                 # records only: the replay below is this call's step
+            self.opt.buckets.new_gradients()
             self.graph.replay()
             self.replays += 1
+            self.opt.buckets.written |= self._written
             loss = self.loss
         self.opt.step()
         return loss

@@ -124,22 +124,26 @@ def _fork_wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, gy_amax=None, 
 
 
 # bench.py sets this to a dict to HIP-event-time the MFMA kernels inside its timed region:
-# {tag: [(start_event, end_event, algorithmic_flops), ...]}.  None = no instrumentation.
+# {tag: [(start_event, end_event, algorithmic_flops), ...]}.  None = no instrumentation.  TIMING_ONLY: tuple of tag prefixes
+# that are timed (None = every tagged launch) -- an event pair costs the stream ~6 us, so the headline region only brackets
+# the kernel family its `roofline` object reports.
 TIMING = None
+TIMING_ONLY = None
 
 
 class _timed(object):
     def __init__(self, tag, flops):
         self.tag, self.flops = tag, flops
+        self.on = TIMING is not None and (TIMING_ONLY is None or tag.startswith(TIMING_ONLY))
 
     def __enter__(self):
-        if TIMING is not None:
+        if self.on:
             self.a = torch.cuda.Event(enable_timing=True)
             self.b = torch.cuda.Event(enable_timing=True)
             self.a.record(_STREAM_OVERRIDE)      # the stream the kernel is launched on (None = torch's current stream)
 
     def __exit__(self, *exc):
-        if TIMING is not None:
+        if self.on:
             self.b.record(_STREAM_OVERRIDE)
             TIMING.setdefault(self.tag, []).append((self.a, self.b, self.flops))
         return False
@@ -250,15 +254,35 @@ def _sf16_err_dev_ptr(device=None):
     return ctypes.c_void_p(_err_dev(device).data_ptr())
 
 
-def check_device_errors(synchronize=False):
+def _nonfinite_poll_is_lagged():
+    return any(getattr(o, "poll_lag", None) is not None for o in _GUARDED)
+
+
+def clear_nonfinite_flags():
+    """Reset the found-non-finite words (host-mapped + device) after they have been reported."""
+    for t in _ERR_DEV.values():
+        t.zero_()
+    torch.cuda.synchronize()
+    if _ERR_FLAG is not None:
+        _ERR_FLAG[1] = 0
+
+
+def check_device_errors(synchronize=False, nonfinite=None):
     """Raise if a kernel reported a run-time failure since the last check (no device synchronisation unless asked: the
     flag is written through host-mapped memory, so a failure surfaces at the next call after the kernel ran).  Only the
-    slot that is reported is cleared."""
+    slot that is reported is cleared.
+
+    nonfinite: whether the found-non-finite word is reported HERE.  Default: yes, unless an optimiser of this process polls it
+    itself at a deterministic point of its step (FusedAdamAmsgrad(poll_lag=...): every rank of a data-parallel job must
+    learn about a refused step at the same iteration, so an opportunistic poll from, say, the GRU's launch check must not
+    pre-empt it).  The inference loop passes True (its batches are its own)."""
     if _ERR_FLAG is None:
         return
     if synchronize:
         torch.cuda.synchronize()
-    if int(_ERR_FLAG[1]):
+    if nonfinite is None:
+        nonfinite = not _nonfinite_poll_is_lagged()
+    if nonfinite and int(_ERR_FLAG[1]):
         torch.cuda.synchronize()                      # rare path: settle, then read how many steps the Adam kernel refused
         skipped = 0
         for opt in list(_GUARDED):                    # every guarded optimiser takes ITS refused steps back, whoever polls
@@ -270,15 +294,24 @@ def check_device_errors(synchronize=False):
                 skipped = max(skipped, k)
         for t in _ERR_DEV.values():
             skipped = max(skipped, int(t[1].item()))  # raw users of adam_amsgrad_ (no optimiser object)
-            t.zero_()
-        torch.cuda.synchronize()
-        _ERR_FLAG[1] = 0
+        clear_nonfinite_flags()
         raise NonFiniteOperand(
             "sound_event_detection_dcase2017_task4_amd: a split-f16 convolution met a NaN / inf operand (diverged training or "
             "non-finite input): its results are NaN.  The Adam kernel refused the %d optimiser step(s) since -- parameters and "
             "moments are those from before the poisoned step.  (Operand scales come from device-side amax values, so a FINITE "
-            "operand cannot overflow at any magnitude.)  The train CLI re-runs such a step on the fp32 MFMA kernels "
-            "(ops.USE_SF16 = False), which propagate NaN exactly like the reference." % skipped, skipped)
+            "operand cannot overflow at any magnitude.)  BatchNorm running statistics were not touched by the poisoned "
+            "forward passes either; roll `num_batches_tracked` back with ops.rollback_bn_counters(model, n).  The train CLI "
+            "re-runs such steps on the fp32 MFMA kernels (ops.USE_SF16 = False), which propagate NaN exactly like the "
+            "reference." % skipped, skipped)
+
+
+def rollback_bn_counters(model, n):
+    """Take `n` refused training steps back out of every BatchNorm `num_batches_tracked` of `model` (the forward pass of a
+    refused step bumped them; the running statistics themselves were guarded on the device)."""
+    bufs = model.bn_counters() if hasattr(model, "bn_counters") else [
+        b for name, b in model.named_buffers() if name.endswith("num_batches_tracked")]
+    if n and bufs:
+        torch._foreach_sub_(bufs, int(n))
     code = int(_ERR_FLAG[0])
     if code:
         _ERR_FLAG[0] = 0
@@ -498,11 +531,17 @@ def _ws(C, device):
 
 
 def bn_finalize(partials, nparts, rows_per_part, N, bn_w, bn_b, running_mean, running_var):
+    """Batch statistics -> folded affine + running-statistics update.  While the found-non-finite guard is on (USE_SF16)
+    NaN / inf batch statistics raise the error words (the Adam kernel then refuses the step) and are NOT blended into
+    running_mean / running_var: a refused step leaves the BatchNorm buffers intact like the parameters.  With
+    USE_SF16 = False the update is torch's (NaN flows into the buffers, as in the reference)."""
     C = bn_w.numel()
     st = BnStats(C, bn_w.device)
+    guard = USE_SF16
     _call("sed_bn_finalize", _ptr(partials), nparts, rows_per_part, N, C, _ptr(bn_w), _ptr(bn_b), BN_EPS, BN_MOMENTUM,
           _ptr(running_mean), _ptr(running_var), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale), _ptr(st.shift),
-          _ptr(_ws(C, bn_w.device)), _stream())
+          _ptr(_ws(C, bn_w.device)), _sf16_err_dev_ptr(bn_w.device) if guard else None, _sf16_err_ptr() if guard else None,
+          _stream())
     return st
 
 
@@ -753,17 +792,27 @@ _AMAX_POOL = {}
 _POOL_ROW = 128          # floats per pool row: an amax vector uses the first 64, a weight scale record 65
 
 
+def _unregister_pool(addr, nfloats):
+    try:
+        _lib.lib().sed_amax_prezeroed_range(ctypes.c_void_p(addr), nfloats, 0)
+    except Exception:                                   # interpreter shutdown
+        pass
+
+
 def _amax_buf(device, n=AMAX_SLOTS):
     """A ZEROED float[n] (n <= 128; default: a 64-slot amax vector): a slice of a pool that is zeroed 64 rows at a time
-    (one fill kernel instead of one memset per producer launch; the library is told that amax buffers arrive zeroed:
-    sed_amax_caller_zeroes).  Each row is handed out once; the views keep their pool alive."""
+    (one fill kernel instead of one memset per producer launch).  The pool's ADDRESS RANGE is registered with the library
+    (sed_amax_prezeroed_range) for as long as the pool's storage lives: only pointers inside it skip the library's own
+    memset, every other amax buffer handed to the C ABI in this process is still zeroed by the entry point itself.  Each
+    row is handed out once; the views keep their pool alive."""
     dev = torch.device(device)
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     ent = _AMAX_POOL.get(key)
     if ent is None or ent[1] >= ent[0].shape[0]:
-        if ent is None:
-            _lib.lib().sed_amax_caller_zeroes(1)
-        ent = _AMAX_POOL[key] = [torch.zeros((64, _POOL_ROW), dtype=torch.float32, device=torch.device("cuda", key)), 0]
+        pool = torch.zeros((64, _POOL_ROW), dtype=torch.float32, device=torch.device("cuda", key))
+        _lib.check(_lib.lib().sed_amax_prezeroed_range(ctypes.c_void_p(pool.data_ptr()), pool.numel(), 1), "sed_amax_prezeroed_range")
+        weakref.finalize(pool, _unregister_pool, pool.data_ptr(), pool.numel())     # views keep `pool` (their _base) alive
+        ent = _AMAX_POOL[key] = [pool, 0]
     v = ent[0][ent[1]][:n]
     ent[1] += 1
     return v
@@ -1510,7 +1559,8 @@ def mixup_rows(x, lam):
     return out
 
 
-def adam_amsgrad_(p, g, m, v, vmax, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, guard=None, skipped=None):
+def adam_amsgrad_(p, g, m, v, vmax, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, guard=None, skipped=None,
+                  status_ptr=None, rank_flag=None):
     """guard (default: on while the split-f16 kernels are in use): found-non-finite skip -- the update is refused when a
     split-f16 kernel of this step met a NaN / inf operand or the (all-reduced) gradient holds one; see NonFiniteOperand.
     With ops.USE_SF16 = False the step behaves exactly like torch.optim.Adam (NaN gradients make NaN parameters)."""
@@ -1520,4 +1570,10 @@ def adam_amsgrad_(p, g, m, v, vmax, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, 
     invalidate_weight_caches()                     # parameters change through raw pointers: `_version` does not see it
     _call("sed_adam_amsgrad", _ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vmax), p.numel(), step, lr, beta1, beta2, eps,
           grad_scale, _sf16_err_dev_ptr(p.device) if guard else None, _ptr(skipped) if guard else None,
-          _sf16_err_ptr() if guard else None, _stream())
+          _sf16_err_ptr() if guard else None, ctypes.c_void_p(status_ptr) if (guard and status_ptr) else None,
+          _ptr(rank_flag) if guard else None, _stream())
+
+
+def guard_publish(flag_out):
+    """flag_out[0] = NaN if this rank's found-non-finite word is set, else 0 (see include/sed_hip.h: sed_guard_publish)."""
+    _call("sed_guard_publish", _sf16_err_dev_ptr(flag_out.device), _ptr(flag_out), _stream())

@@ -150,8 +150,14 @@ class GradBuckets(object):
     Which parameters take part is registered per step by the forward pass (`expect`), so parameters that receive no
     gradient (the reference's unused `att_block.bn_att.*`, models.py:129) never block a bucket."""
 
-    def __init__(self, flat_grad, offsets, numels, cuts):
+    def __init__(self, flat_grad, offsets, numels, cuts, store=None, pad=0):
+        """store / pad: `flat_grad` is store[pad:]; store[0] is the rank flag of the found-non-finite guard (optim.py).  It is
+        published (publish_flag) right before the LAST bucket of a step goes out and rides on that all-reduce when the
+        bucket is the one at the front of the buffer (bucket 0: block 1 / bn0 -- the last to finish in every model), else on
+        a 16-byte all-reduce of its own."""
         self.flat_grad = flat_grad
+        self.store, self.pad = store, int(pad)
+        self.publish_flag = None
         self.offsets, self.numels = list(offsets), list(numels)
         n = flat_grad.numel()
         edges = [0] + sorted(set(int(c) for c in cuts if 0 < int(c) < n)) + [n]
@@ -162,7 +168,10 @@ class GradBuckets(object):
         self.issue_order = []          # bucket indices in the order they were handed to the backend (for tests / logs)
         self.pre_fire_check = None     # callable(bucket index, param indices) run before a bucket goes to the backend
         self.wait_events = None        # bench: list that receives (start, end) CUDA event pairs around the waits of finish()
-        self.deferred = False          # True: ready() never fires a bucket, finish() issues them all (graph.GraphedTrainStep)
+        # deferred: ready() never fires a bucket, finish() issues them all behind the backward pass (graph.GraphedTrainStep
+        # sets it while capturing; SED_ALLREDUCE_OVERLAP=0 selects it for a whole run: the exchange then starts after the last
+        # MFMA kernel of backward instead of beside it -- <= 0.3 ms of exposed all-reduce per step)
+        self.deferred = os.environ.get("SED_ALLREDUCE_OVERLAP", "1") == "0"
         self.begin_step()
         self.last_issue_order = []
 
@@ -209,6 +218,13 @@ class GradBuckets(object):
         self.issue_order.append(b)
         if world_size() > 1:
             lo, hi = self.ranges[b]
+            last = all(self.fired)
+            if last and self.publish_flag is not None and self.store is not None:
+                self.publish_flag()                      # this rank's found-non-finite word -> store[0]
+                if lo == 0:                              # rides on this bucket
+                    self.handles.append(dist.all_reduce(self.store[0:self.pad + hi], op=dist.ReduceOp.SUM, async_op=True))
+                    return
+                self.handles.append(dist.all_reduce(self.store[0:self.pad], op=dist.ReduceOp.SUM, async_op=True))
             self.handles.append(dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):

@@ -20,6 +20,7 @@ runs `evaluate.Evaluator` on the test / evaluation packs when they and their str
 the segment-based metrics restated in utils/utilities.py because sed_eval is not installed; otherwise it logs and skips.
 """
 import argparse
+import collections
 import logging
 import os
 import pickle
@@ -60,6 +61,9 @@ def _build_model(model_type):
     return Model(sample_rate, window_size, hop_size, mel_bins, fmin, fmax, classes_num)
 
 
+POLL_LAG = 2          # optimiser steps between a step and the (rank-consistent) poll of its found-non-finite status
+
+
 def train(args):
     rank, world, local_rank = parallel.init_from_env()
     device = 'cuda' if (args.cuda and torch.cuda.is_available()) else 'cpu'
@@ -89,7 +93,9 @@ def train(args):
         model.load_state_dict(ck['model'])
         iteration = ck['iteration']
     model.to(device)
-    optimizer = FusedAdamAmsgrad(model, lr=args.learning_rate, betas=(0.9, 0.999), eps=1e-08, world_size=world)
+    # poll_lag: the found-non-finite guard is polled deterministically, POLL_LAG steps behind the newest one, so that every rank
+    # learns about a refused step inside the same optimizer.step() call (optim.FusedAdamAmsgrad)
+    optimizer = FusedAdamAmsgrad(model, lr=args.learning_rate, betas=(0.9, 0.999), eps=1e-08, world_size=world, poll_lag=POLL_LAG)
     if args.resume_iteration and 'exp_avg' in ck.get('optimizer', {}):
         optimizer.load_state_dict(ck['optimizer'])
     parallel.broadcast_flat(optimizer.flat)
@@ -106,7 +112,8 @@ def train(args):
     # reference's 8 worker processes + pickled numpy batches deliver ~300-600 waveforms/s, one MI355X consumes 5300
     train_sampler = ShardedBatchSampler(TrainSampler(hdf5_path=train_path, batch_size=rows_global, random_seed=1234),
                                         row_lo, row_hi)
-    train_loader = PinnedBatchLoader(train_path, train_sampler, device=device)
+    # hold: a batch stays valid while POLL_LAG + 1 later ones are requested -- the batches of refused steps are re-run
+    train_loader = PinnedBatchLoader(train_path, train_sampler, device=device, hold=POLL_LAG + 1)
     mixup_augmenter = Mixup(mixup_alpha=1., random_seed=1234) if mix else None
     graphed = GraphedTrainStep(model, optimizer, loss_func, mixup=mix) if getattr(args, 'hip_graph', False) else None
     train_bgn_time = time.time()
@@ -135,8 +142,49 @@ def train(args):
                 statistics_container.load_state_dict(args.resume_iteration)        # keep the history up to the resume point
             evaluator = Evaluator(model=model)
 
+    recent = collections.deque(maxlen=POLL_LAG + 1)      # (wave, target, lam, stripes) of the newest steps, oldest first
+
+    def one_step(wave, target, lam, stripes):
+        model.train()
+        if graphed is not None:                      # same body, captured once per input shape and replayed
+            return graphed(wave, target, lam, stripes)
+        batch_output_dict = model(wave, lam, specaug_stripes=stripes)
+        batch_target_dict = {'target': do_mixup(target, lam) if mix else target}
+        step_loss = loss_func(batch_output_dict, batch_target_dict)
+        optimizer.zero_grad()
+        step_loss.backward()                         # gradient buckets are handed to RCCL as they complete
+        optimizer.step()                             # waits for them; 1/world is folded into the Adam kernel
+        return step_loss
+
+    def recover(err, iteration):
+        """ops.NonFiniteOperand out of optimizer.step() / optimizer.poll(): the Adam kernel refused the last
+        `err.skipped_steps` optimiser steps -- on EVERY rank, and every rank is told inside the same call (deterministic lagged
+        poll, rank flag on the last gradient bucket), so all of them arrive here together and the collectives stay balanced.
+        Parameters, moments and BatchNorm running statistics are those from before the first refused step.  The reference has
+        no guard (main.py:245-258: NaN flows into the weights); here the run continues on the fp32 MFMA kernels, which carry
+        non-finite values exactly like the reference's torch ops, and the refused batches are run again on them, in order."""
+        k = err.skipped_steps
+        logging.warning('iteration %d: %s', iteration, err)
+        logging.warning('%d optimiser step(s) were refused on all %d rank(s); switching to the fp32 MFMA kernels '
+                        '(ops.USE_SF16 = False) and re-running their batches', k, world)
+        ops.rollback_bn_counters(model, k)
+        ops.USE_SF16 = False
+        redo = list(recent)[-k:] if k else []
+        if len(redo) < k:
+            raise RuntimeError('%d steps were refused but only %d batches are retained' % (k, len(redo)))
+        loss = None
+        for batch in redo:
+            loss = one_step(*batch)
+        return loss
+
     for batch_data_dict in train_loader:
         evaluate_now = iteration % 1000 == 0 and iteration > (args.resume_iteration or 0)
+        checkpoint_now = iteration % 10000 == 0
+        if evaluate_now or checkpoint_now:
+            try:                                         # ALL ranks: nothing half-reported may reach an evaluation / checkpoint
+                optimizer.poll(0)
+            except ops.NonFiniteOperand as err:
+                recover(err, iteration)
         if evaluate_now and rank == 0:
             train_fin_time = time.time()
             for data_type, loader, csv_path in eval_sets:
@@ -155,7 +203,7 @@ def train(args):
             train_bgn_time = time.time()
         if evaluate_now:
             parallel.barrier()           # the other ranks wait here (not inside an all-reduce) while rank 0 evaluates
-        if iteration % 10000 == 0 and rank == 0:
+        if checkpoint_now and rank == 0:
             checkpoint = {'iteration': iteration, 'model': model.state_dict(), 'optimizer': optimizer.state_dict()}
             checkpoint_path = os.path.join(checkpoints_dir, '{}_iterations.pth'.format(iteration))
             torch.save(checkpoint, checkpoint_path)
@@ -167,42 +215,23 @@ def train(args):
         # SpecAugment positions of the GLOBAL batch from the global torch generator (all ranks hold the same state), rows
         # of this rank: the stripes do not depend on the number of ranks
         stripes = draw_specaug_stripes(rows_global, wave.shape[1] // hop_size + 1, mel_bins)[row_lo:row_hi]
-        model.train()
         # (move_data_to_device's pageable copy would block the host until the GPU has drained: pinned staging instead)
         lam = ops.upload_small(batch_data_dict['mixup_lambda'], device, torch.float32) if mix else None
-
-        def one_step():
-            if graphed is not None:                      # same body, captured once per input shape and replayed
-                return graphed(wave, target, lam, stripes)
-            batch_output_dict = model(wave, lam, specaug_stripes=stripes)
-            batch_target_dict = {'target': do_mixup(target, lam) if mix else target}
-            step_loss = loss_func(batch_output_dict, batch_target_dict)
-            optimizer.zero_grad()
-            step_loss.backward()                         # gradient buckets are handed to RCCL as they complete
-            optimizer.step()                             # waits for them; 1/world is folded into the Adam kernel
-            return step_loss
-
+        recent.append((wave, target, lam, stripes))
         try:
-            loss = one_step()
+            loss = one_step(wave, target, lam, stripes)
         except ops.NonFiniteOperand as err:
-            if world > 1:
-                raise                                    # ranks notice at different iterations: a one-rank re-run would
-                                                         # unbalance the all-reduces.  (Every rank's guard has refused the
-                                                         # poisoned updates: the last checkpoint / parameters are intact.)
-            # a split-f16 convolution met NaN / inf; the Adam kernel refused every update since (parameters are intact).
-            # From here on the run uses the fp32 MFMA kernels, which carry non-finite values exactly like the reference's
-            # torch ops; this batch is run again on them.
-            logging.warning('iteration %d: %s', iteration, err)
-            logging.warning('%d optimiser step(s) were refused; switching to the fp32 MFMA kernels (ops.USE_SF16 = False) '
-                            'and re-running this batch', err.skipped_steps)
-            ops.USE_SF16 = False
-            loss = one_step()
+            loss = recover(err, iteration)
         if rank == 0 and args.print_every and iteration % args.print_every == 0:
             print(iteration, loss.item())
         if iteration == args.stop_iteration:
             break
         iteration += 1
-    ops.check_device_errors(synchronize=True)
+    try:
+        optimizer.poll(0)                                # steps still un-polled at the end (all ranks)
+    except ops.NonFiniteOperand as err:
+        recover(err, iteration)
+    ops.check_device_errors(synchronize=True, nonfinite=True)
     parallel.shutdown()
 
 

@@ -271,6 +271,12 @@ class _Cnn9Base(nn.Module):
             self._tables_key = key
         return self._tables
 
+    def bn_counters(self):
+        """`num_batches_tracked` of the nine BatchNorms a training-mode forward pass goes through (att_block.bn_att is never
+        applied, models.py:129).  ops.rollback_bn_counters() takes refused steps back out of them."""
+        return [self.bn0.num_batches_tracked] + [bn.num_batches_tracked for blk in (
+            self.conv_block1, self.conv_block2, self.conv_block3, self.conv_block4) for bn in (blk.bn1, blk.bn2)]
+
     def extract_logmel(self, input):
         """(B2, L) waveform (float32 or int16) -> (B2, T, 64) log-mel.  models.py:284-285."""
         return ops.logmel(input, self._frontend(), self.logmel_extractor.amin)
@@ -295,8 +301,7 @@ class _Cnn9Base(nn.Module):
         x = ops.Bn0AugMix.apply(lm, self.bn0.weight, self.bn0.bias, self.bn0.running_mean, self.bn0.running_var,
                                 self.training, stripes, lam)
         if self.training:                                                # nn.BatchNorm2d bookkeeping: one foreach launch
-            torch._foreach_add_([self.bn0.num_batches_tracked] + [bn.num_batches_tracked for blk in (
-                self.conv_block1, self.conv_block2, self.conv_block3, self.conv_block4) for bn in (blk.bn1, blk.bn2)], 1)
+            torch._foreach_add_(self.bn_counters(), 1)
         x = x.view(x.shape[0], T, M, 1)                                  # NHWC, C = 1
         if ops.USE_SF16:                 # split-f16 operands of all seven MFMA conv weights: two launches per optimiser step
             blks = (self.conv_block1, self.conv_block2, self.conv_block3, self.conv_block4)

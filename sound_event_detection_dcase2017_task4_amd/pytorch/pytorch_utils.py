@@ -45,8 +45,12 @@ def forward(model, data_loader, return_input=False, return_target=False):
             out = model(wave_dev)
         host = {key: out[key].detach().cpu().numpy() for key in ('clipwise_output', 'framewise_output') if key in out}
         try:
-            ops.check_device_errors()                    # the copies above synchronised: the flag is current
-        except ops.NonFiniteOperand:
+            ops.check_device_errors(nonfinite=True)      # the copies above synchronised: the flag is current
+        except ops.NonFiniteOperand as err:
+            if err.skipped_steps:
+                # not an inference problem: optimiser steps BEFORE this loop were refused and nobody had polled yet (the train
+                # CLI drains with optimizer.poll(0) before it evaluates) -- the training loop must hear about it
+                raise
             # a non-finite operand in a split-f16 convolution: redo this batch on the fp32 MFMA kernels, which propagate
             # NaN / inf exactly like the reference's torch ops
             logging.warning('non-finite activations in batch %d of the inference loop: re-running it on the fp32 kernels',

@@ -5,6 +5,7 @@ The packed store keeps the reference's dataset names (utils/features.py:232-260)
 (N, 320000), `target` float32 (N, 17), optional `strong_target` bool (N, 1001, 17).  It can be an HDF5 file (needs
 h5py, absent in the build image), a directory of `<name>.npy` files (memory-mapped), or an in-memory synthetic store.
 """
+import collections
 import logging
 import os
 
@@ -177,15 +178,17 @@ class PinnedBatchLoader(object):
     stream one batch ahead and the batch dict holds device tensors.
 
     Yields {'audio_name': list[str], 'waveform': int16 (B2, L) tensor, 'target': float32 (B2, 17) tensor,
-    ['strong_target']}; the tensors of a batch are valid until the next batch is requested."""
+    ['strong_target']}; the tensors of a batch are valid until `hold` + 1 further batches have been requested (hold = 0: until
+    the next one; the train CLI holds 3 so that it can re-run the batches of refused optimiser steps)."""
 
-    def __init__(self, hdf5_path, batch_sampler, device=None, depth=3, threads=4):
+    def __init__(self, hdf5_path, batch_sampler, device=None, depth=3, threads=4, hold=0):
         import torch
         self.torch = torch
         self.store = open_store(hdf5_path)
         self.sampler = batch_sampler
         self.device = device
-        self.depth = max(2, int(depth))
+        self.hold = max(0, int(hold))
+        self.depth = max(2, int(depth), self.hold + 3)
         self.threads = max(1, int(threads))
         self.wave_src = self.store['waveform']
         self.target_src = self.store['target']
@@ -280,15 +283,19 @@ class PinnedBatchLoader(object):
         t = threading.Thread(target=producer, daemon=True)
         t.start()
         prev = None
+        held = collections.deque()                    # slots handed out and still promised to the consumer (oldest first)
         try:
             first = True
             while True:
                 if not first:
-                    # the batch handed out before is no longer needed: mark the point in the consumer's stream after its
-                    # last reader FIRST, then let the producer have the slot (its upload waits for that event)
-                    if prev is not None:
-                        prev['consumed'].record(torch.cuda.current_stream(self.device))
-                    free_slots.release()
+                    # the batch handed out `hold` + 1 requests ago is no longer needed: mark the point in the consumer's stream
+                    # after its last reader FIRST, then let the producer have the slot (its upload waits for that event)
+                    held.append(prev)
+                    while len(held) > self.hold:
+                        old = held.popleft()
+                        if old is not None:
+                            old['consumed'].record(torch.cuda.current_stream(self.device))
+                        free_slots.release()
                 first = False
                 item = q.get()
                 if item is None:

@@ -49,7 +49,7 @@ def test_argument_errors_are_reported_not_crashes():
     assert h.sed_logmel_f32(None, 1, 100, None, None, None, 105, None, 4, None, 866, 1e-10, None, None) == -22     # L <= 512
     assert h.sed_gru_seq_fwd(None, None, None, None, None, 4, 5, 128, None, None, None, None, None, None) == -22        # hidden size != 256
     assert h.sed_mixup_rows(None, None, 3, 17, None, None) == -22
-    assert h.sed_adam_amsgrad(None, None, None, None, None, 10, 0, 1e-3, 0.9, 0.999, 1e-8, 1.0, None, None, None, None) == -22
+    assert h.sed_adam_amsgrad(None, None, None, None, None, 10, 0, 1e-3, 0.9, 0.999, 1e-8, 1.0, None, None, None, None, None, None) == -22
     assert h.sed_act_amax(None, 4, 64, None, None, None, None) == -22
 
 
@@ -282,3 +282,48 @@ def test_mel_task_tables_reproduce_the_filter_bank_and_are_bank_conflict_free():
             for g in range(4):
                 starts = [int(tasks[s][0]) % 32 for s in range(32 * g, 32 * g + 32)]
                 assert len(set(starts)) == 32, (g, starts)
+
+
+def test_loader_refuses_an_experiment_build(tmp_path, monkeypatch):
+    """sed_version() carries the hash of the hipcc flags of every object; _lib.verify_flags() refuses a library that was not
+    built with build.BASE_FLAGS (a stray SED_HIPCC_FLAGS=-D... once built a wrong-results library that nothing detected)
+    unless SED_ALLOW_EXPERIMENT=1.  Built here from heads.hip alone (it holds sed_version) with an extra -D."""
+    import ctypes
+    import shutil
+    import subprocess
+    from sound_event_detection_dcase2017_task4_amd import _lib, build
+    if not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        pytest.skip("needs hipcc")
+    _lib._load_hip_runtime()
+    libs = {}
+    for name, flags in (("exp", build.BASE_FLAGS + ["-DSF_ABL_NOFRAG"]), ("std", list(build.BASE_FLAGS))):
+        obj, so = str(tmp_path / (name + ".o")), str(tmp_path / ("lib%s.so" % name))
+        subprocess.run(build.compile_cmd(os.path.join(build.CSRC, "heads.hip"), obj, flags), check=True, capture_output=True)
+        subprocess.run([os.environ.get("CXX", "g++"), "-shared", "-fPIC", "-o", so, obj], check=True, capture_output=True)
+        libs[name] = ctypes.CDLL(so)
+    monkeypatch.delenv("SED_ALLOW_EXPERIMENT", raising=False)
+    assert _lib.verify_flags(libs["std"]).endswith("flags:" + build.flags_hash())
+    with pytest.raises(RuntimeError, match="experiment build is refused"):
+        _lib.verify_flags(libs["exp"])
+    monkeypatch.setenv("SED_ALLOW_EXPERIMENT", "1")
+    assert "flags:" in _lib.verify_flags(libs["exp"])
+    # the shipped library itself was built with the default flags, and no experiment switch is left in the kernels
+    assert _lib.lib().sed_version().decode().endswith("flags:" + build.flags_hash())
+    src = open(os.path.join(build.CSRC, "conv_sf16.hip")).read()
+    assert src.count("#if") <= 3
+
+
+def test_pinned_batch_loader_hold_keeps_earlier_batches_valid():
+    """hold = h: the tensors of a batch stay untouched while h + 1 later batches are requested (the train CLI re-runs the
+    batches of refused optimiser steps); hold = 0 is the old contract (valid until the next request)."""
+    from sound_event_detection_dcase2017_task4_amd.utils.data_generator import PinnedBatchLoader, TestSampler
+    path = "synthetic:24:4000"
+    for hold in (0, 3):
+        loader = PinnedBatchLoader(path, TestSampler(path, batch_size=2), device=None, hold=hold)
+        assert loader.depth >= hold + 3
+        seen = []
+        for batch in loader:
+            seen.append((batch["waveform"], batch["waveform"].clone()))
+            for wave, copy in seen[-(hold + 1):]:
+                assert torch.equal(wave, copy)
+        assert len(seen) == 12

@@ -12,6 +12,9 @@ pytestmark = pytest.mark.gpu
 from oracle import frontend as ofe
 from oracle import model as om
 
+# per (model, convolution path) floor of the gradient gate, where it is NOT the common 2e-3: none at the moment (round 3 let the
+# split-f16 path have 3e-3 everywhere)
+GRAD_FLOOR = {}
 SEEDS = {mt: i + 1 for i, mt in enumerate(om.MODEL_TYPES)}
 CTOR = (32000, 1024, 320, 64, 50, 14000, 17)
 
@@ -454,7 +457,7 @@ def test_low_noise_training_fixture_vs_float64_reference(mt, golden_dir, conv_pa
                 got = g[sample_index(g.size)]
                 err = float(np.sqrt(((got - want) ** 2).sum() / max((want ** 2).sum(), 1e-300)))
                 ref = float(fx["big_ref32err/" + k][0])
-                gate = max(3e-3 if conv_path == "sf16" else 2e-3, 3.0 * ref)      # fp32 kernels: the floor of before round 2
+                gate = max(GRAD_FLOOR.get((mt, conv_path), 2e-3), 3.0 * ref)     # ONE floor for both convolution paths
                 report[k] = (err, ref)
                 if err > gate:
                     bad[k] = (err, ref, gate)
@@ -462,9 +465,18 @@ def test_low_noise_training_fixture_vs_float64_reference(mt, golden_dir, conv_pa
                 assert abs(float(np.sqrt((g ** 2).sum())) - l2) <= gate * l2, (k, float(np.sqrt((g ** 2).sum())), l2)
             top = sorted(report.items(), key=lambda kv: -kv[1][0])[:5]
             print("gradient relative L2 vs float64 (ours, reference-fp32):", top)
+            n_1e3 = sum(e <= 1e-3 for e, _ in report.values())
             print("tensors where we are below 1e-3: %d of %d; below the reference's own error: %d"
-                  % (sum(e <= 1e-3 for e, _ in report.values()), len(report), sum(e <= r for e, r in report.values())))
+                  % (n_1e3, len(report), sum(e <= r for e, r in report.values())))
             assert not bad, bad
+            # the plain SURVEY 8(d) figure (1e-3) is ASSERTED where no ReLU mask lies between the tensor and the loss -- the head
+            # (and the GRU / attention stack above block 4), where the error is pure arithmetic -- and for a minimum share of all
+            # tensors: below a flipped mask every upstream tensor moves by ~1e-3 in ANY fp32 evaluation (the reference's own
+            # float32 run is 0.7e-3 .. 3.8e-3 from float64 on them), so which tensors pass is decided by the last bit of the
+            # log-mel, not by the kernels
+            head = {k: e for k, (e, _) in report.items() if not k.startswith(("conv_block", "bn0"))}
+            assert head and max(head.values()) <= 1e-3, head
+            assert n_1e3 >= max(len(head), len(report) // 4), (n_1e3, len(report))
         opt.step()
     travel = 3 * 1e-3
     trainable = {k for k, p in m.named_parameters() if p.requires_grad}

@@ -313,6 +313,10 @@ def test_nan_input_is_refused_by_the_guard_and_fp32_fallback_matches_torch_seman
     x, y, lam, stripes = _batch(rows=4)
     xb = x.clone(); xb[1, 5000] = float("nan")
     start = opt.flat.clone()
+    buffers_before = {k: v.clone() for k, v in m.named_buffers()}
+    with torch.no_grad():
+        eval_before = m.eval()(x, None)["clipwise_output"].clone()
+    m.train()
     ops.check_device_errors(synchronize=True)
     loss = clip_bce(m(xb, None, specaug_stripes=stripes), {"target": y})
     opt.zero_grad(); loss.backward()
@@ -320,6 +324,19 @@ def test_nan_input_is_refused_by_the_guard_and_fp32_fallback_matches_torch_seman
         opt.step()
         ops.check_device_errors(synchronize=True)            # (the flag is host-mapped: normally seen by step() itself)
     assert torch.equal(opt.flat, start) and opt.step_count == 0 and opt.skipped_steps == 1
+    # the BatchNorm buffers are as intact as the parameters: the poisoned forward pass did NOT blend its NaN batch statistics
+    # into running_mean / running_var (bn_finalize is guarded on the device), the counters can be rolled back, and an
+    # eval-mode forward -- which uses the running statistics -- is finite and equal to the one before the refused step
+    for name, buf in m.named_buffers():
+        assert torch.isfinite(buf.float()).all(), name
+        assert torch.equal(buf, buffers_before[name]) or name.endswith("num_batches_tracked"), name
+    assert int(m.bn0.num_batches_tracked) == 1
+    ops.rollback_bn_counters(m, 1)
+    assert all(int(c) == 0 for c in m.bn_counters()) and int(m.state_dict().get("att_block.bn_att.num_batches_tracked", 0)) == 0
+    with torch.no_grad():
+        ev = m.eval()(x, None)["clipwise_output"]
+    m.train()
+    assert torch.isfinite(ev).all() and torch.equal(ev, eval_before)
     # a clean batch trains normally afterwards
     loss = clip_bce(m(x, None, specaug_stripes=stripes), {"target": y})
     opt.zero_grad(); loss.backward(); opt.step()
@@ -334,3 +351,54 @@ def test_nan_input_is_refused_by_the_guard_and_fp32_fallback_matches_torch_seman
         assert torch.isnan(opt.flat).any()
     finally:
         ops.USE_SF16 = prev
+
+
+
+def test_lagged_poll_reports_refused_steps_at_a_deterministic_step():
+    """FusedAdamAmsgrad(poll_lag=2): the host learns about a refused step exactly two optimizer.step() calls later -- by
+    waiting for that step's event and reading the status word its Adam kernel wrote -- never earlier, never later, whatever
+    the timing (this is what lets every rank of a data-parallel job raise from the SAME call).  The exception carries the
+    number of refused steps (the poisoned one + the two issued since: the device flag is sticky), step_count is corrected,
+    parameters / moments / BatchNorm buffers are untouched, and training continues afterwards."""
+    from sound_event_detection_dcase2017_task4_amd import ops
+    from sound_event_detection_dcase2017_task4_amd.optim import FusedAdamAmsgrad
+    from sound_event_detection_dcase2017_task4_amd.pytorch.losses import clip_bce
+    m = _build("Cnn_9layers_FrameAvg")
+    opt = FusedAdamAmsgrad(m, lr=1e-3, poll_lag=2)
+    x, y, lam, stripes = _batch(rows=4)
+    xb = x.clone(); xb[1, 5000] = float("nan")
+    ops.check_device_errors(synchronize=True)
+
+    def step(inp):
+        loss = clip_bce(m(inp, None, specaug_stripes=stripes), {"target": y})
+        opt.zero_grad(); loss.backward(); opt.step()
+
+    for _ in range(3):
+        step(x)                                              # clean steps: nothing to report
+    assert opt.step_count == 3
+    before = opt.flat.clone()
+    bufs = {k: v.clone() for k, v in m.named_buffers() if not k.endswith("num_batches_tracked")}
+    step(xb)                                                 # poisoned step 4: refused on the device, not yet reported
+    torch.cuda.synchronize()                                 # (even with the flag long visible to the host ...)
+    ops.check_device_errors()                                # ... an opportunistic poll stays silent in this mode
+    step(x)                                                  # step 5: refused too (sticky flag), still no report
+    with pytest.raises(ops.NonFiniteOperand) as ei:
+        step(x)                                              # step 6 polls step 4: reports 4, 5 and 6
+    assert ei.value.skipped_steps == 3 and opt.step_count == 3 and opt.skipped_steps == 3
+    assert torch.equal(opt.flat, before)
+    for k, v in m.named_buffers():
+        if not k.endswith("num_batches_tracked"):
+            assert torch.equal(v, bufs[k]), k
+    assert int(m.bn0.num_batches_tracked) == 6
+    ops.rollback_bn_counters(m, ei.value.skipped_steps)
+    assert int(m.bn0.num_batches_tracked) == 3
+    for _ in range(3):
+        step(x)                                              # flags were cleared: the run goes on
+    opt.poll(0)
+    assert opt.step_count == 6 and torch.isfinite(opt.flat).all() and not torch.equal(opt.flat, before)
+    # poll(0) drains: a poisoned LAST step is reported without further steps
+    step(xb)
+    with pytest.raises(ops.NonFiniteOperand) as ei:
+        opt.poll(0)
+    assert ei.value.skipped_steps == 1 and opt.step_count == 6
+    ops.check_device_errors(synchronize=True, nonfinite=True)

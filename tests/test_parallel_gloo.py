@@ -206,7 +206,7 @@ def test_bench_roofline_traffic_lookup_matches_the_kernels_that_exist():
     source = "".join(open(os.path.join(csrc, f)).read() for f in os.listdir(csrc) if f.endswith(".hip"))
     text = open(os.path.join(REPO, "bench.py")).read()
     import re
-    front = re.search(r'pmc_traffic\(\["([a-z0-9_]+)"\]\)', text).group(1)
+    front = re.search(r'pmc_traffic\(\["([a-z0-9_]+)"\]', text).group(1)
     for sub in [front] + [s for subs in bench.FAMILY_KERNELS.values() for s in subs]:
         assert sub in source, sub
     tr, src = bench.pmc_traffic([front])
@@ -246,3 +246,56 @@ def test_bucket_refuses_to_fire_before_its_side_stream_gradients_are_joined():
             gb.ready(1)                               # would complete bucket 0 = {0, 1} and fire it
     finally:
         del ops._PENDING[:]
+
+
+def _flag_worker(rank, world, port, out, overlap):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), SED_ALLREDUCE_OVERLAP="1" if overlap else "0")
+    from sound_event_detection_dcase2017_task4_amd import parallel
+    parallel.init_from_env(backend="gloo")
+    numels = [4, 6, 10, 20]
+    offsets = list(np.cumsum([0] + numels[:-1]))
+    pad = 4
+    store = torch.zeros(pad + sum(numels))
+    flat = store[pad:]
+    gb = parallel.GradBuckets(flat, offsets, numels, cuts=[offsets[2], offsets[3]], store=store, pad=pad)
+    assert gb.deferred == (not overlap)
+    published = []
+
+    def publish():                                   # what optim.FusedAdamAmsgrad._publish_flag does on the device
+        published.append(list(gb.issue_order))
+        store[0] = float("nan") if (rank == 1 and len(published) == 2) else 0.0
+
+    gb.publish_flag = publish
+    for step in range(3):
+        for i in range(4):
+            gb.expect(i)
+        gb.new_gradients()
+        store.zero_()
+        for i in (3, 2, 1, 0):
+            flat[offsets[i]:offsets[i] + numels[i]] = float(rank + 1)
+            gb.ready(i)
+            if not overlap:
+                assert gb.issue_order == []              # nothing leaves from inside "backward"
+        gb.finish()
+        assert gb.issue_order == [2, 1, 0]
+        assert published[-1] == [2, 1, 0]                # published right before the LAST bucket (bucket 0) went out
+        assert torch.all(flat == 3.0)
+        # the flag of step 1 (rank 1 only) reaches BOTH ranks on the last bucket's all-reduce; steps 0 and 2 are clean
+        assert bool(torch.isnan(store[0])) == (step == 1), (rank, step, store[:pad])
+        gb.begin_step()
+    dist.barrier()
+    if rank == 0:
+        open(out, "w").write("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_rank_flag_rides_on_the_last_bucket(tmp_path, overlap):
+    """The found-non-finite rank flag (store[0], in front of the flat gradient) is published right before the last bucket
+    of a step is issued and summed with it: one rank's NaN flag is every rank's after the exchange.  With
+    SED_ALLREDUCE_OVERLAP=0 no bucket leaves from inside backward; all go out from finish(), tail first."""
+    out = str(tmp_path / "ok.txt")
+    mp.spawn(_flag_worker, args=(2, _free_port(), out, overlap), nprocs=2, join=True)
+    assert open(out).read() == "ok"
