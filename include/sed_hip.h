@@ -54,14 +54,18 @@ int sed_logmel_i16(const short* wave, int B2, int L, const float* window, const 
  * updates the running statistics (unbiased variance).  ws: >= 2048*C doubles.  rows_per_part = -1: the parts hold
  * varying row counts, given as nparts floats appended after the [nparts][2][C] partials (sed_conv3x3_wino2).
  * guard_dev / guard_host (nullable; the found-non-finite words of the split-f16 path, see sed_adam_amsgrad): batch
- * statistics that are NaN / inf raise them and leave running_mean / running_var untouched; null = torch semantics.
+ * statistics that are NaN / inf raise them; null = torch semantics.  cand (nullable, [2][C]): the new running statistics
+ * are written THERE instead of in place, and sed_bn_commit (n <= 16 BatchNorms per launch) installs them unless
+ * *guard_dev != 0: a forward pass that met a non-finite value anywhere leaves every BatchNorm buffer untouched.
  * sed_bn_eval_affine: eval mode, fold the running statistics instead. */
 int sed_chan_stats(const float* x, long N, int C, float* partials, sed_stream_t stream);
 int sed_stats_rows_per_part(void);
 int sed_bn_finalize(const float* partials, int nparts, int rows_per_part, long N, int C, const float* gamma,
                     const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                     float* mean_out, float* invstd_out, float* scale_out, float* shift_out, double* ws,
-                    int* guard_dev, int* guard_host, sed_stream_t stream);
+                    int* guard_dev, int* guard_host, float* cand, sed_stream_t stream);
+int sed_bn_commit(int n, const float* const* cand, float* const* running_mean, float* const* running_var, const int* C,
+                  const int* guard_dev, sed_stream_t stream);
 int sed_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* mean_out, float* invstd_out, float* scale_out,
                        float* shift_out, sed_stream_t stream);

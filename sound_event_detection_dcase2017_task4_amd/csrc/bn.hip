@@ -101,7 +101,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, int nchunks, i
                                    float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                    float* __restrict__ scale_out, float* __restrict__ shift_out,
-                                   int* __restrict__ guard_dev, int* __restrict__ guard_host) {
+                                   int* __restrict__ guard_dev, int* __restrict__ guard_host, float* __restrict__ cand) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), sub = threadIdx.x & 63;    // 256 threads = 4 channels x one wave
     if (c >= C) return;
     double s1, s2;
@@ -117,16 +117,20 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, int nchunks, i
     scale_out[c] = sc; shift_out[c] = fmaf(-meanf, sc, beta[c]);
     if (guard_dev && !(fabs(mean) < 1e300 && var < 1e300)) {
         // found-non-finite guard (the split-f16 path): batch statistics that are NaN / inf raise the error words -- the Adam
-        // kernel of this step refuses its update -- and are NOT blended into the running statistics: a refused step leaves
-        // the BatchNorm buffers as intact as the parameters.  (guard_dev null: torch semantics, NaN flows into the buffers.)
+        // kernel of this step refuses its update.  (guard_dev null: torch semantics, NaN flows into the buffers.)
         __hip_atomic_store(guard_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (guard_host) __hip_atomic_store(guard_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        return;
     }
     if (running_mean) {
         double unbiased = (N > 1) ? var * (double)N / (double)(N - 1) : var;
-        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
-        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+        const float nm = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+        const float nv = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+        // cand: the new running statistics are only PROPOSED here; sed_bn_commit installs them at the end of the forward
+        // pass unless a kernel of that pass raised the found-non-finite word -- a refused step leaves the BatchNorm buffers
+        // exactly as intact as the parameters (a ReLU swallows NaN: fmaxf(NaN, 0) = 0, so the layers BEHIND a poisoned one
+        // see finite, wrong statistics; only the flag knows)
+        if (cand) { cand[c] = nm; cand[C + c] = nv; }
+        else { running_mean[c] = nm; running_var[c] = nv; }
     }
 }
 
@@ -604,13 +608,48 @@ SED_API int sed_stats_rows_per_part(void) { return 1024; }
 SED_API int sed_bn_finalize(const float* partials, int nparts, int rows_per_part, long N, int C, const float* gamma,
                             const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                             float* mean_out, float* invstd_out, float* scale_out, float* shift_out, double* ws,
-                            int* guard_dev, int* guard_host, hipStream_t stream) {
+                            int* guard_dev, int* guard_host, float* cand, hipStream_t stream) {
     if (nparts <= 0 || C <= 0 || N <= 0) return SED_EINVAL;
     int ppc = reduce_chunks(nparts), nchunks = sed_cdiv(nparts, ppc), K = 2 * C;
     hipLaunchKernelGGL(reduce_parts_kernel<1>, dim3(nchunks, sed_cdiv(K, 256)), dim3(256), 0, stream, partials, nparts, K,
                        ppc, N, rows_per_part, ws);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(sed_cdiv(C, 4)), dim3(256), 0, stream, ws, nchunks, C, N, gamma, beta, eps,
-                       momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out, guard_dev, guard_host);
+                       momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out, guard_dev, guard_host, cand);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+namespace {
+constexpr int SED_BN_COMMIT_MAX = 16;
+struct BnCommitP {
+    const float* cand[SED_BN_COMMIT_MAX];
+    float* rm[SED_BN_COMMIT_MAX];
+    float* rv[SED_BN_COMMIT_MAX];
+    int C[SED_BN_COMMIT_MAX];
+};
+__global__ __launch_bounds__(256) void bn_commit_kernel(BnCommitP p, const int* __restrict__ guard_dev) {
+    if (guard_dev && __hip_atomic_load(guard_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    const int t = blockIdx.y, C = p.C[t];
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
+        p.rm[t][c] = p.cand[t][c];
+        p.rv[t][c] = p.cand[t][C + c];
+    }
+}
+}  // namespace
+
+// Install the running statistics proposed by n <= 16 sed_bn_finalize(..., cand) calls -- unless *guard_dev != 0.
+SED_API int sed_bn_commit(int n, const float* const* cand, float* const* running_mean, float* const* running_var, const int* C,
+                          const int* guard_dev, hipStream_t stream) {
+    if (n <= 0 || n > SED_BN_COMMIT_MAX || !cand || !running_mean || !running_var || !C) return SED_EINVAL;
+    BnCommitP p;
+    int most = 0;
+    for (int t = 0; t < SED_BN_COMMIT_MAX; ++t) {
+        const int s = t < n ? t : 0;
+        if (!cand[s] || !running_mean[s] || !running_var[s] || C[s] <= 0) return SED_EINVAL;
+        p.cand[t] = cand[s]; p.rm[t] = running_mean[s]; p.rv[t] = running_var[s]; p.C[t] = C[s];
+        if (t < n && C[s] > most) most = C[s];
+    }
+    hipLaunchKernelGGL(bn_commit_kernel, dim3(sed_cdiv(most, 256), n), dim3(256), 0, stream, p, guard_dev);
     SED_LAUNCH_CHECK();
     return 0;
 }

@@ -254,10 +254,6 @@ def _sf16_err_dev_ptr(device=None):
     return ctypes.c_void_p(_err_dev(device).data_ptr())
 
 
-def _nonfinite_poll_is_lagged():
-    return any(getattr(o, "poll_lag", None) is not None for o in _GUARDED)
-
-
 def clear_nonfinite_flags():
     """Reset the found-non-finite words (host-mapped + device) after they have been reported."""
     for t in _ERR_DEV.values():
@@ -267,21 +263,19 @@ def clear_nonfinite_flags():
         _ERR_FLAG[1] = 0
 
 
-def check_device_errors(synchronize=False, nonfinite=None):
+def check_device_errors(synchronize=False, nonfinite=True):
     """Raise if a kernel reported a run-time failure since the last check (no device synchronisation unless asked: the
     flag is written through host-mapped memory, so a failure surfaces at the next call after the kernel ran).  Only the
     slot that is reported is cleared.
 
-    nonfinite: whether the found-non-finite word is reported HERE.  Default: yes, unless an optimiser of this process polls it
-    itself at a deterministic point of its step (FusedAdamAmsgrad(poll_lag=...): every rank of a data-parallel job must
-    learn about a refused step at the same iteration, so an opportunistic poll from, say, the GRU's launch check must not
-    pre-empt it).  The inference loop passes True (its batches are its own)."""
+    nonfinite: whether the found-non-finite word is reported HERE.  Callers that only care about the other flags pass False
+    (the fused GRU's launch check; an optimiser that polls the word itself at a deterministic point of its step,
+    FusedAdamAmsgrad(poll_lag=...): every rank of a data-parallel job must learn about a refused step at the same
+    iteration, so an opportunistic poll must not pre-empt it)."""
     if _ERR_FLAG is None:
         return
     if synchronize:
         torch.cuda.synchronize()
-    if nonfinite is None:
-        nonfinite = not _nonfinite_poll_is_lagged()
     if nonfinite and int(_ERR_FLAG[1]):
         torch.cuda.synchronize()                      # rare path: settle, then read how many steps the Adam kernel refused
         skipped = 0
@@ -305,13 +299,6 @@ def check_device_errors(synchronize=False, nonfinite=None):
             "reference." % skipped, skipped)
 
 
-def rollback_bn_counters(model, n):
-    """Take `n` refused training steps back out of every BatchNorm `num_batches_tracked` of `model` (the forward pass of a
-    refused step bumped them; the running statistics themselves were guarded on the device)."""
-    bufs = model.bn_counters() if hasattr(model, "bn_counters") else [
-        b for name, b in model.named_buffers() if name.endswith("num_batches_tracked")]
-    if n and bufs:
-        torch._foreach_sub_(bufs, int(n))
     code = int(_ERR_FLAG[0])
     if code:
         _ERR_FLAG[0] = 0
@@ -320,6 +307,15 @@ def rollback_bn_counters(model, n):
             "partner workgroups -- its 128 persistent workgroups were not all resident (CU mask, partitioned GPU or a "
             "co-tenant kernel).  Its outputs were overwritten with NaN.  Set ops.USE_FUSED_GRU = False to use the "
             "per-step launches on this device." % ("fwd" if code == 1 else "bwd"))
+
+
+def rollback_bn_counters(model, n):
+    """Take `n` refused training steps back out of every BatchNorm `num_batches_tracked` of `model` (the forward pass of a
+    refused step bumped them; the running statistics themselves were guarded on the device)."""
+    bufs = model.bn_counters() if hasattr(model, "bn_counters") else [
+        b for name, b in model.named_buffers() if name.endswith("num_batches_tracked")]
+    if n and bufs:
+        torch._foreach_sub_(bufs, int(n))
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -538,11 +534,44 @@ def bn_finalize(partials, nparts, rows_per_part, N, bn_w, bn_b, running_mean, ru
     C = bn_w.numel()
     st = BnStats(C, bn_w.device)
     guard = USE_SF16
+    cand = torch.empty((2, C), dtype=torch.float32, device=bn_w.device) if (guard and running_mean is not None) else None
     _call("sed_bn_finalize", _ptr(partials), nparts, rows_per_part, N, C, _ptr(bn_w), _ptr(bn_b), BN_EPS, BN_MOMENTUM,
           _ptr(running_mean), _ptr(running_var), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale), _ptr(st.shift),
           _ptr(_ws(C, bn_w.device)), _sf16_err_dev_ptr(bn_w.device) if guard else None, _sf16_err_ptr() if guard else None,
-          _stream())
+          _ptr(cand), _stream())
+    if cand is not None:
+        # the proposed running statistics are installed by ONE launch at the end of the forward pass (models' trunk:
+        # begin_bn_commit / commit_bn) -- or right here for a BatchNorm used on its own -- unless the pass met NaN / inf
+        if _BN_COMMIT is not None:
+            _BN_COMMIT.append((cand, running_mean, running_var, C))
+        else:
+            _commit_bn_entries([(cand, running_mean, running_var, C)])
     return st
+
+
+_BN_COMMIT = None        # [(cand, running_mean, running_var, C)] while a forward pass collects its BatchNorm updates
+
+
+def begin_bn_commit():
+    global _BN_COMMIT
+    _BN_COMMIT = []
+
+
+def commit_bn(drop=False):
+    """End of a forward pass: install the running statistics its BatchNorms proposed (one launch; skipped on the device when
+    the found-non-finite word is set).  drop=True: the pass raised -- forget them."""
+    global _BN_COMMIT
+    entries, _BN_COMMIT = _BN_COMMIT, None
+    if entries and not drop:
+        for i in range(0, len(entries), 16):
+            _commit_bn_entries(entries[i:i + 16])
+
+
+def _commit_bn_entries(entries):
+    n = len(entries)
+    _call("sed_bn_commit", n, (ctypes.c_void_p * n)(*[e[0].data_ptr() for e in entries]),
+          (ctypes.c_void_p * n)(*[e[1].data_ptr() for e in entries]), (ctypes.c_void_p * n)(*[e[2].data_ptr() for e in entries]),
+          (ctypes.c_int * n)(*[e[3] for e in entries]), _sf16_err_dev_ptr(entries[0][1].device), _stream())
 
 
 def bn_eval_affine(bn_w, bn_b, running_mean, running_var):
@@ -1420,7 +1449,7 @@ class GruFn(torch.autograd.Function):
         Hd = w_hh_f.shape[1]
         dev = x.device
         out = torch.empty((B, T, 2 * Hd), dtype=torch.float32, device=dev)
-        check_device_errors()                                                          # a failure of an earlier launch
+        check_device_errors(nonfinite=False)                                           # a give-up of an earlier fused launch
         # stacked / transposed weight operands: device copies, rebuilt only when a parameter changed
         w_ih, b_ih, w_ih_t = _cached("gru_ih", (w_ih_f, w_ih_b, b_ih_f, b_ih_b), lambda: _gru_ih_operands(
             w_ih_f, w_ih_b, b_ih_f, b_ih_b))

@@ -285,6 +285,18 @@ class _Cnn9Base(nn.Module):
         """models.py:284-303 -> features (B, T/8, 512), time-major."""
         if not input.is_cuda:
             raise RuntimeError('the MI355X hot path needs CUDA/HIP tensors (model.to("cuda"), input on the GPU)')
+        # the nine BatchNorms PROPOSE their new running statistics; one launch at the end of the pass installs them unless
+        # a kernel of the pass met NaN / inf (found-non-finite guard: a refused step leaves the buffers intact)
+        ops.begin_bn_commit()
+        try:
+            feat = self._trunk(input, mixup_lambda, stripes)
+        except BaseException:
+            ops.commit_bn(drop=True)
+            raise
+        ops.commit_bn()
+        return feat
+
+    def _trunk(self, input, mixup_lambda=None, stripes=None):
         lm = self.extract_logmel(input)
         B2, T, M = lm.shape
         lam = None

@@ -50,12 +50,13 @@ __global__ __launch_bounds__(256) void pk_probe(unsigned* bad, int iters, unsign
     for (int k = 0; k < FORMS; ++k) if (nb[k]) atomicAdd(&bad[k], nb[k]);
 }
 
-// bare MFMA streams: MODE 0 = f16 smooth operands, 1 = f16 random operands, 2 = bf16 random, 3 = fp32 (32x32x2) random
-template <int MODE>
+// bare MFMA streams: MODE 0 = f16 smooth operands, 1 = f16 random operands, 2 = bf16 random, 3 = fp32 (32x32x2) random;
+// NACC independent accumulators (1 = a dependent chain: every MFMA waits for its predecessor, the pipe is ~half idle)
+template <int MODE, int NACC>
 __global__ __launch_bounds__(256) void aggressor(float* out, int iters) {
     floatx16 acc[4];
     for (int a = 0; a < 4; ++a)
-        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[a][r] = (float)(a + 1) * 0.125f;      // distinct: the compiler must keep all of them
     half8 xs[4], ys[4];
     bf16x8 xb[4], yb[4];
     float xf[4], yf[4];
@@ -74,8 +75,9 @@ __global__ __launch_bounds__(256) void aggressor(float* out, int iters) {
 #pragma unroll
         for (int rep = 0; rep < 9; ++rep)
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const int i = MODE == 0 ? 0 : (a + rep) & 3, j = MODE == 0 ? 0 : (a + 2 * rep + 1) & 3;
+            for (int a4 = 0; a4 < 4; ++a4) {
+                const int a = NACC == 1 ? 0 : a4;
+                const int i = MODE == 0 ? 0 : (a4 + rep) & 3, j = MODE == 0 ? 0 : (a4 + 2 * rep + 1) & 3;
                 if (MODE <= 1) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xs[i], ys[j], acc[a], 0, 0, 0);
                 else if (MODE == 2) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb[i], yb[j], acc[a], 0, 0, 0);
                 else acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[i], yf[j], acc[a], 0, 0, 0);
@@ -87,25 +89,78 @@ __global__ __launch_bounds__(256) void aggressor(float* out, int iters) {
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// f16 MFMA stream whose operands are re-read from LDS before every group of four MFMAs (ds_read_b128, random data): the shape
+// of the package's convolution kernels (fragment reads + MFMAs), still without any global memory traffic
+// MF = 0: the ds_read_b128 stream alone (values summed on the VALU), 1: + f16 MFMAs, 2: + fp32 MFMAs
+template <int MF>
+__global__ __launch_bounds__(256) void aggressor_lds(float* out, int iters) {
+    __shared__ __attribute__((aligned(16))) _Float16 lds[16 * 1024];          // 32 KB
+    unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 777u;
+    for (int i = threadIdx.x; i < 16 * 1024; i += 256) {
+        h = h * 1664525u + 1013904223u;
+        lds[i] = (_Float16)(((int)(h >> 8) % 20001 - 10000) * 1.0e-4f * 1.3f);
+    }
+    __syncthreads();
+    floatx16 acc[4];
+    for (int a = 0; a < 4; ++a)
+        for (int r = 0; r < 16; ++r) acc[a][r] = (float)(a + 1) * 0.125f;
+    const half8* base = reinterpret_cast<const half8*>(lds);
+    int off = threadIdx.x & 63;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int rep = 0; rep < 9; ++rep) {
+            const half8 a0 = base[(off + rep * 64) & 2047], a1 = base[(off + rep * 64 + 517) & 2047];
+            const half8 b0 = base[(off + rep * 64 + 1031) & 2047], b1 = base[(off + rep * 64 + 1543) & 2047];
+            if (MF == 1) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[3], 0, 0, 0);
+            } else if (MF == 2) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((float)a0[0], (float)b0[1], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((float)a0[2], (float)b1[3], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32((float)a1[4], (float)b0[5], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32((float)a1[6], (float)b1[7], acc[3], 0, 0, 0);
+            } else {
+                acc[0][rep] += (float)a0[0] + (float)b0[1]; acc[1][rep] += (float)a0[2] + (float)b1[3];
+                acc[2][rep] += (float)a1[4] + (float)b0[5]; acc[3][rep] += (float)a1[6] + (float)b1[7];
+            }
+        }
+        off = (off + 37) & 2047;
+    }
+    float sum = 0.f;
+    for (int a = 0; a < 4; ++a)
+        for (int r = 0; r < 16; ++r) sum += acc[a][r];
+    out[blockIdx.x * 256 + threadIdx.x] = sum;
+}
+
 int main(int argc, char** argv) {
     const int launches = argc > 1 ? atoi(argv[1]) : 400;
     unsigned* bad; float* out;
     (void)hipMalloc(&bad, 64); (void)hipMalloc(&out, 512 * 256 * sizeof(float));
     hipStream_t sa, sb; (void)hipStreamCreate(&sa); (void)hipStreamCreate(&sb);
-    const char* names[5] = {"nothing", "bare v_mfma_f32_32x32x16_f16, SMOOTH operands (high clock, lower power)",
-                            "bare v_mfma_f32_32x32x16_f16, RANDOM operands (power-limited clock)",
-                            "bare v_mfma_f32_32x32x16_bf16, RANDOM operands", "bare v_mfma_f32_32x32x2_f32, RANDOM operands"};
-    for (int ag = 0; ag < 5; ++ag) {
+    const char* names[10] = {"nothing", "f16 MFMA 32x32x16, 4 accumulators, SMOOTH operands (high clock, lower power)",
+                            "f16 MFMA 32x32x16, 4 accumulators, RANDOM operands (power-limited clock)",
+                            "f16 MFMA 32x32x16, dependent chain, SMOOTH operands", "f16 MFMA 32x32x16, dependent chain, RANDOM operands",
+                            "bf16 MFMA 32x32x16, 4 accumulators, RANDOM operands", "fp32 MFMA 32x32x2, 4 accumulators, RANDOM operands",
+                            "f16 MFMA 32x32x16 fed by ds_read_b128 from LDS (random data): the convolution kernels' shape",
+                             "the same ds_read_b128 stream WITHOUT any MFMA (VALU adds)", "the same ds_read_b128 stream feeding fp32 MFMAs 32x32x2"};
+    for (int ag = 0; ag < 10; ++ag) {
         (void)hipMemset(bad, 0, 64);
         (void)hipDeviceSynchronize();
         hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         (void)hipEventRecord(e0, sa);
         for (int it = 0; it < launches; ++it) {
             // the aggressor fills HALF of each CU's wave slots (1 workgroup of 4 waves per CU x 256 CUs); the probe takes the rest
-            if (ag == 1) hipLaunchKernelGGL((aggressor<0>), dim3(256), dim3(256), 0, sb, out, 1500);
-            if (ag == 2) hipLaunchKernelGGL((aggressor<1>), dim3(256), dim3(256), 0, sb, out, 1500);
-            if (ag == 3) hipLaunchKernelGGL((aggressor<2>), dim3(256), dim3(256), 0, sb, out, 1500);
-            if (ag == 4) hipLaunchKernelGGL((aggressor<3>), dim3(256), dim3(256), 0, sb, out, 200);
+            if (ag == 1) hipLaunchKernelGGL((aggressor<0, 4>), dim3(256), dim3(256), 0, sb, out, 1500);
+            if (ag == 2) hipLaunchKernelGGL((aggressor<1, 4>), dim3(256), dim3(256), 0, sb, out, 1500);
+            if (ag == 3) hipLaunchKernelGGL((aggressor<0, 1>), dim3(256), dim3(256), 0, sb, out, 750);
+            if (ag == 4) hipLaunchKernelGGL((aggressor<1, 1>), dim3(256), dim3(256), 0, sb, out, 750);
+            if (ag == 5) hipLaunchKernelGGL((aggressor<2, 4>), dim3(256), dim3(256), 0, sb, out, 1500);
+            if (ag == 6) hipLaunchKernelGGL((aggressor<3, 4>), dim3(256), dim3(256), 0, sb, out, 200);
+            if (ag == 7) hipLaunchKernelGGL((aggressor_lds<1>), dim3(512), dim3(256), 0, sb, out, 750);
+            if (ag == 8) hipLaunchKernelGGL((aggressor_lds<0>), dim3(512), dim3(256), 0, sb, out, 750);
+            if (ag == 9) hipLaunchKernelGGL((aggressor_lds<2>), dim3(512), dim3(256), 0, sb, out, 750);
             hipLaunchKernelGGL(pk_probe, dim3(512), dim3(256), 0, sa, bad, 100, (unsigned)(it * 7919));
         }
         (void)hipEventRecord(e1, sa);
