@@ -241,7 +241,22 @@ int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale, float*
                      int Cout, const float* in_scale, const float* in_shift, int epi, float* partials,
                      const float* yprev, const float* p_scale, const float* p_shift, const float* p_mean,
                      const float* p_invstd, const float* x_amax, float* minmax, int* err_host, int* err_dev,
-                     sed_stream_t stream);
+                     int flags, sed_stream_t stream);
+/* Block 1 without a materialised conv1 output (round 4).  models.py:99-103 for conv_block1: relu(bn1(conv1(x0))) feeds conv2.
+ * sed_conv1_fwd(y = null) is the statistics / range pass; sed_conv1_act_sf16 then writes a1 = relu(scale*conv1(x0)+shift)
+ * ONCE, as split-f16 operand pairs -- per channel pair two dwords {hi0 | hi1 << 16, lo0 | lo1 << 16}, hi = f16(s*a),
+ * lo = f16(s*a - hi), s = the power-of-two scale of a_amax; B*H*W*64 dwords = the bytes of the fp32 tensor it replaces.
+ * Consumers: sed_conv3x3_sf16(flags = 1: x is such a tensor, x_amax the amax it was written with; epi 0 / 1, no input
+ * transform), sed_conv3x3_wgrad_sf16(flags = 1: likewise for its x operand).  The two backward kernels that need the RAW
+ * y1 recompute it from the one-channel input with sed_conv1_fwd's fma sequence (bit-identical): sed_conv3x3_sf16_dgrad_b1 =
+ * sed_conv3x3_sf16(epi = 2) of conv2 with yprev = conv1(x0) formed in the epilogue from an x0 patch in LDS (p_* = bn1's
+ * folded scale / shift / mean / invstd), and sed_conv1_bwd(bn_y = null). */
+int sed_conv1_act_sf16(const float* x0, const float* w_oihw, int B, int H, int W, const float* scale, const float* shift,
+                       const float* a_amax, void* out_pairs, int* err_host, int* err_dev, sed_stream_t stream);
+int sed_conv3x3_sf16_dgrad_b1(const float* gy, const void* wp, const float* wscale, float* gx, int B, int H, int W, int Cin,
+                              int Cout, float* partials, const float* p_scale, const float* p_shift, const float* p_mean,
+                              const float* p_invstd, const float* x0, const float* w1_oihw, const float* gy_amax,
+                              int* err_host, int* err_dev, sed_stream_t stream);
 /* Weight gradient with split-f16 operands (csrc/conv_sf16.hip): same contract as sed_conv3x3_wgrad; gy_amax = device
  * pointer to max |gy| (sed_amax or the producer kernels), x_amax = device pointer to the amax of the activation operand
  * (as for sed_conv3x3_sf16); err_host / err_dev as there.
@@ -250,7 +265,7 @@ int sed_wgrad_sf16_supported(int H, int W, int Cin, int Cout);
 long sed_wgrad_sf16_partial_floats(int B, int H, int W, int Cin, int Cout);
 int sed_conv3x3_wgrad_sf16(const float* x, const float* gy, float* dw_oihw, float* partial, int B, int H, int W,
                            int Cin, int Cout, const float* in_scale, const float* in_shift, const float* gy_amax,
-                           const float* x_amax, int* err_host, int* err_dev, sed_stream_t stream);
+                           const float* x_amax, int* err_host, int* err_dev, int flags, sed_stream_t stream);
 /* Winograd-domain weight gradient (12 instead of 18 MACs per output pair); same contract as sed_conv3x3_wgrad.
  * Needs W a power of two <= 64 and Cin, Cout % 64 == 0; partial: sed_wgrad_wino_partial_floats(...) floats. */
 long sed_wgrad_wino_partial_floats(long M, int Cin, int Cout, int* nslices_out, int* pix_per_slice_out);

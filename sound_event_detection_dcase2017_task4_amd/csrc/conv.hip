@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = fmaf(xs[t], wr[t][k], o[k]);
-        store_nt4(y, pm * 16 + c4, make_float4(o[0], o[1], o[2], o[3]));
+        if (y) store_nt4(y, pm * 16 + c4, make_float4(o[0], o[1], o[2], o[3]));     // null: statistics / range pass only
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float d = o[k] - piv[k]; s[k] += d; q[k] = fmaf(d, d, q[k]);
@@ -605,6 +605,69 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     }
 }
 
+// Second pass of block 1's first layer in training (round 4): a1 = relu(scale * conv1(x0) + shift) written ONCE, already in
+// the operand format of the split-f16 kernels -- per channel PAIR two dwords {hi0 | hi1 << 16, lo0 | lo1 << 16} with
+// hi = f16(sa * a), lo = f16(sa * a - hi), sa = the power-of-two scale of a_amax (what the fused-input staging of
+// conv_sf16 / wgrad_sf16 computes from the raw y1 on every K-step and in every tile that reads it).  Same 4 bytes per
+// element as the raw fp32 y1 this replaces; y1 itself is never materialised (BatchNorm's statistics come from a
+// statistics-only pass of conv1_fwd_kernel; the backward kernels recompute it from the one-channel input where they
+// need it).  The consumers' staging becomes a plain copy, and the MFMA operands are bit-identical to the fused path's.
+__device__ __forceinline__ void c1_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+        "v_fma_mixlo_f16 %1, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(hi), "=&v"(lo)
+        : "v"(a), "v"(b));
+}
+__device__ __forceinline__ float c1_scale_of(float amax) {      // = sf_scale_of of conv_sf16.hip
+    if (!(amax > 0.f) || !(amax < __builtin_inff())) return 1.f;
+    int e;
+    frexpf(amax, &e);
+    e = 14 - e;
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    return ldexpf(1.f, e);
+}
+
+__global__ __launch_bounds__(256) void conv1_act_sf16_kernel(const float* __restrict__ x0, const float* __restrict__ w,
+                                                             long M, int H, int W, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, const float* __restrict__ a_amax,
+                                                             unsigned* __restrict__ out, int* __restrict__ err_host,
+                                                             int* __restrict__ err_dev) {
+    const int c4 = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    float wr[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wr[t][k] = w[(c4 * 4 + k) * 9 + t];
+    const float sa = c1_scale_of(amax_read(a_amax));
+    float4 sc = reinterpret_cast<const float4*>(scale)[c4], sh = reinterpret_cast<const float4*>(shift)[c4];
+    // the power-of-two operand scale rides on the affine: relu(sa*sc*y + sa*sh) == sa*relu(sc*y + sh) bit for bit
+    sc.x *= sa; sc.y *= sa; sc.z *= sa; sc.w *= sa; sh.x *= sa; sh.y *= sa; sh.z *= sa; sh.w *= sa;
+    const long base = (long)blockIdx.x * C1_ROWS;
+    const long nrows = min((long)C1_ROWS, M - base);
+    bool bad = false;
+    C1Walk pos(base + pl, H, W);
+    for (int r = pl; r < nrows; r += 16, pos.advance(16, H, W)) {
+        const long pm = base + r;
+        float xs[9], o[4] = {0, 0, 0, 0};
+        c1_taps(x0, pm, pos.h, pos.w, H, W, xs);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = fmaf(xs[t], wr[t][k], o[k]);       // the very sequence of conv1_fwd_kernel
+        bad |= !((fabsf(o[0]) + fabsf(o[1])) + (fabsf(o[2]) + fabsf(o[3])) < __builtin_inff());   // (ReLU's fmaxf would swallow a NaN)
+        unsigned h01, l01, h23, l23;
+        c1_split2(bn_relu(o[0], sc.x, sh.x), bn_relu(o[1], sc.y, sh.y), h01, l01);
+        c1_split2(bn_relu(o[2], sc.z, sh.z), bn_relu(o[3], sc.w, sh.w), h23, l23);
+        const floatx4 ov = {__uint_as_float(h01), __uint_as_float(l01), __uint_as_float(h23), __uint_as_float(l23)};
+        __builtin_nontemporal_store(ov, reinterpret_cast<floatx4*>(out) + (pm * 16 + c4));
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) {
+        if (err_host) __hip_atomic_store(err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (err_dev) __hip_atomic_store(err_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // sum over the 16 lanes of a DPP row, result in every lane: four v_add_f32 with DPP operands (xor 1, xor 2 inside the
 // quads, then half-mirror and mirror), no LDS crossbar traffic (__shfl_xor = ds_bpermute made this kernel LDS-issue-bound)
 __device__ __forceinline__ float row16_sum(float v) {
@@ -620,6 +683,8 @@ __device__ __forceinline__ float row16_sum(float v) {
 constexpr int C1B_ROWS = 4096;      // rows per workgroup (scratch sized for 1024 by the callers: an upper bound)
 // AFF: gy is the masked dgrad output dz of the NEXT conv and the BatchNorm backward g = a*dz + b*y + c (coef [3][64])
 // is applied on load, which saves the separate sed_bn_bwd_apply pass over the two largest tensors of the model.
+// yraw null (round 4): y = conv1(x0) is RECOMPUTED from the nine taps the kernel loads anyway (36 FMAs per lane and row, the
+// fma sequence of conv1_fwd_kernel: bit-identical) instead of read back -- 4.2 GB less traffic per step at batch 256
 template <bool AFF>
 __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict__ x0, const float* __restrict__ w,
                                                         const float* __restrict__ gy, const float* __restrict__ yraw,
@@ -648,13 +713,23 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
     for (int r = pl; r < nrows; r += 16, pos.advance(16, H, W)) {
         long pm = base + r;
         float4 g = load_nt4(gy, pm * 16 + c4);
+        float xs[9];
+        c1_taps(x0, pm, pos.h, pos.w, H, W, xs);
         if (AFF) {
-            const float4 v = load_nt4(yraw, pm * 16 + c4);
+            float4 v;
+            if (yraw) {
+                v = load_nt4(yraw, pm * 16 + c4);
+            } else {
+                float o[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = fmaf(xs[t], wr[t][k], o[k]);
+                v = make_float4(o[0], o[1], o[2], o[3]);
+            }
             g.x = fmaf(ca.x, g.x, fmaf(cb.x, v.x, cc.x)); g.y = fmaf(ca.y, g.y, fmaf(cb.y, v.y, cc.y));
             g.z = fmaf(ca.z, g.z, fmaf(cb.z, v.z, cc.z)); g.w = fmaf(ca.w, g.w, fmaf(cb.w, v.w, cc.w));
         }
-        float xs[9];
-        c1_taps(x0, pm, pos.h, pos.w, H, W, xs);
         float tp[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -886,14 +961,25 @@ SED_API int sed_conv1_fwd(const float* x0, const float* w_oihw, float* y, int B,
 }
 SED_API int sed_conv1_rows_per_part(void) { return C1_ROWS; }
 
+// a1 = relu(scale * conv1(x0) + shift) as split-f16 operand pairs (see conv1_act_sf16_kernel); out: B*H*W*64 dwords.
+SED_API int sed_conv1_act_sf16(const float* x0, const float* w_oihw, int B, int H, int W, const float* scale, const float* shift,
+                               const float* a_amax, void* out, int* err_host, int* err_dev, hipStream_t stream) {
+    long M = (long)B * H * W;
+    if (!x0 || !w_oihw || !scale || !shift || !a_amax || !out || M <= 0 || M >= (1L << 31)) return SED_EINVAL;
+    hipLaunchKernelGGL(conv1_act_sf16_kernel, dim3(sed_cdiv(M, C1_ROWS)), dim3(256), 0, stream, x0, w_oihw, M, H, W, scale, shift,
+                       a_amax, (unsigned*)out, err_host, err_dev);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
 // backward of conv_block1.conv1: dw [64][1][3][3]; gx0 [M] (nullable: skip the input gradient).
 // scratch: dw_partials ceil(M/1024)*576 floats; tbuf M*9 floats (only if gx0).
-// bn_y / bn_coef (both or neither): gy is then the masked dgrad output dz and g = a*dz + b*bn_y + c is formed on load
-// (coef [3][64] from sed_bn_bwd_finalize), replacing a sed_bn_bwd_apply pass.
+// bn_coef (nullable): gy is then the masked dgrad output dz and g = a*dz + b*y1 + c is formed on load (coef [3][64] from
+// sed_bn_bwd_finalize), replacing a sed_bn_bwd_apply pass; y1 = bn_y, or recomputed from x0 when bn_y is null.
 SED_API int sed_conv1_bwd(const float* x0, const float* w_oihw, const float* gy, const float* bn_y, const float* bn_coef,
                           int B, int H, int W, float* dw, float* gx0, float* dw_partials, float* tbuf, hipStream_t stream) {
     long M = (long)B * H * W;
-    if (M <= 0 || M >= (1L << 31) / 9 || ((bn_y == nullptr) != (bn_coef == nullptr))) return SED_EINVAL;
+    if (M <= 0 || M >= (1L << 31) / 9 || (bn_y != nullptr && bn_coef == nullptr)) return SED_EINVAL;
     int nblk = sed_cdiv(M, C1B_ROWS);
     if (bn_coef)
         hipLaunchKernelGGL(conv1_bwd_kernel<true>, dim3(nblk), dim3(256), 0, stream, x0, w_oihw, gy, bn_y, bn_coef, M, H, W,

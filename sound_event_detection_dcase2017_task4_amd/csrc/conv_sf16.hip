@@ -57,6 +57,9 @@ struct Sf16P {
     int* err_dev;              // nullable, device: same (read by sed_adam_amsgrad)
     float* pool_amax;          // EPI 3: amax slots of the pooled output
     int ph, pw;                // EPI 3: pooling window, (2, 2) or (1, W)
+    // EPI 4 (block 1's dgrad): the previous activations y1 = conv1(x0) are RECOMPUTED from the one-channel input
+    const float* x0;           // [B][H][W]
+    const float* w1;           // conv1 weights [64][9] (OIHW with I = 1)
 };
 
 __device__ __forceinline__ int sf_sw(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 3) & 1)) << 4); }
@@ -99,7 +102,19 @@ __device__ __forceinline__ void sf_split2(float a, float b, unsigned& hi, unsign
         : "v"(a), "v"(b));
 }
 
-template <int MW, bool INT, int EPI>
+// PRE: the input is ALREADY split (per channel pair {hi0 | hi1 << 16, lo0 | lo1 << 16}, scaled by the power of two of
+// x_amax: conv1_act_sf16_kernel) -- the staging is a plain copy
+// One v_fma_f32, opaque to the SLP vectoriser: left to itself it pairs neighbouring pixels' fmas into v_pk_fma_f32 with the
+// weight broadcast from the HIGH half of src1 (op_sel:[0,1,0]) -- the operand form that returns wrong values beside LDS-fed
+// f16 MFMAs (tests/test_isa_audit.py caught exactly that in the first build of epilogue 4; the co-resident workgroups of
+// this very kernel are such neighbours)
+__device__ __forceinline__ float fma_scalar(float a, float b, float c) {
+    float d;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+template <int MW, bool INT, int EPI, bool PRE = false>
 __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p) {
     constexpr int NW = 4 / MW, BN = 64 * NW, RB = BN / 32;
     constexpr int AROWS = MW == 2 ? 264 : 408;         // >= (TR+2) * WP over the supported W (W = 8: 34 * 12)
@@ -168,7 +183,13 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
         SF_ALOAD(0) SF_ALOAD(1) SF_ALOAD(2) SF_ALOAD(3) SF_ALOAD(4) SF_ALOAD(5)                                 \
     }
 #define SF_ASTORE(i)                                                                                            \
-    if (i < NI && (INT ? sok##i : val##i)) {   /* INT: rows outside the image were zeroed once and are never written */ \
+    if (PRE) {                                                                                                  \
+        if (i < NI && val##i) {                    /* {h01, l01, h23, l23}; out-of-image loads returned 0 */     \
+            const uint4 u = __builtin_bit_cast(uint4, areg##i);                                                 \
+            *reinterpret_cast<uint2*>(As + lso##i) = make_uint2(u.x, u.z);                                      \
+            *reinterpret_cast<uint2*>(As + APLANE + lso##i) = make_uint2(u.y, u.w);                             \
+        }                                                                                                       \
+    } else if (i < NI && (INT ? sok##i : val##i)) {   /* INT: rows outside the image were zeroed once and are never written */ \
         float4 v = areg##i;                                                                                     \
         if (INT) {                                                                                              \
             v.x = bn_relu(v.x, sc4.x, sh4.x); v.y = bn_relu(v.y, sc4.y, sh4.y);                                 \
@@ -411,6 +432,18 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
         nv = nv < 0 ? 0 : (nv > rows_w ? rows_w : nv);
         return (float)(nv * W);
     };
+    // EPI 4: the (TR + 2) x (W + 2) patch of the one-channel input x0 around this tile, zero outside the image, behind the
+    // 4 KB of per-wave statistics in the (now free) staging memory
+    float* const xpatch = reinterpret_cast<float*>(smem) + 2048;
+    if (EPI == 4) {
+        const float* const x0b = p.x0 + (long)b * p.H * W;
+        for (int i = tid; i < (TR + 2) * (W + 2); i += 256) {
+            const int rr = i / (W + 2), cc = i - rr * (W + 2);
+            const int h = h0 - 1 + rr, w = cc - 1;
+            xpatch[i] = ((unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)W) ? x0b[h * W + w] : 0.f;
+        }
+        __syncthreads();
+    }
     int yoff[2][16];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
@@ -426,6 +459,12 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
         float vmx = -__builtin_inff(), vmn = __builtin_inff();
         float e_sc = 0.f, e_sh = 0.f, e_mu = 0.f, e_is = 0.f;
         if (EPI == 2) { e_sc = p.p_scale[col]; e_sh = p.p_shift[col]; e_mu = p.p_mean[col]; e_is = p.p_invstd[col]; }
+        float w1r[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (EPI == 4) {
+            e_sc = p.p_scale[col]; e_sh = p.p_shift[col]; e_mu = p.p_mean[col]; e_is = p.p_invstd[col];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) w1r[t] = p.w1[col * 9 + t];
+        }
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             float yp[16];
@@ -436,9 +475,31 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+                if (EPI == 4 && (r & 3) == 0) {
+                    // y1 = conv1(x0) at the next four of this lane's pixels (consecutive pixels of one image row), recomputed from
+                    // the x0 patch in LDS with the fma sequence of conv1_fwd_kernel (taps in order, from zero): bit-identical
+                    // to the tensor the round-3 dataflow read back here -- 4.2 GB per step at batch 256 that never exist now
+                    const int pix0 = 64 * wm + 32 * mb + 2 * r + 4 * kh;
+                    const float* wp0 = xpatch + (pix0 >> logW) * (W + 2) + (pix0 & (W - 1));
+                    float win[3][6];
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const float2 t2 = *reinterpret_cast<const float2*>(wp0 + dy * (W + 2) + 2 * j);
+                            win[dy][2 * j] = t2.x; win[dy][2 * j + 1] = t2.y;
+                        }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float o = 0.f;
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) o = fma_scalar(win[t / 3][j + t % 3], w1r[t], o);
+                        yp[r + j] = o;
+                    }
+                }
                 float v = acc[mb][nk][r] * inv;
                 const bool ok = (unsigned)yoff[mb][r] < y_img_bytes;
-                if (EPI == 2) {
+                if (EPI == 2 || EPI == 4) {
                     v = (ok && bn_relu_active(yp[r], e_sc, e_sh)) ? v : 0.f;
                     s2 = fmaf(v, (yp[r] - e_mu) * e_is, s2);
                     s1 += v;
@@ -446,7 +507,7 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
                     v = ok ? v : 0.f;
                     s1 += v;
                 }
-                if (EPI != 2 && p.mm) {
+                if (EPI != 2 && EPI != 4 && p.mm) {
                     vmx = fmaxf(vmx, ok ? v : -__builtin_inff());
                     vmn = fminf(vmn, ok ? v : __builtin_inff());
                 }
@@ -455,7 +516,7 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
             }
         }
         float* const mine = red + ((wvu * 2 + nk) * 32 + (lane & 31)) * 4;
-        if (EPI != 2 && p.mm) {      // range of this wave's 64 pixels per channel: the consumer's operand amax comes from it
+        if (EPI != 2 && EPI != 4 && p.mm) {      // range of this wave's 64 pixels per channel: the consumer's operand amax comes from it
             vmx = fmaxf(vmx, __shfl_xor(vmx, 32, 64));
             vmn = fminf(vmn, __shfl_xor(vmn, 32, 64));
             if (kh == 0) { mine[2] = vmx; mine[3] = vmn; }
@@ -475,7 +536,7 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
             s2 += __shfl_xor(s2, 32, 64);
             if (kh == 0) { mine[0] = s1; mine[1] = s2; }
         }
-        if (EPI == 2) {
+        if (EPI == 2 || EPI == 4) {
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
             if (kh == 0) { mine[0] = s1; mine[1] = s2; }
@@ -487,7 +548,7 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
     {
         const int nk = lane >> 5, col = colb + 32 * nk;            // lane -> one of this wave's 64 columns
         const float* const theirs = red + (((wn * MW) * 2 + nk) * 32 + (lane & 31)) * 4;       // + w * 256: wave (w, wn)
-        if (EPI != 2 && p.mm) {
+        if (EPI != 2 && EPI != 4 && p.mm) {
             float vmx = theirs[2], vmn = theirs[3];
 #pragma unroll
             for (int w = 1; w < MW; ++w) { vmx = fmaxf(vmx, theirs[w * 256 + 2]); vmn = fminf(vmn, theirs[w * 256 + 3]); }
@@ -511,7 +572,7 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
             p.partials[(part * 2 + 1) * p.N + col] = M2;
             if (wn == 0 && n0 == 0 && lane == 0) p.partials[(long)p.B * p.ntile * 2 * p.N + part] = Nn;
         }
-        if (EPI == 2) {
+        if (EPI == 2 || EPI == 4) {
             float a = 0.f, c = 0.f;
 #pragma unroll
             for (int w = 0; w < MW; ++w) { a += theirs[w * 256]; c += theirs[w * 256 + 1]; }
@@ -717,6 +778,7 @@ SED_API int sed_conv3x3_sf16_eval_pool(const float* x, const void* wp, const flo
     p.ntile = (H + p.TR - 1) / p.TR;
     p.mm = nullptr; p.err_host = err_host; p.err_dev = err_dev;
     p.pool_amax = out_amax; p.ph = ph; p.pw = pw;
+    p.x0 = p.w1 = nullptr;
     const long nblk = (long)B * p.ntile * (Cout / 64);
     if (nblk > 0x7fffffffL) return SED_EINVAL;
     if (in_scale) hipLaunchKernelGGL((conv_sf16_kernel<4, true, 3>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
@@ -729,9 +791,12 @@ SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale
                              int Cout, const float* in_scale, const float* in_shift, int epi, float* partials,
                              const float* yprev, const float* p_scale, const float* p_shift, const float* p_mean,
                              const float* p_invstd, const float* x_amax, float* minmax, int* err_host, int* err_dev,
-                             sed_stream_t stream) {
+                             int flags, sed_stream_t stream) {
     if (!x || !wp || !wscale || !y || !x_amax || B <= 0 || !sed_conv3x3_sf16_supported(H, W, Cin, Cout) || epi < 0 || epi > 2)
         return SED_EINVAL;
+    // flags bit 0: x holds split-f16 pairs already (sed_conv1_act_sf16 format, scaled by x_amax): epi 0 / 1, no input transform
+    const bool pre = (flags & 1) != 0;
+    if ((flags & ~1) || (pre && (in_scale || epi == 2 || sf_mw(Cout) != 4))) return SED_EINVAL;
     if (minmax && epi == 2) return SED_EINVAL;
     if ((in_scale == nullptr) != (in_shift == nullptr)) return SED_EINVAL;
     if (epi >= 1 && !partials) return SED_EINVAL;
@@ -748,13 +813,17 @@ SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale
     p.ntile = (H + p.TR - 1) / p.TR;
     p.mm = minmax; p.err_host = err_host; p.err_dev = err_dev;
     p.pool_amax = nullptr; p.ph = p.pw = 1;
+    p.x0 = p.w1 = nullptr;
     const long nblk = (long)B * p.ntile * (Cout / (mw == 2 ? 128 : 64));
     if (nblk > 0x7fffffffL) return SED_EINVAL;
     const dim3 g((unsigned)nblk), blk(256);
     hipStream_t s = (hipStream_t)stream;
 #define SF_LAUNCH(MWV, INTV, EPIV) hipLaunchKernelGGL((conv_sf16_kernel<MWV, INTV, EPIV>), g, blk, 0, s, p)
     const bool it = in_scale != nullptr;
-    if (mw == 2) {
+    if (pre) {
+        if (epi == 0) hipLaunchKernelGGL((conv_sf16_kernel<4, false, 0, true>), g, blk, 0, s, p);
+        else hipLaunchKernelGGL((conv_sf16_kernel<4, false, 1, true>), g, blk, 0, s, p);
+    } else if (mw == 2) {
         if (epi == 0) { if (it) SF_LAUNCH(2, true, 0); else SF_LAUNCH(2, false, 0); }
         else if (epi == 1) { if (it) SF_LAUNCH(2, true, 1); else SF_LAUNCH(2, false, 1); }
         else SF_LAUNCH(2, false, 2);
@@ -764,6 +833,35 @@ SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale
         else SF_LAUNCH(4, false, 2);
     }
 #undef SF_LAUNCH
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// Block 1's dgrad (round 4): g_y1 = conv_transpose(gy, w2) masked by relu'(bn1(y1)) + the BatchNorm-backward sums of bn1, with
+// y1 = conv1(x0) RECOMPUTED in the epilogue from the one-channel input (an x0 patch in LDS, 9 fmas per element, the fma
+// sequence of sed_conv1_fwd: the same bits) instead of read back: same results as sed_conv3x3_sf16(epi = 2, yprev = y1),
+// without y1 ever existing.  Cin (channels of gy) % 16 == 0, Cout = 64.
+SED_API int sed_conv3x3_sf16_dgrad_b1(const float* gy, const void* wp, const float* wscale, float* gx, int B, int H, int W,
+                                      int Cin, int Cout, float* partials, const float* p_scale, const float* p_shift,
+                                      const float* p_mean, const float* p_invstd, const float* x0, const float* w1_oihw,
+                                      const float* gy_amax, int* err_host, int* err_dev, sed_stream_t stream) {
+    if (!gy || !wp || !wscale || !gx || !partials || !p_scale || !p_shift || !p_mean || !p_invstd || !x0 || !w1_oihw || !gy_amax ||
+        B <= 0 || Cout != 64 || !sed_conv3x3_sf16_supported(H, W, Cin, Cout) || sf_mw(Cout) != 4)
+        return SED_EINVAL;
+    Sf16P p;
+    p.x = gy; p.wp = (const _Float16*)wp; p.wscale = wscale; p.x_amax = gy_amax; p.y = gx;
+    p.in_scale = nullptr; p.in_shift = nullptr; p.partials = partials; p.yprev = nullptr;
+    p.p_scale = p_scale; p.p_shift = p_shift; p.p_mean = p_mean; p.p_invstd = p_invstd;
+    p.B = B; p.H = H; p.W = W; p.K = Cin; p.N = Cout;
+    p.logW = sf_log2w(W);
+    p.TR = 256 >> p.logW;
+    p.ntile = (H + p.TR - 1) / p.TR;
+    p.mm = nullptr; p.err_host = err_host; p.err_dev = err_dev;
+    p.pool_amax = nullptr; p.ph = p.pw = 1;
+    p.x0 = x0; p.w1 = w1_oihw;
+    const long nblk = (long)B * p.ntile * (Cout / 64);
+    if (nblk > 0x7fffffffL) return SED_EINVAL;
+    hipLaunchKernelGGL((conv_sf16_kernel<4, false, 4>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
     SED_LAUNCH_CHECK();
     return 0;
 }
@@ -813,7 +911,8 @@ __device__ __forceinline__ half4 sf_tr_read(const unsigned char* p) {
         (__attribute__((address_space(3))) short4v*)(p)));
 }
 
-template <int LOGW, bool INT>
+// XPRE: the activation operand x is ALREADY split (sed_conv1_act_sf16 format, scaled by x_amax): its staging is a plain copy
+template <int LOGW, bool INT, bool XPRE = false>
 __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
     constexpr int W = 1 << LOGW, TRS = 64 >> LOGW, WP = W + 2;
     constexpr int RING = TRS <= 2 ? 4 : (TRS == 4 ? 8 : 16);
@@ -892,6 +991,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
     }
 #define WSF_XSTORE(ROW0)                                                                                        \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                             \
+        if (XPRE) {                                /* {h01, l01, h23, l23}; rows outside the image loaded as 0 */ \
+            const uint4 u = __builtin_bit_cast(uint4, xreg[i]);                                                 \
+            const int slot = ((ROW0) + xrr[i] + 1) & (RING - 1);                                                \
+            const int o = (slot * WP + xcc[i] + 1) * 64 + xq * 8;                                               \
+            *reinterpret_cast<uint2*>(Xs + o) = make_uint2(u.x, u.z);                                           \
+            *reinterpret_cast<uint2*>(Xs + XPL + o) = make_uint2(u.y, u.w);                                     \
+            continue;                                                                                           \
+        }                                                                                                       \
         float4 v = xreg[i];                                                                                     \
         if (INT) {                                                                                              \
             v.x = bn_relu(v.x, xsc.x, xsh.x); v.y = bn_relu(v.y, xsc.y, xsh.y);                                 \
@@ -1091,10 +1198,13 @@ SED_API long sed_wgrad_sf16_partial_floats(int B, int H, int W, int Cin, int Cou
 
 SED_API int sed_conv3x3_wgrad_sf16(const float* x, const float* gy, float* dw_oihw, float* partial, int B, int H, int W,
                                    int Cin, int Cout, const float* in_scale, const float* in_shift, const float* gy_amax,
-                                   const float* x_amax, int* err_host, int* err_dev, sed_stream_t stream) {
+                                   const float* x_amax, int* err_host, int* err_dev, int flags, sed_stream_t stream) {
     if (!x || !gy || !dw_oihw || !partial || !gy_amax || !x_amax || B <= 0 || !sed_wgrad_sf16_supported(H, W, Cin, Cout))
         return SED_EINVAL;
     if ((in_scale == nullptr) != (in_shift == nullptr)) return SED_EINVAL;
+    // flags bit 0: x holds split-f16 pairs already (sed_conv1_act_sf16 format, scaled by x_amax); no input transform then
+    const bool xpre = (flags & 1) != 0;
+    if ((flags & ~1) || (xpre && in_scale)) return SED_EINVAL;
     WSf16P p;
     p.x = x; p.gy = gy; p.partial = partial; p.in_scale = in_scale; p.in_shift = in_shift; p.g_amax = gy_amax;
     p.x_amax = x_amax;
@@ -1107,7 +1217,8 @@ SED_API int sed_conv3x3_wgrad_sf16(const float* x, const float* gy, float* dw_oi
     hipStream_t s = (hipStream_t)stream;
     const bool it = in_scale != nullptr;
 #define WSF_LAUNCH(LW)                                                                                          \
-    if (it) hipLaunchKernelGGL((wgrad_sf16_kernel<LW, true>), g, blk, 0, s, p);                                 \
+    if (xpre) hipLaunchKernelGGL((wgrad_sf16_kernel<LW, false, true>), g, blk, 0, s, p);                        \
+    else if (it) hipLaunchKernelGGL((wgrad_sf16_kernel<LW, true>), g, blk, 0, s, p);                            \
     else hipLaunchKernelGGL((wgrad_sf16_kernel<LW, false>), g, blk, 0, s, p);
     if (W == 64) { WSF_LAUNCH(6) } else if (W == 32) { WSF_LAUNCH(5) } else if (W == 16) { WSF_LAUNCH(4) } else { WSF_LAUNCH(3) }
 #undef WSF_LAUNCH

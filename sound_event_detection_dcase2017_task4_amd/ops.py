@@ -36,6 +36,12 @@ USE_FUSED_GRU = True        # False: per-step GEMM + gate launches (any hidden s
 # perfect overlap would give.  SED_WGRAD_SIDE_STREAM=0 turns it off (A/B runs).
 WGRAD_SIDE_STREAM = os.environ.get("SED_WGRAD_SIDE_STREAM", "1") != "0"
 EVAL_POOL_FUSION = os.environ.get("SED_EVAL_POOL_FUSION", "1") != "0"     # inference: pool inside the conv2 epilogue (csrc/conv_sf16.hip)
+# Block 1 in training (round 4): the raw conv1 output y1 (the largest tensor of the model: 4.2 GB at batch 256) is never
+# materialised.  A statistics pass of the Cin = 1 convolution feeds bn1; a second pass writes a1 = relu(bn1(y1)) ONCE, already as
+# the split-f16 operand pairs conv2's forward and weight-gradient kernels would otherwise re-derive from y1 in every tile
+# (same bytes as y1; their staging becomes a plain copy, the MFMA operands are bit-identical); conv2's dgrad epilogue and
+# conv1's backward recompute the raw y1 they need from the one-channel input (same fma sequence: same bits).  0: round-3 dataflow.
+B1_ACT_PAIRS = os.environ.get("SED_B1_ACT_PAIRS", "1") != "0"
 _SIDE = {}
 _PENDING = []            # [(event recorded on the side stream, sink or None)] of weight gradients not yet joined
 
@@ -86,7 +92,7 @@ def drop_pending_wgrads():
 _STREAM_OVERRIDE = None     # set while kernels are being enqueued on the side stream (see _fork_wgrad)
 
 
-def _fork_wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, gy_amax=None, x_amax=None):
+def _fork_wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, gy_amax=None, x_amax=None, x_presplit=False):
     """_wgrad on the side stream behind everything enqueued on the main stream so far.  With a sink the gradient lands in
     the flat buffer and is joined later (join_side_stream); without one the tensor is returned after an immediate join.
 
@@ -109,7 +115,8 @@ def _fork_wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, gy_amax=None, 
     keep = [x, gy, in_st, gy_amax, x_amax]
     _STREAM_OVERRIDE = side
     try:
-        dw = _wgrad(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=False, gy_amax=gy_amax, x_amax=x_amax, keep=keep)
+        dw = _wgrad(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=False, gy_amax=gy_amax, x_amax=x_amax, keep=keep,
+                    x_presplit=x_presplit)
     finally:
         _STREAM_OVERRIDE = None
     ev = torch.cuda.Event()
@@ -753,7 +760,9 @@ def _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, 
     return _ret(sink, dw) if signal else (None if sink is not None else dw)
 
 
-def _wgrad_sf16(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, gy_amax=None, x_amax=None, keep=None):
+def _wgrad_sf16(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, gy_amax=None, x_amax=None, keep=None,
+                x_presplit=False):
+    """x_presplit: x holds split-f16 operand pairs (conv1_act_sf16) scaled by x_amax -- no input transform, plain-copy staging."""
     nfl = _lib.lib().sed_wgrad_sf16_partial_floats(B, H, W, Cin, Cout)
     if nfl <= 0:
         raise RuntimeError("sed_conv3x3_wgrad_sf16 does not support this shape")
@@ -773,7 +782,7 @@ def _wgrad_sf16(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, g
                 2.0 * 9 * B * H * W * Cin * Cout):
         _call("sed_conv3x3_wgrad_sf16", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
               _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None,
-              _ptr(gy_amax), _ptr(x_amax), _sf16_err_ptr(), _sf16_err_dev_ptr(x.device), _stream())
+              _ptr(gy_amax), _ptr(x_amax), _sf16_err_ptr(), _sf16_err_dev_ptr(x.device), 1 if x_presplit else 0, _stream())
     return _ret(sink, dw) if signal else (None if sink is not None else dw)
 
 
@@ -787,10 +796,13 @@ def _wgrad_algo(H, W, Cin, Cout):
     return 3 if (USE_SF16 and Cin >= WGRAD_SF16_MIN_CIN and _lib.lib().sed_wgrad_sf16_supported(H, W, Cin, Cout)) else 0
 
 
-def _wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, gy_amax=None, x_amax=None, keep=None):
+def _wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, gy_amax=None, x_amax=None, keep=None,
+           x_presplit=False):
     if _wgrad_algo(H, W, Cin, Cout) == 3:
         return _wgrad_sf16(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=signal, gy_amax=gy_amax, x_amax=x_amax,
-                           keep=keep)
+                           keep=keep, x_presplit=x_presplit)
+    if x_presplit:
+        raise RuntimeError("split-f16 operand pairs can only feed the split-f16 weight-gradient kernel")
     if USE_WINOGRAD >= 2 and W in (8, 16, 32, 64) and Cin % 32 == 0 and Cout % 64 == 0:
         return _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=signal, keep=keep)
     if USE_WINOGRAD and _wgrad_wino_ok(W, Cin, Cout):
@@ -942,11 +954,13 @@ def act_amax_full(y, st):
 
 
 def conv3x3_sf16(x, pack, B, H, W, Cin, Cout, in_st=None, epi=0, partials=None, yprev=None, p_st=None, x_amax=None,
-                 minmax=None):
+                 minmax=None, presplit=False):
     """y = conv3x3(relu(scale*x + shift) or x) on the f16 MFMA pipe with split operands; x NHWC fp32 -> y NHWC fp32.
     x_amax: device scalar = amax of the operand as the MFMAs see it (None: computed here by a pass over x);
     minmax: optional [nparts][2][Cout] buffer that receives the per-part range of y (for act_amax of the next conv)."""
     wp, wscale = pack
+    if presplit and (x_amax is None or in_st is not None):
+        raise RuntimeError("a pre-split operand comes with the amax it was scaled by and takes no input transform")
     if x_amax is None:
         x_amax = act_amax_full(x, in_st) if in_st is not None else amax_of(x)
     y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
@@ -957,7 +971,7 @@ def conv3x3_sf16(x, pack, B, H, W, Cin, Cout, in_st=None, epi=0, partials=None, 
               _ptr(partials), _ptr(yprev), _ptr(p_st.scale) if p_st is not None else None,
               _ptr(p_st.shift) if p_st is not None else None, _ptr(p_st.mean) if p_st is not None else None,
               _ptr(p_st.invstd) if p_st is not None else None, _ptr(x_amax), _ptr(minmax), _sf16_err_ptr(),
-              _sf16_err_dev_ptr(x.device), _stream())
+              _sf16_err_dev_ptr(x.device), 1 if presplit else 0, _stream())
     return y
 
 
@@ -980,11 +994,14 @@ def _conv_fwd_like(x, w_oihw, B, H, W, Cin, Cout, dgrad=False, **kw):
     x_amax = kw.pop("x_amax", None)
     minmax = kw.pop("minmax", None)
     packs = kw.pop("packs", None)                    # (forward, dgrad) split-f16 packs of w_oihw, when the caller holds them
+    presplit = kw.pop("presplit", False)
     if algo == 3:
         pack = packs[1 if dgrad else 0] if packs is not None else None
         if pack is None:
             pack = sf16_packs(w_oihw, dgrad)[1 if dgrad else 0]
-        return conv3x3_sf16(x, pack, B, H, W, Cin, Cout, x_amax=x_amax, minmax=minmax, **kw)
+        return conv3x3_sf16(x, pack, B, H, W, Cin, Cout, x_amax=x_amax, minmax=minmax, presplit=presplit, **kw)
+    if presplit:
+        raise RuntimeError("split-f16 operand pairs can only feed the split-f16 convolution kernel")
     if algo == 2:
         uf, ud = _pack_wino2(w_oihw, want_f=not dgrad, want_d=dgrad)
         return _conv_wino2(x, ud if dgrad else uf, B, H, W, Cin, Cout, **kw)
@@ -1048,7 +1065,22 @@ class ConvBlockFn(torch.autograd.Function):
         pk2 = sf16_packs(w2c, bool(training)) if _conv_algo(H, W, Cout, Cout) == 3 else None
         # conv1 (+ statistics, + per-channel output range for the amax of relu(bn1(y1)))
         mm1 = None
-        if Cin == 1:
+        b1_pairs = (B1_ACT_PAIRS and Cin == 1 and training and not no_backward and USE_SF16 and pool_mode == 0
+                    and _conv_algo(H, W, Cout, Cout) == 3 and _wgrad_algo(H, W, Cout, Cout) == 3 and pk2 is not None
+                    and pk2[1] is not None)
+        if b1_pairs:
+            rpp1 = L.sed_conv1_rows_per_part()
+            np1 = (M + rpp1 - 1) // rpp1
+            part1 = torch.empty((np1, 2, Cout), dtype=torch.float32, device=dev)
+            mm1 = torch.empty((np1, 2, Cout), dtype=torch.float32, device=dev)
+            _call("sed_conv1_fwd", _ptr(x), _ptr(w1c), None, B, H, W, _ptr(part1), _ptr(mm1), _stream())   # statistics + range only
+            st1 = bn_finalize(part1, np1, rpp1, M, g1, b1, rm1, rv1)
+            a1 = act_amax(mm1, np1, Cout, st1)
+            del mm1
+            y1 = torch.empty((B, H, W, Cout), dtype=torch.int32, device=dev)       # split-f16 PAIRS of relu(bn1(conv1(x)))
+            _call("sed_conv1_act_sf16", _ptr(x), _ptr(w1c), B, H, W, _ptr(st1.scale), _ptr(st1.shift), _ptr(a1), _ptr(y1),
+                  _sf16_err_ptr(), _sf16_err_dev_ptr(dev), _stream())
+        elif Cin == 1:
             rpp1 = L.sed_conv1_rows_per_part()
             np1 = (M + rpp1 - 1) // rpp1
             part1 = torch.empty((np1, 2, Cout), dtype=torch.float32, device=dev) if training else None
@@ -1062,11 +1094,12 @@ class ConvBlockFn(torch.autograd.Function):
                 mm1 = torch.empty((np1, 2, Cout), dtype=torch.float32, device=dev)
             y1 = _conv_fwd_like(x, w1c, B, H, W, Cin, Cout, epi=1 if training else 0, partials=part1, x_amax=x_amax, minmax=mm1,
                                 packs=pk1)
-        st1 = bn_finalize(part1, np1, rpp1, M, g1, b1, rm1, rv1) if training else bn_eval_affine(g1, b1, rm1, rv1)
-        a1 = None
-        if need_a1:
-            a1 = act_amax(mm1, np1, Cout, st1) if mm1 is not None else act_amax_full(y1, st1)
-        del mm1
+        if not b1_pairs:
+            st1 = bn_finalize(part1, np1, rpp1, M, g1, b1, rm1, rv1) if training else bn_eval_affine(g1, b1, rm1, rv1)
+            a1 = None
+            if need_a1:
+                a1 = act_amax(mm1, np1, Cout, st1) if mm1 is not None else act_amax_full(y1, st1)
+            del mm1
         if (EVAL_POOL_FUSION and no_backward and not training and pool_mode == 0 and pk2 is not None
                 and L.sed_conv3x3_sf16_eval_pool_supported(H, W, Cout, Cout, ph, pw)):
             # inference: conv2 + eval-mode BatchNorm + ReLU + average pool in ONE kernel -- the
@@ -1082,8 +1115,8 @@ class ConvBlockFn(torch.autograd.Function):
         # conv2 over relu(bn1(y1)) computed on the fly (+ statistics)
         np2, rpp2, nf2 = _conv_parts(B, H, W, Cout, Cout)
         part2 = torch.empty((nf2,), dtype=torch.float32, device=dev) if training else None
-        y2 = _conv_fwd_like(y1, w2c, B, H, W, Cout, Cout, in_st=st1, epi=1 if training else 0, partials=part2, x_amax=a1,
-                            packs=pk2)
+        y2 = _conv_fwd_like(y1, w2c, B, H, W, Cout, Cout, in_st=None if b1_pairs else st1, epi=1 if training else 0,
+                            partials=part2, x_amax=a1, packs=pk2, presplit=b1_pairs)
         st2 = bn_finalize(part2, np2, rpp2, M, g2, b2, rm2, rv2) if training else bn_eval_affine(g2, b2, rm2, rv2)
         out = torch.empty((B, H // ph, W // pw, Cout), dtype=torch.float32, device=dev)
         out_amax = _amax_buf(dev)
@@ -1103,6 +1136,7 @@ class ConvBlockFn(torch.autograd.Function):
             ctx.save_for_backward(x, y1, y2, w1c, w2c, out, cnt, _f32c(g2), _f32c(b2))
         else:
             ctx.save_for_backward(x, y1, y2, w1c, w2c)
+        ctx.b1_pairs = b1_pairs
         ctx.st1, ctx.st2, ctx.pool, ctx.training, ctx.pool_mode = st1, st2, (ph, pw), bool(training), int(pool_mode)
         ctx.xa, ctx.a1 = x_amax, a1
         ctx.pk1, ctx.pk2 = pk1, pk2
@@ -1151,12 +1185,24 @@ class ConvBlockFn(torch.autograd.Function):
         fork = WGRAD_SIDE_STREAM
         npb, _, nfb = _conv_parts(B, H, W, Cout, Cout)
         partb = torch.empty((nfb,), dtype=torch.float32, device=dev)
-        gy1 = _conv_fwd_like(gy2, w2, B, H, W, Cout, Cout, dgrad=True, epi=2, partials=partb, yprev=y1, p_st=st1, x_amax=amax2,
-                             packs=ctx.pk2)
-        if fork and sk[5] is not None:
-            dw2 = _fork_wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=st1, sink=sk[5], gy_amax=amax2, x_amax=ctx.a1)
+        b1_pairs = ctx.b1_pairs
+        if b1_pairs:
+            # block 1: y1 holds the split-f16 pairs of a1 = relu(bn1(conv1(x))); the raw conv1 output the ReLU mask and xhat
+            # need is recomputed from x inside the kernel's epilogue (bit-identical to the tensor it used to read back)
+            gy1 = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
+            wpd, wsd = ctx.pk2[1]
+            with _timed("conv3x3_sf16_mfma(fwd+dgrad)|%d->%d@%dx%d epi4" % (Cout, Cout, H, W), 2.0 * 9 * B * H * W * Cout * Cout):
+                _call("sed_conv3x3_sf16_dgrad_b1", _ptr(gy2), _ptr(wpd), _ptr(wsd), _ptr(gy1), B, H, W, Cout, Cout, _ptr(partb),
+                      _ptr(st1.scale), _ptr(st1.shift), _ptr(st1.mean), _ptr(st1.invstd), _ptr(x), _ptr(w1), _ptr(amax2),
+                      _sf16_err_ptr(), _sf16_err_dev_ptr(dev), _stream())
         else:
-            dw2 = _wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=st1, sink=sk[5], gy_amax=amax2, x_amax=ctx.a1)
+            gy1 = _conv_fwd_like(gy2, w2, B, H, W, Cout, Cout, dgrad=True, epi=2, partials=partb, yprev=y1, p_st=st1, x_amax=amax2,
+                                 packs=ctx.pk2)
+        w_in_st = None if b1_pairs else st1
+        if fork and sk[5] is not None:
+            dw2 = _fork_wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=w_in_st, sink=sk[5], gy_amax=amax2, x_amax=ctx.a1, x_presplit=b1_pairs)
+        else:
+            dw2 = _wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=w_in_st, sink=sk[5], gy_amax=amax2, x_amax=ctx.a1, x_presplit=b1_pairs)
         del gy2
         dg1, db1, coef1 = bn_bwd_finalize(partb, npb, M, st1, batch_stats=ctx.training, sinks=(sk[1], sk[2]))
         # conv1
@@ -1173,8 +1219,9 @@ class ConvBlockFn(torch.autograd.Function):
             want_gx = ctx.needs_input_grad[0]
             tbuf = torch.empty((M, 9), dtype=torch.float32, device=dev) if want_gx else None
             gx = torch.empty((B, H, W, 1), dtype=torch.float32, device=dev) if want_gx else None
-            _call("sed_conv1_bwd", _ptr(x), _ptr(w1), _ptr(gy1), _ptr(y1), _ptr(coef1), B, H, W, _ptr(dw1), _ptr(gx), _ptr(dwp),
-                  _ptr(tbuf), _stream())
+            # (block 1 without a materialised y1: the kernel recomputes it from x)
+            _call("sed_conv1_bwd", _ptr(x), _ptr(w1), _ptr(gy1), None if b1_pairs else _ptr(y1), _ptr(coef1), B, H, W, _ptr(dw1),
+                  _ptr(gx), _ptr(dwp), _ptr(tbuf), _stream())
             dw1 = _ret(sk[0], dw1)
             join_side_stream()
         else:

@@ -327,3 +327,73 @@ def test_sf16_eval_pool_epilogue(B, H, W, C, ph, pw):
     z = torch.relu(z * s2.double()[None, :, None, None] + h2.double()[None, :, None, None])
     want = F.avg_pool2d(z, kernel_size=(ph, pw)).permute(0, 2, 3, 1)
     assert float((out.cpu().double() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("B,H", [(3, 21), (2, 1001), (5, 7)])
+def test_block1_without_a_materialised_conv1_output_is_bit_identical(B, H):
+    """Round 4: in training, block 1 never writes the raw conv1 output y1 (4.2 GB at batch 256).  A statistics pass feeds bn1,
+    sed_conv1_act_sf16 writes relu(bn1(y1)) once as split-f16 operand pairs (plain-copy staging in conv2's forward and weight
+    gradient), and the two backward kernels that need the RAW y1 recompute it from the one-channel input with conv1's own
+    fma sequence.  Every MFMA operand, ReLU mask and BatchNorm sum is therefore the same number as in the round-3 dataflow
+    (ops.B1_ACT_PAIRS = False): outputs, amax, all gradients and the running statistics must be EQUAL, bit for bit --
+    including ragged image bottoms (H = 21: tiles of 4 rows; H = 7: one odd tile) and the full 10 s frame count."""
+    from sound_event_detection_dcase2017_task4_amd import ops
+    W, Cout = 64, 64
+    g = torch.Generator().manual_seed(100 + H)
+    x = torch.randn(B, H, W, 1, generator=g).cuda()
+    base = [(torch.randn(Cout, 1, 3, 3, generator=g) * 0.5), 1 + 0.2 * torch.randn(Cout, generator=g), 0.2 * torch.randn(Cout, generator=g),
+            0.1 * torch.randn(Cout, generator=g), 0.5 + torch.rand(Cout, generator=g),
+            (torch.randn(Cout, Cout, 3, 3, generator=g) * (1.5 / np.sqrt(9 * Cout))), 1 + 0.2 * torch.randn(Cout, generator=g),
+            0.2 * torch.randn(Cout, generator=g), 0.1 * torch.randn(Cout, generator=g), 0.5 + torch.rand(Cout, generator=g)]
+    gout = torch.randn(B, H // 2, W // 2, Cout, generator=g).cuda()
+    results = []
+    prev = (ops.B1_ACT_PAIRS, ops.USE_SF16)
+    try:
+        ops.USE_SF16 = True
+        for flag in (False, True):
+            ops.B1_ACT_PAIRS = flag
+            params = [t.clone().cuda() for t in base]
+            for i in (0, 1, 2, 5, 6, 7):
+                params[i].requires_grad_(True)
+            xg = x.clone().requires_grad_(True)
+            out, out_amax = ops.ConvBlockFn.apply(xg, *params, True, 2, 2)
+            out.backward(gout)
+            torch.cuda.synchronize()
+            ops.check_device_errors()
+            results.append([out.detach(), out_amax, xg.grad] + [params[i].grad for i in (0, 1, 2, 5, 6, 7)] + [params[i] for i in (3, 4, 8, 9)])
+    finally:
+        ops.B1_ACT_PAIRS, ops.USE_SF16 = prev
+    names = ["out", "out_amax", "dx", "dw1", "dgamma1", "dbeta1", "dw2", "dgamma2", "dbeta2", "rm1", "rv1", "rm2", "rv2"]
+    for n, a, b in zip(names, results[0], results[1]):
+        assert torch.isfinite(a).all() and float(a.abs().max()) > 0, n
+        assert torch.equal(a, b), (n, float((a - b).abs().max()))
+
+
+def test_conv1_act_pairs_decode_to_relu_bn_conv1():
+    """sed_conv1_act_sf16: hi + lo of every pair, unscaled by the power of two of the amax, is relu(scale * conv1(x0) + shift)
+    to 2^-22 of the amax; a NaN input raises the found-non-finite words (the ReLU's fmaxf would swallow it)."""
+    import ctypes
+    from sound_event_detection_dcase2017_task4_amd import ops
+    B, H, W = 2, 13, 64
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, H, W, 1, generator=g).cuda()
+    w = (torch.randn(64, 1, 3, 3, generator=g) * 0.5).cuda()
+    sc, sh = (1 + 0.3 * torch.randn(64, generator=g)).cuda(), (0.3 * torch.randn(64, generator=g)).cuda()
+    y = torch.empty((B, H, W, 64), device="cuda")
+    ops._call("sed_conv1_fwd", ops._ptr(x), ops._ptr(w), ops._ptr(y), B, H, W, None, None, ops._stream())
+    ref = torch.relu(y * sc + sh)
+    amax = ops.amax_of(ref)
+    pairs = torch.empty((B, H, W, 64), dtype=torch.int32, device="cuda")
+    ops.check_device_errors(synchronize=True)
+    ops._call("sed_conv1_act_sf16", ops._ptr(x), ops._ptr(w), B, H, W, ops._ptr(sc), ops._ptr(sh), ops._ptr(amax), ops._ptr(pairs),
+              ops._sf16_err_ptr(), ops._sf16_err_dev_ptr(x.device), ops._stream())
+    halves = pairs.view(torch.float16).view(B, H, W, 32, 2, 2).float()          # [.., channel pair, {hi, lo} dword, channel of the pair]
+    s = 2.0 ** (14 - int(np.ceil(np.log2(float(amax.max()) * (1 + 1e-7)))))
+    dec = (halves[..., 0, :] + halves[..., 1, :]).reshape(B, H, W, 64) / s
+    assert float((dec - ref).abs().max()) <= float(amax.max()) * 2.0 ** -21
+    ops.check_device_errors(synchronize=True)
+    xb = x.clone(); xb[1, 5, 9, 0] = float("nan")
+    ops._call("sed_conv1_act_sf16", ops._ptr(xb), ops._ptr(w), B, H, W, ops._ptr(sc), ops._ptr(sh), ops._ptr(amax), ops._ptr(pairs),
+              ops._sf16_err_ptr(), ops._sf16_err_dev_ptr(x.device), ops._stream())
+    with pytest.raises(ops.NonFiniteOperand):
+        ops.check_device_errors(synchronize=True)
