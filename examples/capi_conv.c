@@ -83,7 +83,7 @@ int main(void) {
             CHECK_SED(sed_pack_conv_weights_sf16(dw, Cout, Cin, 0, dwscale, dwp, (sed_stream_t)stream));
             CHECK_SED(sed_amax(dx, M * Cin, dxamax, (sed_stream_t)stream));      /* operand scale: taken on the device */
             CHECK_SED(sed_conv3x3_sf16(dx, dwp, dwscale, dy, B, H, W, Cin, Cout, NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL,
-                                       dxamax, NULL, NULL, NULL, 0, (sed_stream_t)stream));
+                                       dxamax, NULL, NULL, NULL, 0, NULL, (sed_stream_t)stream));
         } else {
             CHECK_SED(sed_pack_conv_weights(dw, Cout, Cin, dwf, NULL, (sed_stream_t)stream));
             CHECK_SED(sed_conv3x3_igemm(dx, dwf, dy, B, H, W, Cin, Cout, NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL,

@@ -116,6 +116,25 @@ int sed_bn_relu_pool_bwd_reduce_mode(const float* y, const float* g_out, int B, 
 int sed_bn_relu_pool_bwd_apply_mode(const float* y, const float* g_out, int B, int H, int W, int C, int ph, int pw,
                                     int pool_mode, const float* scale, const float* shift, const float* coef, float* gy,
                                     float* amax_out, sed_stream_t stream);
+/* Gradients as split-f16 operand pairs (round 4; format: see sed_conv1_act_sf16).  sed_grad_bound: upper bound of
+ * max |a*dy + b*y + c| (coef [3][C] of sed_bn_bwd_finalize) from the per-part per-channel range of y (minmax [nparts][2][C], as
+ * left by the conv epilogues) and the amax vector of the incoming gradient (times ginv = 1 / pool window); the two apply
+ * kernels then write their result as pairs scaled by the power of two of that bound (bound = the vector their consumers
+ * take as gy_amax / x_amax together with the pairs flag).  models.py:102-107 backward. */
+int sed_grad_bound(const float* minmax, int nparts, int C, const float* coef, const float* g_amax, float ginv, float* bound_out,
+                   const float* y_amax /* instead of minmax (exactly one of the two): |y| <= its amax, every channel */,
+                   sed_stream_t stream);
+int sed_bn_bwd_apply_pairs(float* dy_inout, const float* y, long nrows, int C, const float* coef, const float* bound,
+                           sed_stream_t stream);
+int sed_bn_relu_pool_bwd_apply_pairs(const float* y, const float* g_out, int B, int H, int W, int C, int ph, int pw,
+                                     const float* scale, const float* shift, const float* coef, void* gy_pairs,
+                                     const float* bound, sed_stream_t stream);
+/* The pooled block output as operand pairs (round 4): sed_act_bound = max_c max(|scale_c| * amax|y| + shift_c, 0) >= every
+ * average of relu(scale*y + shift); sed_bn_relu_pool_fwd_cnt_pairs = sed_bn_relu_pool_fwd_cnt writing pairs scaled by it. */
+int sed_act_bound(const float* y_amax, const float* scale, const float* shift, int C, float* bound_out, sed_stream_t stream);
+int sed_bn_relu_pool_fwd_cnt_pairs(const float* y, int B, int H, int W, int C, int ph, int pw, const float* scale,
+                                   const float* shift, void* out_pairs, unsigned char* cnt, const float* bound,
+                                   sed_stream_t stream);
 /* amax of a = relu(scale*y + shift) -- the operand `conv2` of a ConvBlock (models.py:102-103) consumes without it ever
  * being materialised -- for the split-f16 scale of that convolution.  sed_act_amax: from per-part per-channel (max, min)
  * of y, minmax [nparts][2][C], which sed_conv1_fwd / sed_conv3x3_sf16 leave beside their statistics (the affine + ReLU
@@ -136,6 +155,7 @@ int sed_bn_relu_pool_bwd_reduce_auto(const float* y, const float* g_out, const f
                                      int B, int H, int W, int C, int ph, int pw, const float* scale,
                                      const float* shift, const float* mean, const float* invstd, const float* gamma,
                                      const float* beta, float gamma_min, float* partials, int* nparts_out,
+                                     const float* pooled_bound /* nullable: `pooled` holds operand pairs scaled by it */,
                                      sed_stream_t stream);
 int sed_pool_bwd_rows_per_block(long M);
 int sed_bn_relu_pool_bwd_reduce(const float* y, const float* g_out, int B, int H, int W, int C, int ph, int pw,
@@ -241,7 +261,7 @@ int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale, float*
                      int Cout, const float* in_scale, const float* in_shift, int epi, float* partials,
                      const float* yprev, const float* p_scale, const float* p_shift, const float* p_mean,
                      const float* p_invstd, const float* x_amax, float* minmax, int* err_host, int* err_dev,
-                     int flags, sed_stream_t stream);
+                     int flags, float* out_amax /* nullable: amax vector of |y| as written */, sed_stream_t stream);
 /* Block 1 without a materialised conv1 output (round 4).  models.py:99-103 for conv_block1: relu(bn1(conv1(x0))) feeds conv2.
  * sed_conv1_fwd(y = null) is the statistics / range pass; sed_conv1_act_sf16 then writes a1 = relu(scale*conv1(x0)+shift)
  * ONCE, as split-f16 operand pairs -- per channel pair two dwords {hi0 | hi1 << 16, lo0 | lo1 << 16}, hi = f16(s*a),
@@ -256,7 +276,8 @@ int sed_conv1_act_sf16(const float* x0, const float* w_oihw, int B, int H, int W
 int sed_conv3x3_sf16_dgrad_b1(const float* gy, const void* wp, const float* wscale, float* gx, int B, int H, int W, int Cin,
                               int Cout, float* partials, const float* p_scale, const float* p_shift, const float* p_mean,
                               const float* p_invstd, const float* x0, const float* w1_oihw, const float* gy_amax,
-                              int* err_host, int* err_dev, sed_stream_t stream);
+                              int* err_host, int* err_dev, int flags /* bit 0: gy holds pairs */, float* out_amax,
+                              sed_stream_t stream);
 /* Weight gradient with split-f16 operands (csrc/conv_sf16.hip): same contract as sed_conv3x3_wgrad; gy_amax = device
  * pointer to max |gy| (sed_amax or the producer kernels), x_amax = device pointer to the amax of the activation operand
  * (as for sed_conv3x3_sf16); err_host / err_dev as there.

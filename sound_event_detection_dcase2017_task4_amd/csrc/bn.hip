@@ -285,11 +285,15 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __re
                                                                int ph, int pw, const float* __restrict__ scale,
                                                                const float* __restrict__ shift,
                                                                float* __restrict__ out, unsigned* __restrict__ cnt4,
-                                                               float* __restrict__ amax_out) {
+                                                               float* __restrict__ amax_out,
+                                                               const float* __restrict__ pair_bound = nullptr) {
     const int Ho = H / ph, Wo = W / pw, c4n = C >> 2;
     const long total = (long)B * Ho * Wo * c4n;
     const float inv = 1.0f / (float)(ph * pw);
     float amax = 0.f;
+    // pair_bound: the pooled tensor is written as split-f16 operand pairs (the next block's conv1 and its weight gradient copy
+    // them into LDS), scaled by the power of two of that upper bound of its amax
+    const float so = pair_bound ? sed_sf_scale_of(amax_read(pair_bound)) : 1.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         int c4 = (int)(i % c4n);
         long p = i / c4n;
@@ -315,7 +319,8 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __re
         float4 o = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
         if (MODE == 1) o = mx;
         if (MODE == 2) { o.x += mx.x; o.y += mx.y; o.z += mx.z; o.w += mx.w; }
-        store_nt4(out, i, o);
+        if (pair_bound) sed_store_pairs4(out, i, make_float4(o.x * so, o.y * so, o.z * so, o.w * so));
+        else store_nt4(out, i, o);
         amax = fmaxf(fmaxf(amax, fmaxf(o.x, o.y)), fmaxf(o.z, o.w));          // o >= 0
         if (CNT) cnt4[i] = n4;
     }
@@ -384,9 +389,12 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const float* __re
                                                                const float* __restrict__ coef, int rows_per_block,
                                                                float* __restrict__ partials, float* __restrict__ gy,
                                                                const float* __restrict__ gamma, float gmin,
-                                                               float* __restrict__ amax_out) {
+                                                               float* __restrict__ amax_out,
+                                                               const float* __restrict__ pair_bound = nullptr) {
     __shared__ float4 red_a[256], red_b[256];
     float amax = 0.f;
+    // PASS 2 with pair_bound: gy is written as split-f16 operand pairs scaled by the power of two of that BOUND of its amax
+    const float sg = (PASS == 2 && pair_bound) ? sed_sf_scale_of(amax_read(pair_bound)) : 1.f;
     // PASS 1 with a gamma pointer is the exact fallback of the windowed pass: it runs only when that one declines
     if (PASS == 1 && gamma && !any_small_gamma(gamma, C, gmin)) return;
     const int Ho = H / ph, Wo = W / pw, c4n = C >> 2;
@@ -447,7 +455,8 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const float* __re
             float4 o;
             o.x = fmaf(ca.x, dy.x, fmaf(cb.x, v.x, cc.x)); o.y = fmaf(ca.y, dy.y, fmaf(cb.y, v.y, cc.y));
             o.z = fmaf(ca.z, dy.z, fmaf(cb.z, v.z, cc.z)); o.w = fmaf(ca.w, dy.w, fmaf(cb.w, v.w, cc.w));
-            store_nt4(gy, r * c4n + c4, o);
+            if (pair_bound) sed_store_pairs4(gy, r * c4n + c4, make_float4(o.x * sg, o.y * sg, o.z * sg, o.w * sg));
+            else store_nt4(gy, r * c4n + c4, o);
             amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
     }
@@ -481,9 +490,11 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_win_kernel(const float* _
                                                                   const unsigned* __restrict__ cnt4, long nrows, int C,
                                                                   float inv, const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, int rows_per_block,
-                                                                  float* __restrict__ partials, float gmin) {
+                                                                  float* __restrict__ partials, float gmin,
+                                                                  const float* __restrict__ pair_bound = nullptr) {
     __shared__ float4 red_a[256], red_b[256];
     if (gmin > 0.f && any_small_gamma(gamma, C, gmin)) return;     // the exact pass takes over (partials pre-zeroed)
+    const float pinv = pair_bound ? 1.0f / sed_sf_scale_of(amax_read(pair_bound)) : 1.f;     // pooled stored as pairs: decode
     const int c4n = C >> 2;
     const int rpp = 256 / c4n;
     const int c4 = threadIdx.x % c4n, r0 = threadIdx.x / c4n;
@@ -494,7 +505,13 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_win_kernel(const float* _
     float4 sa = make_float4(0, 0, 0, 0), sb = make_float4(0, 0, 0, 0);
     for (long r = row_base + r0; r < row_end; r += rpp) {
         const float4 g = reinterpret_cast<const float4*>(gout)[r * c4n + c4];
-        const float4 p = reinterpret_cast<const float4*>(pooled)[r * c4n + c4];
+        float4 p;
+        if (pair_bound) {
+            p = sed_load_pairs4(pooled, r * c4n + c4);
+            p.x *= pinv; p.y *= pinv; p.z *= pinv; p.w *= pinv;
+        } else {
+            p = reinterpret_cast<const float4*>(pooled)[r * c4n + c4];
+        }
         const unsigned n4 = cnt4[r * c4n + c4];
         float4 gc;
         gc.x = g.x * ((float)(n4 & 255u) * inv); gc.y = g.y * ((float)((n4 >> 8) & 255u) * inv);
@@ -520,10 +537,11 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_win_kernel(const float* _
 // g_y = a*dy + b*y + c, in place on dy (the conv1-side BN backward, dy produced by the dgrad epilogue)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ dy, const float* __restrict__ y,
                                                            long nrows, int C, const float* __restrict__ coef,
-                                                           float* __restrict__ amax_out) {
+                                                           float* __restrict__ amax_out, const float* __restrict__ pair_bound) {
     const int c4n = C >> 2;
     const long total = nrows * c4n;
     float amax = 0.f;
+    const float sg = pair_bound ? sed_sf_scale_of(amax_read(pair_bound)) : 1.f;     // pairs out: see bn_relu_pool_bwd_kernel
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         int c4 = (int)(i % c4n);
         float4 ca = reinterpret_cast<const float4*>(coef)[c4], cb = reinterpret_cast<const float4*>(coef)[c4n + c4],
@@ -532,7 +550,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ d
         float4 o;
         o.x = fmaf(ca.x, d.x, fmaf(cb.x, v.x, cc.x)); o.y = fmaf(ca.y, d.y, fmaf(cb.y, v.y, cc.y));
         o.z = fmaf(ca.z, d.z, fmaf(cb.z, v.z, cc.z)); o.w = fmaf(ca.w, d.w, fmaf(cb.w, v.w, cc.w));
-        store_nt4(dy, i, o);
+        if (pair_bound) sed_store_pairs4(dy, i, make_float4(o.x * sg, o.y * sg, o.z * sg, o.w * sg));
+        else store_nt4(dy, i, o);
         amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
     if (amax_out) {
@@ -730,6 +749,47 @@ SED_API int sed_bn_relu_pool_fwd_cnt(const float* y, int B, int H, int W, int C,
     return 0;
 }
 
+// ---- the pooled block output as split-f16 operand pairs (round 4): read only by the next block's conv1 (forward and weight
+// gradient: plain-copy staging) and by this block's windowed backward pass 1 (decodes).  The scale needs an upper bound of the
+// pooled amax BEFORE the pass: the average of relu(scale*y + shift) over a window is <= max_c (|scale_c| * amax|y| + |shift_c|).
+namespace {
+__global__ __launch_bounds__(256) void act_bound_kernel(const float* __restrict__ y_amax, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, int C, float* __restrict__ bound_out) {
+    __shared__ float red[256];
+    const float A = amax_read(y_amax);
+    float best = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) best = fmaxf(best, fmaxf(fmaf(fabsf(scale[c]), A, shift[c]), 0.f) * 1.0001f);
+    red[threadIdx.x] = best;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bound_out[0] = red[0];
+}
+}  // namespace
+
+SED_API int sed_act_bound(const float* y_amax, const float* scale, const float* shift, int C, float* bound_out, hipStream_t stream) {
+    if (!y_amax || !scale || !shift || !bound_out || C <= 0) return SED_EINVAL;
+    hipError_t e = sed_amax_clear(bound_out, stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(act_bound_kernel, dim3(1), dim3(256), 0, stream, y_amax, scale, shift, C, bound_out);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+SED_API int sed_bn_relu_pool_fwd_cnt_pairs(const float* y, int B, int H, int W, int C, int ph, int pw, const float* scale,
+                                           const float* shift, void* out_pairs, unsigned char* cnt, const float* bound,
+                                           hipStream_t stream) {
+    if (!y || !out_pairs || !bound || B <= 0 || (C & 3) || ph <= 0 || pw <= 0 || H / ph <= 0 || W / pw <= 0 || ph * pw > 255 || !cnt)
+        return SED_EINVAL;
+    long total = (long)B * (H / ph) * (W / pw) * (C / 4);
+    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<true>, dim3(stream_grid(total)), dim3(256), 0, stream, y, B, H, W, C, ph, pw,
+                       scale, shift, (float*)out_pairs, reinterpret_cast<unsigned*>(cnt), (float*)nullptr, bound);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
 // Backward pass 1 from the pooled tensors: g_out, pooled, cnt [B*Ho*Wo][C]; gamma / beta = the BatchNorm weight / bias.
 // partials must hold ceil(M' / sed_pool_bwd_rows_per_block(M')) * 2*C floats, M' = B*Ho*Wo.
 SED_API int sed_bn_relu_pool_bwd_reduce_win(const float* g_out, const float* pooled, const unsigned char* cnt, long Mp,
@@ -758,7 +818,8 @@ SED_API int sed_bn_relu_pool_bwd_reduce_auto(const float* y, const float* g_out,
                                              const unsigned char* cnt, int B, int H, int W, int C, int ph, int pw,
                                              const float* scale, const float* shift, const float* mean,
                                              const float* invstd, const float* gamma, const float* beta,
-                                             float gamma_min, float* partials, int* nparts_out, hipStream_t stream) {
+                                             float gamma_min, float* partials, int* nparts_out, const float* pooled_bound,
+                                             hipStream_t stream) {
     if (B <= 0 || C < 64 || C > 512 || (256 % (C / 4)) != 0 || ph * pw > 255 || !(gamma_min > 0.f)) return SED_EINVAL;
     const long nparts = sed_bn_relu_pool_bwd_reduce_auto_parts(B, H, W, ph, pw);
     if (nparts <= 0) return SED_EINVAL;
@@ -768,7 +829,7 @@ SED_API int sed_bn_relu_pool_bwd_reduce_auto(const float* y, const float* g_out,
     const int rpb = sed_pool_bwd_rows_per_block(M), rpbw = sed_pool_bwd_rows_per_block(Mp);
     hipLaunchKernelGGL(pool_bwd_reduce_win_kernel, dim3(sed_cdiv(Mp, rpbw)), dim3(256), 0, stream, g_out, pooled,
                        reinterpret_cast<const unsigned*>(cnt), Mp, C, 1.0f / (float)(ph * pw), gamma, beta, rpbw, partials,
-                       gamma_min);
+                       gamma_min, pooled_bound);
     hipLaunchKernelGGL(bn_relu_pool_bwd_kernel<1>, dim3(sed_cdiv(M, rpb)), dim3(256), 0, stream, y, g_out, B, H, W, C, ph, pw,
                        scale, shift, mean, invstd, (const float*)nullptr, rpb, partials, (float*)nullptr, gamma, gamma_min, (float*)nullptr);
     if (nparts_out) *nparts_out = (int)nparts;
@@ -912,7 +973,83 @@ SED_API int sed_bn_bwd_apply(float* dy_inout, const float* y, long nrows, int C,
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(nrows * (C / 4))), dim3(256), 0, stream, dy_inout, y, nrows, C,
-                       coef, amax_out);
+                       coef, amax_out, (const float*)nullptr);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- gradients written as split-f16 operand pairs (round 4).  The BatchNorm-backward apply kernels produce the tensors that ONLY
+// the split-f16 dgrad / weight-gradient kernels read; written as pairs (same bytes), every consumer tile copies them into
+// LDS instead of re-deriving (hi, lo) -- 64/32 of them re-derive the same values today.  The scale must be known BEFORE the
+// pass: sed_grad_bound gives an upper bound of max |a*dy + b*y + c| from what is known per channel -- the coefficients, the
+// range of y (the conv epilogue's minmax partials) and the amax of the incoming gradient: |a|*G*ginv + max(|b*ymax + c|,
+// |b*ymin + c|).  A bound that is a few times too large costs nothing: hi and lo are floating-point numbers.
+namespace {
+__global__ __launch_bounds__(256) void grad_bound_kernel(const float* __restrict__ mm, int nparts, int C,
+                                                         const float* __restrict__ coef, const float* __restrict__ g_amax,
+                                                         float ginv, int parts_per_block, float* __restrict__ bound_out,
+                                                         const float* __restrict__ y_amax) {
+    __shared__ float red[256];
+    const int p0 = blockIdx.x * parts_per_block, p1 = min(nparts, p0 + parts_per_block);
+    const float G = amax_read(g_amax) * ginv;
+    const float A = y_amax ? amax_read(y_amax) : 0.f;        // mm null: |y| <= A for every channel (the looser, cheaper range)
+    float best = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float mx = mm ? -__builtin_inff() : A, mn = mm ? __builtin_inff() : -A;
+        for (int q = p0; mm && q < p1; ++q) {
+            mx = fmaxf(mx, mm[((long)q * 2 + 0) * C + c]);
+            mn = fminf(mn, mm[((long)q * 2 + 1) * C + c]);
+        }
+        if (mx >= mn) {
+            const float a = coef[c], b = coef[C + c], cc = coef[2 * C + c];
+            // 1.0001: the kernels evaluate a*dy + (b*y + c) with two roundings; the bound must never fall below the value
+            best = fmaxf(best, (fabsf(a) * G + fmaxf(fabsf(fmaf(b, mx, cc)), fabsf(fmaf(b, mn, cc)))) * 1.0001f);
+        }
+    }
+    red[threadIdx.x] = best;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        atomicMax(reinterpret_cast<unsigned*>(bound_out) + (blockIdx.x & (SED_AMAX_SLOTS - 1)), __float_as_uint(red[0]));
+}
+}  // namespace
+
+SED_API int sed_grad_bound(const float* minmax, int nparts, int C, const float* coef, const float* g_amax, float ginv,
+                           float* bound_out, const float* y_amax, hipStream_t stream) {
+    if ((minmax == nullptr) == (y_amax == nullptr) || !coef || !g_amax || !bound_out || C <= 0 || (minmax && nparts <= 0))
+        return SED_EINVAL;
+    hipError_t e = sed_amax_clear(bound_out, stream);
+    if (e != hipSuccess) return (int)e;
+    if (!minmax) nparts = 1;
+    int ppb = sed_cdiv(nparts, 1024);
+    if (ppb < 8) ppb = 8;
+    hipLaunchKernelGGL(grad_bound_kernel, dim3(sed_cdiv(nparts, ppb)), dim3(256), 0, stream, minmax, nparts, C, coef, g_amax, ginv,
+                       ppb, bound_out, y_amax);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+SED_API int sed_bn_bwd_apply_pairs(float* dy_inout, const float* y, long nrows, int C, const float* coef, const float* bound,
+                                   hipStream_t stream) {
+    if (!dy_inout || !y || !coef || !bound || nrows <= 0 || (C & 3)) return SED_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(nrows * (C / 4))), dim3(256), 0, stream, dy_inout, y, nrows, C,
+                       coef, (float*)nullptr, bound);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+SED_API int sed_bn_relu_pool_bwd_apply_pairs(const float* y, const float* g_out, int B, int H, int W, int C, int ph, int pw,
+                                             const float* scale, const float* shift, const float* coef, void* gy_pairs,
+                                             const float* bound, hipStream_t stream) {
+    if (!y || !g_out || !coef || !gy_pairs || !bound || B <= 0 || C < 64 || C > 512 || (256 % (C / 4)) != 0) return SED_EINVAL;
+    const int rpb = sed_pool_bwd_rows_per_block((long)B * H * W);
+    int nblk = sed_cdiv((long)B * H * W, rpb);
+    hipLaunchKernelGGL(bn_relu_pool_bwd_kernel<2>, dim3(nblk), dim3(256), 0, stream, y, g_out, B, H, W, C, ph, pw, scale, shift,
+                       (const float*)nullptr, (const float*)nullptr, coef, rpb, (float*)nullptr, (float*)gy_pairs,
+                       (const float*)nullptr, 0.f, (float*)nullptr, bound);
     SED_LAUNCH_CHECK();
     return 0;
 }

@@ -67,6 +67,40 @@ static inline hipError_t sed_amax_clear(float* amax_out, hipStream_t stream) {
                                                             : hipSuccess;
 }
 
+// Split-f16 operand format (csrc/conv_sf16.hip): x = (hi + lo) / s with hi = f16(s*x), lo = f16(s*x - hi), s = the power of two
+// that brings the tensor's amax (or an upper BOUND of it) to [2^13, 2^14).  A tensor stored "as pairs" holds, per channel
+// pair, two dwords {hi0 | hi1 << 16, lo0 | lo1 << 16}: the bytes of the fp32 tensor, and the consumers' staging is a copy.
+__device__ __forceinline__ float sed_sf_scale_of(float amax) {
+    if (!(amax > 0.f) || !(amax < __builtin_inff())) return 1.f;
+    int e;
+    frexpf(amax, &e);
+    e = 14 - e;
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    return ldexpf(1.f, e);
+}
+__device__ __forceinline__ void sed_sf_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+        "v_fma_mixlo_f16 %1, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(hi), "=&v"(lo)
+        : "v"(a), "v"(b));
+}
+// four scaled values -> the 16 bytes {h01, l01, h23, l23} of their two channel pairs, streamed out
+__device__ __forceinline__ void sed_store_pairs4(void* base, long idx4, float4 v) {
+    unsigned h01, l01, h23, l23;
+    sed_sf_split2(v.x, v.y, h01, l01);
+    sed_sf_split2(v.z, v.w, h23, l23);
+    const floatx4 ov = {__uint_as_float(h01), __uint_as_float(l01), __uint_as_float(h23), __uint_as_float(l23)};
+    __builtin_nontemporal_store(ov, reinterpret_cast<floatx4*>(base) + idx4);
+}
+// ... and back: the four fp32 values (times s) of such 16 bytes
+__device__ __forceinline__ float4 sed_load_pairs4(const void* base, long idx4) {
+    const floatx4 r = reinterpret_cast<const floatx4*>(base)[idx4];
+    const unsigned h01 = __float_as_uint(r[0]), l01 = __float_as_uint(r[1]), h23 = __float_as_uint(r[2]), l23 = __float_as_uint(r[3]);
+    auto f = [](unsigned w, int hi) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(hi ? (w >> 16) : (w & 0xffffu))); };
+    return make_float4(f(h01, 0) + f(l01, 0), f(h01, 1) + f(l01, 1), f(h23, 0) + f(l23, 0), f(h23, 1) + f(l23, 1));
+}
+
 // Streaming 16-byte store of a tensor that is written once and read by a LATER kernel after everything else has passed through the
 // caches: non-temporal (conv1_fwd writes its 4.2 GB at 4.5 instead of 3.4 TB/s with it: profiles/r03).
 __device__ __forceinline__ void store_nt4(float* base, long idx4, float4 v) {

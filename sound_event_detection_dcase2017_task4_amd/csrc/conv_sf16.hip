@@ -56,6 +56,7 @@ struct Sf16P {
     int* err_host;             // nullable, host-mapped: set to 1 when an operand is not finite
     int* err_dev;              // nullable, device: same (read by sed_adam_amsgrad)
     float* pool_amax;          // EPI 3: amax slots of the pooled output
+    float* out_amax;           // nullable (EPI 0 / 1 / 2 / 4): amax slots of |y| as written (masked, unscaled) -- one atomic per wave
     int ph, pw;                // EPI 3: pooling window, (2, 2) or (1, W)
     // EPI 4 (block 1's dgrad): the previous activations y1 = conv1(x0) are RECOMPUTED from the one-channel input
     const float* x0;           // [B][H][W]
@@ -421,6 +422,7 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
         const_cast<float*>(EPI == 2 ? p.yprev + (long)b * p.H * W * p.N : p.x), 0, (int)y_img_bytes, 0x00020000);
     const int colb = n0 + 64 * wn + (lane & 31);       // + 32*nk
     const long part = (long)b * p.ntile + tile;        // ONE part per workgroup: the MW waves' sums are merged below
+    float vabs = 0.f;                                  // max |y| this lane stores (p.out_amax)
     // per-wave (sum, M2 | second sum, max, min) of its 64 pixels per channel -> LDS (the staging buffers are free behind the
     // loop's last barrier) -> merged by wave wm = 0 of every channel half: a quarter of the partial rows in memory and in the
     // BatchNorm merge kernels (131 -> 33 MB of partials per launch on block 1 at B = 256; step time unchanged: measured)
@@ -512,6 +514,7 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
                     vmn = fminf(vmn, ok ? v : __builtin_inff());
                 }
                 acc[mb][nk][r] = v;
+                vabs = fmaxf(vabs, ok ? fabsf(v) : 0.f);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, yoff[mb][r], nk * 128, 0);
             }
         }
@@ -541,6 +544,10 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
             s2 += __shfl_xor(s2, 32, 64);
             if (kh == 0) { mine[0] = s1; mine[1] = s2; }
         }
+    }
+    if (p.out_amax) {      // the consumer's split-f16 scale (or the bound of what a BatchNorm-backward pass makes of this tensor)
+        vabs = wave_max(vabs);
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(p.out_amax) + ((blockIdx.x * 4 + wvu) & (SED_AMAX_SLOTS - 1)), __float_as_uint(vabs));
     }
     if (EPI == 0 && !p.mm) return;
     __syncthreads();
@@ -778,7 +785,7 @@ SED_API int sed_conv3x3_sf16_eval_pool(const float* x, const void* wp, const flo
     p.ntile = (H + p.TR - 1) / p.TR;
     p.mm = nullptr; p.err_host = err_host; p.err_dev = err_dev;
     p.pool_amax = out_amax; p.ph = ph; p.pw = pw;
-    p.x0 = p.w1 = nullptr;
+    p.x0 = p.w1 = nullptr; p.out_amax = nullptr;
     const long nblk = (long)B * p.ntile * (Cout / 64);
     if (nblk > 0x7fffffffL) return SED_EINVAL;
     if (in_scale) hipLaunchKernelGGL((conv_sf16_kernel<4, true, 3>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
@@ -791,12 +798,16 @@ SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale
                              int Cout, const float* in_scale, const float* in_shift, int epi, float* partials,
                              const float* yprev, const float* p_scale, const float* p_shift, const float* p_mean,
                              const float* p_invstd, const float* x_amax, float* minmax, int* err_host, int* err_dev,
-                             int flags, sed_stream_t stream) {
+                             int flags, float* out_amax, sed_stream_t stream) {
     if (!x || !wp || !wscale || !y || !x_amax || B <= 0 || !sed_conv3x3_sf16_supported(H, W, Cin, Cout) || epi < 0 || epi > 2)
         return SED_EINVAL;
     // flags bit 0: x holds split-f16 pairs already (sed_conv1_act_sf16 format, scaled by x_amax): epi 0 / 1, no input transform
     const bool pre = (flags & 1) != 0;
-    if ((flags & ~1) || (pre && (in_scale || epi == 2 || sf_mw(Cout) != 4))) return SED_EINVAL;
+    if ((flags & ~1) || (pre && (in_scale || sf_mw(Cout) != 4))) return SED_EINVAL;
+    if (out_amax) {
+        hipError_t e = sed_amax_clear(out_amax, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
     if (minmax && epi == 2) return SED_EINVAL;
     if ((in_scale == nullptr) != (in_shift == nullptr)) return SED_EINVAL;
     if (epi >= 1 && !partials) return SED_EINVAL;
@@ -813,7 +824,7 @@ SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale
     p.ntile = (H + p.TR - 1) / p.TR;
     p.mm = minmax; p.err_host = err_host; p.err_dev = err_dev;
     p.pool_amax = nullptr; p.ph = p.pw = 1;
-    p.x0 = p.w1 = nullptr;
+    p.x0 = p.w1 = nullptr; p.out_amax = out_amax;
     const long nblk = (long)B * p.ntile * (Cout / (mw == 2 ? 128 : 64));
     if (nblk > 0x7fffffffL) return SED_EINVAL;
     const dim3 g((unsigned)nblk), blk(256);
@@ -822,7 +833,8 @@ SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale
     const bool it = in_scale != nullptr;
     if (pre) {
         if (epi == 0) hipLaunchKernelGGL((conv_sf16_kernel<4, false, 0, true>), g, blk, 0, s, p);
-        else hipLaunchKernelGGL((conv_sf16_kernel<4, false, 1, true>), g, blk, 0, s, p);
+        else if (epi == 1) hipLaunchKernelGGL((conv_sf16_kernel<4, false, 1, true>), g, blk, 0, s, p);
+        else hipLaunchKernelGGL((conv_sf16_kernel<4, false, 2, true>), g, blk, 0, s, p);
     } else if (mw == 2) {
         if (epi == 0) { if (it) SF_LAUNCH(2, true, 0); else SF_LAUNCH(2, false, 0); }
         else if (epi == 1) { if (it) SF_LAUNCH(2, true, 1); else SF_LAUNCH(2, false, 1); }
@@ -844,10 +856,15 @@ SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale
 SED_API int sed_conv3x3_sf16_dgrad_b1(const float* gy, const void* wp, const float* wscale, float* gx, int B, int H, int W,
                                       int Cin, int Cout, float* partials, const float* p_scale, const float* p_shift,
                                       const float* p_mean, const float* p_invstd, const float* x0, const float* w1_oihw,
-                                      const float* gy_amax, int* err_host, int* err_dev, sed_stream_t stream) {
+                                      const float* gy_amax, int* err_host, int* err_dev, int flags, float* out_amax,
+                                      sed_stream_t stream) {
     if (!gy || !wp || !wscale || !gx || !partials || !p_scale || !p_shift || !p_mean || !p_invstd || !x0 || !w1_oihw || !gy_amax ||
-        B <= 0 || Cout != 64 || !sed_conv3x3_sf16_supported(H, W, Cin, Cout) || sf_mw(Cout) != 4)
+        B <= 0 || Cout != 64 || !sed_conv3x3_sf16_supported(H, W, Cin, Cout) || sf_mw(Cout) != 4 || (flags & ~1))
         return SED_EINVAL;
+    if (out_amax) {
+        hipError_t e = sed_amax_clear(out_amax, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
     Sf16P p;
     p.x = gy; p.wp = (const _Float16*)wp; p.wscale = wscale; p.x_amax = gy_amax; p.y = gx;
     p.in_scale = nullptr; p.in_shift = nullptr; p.partials = partials; p.yprev = nullptr;
@@ -858,10 +875,11 @@ SED_API int sed_conv3x3_sf16_dgrad_b1(const float* gy, const void* wp, const flo
     p.ntile = (H + p.TR - 1) / p.TR;
     p.mm = nullptr; p.err_host = err_host; p.err_dev = err_dev;
     p.pool_amax = nullptr; p.ph = p.pw = 1;
-    p.x0 = x0; p.w1 = w1_oihw;
+    p.x0 = x0; p.w1 = w1_oihw; p.out_amax = out_amax;
     const long nblk = (long)B * p.ntile * (Cout / 64);
     if (nblk > 0x7fffffffL) return SED_EINVAL;
-    hipLaunchKernelGGL((conv_sf16_kernel<4, false, 4>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
+    if (flags & 1) hipLaunchKernelGGL((conv_sf16_kernel<4, false, 4, true>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((conv_sf16_kernel<4, false, 4>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
     SED_LAUNCH_CHECK();
     return 0;
 }
@@ -912,7 +930,8 @@ __device__ __forceinline__ half4 sf_tr_read(const unsigned char* p) {
 }
 
 // XPRE: the activation operand x is ALREADY split (sed_conv1_act_sf16 format, scaled by x_amax): its staging is a plain copy
-template <int LOGW, bool INT, bool XPRE = false>
+// GPRE: likewise for the gradient operand gy (pairs written by the BatchNorm-backward apply kernels, scaled by g_amax)
+template <int LOGW, bool INT, bool XPRE = false, bool GPRE = false>
 __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
     constexpr int W = 1 << LOGW, TRS = 64 >> LOGW, WP = W + 2;
     constexpr int RING = TRS <= 2 ? 4 : (TRS == 4 ? 8 : 16);
@@ -1021,6 +1040,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
         greg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(grs, goff[i], (H0) * W * p.N * 4, 0));
 #define WSF_GSTORE(GB)                                                                                          \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                             \
+        if (GPRE) {                                                                                             \
+            const uint4 u = __builtin_bit_cast(uint4, greg[i]);                                                 \
+            *reinterpret_cast<uint2*>(Gs + (GB) + gls[i]) = make_uint2(u.x, u.z);                               \
+            *reinterpret_cast<uint2*>(Gs + (GB) + GPL + gls[i]) = make_uint2(u.y, u.w);                         \
+            continue;                                                                                           \
+        }                                                                                                       \
         float4 v = greg[i];                                                                                     \
         v.x *= sg; v.y *= sg; v.z *= sg; v.w *= sg;                                                             \
         overflow |= !((fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w)) < 3.0e5f);                         \
@@ -1202,9 +1227,10 @@ SED_API int sed_conv3x3_wgrad_sf16(const float* x, const float* gy, float* dw_oi
     if (!x || !gy || !dw_oihw || !partial || !gy_amax || !x_amax || B <= 0 || !sed_wgrad_sf16_supported(H, W, Cin, Cout))
         return SED_EINVAL;
     if ((in_scale == nullptr) != (in_shift == nullptr)) return SED_EINVAL;
-    // flags bit 0: x holds split-f16 pairs already (sed_conv1_act_sf16 format, scaled by x_amax); no input transform then
-    const bool xpre = (flags & 1) != 0;
-    if ((flags & ~1) || (xpre && in_scale)) return SED_EINVAL;
+    // flags bit 0: x holds split-f16 pairs already (sed_conv1_act_sf16 format, scaled by x_amax); no input transform then;
+    // bit 1: gy holds such pairs (scaled by gy_amax)
+    const bool xpre = (flags & 1) != 0, gpre = (flags & 2) != 0;
+    if ((flags & ~3) || (xpre && in_scale)) return SED_EINVAL;
     WSf16P p;
     p.x = x; p.gy = gy; p.partial = partial; p.in_scale = in_scale; p.in_shift = in_shift; p.g_amax = gy_amax;
     p.x_amax = x_amax;
@@ -1217,7 +1243,11 @@ SED_API int sed_conv3x3_wgrad_sf16(const float* x, const float* gy, float* dw_oi
     hipStream_t s = (hipStream_t)stream;
     const bool it = in_scale != nullptr;
 #define WSF_LAUNCH(LW)                                                                                          \
-    if (xpre) hipLaunchKernelGGL((wgrad_sf16_kernel<LW, false, true>), g, blk, 0, s, p);                        \
+    if (gpre) {                                                                                                 \
+        if (xpre) hipLaunchKernelGGL((wgrad_sf16_kernel<LW, false, true, true>), g, blk, 0, s, p);              \
+        else if (it) hipLaunchKernelGGL((wgrad_sf16_kernel<LW, true, false, true>), g, blk, 0, s, p);           \
+        else hipLaunchKernelGGL((wgrad_sf16_kernel<LW, false, false, true>), g, blk, 0, s, p);                  \
+    } else if (xpre) hipLaunchKernelGGL((wgrad_sf16_kernel<LW, false, true>), g, blk, 0, s, p);                 \
     else if (it) hipLaunchKernelGGL((wgrad_sf16_kernel<LW, true>), g, blk, 0, s, p);                            \
     else hipLaunchKernelGGL((wgrad_sf16_kernel<LW, false>), g, blk, 0, s, p);
     if (W == 64) { WSF_LAUNCH(6) } else if (W == 32) { WSF_LAUNCH(5) } else if (W == 16) { WSF_LAUNCH(4) } else { WSF_LAUNCH(3) }

@@ -41,7 +41,18 @@ EVAL_POOL_FUSION = os.environ.get("SED_EVAL_POOL_FUSION", "1") != "0"     # infe
 # the split-f16 operand pairs conv2's forward and weight-gradient kernels would otherwise re-derive from y1 in every tile
 # (same bytes as y1; their staging becomes a plain copy, the MFMA operands are bit-identical); conv2's dgrad epilogue and
 # conv1's backward recompute the raw y1 they need from the one-channel input (same fma sequence: same bits).  0: round-3 dataflow.
-B1_ACT_PAIRS = os.environ.get("SED_B1_ACT_PAIRS", "1") != "0"
+# Measured (profiles/r04): conv2 forward -0.20 ms, its weight gradient -0.21 ms, conv1 backward -0.24 ms at batch 256, but the two
+# conv1 passes cost +0.5 ms over the single one (both are bound by their x0 gathers, not by the 4.2 GB write) and the
+# recomputing dgrad epilogue +0.27 ms: +0.1 ms net -- built, bit-identical, OFF by default.
+B1_ACT_PAIRS = os.environ.get("SED_B1_ACT_PAIRS", "0") != "0"
+# Gradients as split-f16 operand pairs (round 4): the two BatchNorm-backward apply passes of a ConvBlock write the tensors that only
+# the split-f16 dgrad / weight-gradient kernels read; as pairs (same bytes) those kernels' staging is a plain copy.  The scale
+# comes from an upper BOUND of the tensor's amax, computed on the device before the pass (sed_grad_bound).  0: fp32 tensors.
+GRAD_PAIRS = os.environ.get("SED_GRAD_PAIRS", "1") != "0"
+# ... and the pooled outputs of blocks 1-3 (read only by the next block's conv1, forward and weight gradient, and by the
+# block's own windowed backward pass): requested by the models' trunk (ConvBlock.forward(pairs_out=True))
+ACT_PAIRS = os.environ.get("SED_ACT_PAIRS", "1") != "0"
+_GRAD_AMAX = {}          # data_ptr of an input gradient a ConvBlock returned -> (its amax vector, numel): the next backward's bound
 _SIDE = {}
 _PENDING = []            # [(event recorded on the side stream, sink or None)] of weight gradients not yet joined
 
@@ -92,7 +103,7 @@ def drop_pending_wgrads():
 _STREAM_OVERRIDE = None     # set while kernels are being enqueued on the side stream (see _fork_wgrad)
 
 
-def _fork_wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, gy_amax=None, x_amax=None, x_presplit=False):
+def _fork_wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, gy_amax=None, x_amax=None, x_presplit=False, gy_presplit=False):
     """_wgrad on the side stream behind everything enqueued on the main stream so far.  With a sink the gradient lands in
     the flat buffer and is joined later (join_side_stream); without one the tensor is returned after an immediate join.
 
@@ -116,7 +127,7 @@ def _fork_wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, gy_amax=None, 
     _STREAM_OVERRIDE = side
     try:
         dw = _wgrad(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=False, gy_amax=gy_amax, x_amax=x_amax, keep=keep,
-                    x_presplit=x_presplit)
+                    x_presplit=x_presplit, gy_presplit=gy_presplit)
     finally:
         _STREAM_OVERRIDE = None
     ev = torch.cuda.Event()
@@ -761,7 +772,7 @@ def _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, 
 
 
 def _wgrad_sf16(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, gy_amax=None, x_amax=None, keep=None,
-                x_presplit=False):
+                x_presplit=False, gy_presplit=False):
     """x_presplit: x holds split-f16 operand pairs (conv1_act_sf16) scaled by x_amax -- no input transform, plain-copy staging."""
     nfl = _lib.lib().sed_wgrad_sf16_partial_floats(B, H, W, Cin, Cout)
     if nfl <= 0:
@@ -782,7 +793,8 @@ def _wgrad_sf16(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, g
                 2.0 * 9 * B * H * W * Cin * Cout):
         _call("sed_conv3x3_wgrad_sf16", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
               _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None,
-              _ptr(gy_amax), _ptr(x_amax), _sf16_err_ptr(), _sf16_err_dev_ptr(x.device), 1 if x_presplit else 0, _stream())
+              _ptr(gy_amax), _ptr(x_amax), _sf16_err_ptr(), _sf16_err_dev_ptr(x.device),
+              (1 if x_presplit else 0) | (2 if gy_presplit else 0), _stream())
     return _ret(sink, dw) if signal else (None if sink is not None else dw)
 
 
@@ -797,11 +809,11 @@ def _wgrad_algo(H, W, Cin, Cout):
 
 
 def _wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, gy_amax=None, x_amax=None, keep=None,
-           x_presplit=False):
+           x_presplit=False, gy_presplit=False):
     if _wgrad_algo(H, W, Cin, Cout) == 3:
         return _wgrad_sf16(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=signal, gy_amax=gy_amax, x_amax=x_amax,
-                           keep=keep, x_presplit=x_presplit)
-    if x_presplit:
+                           keep=keep, x_presplit=x_presplit, gy_presplit=gy_presplit)
+    if x_presplit or gy_presplit:
         raise RuntimeError("split-f16 operand pairs can only feed the split-f16 weight-gradient kernel")
     if USE_WINOGRAD >= 2 and W in (8, 16, 32, 64) and Cin % 32 == 0 and Cout % 64 == 0:
         return _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=signal, keep=keep)
@@ -954,7 +966,7 @@ def act_amax_full(y, st):
 
 
 def conv3x3_sf16(x, pack, B, H, W, Cin, Cout, in_st=None, epi=0, partials=None, yprev=None, p_st=None, x_amax=None,
-                 minmax=None, presplit=False):
+                 minmax=None, presplit=False, out_amax=None):
     """y = conv3x3(relu(scale*x + shift) or x) on the f16 MFMA pipe with split operands; x NHWC fp32 -> y NHWC fp32.
     x_amax: device scalar = amax of the operand as the MFMAs see it (None: computed here by a pass over x);
     minmax: optional [nparts][2][Cout] buffer that receives the per-part range of y (for act_amax of the next conv)."""
@@ -971,7 +983,7 @@ def conv3x3_sf16(x, pack, B, H, W, Cin, Cout, in_st=None, epi=0, partials=None, 
               _ptr(partials), _ptr(yprev), _ptr(p_st.scale) if p_st is not None else None,
               _ptr(p_st.shift) if p_st is not None else None, _ptr(p_st.mean) if p_st is not None else None,
               _ptr(p_st.invstd) if p_st is not None else None, _ptr(x_amax), _ptr(minmax), _sf16_err_ptr(),
-              _sf16_err_dev_ptr(x.device), 1 if presplit else 0, _stream())
+              _sf16_err_dev_ptr(x.device), 1 if presplit else 0, _ptr(out_amax), _stream())
     return y
 
 
@@ -995,12 +1007,13 @@ def _conv_fwd_like(x, w_oihw, B, H, W, Cin, Cout, dgrad=False, **kw):
     minmax = kw.pop("minmax", None)
     packs = kw.pop("packs", None)                    # (forward, dgrad) split-f16 packs of w_oihw, when the caller holds them
     presplit = kw.pop("presplit", False)
+    out_amax = kw.pop("out_amax", None)
     if algo == 3:
         pack = packs[1 if dgrad else 0] if packs is not None else None
         if pack is None:
             pack = sf16_packs(w_oihw, dgrad)[1 if dgrad else 0]
-        return conv3x3_sf16(x, pack, B, H, W, Cin, Cout, x_amax=x_amax, minmax=minmax, presplit=presplit, **kw)
-    if presplit:
+        return conv3x3_sf16(x, pack, B, H, W, Cin, Cout, x_amax=x_amax, minmax=minmax, presplit=presplit, out_amax=out_amax, **kw)
+    if presplit or out_amax is not None:
         raise RuntimeError("split-f16 operand pairs can only feed the split-f16 convolution kernel")
     if algo == 2:
         uf, ud = _pack_wino2(w_oihw, want_f=not dgrad, want_d=dgrad)
@@ -1031,13 +1044,23 @@ def _conv_parts(B, H, W, Cin, Cout):
     return P, L.sed_conv_rows_per_part(M, Cout), P * 2 * Cout
 
 
+def block_out_pairs_ok(training, pool_mode, ph, pw, H, W, Cout):
+    """Will ConvBlockFn(..., out_pairs=True) really write its pooled output as operand pairs?  (Asked by the module, which
+    must tell the next block; decided by the same rule inside the Function.  Both add "a backward pass will follow": the module
+    from torch.is_grad_enabled(), the Function -- whose forward always runs with grad mode off -- from its no_backward flag.)"""
+    return bool(ACT_PAIRS and GRAD_PAIRS and USE_SF16 and training and pool_mode == 0 and ph * pw > 1
+                and POOL_BWD_WINDOWED and _conv_algo(H, W, Cout, Cout) == 3 and _wgrad_algo(H, W, Cout, Cout) == 3
+                and _conv_algo(H // ph, W // pw, Cout, 2 * Cout) == 3 and _wgrad_algo(H // ph, W // pw, Cout, 2 * Cout) == 3)
+
+
 class ConvBlockFn(torch.autograd.Function):
     """One reference ConvBlock (models.py:99-115, pool_type='avg'), NHWC, training or eval.
     x (B,H,W,Cin) -> (B,H//ph,W//pw,Cout).  Only the two raw conv outputs are saved; BN+ReLU is recomputed
     on the fly by the consumers."""
 
     @staticmethod
-    def forward(ctx, x, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, training, ph, pw, x_amax=None, pool_mode=0, no_backward=False):
+    def forward(ctx, x, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, training, ph, pw, x_amax=None, pool_mode=0, no_backward=False,
+                x_pairs=False, out_pairs=False):
         """Returns (out, out_amax): out_amax = device amax vector of `out` for the next block's split-f16 scale (x_amax
         there).  pool_mode: 0 = 'avg' (every model), 1 = 'max', 2 = 'avg+max' (models.py:104-111).  no_backward: the caller
         runs under torch.no_grad() (the Function cannot see that itself): nothing is kept for a backward pass and the
@@ -1052,7 +1075,11 @@ class ConvBlockFn(torch.autograd.Function):
         M = B * H * W
         w1c, w2c = _f32c(w1), _f32c(w2)
         # split-f16 operand scales come from the amax of each operand, left on the device by its producer
+        # x_pairs: x holds split-f16 operand pairs (the previous block's pooled output, scaled by x_amax); out_pairs: write ours so
         sf_c1 = Cin != 1 and _conv_algo(H, W, Cin, Cout) == 3
+        if x_pairs and not (sf_c1 and x_amax is not None and (not training or _wgrad_algo(H, W, Cin, Cout) == 3)):
+            raise RuntimeError("operand pairs can only feed the split-f16 kernels (and come with the amax they were scaled by)")
+        out_pairs = bool(out_pairs) and not no_backward and block_out_pairs_ok(training, pool_mode, ph, pw, H, W, Cout)
         need_xa = sf_c1 or (training and Cin != 1 and _wgrad_algo(H, W, Cin, Cout) == 3)
         need_a1 = _conv_algo(H, W, Cout, Cout) == 3 or (training and _wgrad_algo(H, W, Cout, Cout) == 3)
         if need_xa and x_amax is None:
@@ -1065,6 +1092,7 @@ class ConvBlockFn(torch.autograd.Function):
         pk2 = sf16_packs(w2c, bool(training)) if _conv_algo(H, W, Cout, Cout) == 3 else None
         # conv1 (+ statistics, + per-channel output range for the amax of relu(bn1(y1)))
         mm1 = None
+        keep_mm1 = None
         b1_pairs = (B1_ACT_PAIRS and Cin == 1 and training and not no_backward and USE_SF16 and pool_mode == 0
                     and _conv_algo(H, W, Cout, Cout) == 3 and _wgrad_algo(H, W, Cout, Cout) == 3 and pk2 is not None
                     and pk2[1] is not None)
@@ -1092,8 +1120,9 @@ class ConvBlockFn(torch.autograd.Function):
             part1 = torch.empty((nf1,), dtype=torch.float32, device=dev) if training else None
             if need_a1 and sf_c1:
                 mm1 = torch.empty((np1, 2, Cout), dtype=torch.float32, device=dev)
+                keep_mm1 = (mm1, np1)                    # backward: the range of y1 bounds bn1's backward output (GRAD_PAIRS)
             y1 = _conv_fwd_like(x, w1c, B, H, W, Cin, Cout, epi=1 if training else 0, partials=part1, x_amax=x_amax, minmax=mm1,
-                                packs=pk1)
+                                packs=pk1, presplit=bool(x_pairs))
         if not b1_pairs:
             st1 = bn_finalize(part1, np1, rpp1, M, g1, b1, rm1, rv1) if training else bn_eval_affine(g1, b1, rm1, rv1)
             a1 = None
@@ -1115,8 +1144,12 @@ class ConvBlockFn(torch.autograd.Function):
         # conv2 over relu(bn1(y1)) computed on the fly (+ statistics)
         np2, rpp2, nf2 = _conv_parts(B, H, W, Cout, Cout)
         part2 = torch.empty((nf2,), dtype=torch.float32, device=dev) if training else None
+        keep_mm2 = None
+        if (GRAD_PAIRS and training and not no_backward and pool_mode == 0 and pk2 is not None
+                and _wgrad_algo(H, W, Cout, Cout) == 3):
+            keep_mm2 = _amax_buf(dev)        # amax of y2, published by conv2's epilogue: bounds bn2's backward output
         y2 = _conv_fwd_like(y1, w2c, B, H, W, Cout, Cout, in_st=None if b1_pairs else st1, epi=1 if training else 0,
-                            partials=part2, x_amax=a1, packs=pk2, presplit=b1_pairs)
+                            partials=part2, x_amax=a1, packs=pk2, presplit=b1_pairs, out_amax=keep_mm2)
         st2 = bn_finalize(part2, np2, rpp2, M, g2, b2, rm2, rv2) if training else bn_eval_affine(g2, b2, rm2, rv2)
         out = torch.empty((B, H // ph, W // pw, Cout), dtype=torch.float32, device=dev)
         out_amax = _amax_buf(dev)
@@ -1124,6 +1157,12 @@ class ConvBlockFn(torch.autograd.Function):
         if pool_mode != 0:
             _call("sed_bn_relu_pool_fwd_mode", _ptr(y2), B, H, W, Cout, ph, pw, int(pool_mode), _ptr(st2.scale), _ptr(st2.shift),
                   _ptr(out), _ptr(out_amax), _stream())
+        elif out_pairs and keep_mm2 is not None:
+            # the pooled output as split-f16 operand pairs, scaled by a bound of its amax known before the pass
+            cnt = torch.empty((B, H // ph, W // pw, Cout), dtype=torch.uint8, device=dev)
+            _call("sed_act_bound", _ptr(keep_mm2), _ptr(st2.scale), _ptr(st2.shift), Cout, _ptr(out_amax), _stream())
+            _call("sed_bn_relu_pool_fwd_cnt_pairs", _ptr(y2), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift), _ptr(out),
+                  _ptr(cnt), _ptr(out_amax), _stream())
         elif training and POOL_BWD_WINDOWED and ph * pw > 1:
             # per-window ReLU counts: with them backward pass 1 runs on the pooled tensors and never reads y2
             cnt = torch.empty((B, H // ph, W // pw, Cout), dtype=torch.uint8, device=dev)
@@ -1137,6 +1176,9 @@ class ConvBlockFn(torch.autograd.Function):
         else:
             ctx.save_for_backward(x, y1, y2, w1c, w2c)
         ctx.b1_pairs = b1_pairs
+        ctx.x_pairs = bool(x_pairs)
+        ctx.out_bound = out_amax if (out_pairs and keep_mm2 is not None) else None
+        ctx.mm1, ctx.mm2 = (keep_mm1 if GRAD_PAIRS and training else None), keep_mm2
         ctx.st1, ctx.st2, ctx.pool, ctx.training, ctx.pool_mode = st1, st2, (ph, pw), bool(training), int(pool_mode)
         ctx.xa, ctx.a1 = x_amax, a1
         ctx.pk1, ctx.pk2 = pk1, pk2
@@ -1163,7 +1205,7 @@ class ConvBlockFn(torch.autograd.Function):
             part = torch.empty((npmax, 2, Cout), dtype=torch.float32, device=dev)
             _call("sed_bn_relu_pool_bwd_reduce_auto", _ptr(y2), _ptr(g_out), _ptr(pooled), _ptr(cnt), B, H, W, Cout, ph, pw,
                   _ptr(st2.scale), _ptr(st2.shift), _ptr(st2.mean), _ptr(st2.invstd), _ptr(gam), _ptr(bet), POOL_BWD_GAMMA_MIN,
-                  _ptr(part), ctypes.byref(n), _stream())
+                  _ptr(part), ctypes.byref(n), _ptr(ctx.out_bound), _stream())
             del pooled, cnt, win
         else:
             rpb = _lib.lib().sed_pool_bwd_rows_per_block(M)
@@ -1175,9 +1217,26 @@ class ConvBlockFn(torch.autograd.Function):
         dg2, db2, coef2 = bn_bwd_finalize(part, n.value, M, st2, batch_stats=ctx.training, sinks=(sk[6], sk[7]))
         gy2 = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
         sf2 = _conv_algo(H, W, Cout, Cout) == 3 or _wgrad_algo(H, W, Cout, Cout) == 3   # split-f16 consumers scale by the amax
-        amax2 = _amax_buf(dev) if sf2 else None
-        _call("sed_bn_relu_pool_bwd_apply_mode", _ptr(y2), _ptr(g_out), B, H, W, Cout, ph, pw, ctx.pool_mode, _ptr(st2.scale),
-              _ptr(st2.shift), _ptr(coef2), _ptr(gy2), _ptr(amax2), _stream())
+        # gradients as operand pairs: both consumers of gy2 (conv2's dgrad and weight gradient) must be the split-f16 kernels
+        pair2 = (ctx.mm2 is not None and ctx.pool_mode == 0 and _conv_algo(H, W, Cout, Cout) == 3
+                 and _wgrad_algo(H, W, Cout, Cout) == 3)
+        if pair2:
+            ent = _GRAD_AMAX.pop(g_out.data_ptr(), None)
+            g_amax = ent[0] if (ent is not None and ent[1] == g_out.numel()) else amax_of(g_out)
+            amax2 = _amax_buf(dev)                       # an upper BOUND of max |gy2|: the scale the pairs are written with
+            _call("sed_grad_bound", None, 0, Cout, _ptr(coef2), _ptr(g_amax), 1.0 / float(ph * pw), _ptr(amax2), _ptr(ctx.mm2), _stream())
+            _call("sed_bn_relu_pool_bwd_apply_pairs", _ptr(y2), _ptr(g_out), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift),
+                  _ptr(coef2), _ptr(gy2), _ptr(amax2), _stream())
+        else:
+            amax2 = _amax_buf(dev) if sf2 else None
+            _call("sed_bn_relu_pool_bwd_apply_mode", _ptr(y2), _ptr(g_out), B, H, W, Cout, ph, pw, ctx.pool_mode, _ptr(st2.scale),
+                  _ptr(st2.shift), _ptr(coef2), _ptr(gy2), _ptr(amax2), _stream())
+        if len(_GRAD_AMAX) > 8:
+            _GRAD_AMAX.clear()
+        # will gy1 (bn1's backward output) be written as pairs?  Its consumers: conv1's dgrad and weight gradient (Cin != 1)
+        pair1 = (Cin != 1 and ctx.mm1 is not None and _wgrad_algo(H, W, Cin, Cout) == 3
+                 and (not ctx.needs_input_grad[0] or _conv_algo(H, W, Cout, Cin) == 3))
+        d_amax = _amax_buf(dev) if pair1 else None       # amax of conv2's (masked) dgrad output, published by its epilogue
         # conv2: dgrad fused with relu-mask + BN1 backward sums, then the weight gradient (operand relu(bn1(y1)) on the
         # fly).  With gradient sinks the weight gradients run on the side stream: conv2's beside BN1's backward passes
         # below, conv1's beside the NEXT block's pool backward (joined there, right here, before its first MFMA kernel).
@@ -1194,21 +1253,27 @@ class ConvBlockFn(torch.autograd.Function):
             with _timed("conv3x3_sf16_mfma(fwd+dgrad)|%d->%d@%dx%d epi4" % (Cout, Cout, H, W), 2.0 * 9 * B * H * W * Cout * Cout):
                 _call("sed_conv3x3_sf16_dgrad_b1", _ptr(gy2), _ptr(wpd), _ptr(wsd), _ptr(gy1), B, H, W, Cout, Cout, _ptr(partb),
                       _ptr(st1.scale), _ptr(st1.shift), _ptr(st1.mean), _ptr(st1.invstd), _ptr(x), _ptr(w1), _ptr(amax2),
-                      _sf16_err_ptr(), _sf16_err_dev_ptr(dev), _stream())
+                      _sf16_err_ptr(), _sf16_err_dev_ptr(dev), 1 if pair2 else 0, None, _stream())
         else:
             gy1 = _conv_fwd_like(gy2, w2, B, H, W, Cout, Cout, dgrad=True, epi=2, partials=partb, yprev=y1, p_st=st1, x_amax=amax2,
-                                 packs=ctx.pk2)
+                                 packs=ctx.pk2, presplit=pair2, out_amax=d_amax)
         w_in_st = None if b1_pairs else st1
         if fork and sk[5] is not None:
-            dw2 = _fork_wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=w_in_st, sink=sk[5], gy_amax=amax2, x_amax=ctx.a1, x_presplit=b1_pairs)
+            dw2 = _fork_wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=w_in_st, sink=sk[5], gy_amax=amax2, x_amax=ctx.a1, x_presplit=b1_pairs,
+                              gy_presplit=pair2)
         else:
-            dw2 = _wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=w_in_st, sink=sk[5], gy_amax=amax2, x_amax=ctx.a1, x_presplit=b1_pairs)
+            dw2 = _wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=w_in_st, sink=sk[5], gy_amax=amax2, x_amax=ctx.a1, x_presplit=b1_pairs,
+                         gy_presplit=pair2)
         del gy2
         dg1, db1, coef1 = bn_bwd_finalize(partb, npb, M, st1, batch_stats=ctx.training, sinks=(sk[1], sk[2]))
         # conv1
         gx = None
         amax1 = None
-        if Cin != 1:
+        if Cin != 1 and pair1:
+            amax1 = _amax_buf(dev)                       # BOUND of max |a*gy1 + b*y1 + c| from the range of y1 and the amax of gy1
+            _call("sed_grad_bound", _ptr(ctx.mm1[0]), ctx.mm1[1], Cout, _ptr(coef1), _ptr(d_amax), 1.0, _ptr(amax1), None, _stream())
+            _call("sed_bn_bwd_apply_pairs", _ptr(gy1), _ptr(y1), M, Cout, _ptr(coef1), _ptr(amax1), _stream())
+        elif Cin != 1:
             if (ctx.needs_input_grad[0] and _conv_algo(H, W, Cout, Cin) == 3) or _wgrad_algo(H, W, Cin, Cout) == 3:
                 amax1 = _amax_buf(dev)
             _call("sed_bn_bwd_apply", _ptr(gy1), _ptr(y1), M, Cout, _ptr(coef1), _ptr(amax1), _stream())
@@ -1227,12 +1292,18 @@ class ConvBlockFn(torch.autograd.Function):
         else:
             join_side_stream()                         # conv2's weight gradient is done before the next MFMA kernel starts
             if ctx.needs_input_grad[0]:
-                gx = _conv_fwd_like(gy1, w1, B, H, W, Cout, Cin, dgrad=True, epi=0, x_amax=amax1, packs=ctx.pk1)
+                gx_amax = _amax_buf(dev) if (GRAD_PAIRS and _conv_algo(H, W, Cout, Cin) == 3) else None
+                gx = _conv_fwd_like(gy1, w1, B, H, W, Cout, Cin, dgrad=True, epi=0, x_amax=amax1, packs=ctx.pk1, presplit=pair1,
+                                    out_amax=gx_amax)
+                if gx_amax is not None:                  # the previous block's backward bounds ITS gradient with it
+                    _GRAD_AMAX[gx.data_ptr()] = (gx_amax, gx.numel())
             if fork and sk[0] is not None:
-                dw1 = _fork_wgrad(x, gy1, B, H, W, Cin, Cout, sink=sk[0], gy_amax=amax1, x_amax=ctx.xa)
+                dw1 = _fork_wgrad(x, gy1, B, H, W, Cin, Cout, sink=sk[0], gy_amax=amax1, x_amax=ctx.xa, gy_presplit=pair1,
+                                  x_presplit=ctx.x_pairs)
             else:
-                dw1 = _wgrad(x, gy1, B, H, W, Cin, Cout, sink=sk[0], gy_amax=amax1, x_amax=ctx.xa)
-        return gx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, None, None, None, None, None, None
+                dw1 = _wgrad(x, gy1, B, H, W, Cin, Cout, sink=sk[0], gy_amax=amax1, x_amax=ctx.xa, gy_presplit=pair1,
+                             x_presplit=ctx.x_pairs)
+        return gx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, None, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -151,7 +151,10 @@ class ConvBlock(nn.Module):
         init_bn(self.bn1)
         init_bn(self.bn2)
 
-    def forward(self, input, pool_size=(2, 2), pool_type='avg'):
+    def forward(self, input, pool_size=(2, 2), pool_type='avg', pairs_out=False):
+        """pairs_out (extension, used by the models' trunk between blocks): the output may be written as split-f16 OPERAND PAIRS
+        (ops.ACT_PAIRS) -- same shape and bytes, float32-typed for autograd's sake, but only meaningful to the next ConvBlock,
+        which recognises it by the `_sed_pairs` attribute.  A caller that reads the values must leave it False."""
         if pool_type not in self.POOL_MODES:
             raise Exception('Incorrect argument!')
         # the amax of a block's output (left on the device by its pool kernel) rides on the tensor to the next block, whose
@@ -160,8 +163,12 @@ class ConvBlock(nn.Module):
                                               self.bn1.running_mean, self.bn1.running_var, self.conv2.weight,
                                               self.bn2.weight, self.bn2.bias, self.bn2.running_mean, self.bn2.running_var,
                                               self.training, pool_size[0], pool_size[1], getattr(input, '_sed_amax', None),
-                                              self.POOL_MODES[pool_type], not torch.is_grad_enabled())
+                                              self.POOL_MODES[pool_type], not torch.is_grad_enabled(),
+                                              bool(getattr(input, '_sed_pairs', False)), bool(pairs_out))
         out._sed_amax = out_amax
+        out._sed_pairs = bool(pairs_out) and torch.is_grad_enabled() and ops.block_out_pairs_ok(
+            self.training, self.POOL_MODES[pool_type], pool_size[0], pool_size[1], input.shape[1], input.shape[2],
+            self.conv1.weight.shape[0])
         if self.training and not getattr(self, '_defer_counters', False):
             self.bn1.num_batches_tracked += 1
             self.bn2.num_batches_tracked += 1
@@ -319,9 +326,9 @@ class _Cnn9Base(nn.Module):
             blks = (self.conv_block1, self.conv_block2, self.conv_block3, self.conv_block4)
             ops.prepack_sf16([b.conv1.weight for b in blks[1:]] + [b.conv2.weight for b in blks],
                              self.training and torch.is_grad_enabled())
-        x = self.conv_block1(x, pool_size=(2, 2), pool_type='avg')
-        x = self.conv_block2(x, pool_size=(2, 2), pool_type='avg')
-        x = self.conv_block3(x, pool_size=(2, 2), pool_type='avg')
+        x = self.conv_block1(x, pool_size=(2, 2), pool_type='avg', pairs_out=True)     # (pairs: only when the next block takes them)
+        x = self.conv_block2(x, pool_size=(2, 2), pool_type='avg', pairs_out=True)
+        x = self.conv_block3(x, pool_size=(2, 2), pool_type='avg', pairs_out=True)
         # block 4: pool (1,1) followed by torch.mean(dim=3)  ==  one (1, W) average pool
         x = self.conv_block4(x, pool_size=(1, x.shape[2]), pool_type='avg')
         return x.view(x.shape[0], x.shape[1], x.shape[3])               # (B, T', 512)

@@ -397,3 +397,110 @@ def test_conv1_act_pairs_decode_to_relu_bn_conv1():
               ops._sf16_err_ptr(), ops._sf16_err_dev_ptr(x.device), ops._stream())
     with pytest.raises(ops.NonFiniteOperand):
         ops.check_device_errors(synchronize=True)
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W,ph,pw", [(64, 128, 22, 32, 2, 2), (128, 256, 20, 16, 2, 2), (256, 512, 12, 8, 1, 8), (1, 64, 21, 64, 2, 2)])
+def test_gradients_as_operand_pairs_match_the_fp32_tensors(Cin, Cout, H, W, ph, pw):
+    """ops.GRAD_PAIRS: the BatchNorm-backward apply kernels write gy2 / gy1 as split-f16 pairs scaled by a device-side BOUND
+    of their amax (sed_grad_bound); dgrad and weight-gradient kernels copy them into LDS.  hi and lo are floating-point
+    halves, so a scale that is a few powers of two lower than the exact-amax scale changes nothing but the exponent:
+    every gradient must agree with the fp32-tensor dataflow to rounding noise -- at gradient magnitudes 1e-6 .. 1e+3 --
+    and the bound must really bound (no overflow, nothing non-finite)."""
+    from sound_event_detection_dcase2017_task4_amd import ops
+    B = 3
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(B, H, W, Cin, generator=g).abs_().cuda() if Cin != 1 else torch.randn(B, H, W, 1, generator=g).cuda()
+    base = [(torch.randn(Cout, Cin, 3, 3, generator=g) * (1.5 / np.sqrt(9 * Cin))), 1 + 0.2 * torch.randn(Cout, generator=g),
+            0.2 * torch.randn(Cout, generator=g), 0.1 * torch.randn(Cout, generator=g), 0.5 + torch.rand(Cout, generator=g),
+            (torch.randn(Cout, Cout, 3, 3, generator=g) * (1.5 / np.sqrt(9 * Cout))), 1 + 0.2 * torch.randn(Cout, generator=g),
+            0.2 * torch.randn(Cout, generator=g), 0.1 * torch.randn(Cout, generator=g), 0.5 + torch.rand(Cout, generator=g)]
+    g0 = torch.randn(B, H // ph, W // pw, Cout, generator=g).cuda()
+    prev = (ops.GRAD_PAIRS, ops.USE_SF16)
+    try:
+        ops.USE_SF16 = True
+        for mag in (1.0, 1e-6, 1e3):
+            res = []
+            for flag in (False, True):
+                ops.GRAD_PAIRS = flag
+                params = [t.clone().cuda() for t in base]
+                for i in (0, 1, 2, 5, 6, 7):
+                    params[i].requires_grad_(True)
+                xg = x.clone().requires_grad_(True)
+                out, _ = ops.ConvBlockFn.apply(xg, *params, True, ph, pw)
+                out.backward(g0 * mag)
+                torch.cuda.synchronize()
+                ops.check_device_errors()
+                res.append([xg.grad] + [params[i].grad for i in (0, 1, 2, 5, 6, 7)])
+            for n, a, b in zip(["dx", "dw1", "dgamma1", "dbeta1", "dw2", "dgamma2", "dbeta2"], res[0], res[1]):
+                assert torch.isfinite(b).all(), (n, mag)
+                err = float((a - b).double().norm() / max(float(a.double().norm()), 1e-300))
+                assert err < 2e-6, (n, mag, err)
+    finally:
+        ops.GRAD_PAIRS, ops.USE_SF16 = prev
+
+
+def test_grad_bound_bounds_and_is_tight_enough():
+    """sed_grad_bound >= max |a*dy + b*y + c| over any dy with |dy| <= G * ginv and y inside its per-channel range, and within
+    a small factor of the attained maximum for typical coefficients (it only picks a power-of-two scale)."""
+    from sound_event_detection_dcase2017_task4_amd import ops
+    C, N, nparts = 128, 4096, 16
+    g = torch.Generator().manual_seed(3)
+    y = (torch.randn(N, C, generator=g) * (0.5 + torch.rand(C, generator=g)) + torch.randn(C, generator=g)).cuda()
+    dy = (torch.randn(N, C, generator=g) * 3e-3).cuda()
+    coef = torch.stack([1 + 0.3 * torch.randn(C, generator=g), 1e-3 * torch.randn(C, generator=g), 1e-3 * torch.randn(C, generator=g)]).cuda()
+    yp = y.view(nparts, N // nparts, C)
+    mm = torch.stack([yp.max(1)[0], yp.min(1)[0]], dim=1).contiguous()           # [nparts][2][C]
+    G = ops.amax_of(dy)
+    out = ops._amax_buf(y.device)
+    ops._call("sed_grad_bound", ops._ptr(mm), nparts, C, ops._ptr(coef), ops._ptr(G), 1.0, ops._ptr(out), None, ops._stream())
+    bound = float(out.max())
+    true = float((coef[0] * dy + coef[1] * y + coef[2]).abs().max())
+    assert true <= bound <= 4.0 * true, (true, bound)
+    out2 = ops._amax_buf(y.device)                      # the looser form: |y| <= amax(y) for every channel
+    ops._call("sed_grad_bound", None, 0, C, ops._ptr(coef), ops._ptr(G), 1.0, ops._ptr(out2), ops._ptr(ops.amax_of(y)), ops._stream())
+    assert bound <= float(out2.max()) <= 8.0 * true
+
+
+@pytest.mark.parametrize("mt", ["Cnn_9layers_FrameAvg", "Cnn_9layers_Gru_FrameAtt"])
+def test_operand_pair_dataflows_leave_a_training_step_unchanged(mt):
+    """Whole model, one training step: with gradients and pooled block outputs written as operand pairs (ops.GRAD_PAIRS,
+    ops.ACT_PAIRS) -- and with block 1's activation pairs (ops.B1_ACT_PAIRS) -- loss, outputs and every gradient equal the
+    fp32-tensor dataflow's to rounding noise (a pair differs from the fp32 value it replaces by 2^-22 of the tensor's amax
+    bound at most, and only the power-of-two scale depends on how tight that bound is)."""
+    from oracle import model as om
+    from sound_event_detection_dcase2017_task4_amd import ops
+    from sound_event_detection_dcase2017_task4_amd.optim import FusedAdamAmsgrad
+    from sound_event_detection_dcase2017_task4_amd.pytorch import models
+    from sound_event_detection_dcase2017_task4_amd.pytorch.losses import clip_bce
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy((rs.randn(8, 64000) * 0.1).astype(np.float32)).cuda()
+    y = torch.from_numpy((rs.rand(8, 17) < 0.2).astype(np.float32)).cuda()
+    stripes = torch.zeros((8, 8), dtype=torch.int32)
+    prev = (ops.GRAD_PAIRS, ops.ACT_PAIRS, ops.B1_ACT_PAIRS, ops.USE_SF16)
+    res = []
+    try:
+        ops.USE_SF16 = True
+        for gp, ap, b1 in ((False, False, False), (True, False, False), (True, True, False), (True, True, True)):
+            ops.GRAD_PAIRS, ops.ACT_PAIRS, ops.B1_ACT_PAIRS = gp, ap, b1
+            m = getattr(models, mt)(32000, 1024, 320, 64, 50, 14000, 17)
+            m.load_state_dict(om.recipe_state(mt, 4))
+            m = m.cuda().train()
+            opt = FusedAdamAmsgrad(m, lr=1e-3)
+            out = m(x, None, specaug_stripes=stripes)
+            loss = clip_bce(out, {"target": y})
+            opt.zero_grad(); loss.backward()
+            torch.cuda.synchronize()
+            ops.check_device_errors()
+            res.append((float(loss), out["clipwise_output"].detach().clone(), opt.flat_grad.clone(), opt.offsets, [n for n, p in m.named_parameters() if p.requires_grad],
+                        [p.numel() for p in m.parameters() if p.requires_grad]))
+    finally:
+        ops.GRAD_PAIRS, ops.ACT_PAIRS, ops.B1_ACT_PAIRS, ops.USE_SF16 = prev
+    ref = res[0]
+    for k, r in enumerate(res[1:], start=1):
+        assert abs(r[0] - ref[0]) < 2e-6 and float((r[1] - ref[1]).abs().max()) < 2e-6, k
+        for name, off, n in zip(ref[4], ref[3], ref[5]):
+            a, b = ref[2][off:off + n].double(), r[2][off:off + n].double()
+            if float(a.norm()) < 1e-6:          # structurally zero gradients (attention shift invariance): rounding noise only
+                assert float((a - b).norm()) < 1e-6, (k, name)
+                continue
+            assert float((a - b).norm() / a.norm()) < 5e-5, (k, name, float((a - b).norm() / a.norm()))
