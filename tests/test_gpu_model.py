@@ -12,9 +12,13 @@ pytestmark = pytest.mark.gpu
 from oracle import frontend as ofe
 from oracle import model as om
 
-# per (model, convolution path) floor of the gradient gate, where it is NOT the common 2e-3: none at the moment (round 3 let the
-# split-f16 path have 3e-3 everywhere)
-GRAD_FLOOR = {}
+# per (model, convolution path) floor of the gradient gate, where it is NOT the common 2e-3 (round 3 let the split-f16 path have
+# 3e-3 everywhere).  FrameMax: arg-max pooling sends the whole gradient of a clip and class through ONE frame, so a single ReLU
+# unit of block 4 whose pre-activation is within rounding distance of zero -- active in one fp32 evaluation, inactive in
+# another -- moves every tensor below it by 1.5e-3 .. 2.8e-3 (profiles/r02/grad_report_FrameMax.txt; the reference's own float32
+# run differs from its float64 run the same way).  Which evaluation flips is decided by the last bit: with the round-4 operand
+# pairs the split-f16 path reads 2.1e-3 .. 2.6e-3 on block 1-2 tensors of this fixture, the fp32 path stays below 2e-3.
+GRAD_FLOOR = {("Cnn_9layers_FrameMax", "sf16"): 3e-3}
 SEEDS = {mt: i + 1 for i, mt in enumerate(om.MODEL_TYPES)}
 CTOR = (32000, 1024, 320, 64, 50, 14000, 17)
 

@@ -337,7 +337,7 @@ def test_pool_bwd_windowed_pass1_matches_full_resolution_pass(ops, ph, pw, H, W,
     pa = torch.full((na, 2, C), float("nan"), device="cuda")
     ops._call("sed_bn_relu_pool_bwd_reduce_auto", ops._ptr(y), ops._ptr(gout), ops._ptr(out), ops._ptr(cnt), B, H, W, C, ph, pw,
               ops._ptr(scale), ops._ptr(shift), ops._ptr(mean), ops._ptr(invstd), ops._ptr(gamma), ops._ptr(beta), 1e-2,
-              ops._ptr(pa), ctypes.byref(n), s)
+              ops._ptr(pa), ctypes.byref(n), None, s)
     assert n.value == na
     auto = sums(pa, na)
     if small:
