@@ -10,7 +10,9 @@ R=$PWD
 OUT=$R/gpurun_out/prof_$ROUND
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-B="python $R/bench.py --no_cpu_baseline --no_extra"
+# Since round 4 bench.py's default workload is the metric's own configuration (bs=32); configs[1] needs --batch_size 256.
+B="python $R/bench.py --no_cpu_baseline --no_extra --batch_size 256"
+B32="python $R/bench.py --no_cpu_baseline --no_extra"
 # Pass 1: the default command (weight gradients on the side stream).  Two kernels then run at once and each one's duration
 # includes the time it waited for CU slots, so kernel-time sums no longer add up to the step; the conv_wino2 kernels (the
 # roofline's dominant family) never run beside another kernel and are unaffected.
@@ -31,9 +33,13 @@ rocprofv3 --kernel-trace --output-format csv -d $OUT/timeline -o t -- $B --steps
 python $R/tools/timeline_overlap.py $OUT/timeline/t_kernel_trace.csv > $OUT/timeline_overlap_default_schedule.txt 2>&1
 rm -rf $OUT/timeline
 # the metric's own batch size (bs=32): serial kernel trace + per-step gap digest + by-shape table
-SED_WGRAD_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_b32 -o bench -- $B --batch_size 32 --steps 6 --warmup 3 > $OUT/bench_line_b32_under_rocprofv3_main_stream_only.json 2> $OUT/stats_b32.err
+SED_WGRAD_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_b32 -o bench -- $B32 --steps 6 --warmup 3 > $OUT/bench_line_b32_under_rocprofv3_main_stream_only.json 2> $OUT/stats_b32.err
 python $R/tools/step_gaps.py $(find $OUT/stats_b32 -name "*kernel_trace.csv") 5 > $OUT/step_digest_b32_main_stream_only.txt 2>&1
 python $R/tools/step_gaps.py $(find $OUT/stats_serial -name "*kernel_trace.csv") 4 > $OUT/step_digest_b256_main_stream_only.txt 2>&1
-$B --batch_size 32 --steps 40 --warmup 5 --by_shape > $OUT/bench_line_b32.json 2> $OUT/by_shape_b32.txt
+$B32 --steps 40 --warmup 5 --by_shape > $OUT/bench_line_b32.json 2> $OUT/by_shape_b32.txt
+for pass in "fetch FETCH_SIZE" "write WRITE_SIZE"; do
+  set -- $pass; name=$1; shift
+  SED_WGRAD_SIDE_STREAM=0 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_b32_$name -o p -- $B32 --steps 1 --warmup 1 > /dev/null 2> $OUT/pmc_b32_$name.err
+done
 find $OUT -name "*kernel_trace.csv" -size +30M -delete
 ls $OUT
