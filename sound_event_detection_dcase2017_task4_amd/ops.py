@@ -67,13 +67,27 @@ def _side_stream(device):
     return st
 
 
+_STREAM_OBJ = {}
+
+
+def _current_stream_obj():
+    """torch.cuda.current_stream() without its 11 us of Python: the Stream object is cached per raw handle."""
+    raw = torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    st = _STREAM_OBJ.get(raw)
+    if st is None:
+        if len(_STREAM_OBJ) > 64:
+            _STREAM_OBJ.clear()
+        st = _STREAM_OBJ[raw] = torch.cuda.current_stream()
+    return st
+
+
 def join_side_stream():
     """Main stream waits for every weight gradient issued on the side stream; their sinks report ready (the bucketed
     all-reduce may fire here) and the tensors they used are released.  Called at the join points of ConvBlockFn.backward
     and once when the backward pass ends."""
     if not _PENDING:
         return
-    main = torch.cuda.current_stream()
+    main = _current_stream_obj()
     pend = list(_PENDING)
     del _PENDING[:]
     for ev, sink, keep in pend:
@@ -94,7 +108,7 @@ def drop_pending_wgrads():
     join): the main stream waits for the side stream, the entries' tensors are released, and NO sink reports ready --
     the gradients of that pass are void.  Called by FusedAdamAmsgrad.zero_grad()."""
     if _PENDING:
-        main = torch.cuda.current_stream()
+        main = _current_stream_obj()
         for ev, sink, keep in _PENDING:
             main.wait_event(ev)
         del _PENDING[:]
@@ -113,7 +127,7 @@ def _fork_wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, gy_amax=None, 
     used torch.cuda.stream(side) + Tensor.record_stream: correct, but the allocator then parks every such block until
     the side stream's events are polled and reserved memory crept from 78 to 223 GB over 200 steps.)"""
     global _STREAM_OVERRIDE
-    main = torch.cuda.current_stream()
+    main = _current_stream_obj()
     side = _side_stream(x.device)
     if _wgrad_algo(H, W, Cin, Cout) == 3:
         # operand amaxes the caller did not bring are taken HERE, on the main stream: their zeroed pool rows (a fill on
@@ -150,9 +164,12 @@ TIMING_ONLY = None
 
 
 class _timed(object):
-    def __init__(self, tag, flops):
-        self.tag, self.flops = tag, flops
-        self.on = TIMING is not None and (TIMING_ONLY is None or tag.startswith(TIMING_ONLY))
+    def __init__(self, fmt, args, flops):
+        # the tag is only formatted while bench.py is timing (21 conv launches per step would pay for the string otherwise)
+        self.on = TIMING is not None
+        if self.on:
+            self.tag, self.flops = (fmt % args if args is not None else fmt), flops
+            self.on = TIMING_ONLY is None or self.tag.startswith(TIMING_ONLY)
 
     def __enter__(self):
         if self.on:
@@ -168,9 +185,10 @@ class _timed(object):
 
 
 def _ptr(t):
+    """Device address for a `void*` / `float*` parameter of the C ABI (plain int: the prototypes installed by _lib convert it)."""
     if t is None:
         return None
-    return ctypes.c_void_p(t.data_ptr())
+    return t.data_ptr()
 
 
 # Small per-step host arrays (mixup lambdas, SpecAugment stripe tables) go up through a ring of PINNED staging buffers with a
@@ -202,8 +220,12 @@ def upload_small(arr, device, dtype=torch.float32, slots=8):
 
 
 def _stream():
-    st = _STREAM_OVERRIDE if _STREAM_OVERRIDE is not None else torch.cuda.current_stream()
-    return ctypes.c_void_p(st.cuda_stream)
+    """hipStream_t the next kernel goes to: the side stream while _STREAM_OVERRIDE is set, else torch's current stream of the
+    current device.  (torch.cuda.current_stream() builds a Stream object through four Python layers: 11 us per call, a third of
+    the host time of a training step at ~100 launches; the raw query is 0.3 us -- tools/host_profile.py.)"""
+    if _STREAM_OVERRIDE is not None:
+        return _STREAM_OVERRIDE.cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _chk_dev(*ts):
@@ -219,9 +241,16 @@ def _f32c(t):
     return t.contiguous()
 
 
+_FN = {}
+
+
 def _call(name, *args):
-    fn = getattr(_lib.lib(), name)
-    _lib.check(fn(*args), name)
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(_lib.lib(), name)
+    rc = fn(*args)
+    if rc:
+        _lib.check(rc, name)
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -522,7 +551,7 @@ def logmel(wave, tables, amin=1e-10):
     if wave.dtype not in (torch.int16, torch.float32):
         wave = wave.float()
     in_bytes = 2 if wave.dtype == torch.int16 else 4
-    with _timed("logmel_frontend", float(B2) * (L * in_bytes + T * 64 * 4)):      # "flops" slot carries ALGORITHMIC BYTES
+    with _timed("logmel_frontend", None, float(B2) * (L * in_bytes + T * 64 * 4)):      # "flops" slot carries ALGORITHMIC BYTES
         _call(name, _ptr(wave), B2, L, _ptr(tables["window"]), _ptr(tables["tw1024t"]),
               _ptr(tables["mel_tasks"]), tables["n_tasks"], _ptr(tables["mel_bands"]), tables["max_band_tasks"],
               _ptr(tables["mel_w"]), tables["mel_nnz"], amin, _ptr(out), _stream())
@@ -671,7 +700,7 @@ class Bn0AugMix(torch.autograd.Function):
 
 def _conv_igemm(x, w_packed, B, H, W, Cin, Cout, in_st=None, epi=0, partials=None, yprev=None, p_st=None):
     y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
-    with _timed("conv3x3_igemm_mfma(fwd+dgrad)|%d->%d@%dx%d epi%d%s" % (Cin, Cout, H, W, epi, "+inT" if in_st is not None else ""),
+    with _timed("conv3x3_igemm_mfma(fwd+dgrad)|%d->%d@%dx%d epi%d%s", (Cin, Cout, H, W, epi, "+inT" if in_st is not None else ""),
                 2.0 * 9 * B * H * W * Cin * Cout):
         _call("sed_conv3x3_igemm", _ptr(x), _ptr(w_packed), _ptr(y), B, H, W, Cin, Cout,
               _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, epi,
@@ -692,7 +721,7 @@ def _pack_wino(w, want_f=True, want_d=False):
 
 def _conv_wino(x, w_wino, B, H, W, Cin, Cout, in_st=None, epi=0, partials=None, yprev=None, p_st=None):
     y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
-    with _timed("conv3x3_wino_mfma(fwd+dgrad)|%d->%d@%dx%d epi%d%s" % (Cin, Cout, H, W, epi, "+inT" if in_st is not None else ""),
+    with _timed("conv3x3_wino_mfma(fwd+dgrad)|%d->%d@%dx%d epi%d%s", (Cin, Cout, H, W, epi, "+inT" if in_st is not None else ""),
                 2.0 * 9 * B * H * W * Cin * Cout):
         _call("sed_conv3x3_wino", _ptr(x), _ptr(w_wino), _ptr(y), B, H, W, Cin, Cout,
               _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, epi,
@@ -719,7 +748,7 @@ def _wino2_partials(B, H, W, C, device):
 
 def _conv_wino2(x, w_wino2, B, H, W, Cin, Cout, in_st=None, epi=0, partials=None, yprev=None, p_st=None):
     y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
-    with _timed("conv3x3_wino2d_mfma(fwd+dgrad)|%d->%d@%dx%d epi%d%s" % (Cin, Cout, H, W, epi, "+inT" if in_st is not None else ""),
+    with _timed("conv3x3_wino2d_mfma(fwd+dgrad)|%d->%d@%dx%d epi%d%s", (Cin, Cout, H, W, epi, "+inT" if in_st is not None else ""),
                 2.0 * 9 * B * H * W * Cin * Cout):
         _call("sed_conv3x3_wino2", _ptr(x), _ptr(w_wino2), _ptr(y), B, H, W, Cin, Cout,
               _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, epi,
@@ -748,7 +777,7 @@ def _wgrad_wino(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, k
     dw = _dst(sink, (Cout, Cin, 3, 3), x.device)
     if keep is not None:
         keep.extend((partial, dw))                   # alive until the side stream has been joined
-    with _timed("conv3x3_wgrad_wino_mfma(+slice reduce)|%d->%d@%dx%d%s" % (Cin, Cout, H, W, "+inT" if in_st is not None else ""),
+    with _timed("conv3x3_wgrad_wino_mfma(+slice reduce)|%d->%d@%dx%d%s", (Cin, Cout, H, W, "+inT" if in_st is not None else ""),
                 2.0 * 9 * B * H * W * Cin * Cout):
         _call("sed_conv3x3_wgrad_wino", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
               _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, _stream())
@@ -764,7 +793,7 @@ def _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, 
     dw = _dst(sink, (Cout, Cin, 3, 3), x.device)
     if keep is not None:
         keep.extend((partial, dw))                   # alive until the side stream has been joined
-    with _timed("conv3x3_wgrad_wino2d_mfma(+slice reduce)|%d->%d@%dx%d%s" % (Cin, Cout, H, W, "+inT" if in_st is not None else ""),
+    with _timed("conv3x3_wgrad_wino2d_mfma(+slice reduce)|%d->%d@%dx%d%s", (Cin, Cout, H, W, "+inT" if in_st is not None else ""),
                 2.0 * 9 * B * H * W * Cin * Cout):
         _call("sed_conv3x3_wgrad_wino2", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
               _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, _stream())
@@ -789,7 +818,7 @@ def _wgrad_sf16(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, g
     dw = _dst(sink, (Cout, Cin, 3, 3), x.device)
     if keep is not None:
         keep.extend((partial, dw))                   # alive until the side stream has been joined
-    with _timed("conv3x3_wgrad_sf16_mfma(+slice reduce)|%d->%d@%dx%d%s" % (Cin, Cout, H, W, "+inT" if in_st is not None else ""),
+    with _timed("conv3x3_wgrad_sf16_mfma(+slice reduce)|%d->%d@%dx%d%s", (Cin, Cout, H, W, "+inT" if in_st is not None else ""),
                 2.0 * 9 * B * H * W * Cin * Cout):
         _call("sed_conv3x3_wgrad_sf16", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
               _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None,
@@ -829,7 +858,7 @@ def _wgrad_direct(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True,
     dw = _dst(sink, (Cout, Cin, 3, 3), x.device)
     if keep is not None:
         keep.extend((partial, dw))                   # alive until the side stream has been joined
-    with _timed("conv3x3_wgrad_mfma(+slice reduce)|%d->%d@%dx%d%s" % (Cin, Cout, H, W, "+inT" if in_st is not None else ""),
+    with _timed("conv3x3_wgrad_mfma(+slice reduce)|%d->%d@%dx%d%s", (Cin, Cout, H, W, "+inT" if in_st is not None else ""),
                 2.0 * 9 * B * H * W * Cin * Cout):
         _call("sed_conv3x3_wgrad", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
               _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, _stream())
@@ -976,7 +1005,7 @@ def conv3x3_sf16(x, pack, B, H, W, Cin, Cout, in_st=None, epi=0, partials=None, 
     if x_amax is None:
         x_amax = act_amax_full(x, in_st) if in_st is not None else amax_of(x)
     y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
-    with _timed("conv3x3_sf16_mfma(fwd+dgrad)|%d->%d@%dx%d epi%d%s" % (Cin, Cout, H, W, epi, "+inT" if in_st is not None else ""),
+    with _timed("conv3x3_sf16_mfma(fwd+dgrad)|%d->%d@%dx%d epi%d%s", (Cin, Cout, H, W, epi, "+inT" if in_st is not None else ""),
                 2.0 * 9 * B * H * W * Cin * Cout):
         _call("sed_conv3x3_sf16", _ptr(x), _ptr(wp), _ptr(wscale), _ptr(y), B, H, W, Cin, Cout,
               _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, epi,
@@ -1250,7 +1279,7 @@ class ConvBlockFn(torch.autograd.Function):
             # need is recomputed from x inside the kernel's epilogue (bit-identical to the tensor it used to read back)
             gy1 = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
             wpd, wsd = ctx.pk2[1]
-            with _timed("conv3x3_sf16_mfma(fwd+dgrad)|%d->%d@%dx%d epi4" % (Cout, Cout, H, W), 2.0 * 9 * B * H * W * Cout * Cout):
+            with _timed("conv3x3_sf16_mfma(fwd+dgrad)|%d->%d@%dx%d epi4", (Cout, Cout, H, W), 2.0 * 9 * B * H * W * Cout * Cout):
                 _call("sed_conv3x3_sf16_dgrad_b1", _ptr(gy2), _ptr(wpd), _ptr(wsd), _ptr(gy1), B, H, W, Cout, Cout, _ptr(partb),
                       _ptr(st1.scale), _ptr(st1.shift), _ptr(st1.mean), _ptr(st1.invstd), _ptr(x), _ptr(w1), _ptr(amax2),
                       _sf16_err_ptr(), _sf16_err_dev_ptr(dev), 1 if pair2 else 0, None, _stream())
