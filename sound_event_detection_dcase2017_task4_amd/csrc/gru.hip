@@ -1,22 +1,28 @@
 // nn.GRU(512, 256, bidirectional) recurrence (reference models.py:529-530, :565-567) as ONE persistent launch per
-// pass for BOTH directions: hidden projection h_prev x W_hh^T on fp32 MFMA + the gate math for all T steps, instead of
+// pass for BOTH directions: hidden projection h_prev x W_hh^T + the gate math for all T steps, instead of
 // T x (a 128x128-tile GEMM launch on 8-24 workgroups, 10-19 us, + a gate launch + two dependent-launch gaps).
 //
 // The recurrence is latency-bound (125 dependent steps of 0.1 GFLOP per direction), so the kernel is laid out for a
 // short per-step critical path, not for MFMA utilisation:
 //  * workgroup = 32 batch rows x 32 hidden units (x 3 gates) of one direction -> (H/32) x ceil(B/32) x 2 = 128
 //    workgroups at B=256, all co-resident (1 per CU); its 8 waves split the K reduction;
-//  * the workgroup's slice of W_hh (96 rows x 256, 96 KB) lives in REGISTERS for the whole sequence (48 VGPRs per lane:
-//    the MFMA k index is permuted consistently for both operands, which a dot product allows, so every lane holds
-//    contiguous float4 runs of its weight row); per step only the 32 x 256 h_prev block is loaded;
-//  * a step of direction d / row block rb depends only on the 8 workgroups (hidden blocks) of the same (d, rb): they
-//    synchronise through one monotonic counter in global memory (release: barrier, agent-scope fence, atomic add;
-//    acquire: bounded spin on the counter, fence, barrier) - no grid-wide barrier.  The members of a group have
-//    linear ids group + 16*jb, i.e. land on one XCD when B = 256;
+//  * the workgroup's slice of W_hh (96 rows x 256) lives in REGISTERS for the whole sequence (48 VGPRs per lane) as
+//    split-f16 operands (round 4): w = (hi + lo) / s with a power-of-two scale per (gate, hidden unit, wave) taken from the
+//    lane pair's own 32 values; per step the 32 x 256 h_prev block is loaded, split the same way (|h| <= 1: fixed scale 2^13)
+//    and multiplied as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 -- exact products, fp32 accumulation, the error of an
+//    fp32 dot product (as in csrc/conv_sf16.hip) at 18 MFMAs of 32 cycles per wave and step instead of 48 fp32 MFMAs of 64
+//    (the MFMA k index is permuted consistently for both operands, which a dot product allows, so every lane reads
+//    contiguous float4 runs);
+//  * a step of direction d / row block rb depends only on the 8 workgroups (hidden blocks) of the same (d, rb).  They hand
+//    over THROUGH THE DATA (round 4): the exchange buffers (h_t forward, dgh_t backward) are pre-filled with a sentinel NaN
+//    by the launcher, producers write their values with agent-scope atomic stores, and every consumer wave polls its own
+//    operand block with `sc0 sc1` loads until no sentinel is left.  Per step that is one store-to-load trip to the coherence
+//    point; the counter protocol of rounds 1-3 (stores -> wait -> barrier -> atomic add -> spin on the counter -> barrier ->
+//    loads) was three such trips in a row.  The members of a group have linear ids group + 16*jb, i.e. land on one XCD at B = 256;
 //  * everything a step needs that does NOT depend on the previous step (gi / g_out / saved gates) is loaded before
 //    the wait.
-// The spin is bounded: a workgroup that never sees its partners (which cannot happen while all workgroups are
-// resident: 128 x 512 threads, 48 KB LDS) gives up after ~1 s and raises the error word instead of hanging the GPU.
+// The spin is bounded: a wave that never sees its operands (which cannot happen while all workgroups are resident:
+// 128 x 512 threads, 48 KB LDS) gives up after ~1 s and raises the error word instead of hanging the GPU.
 #include "common.h"
 #include "sed_hip.h"
 SED_OBJECT_FLAGS(gru)
@@ -24,7 +30,7 @@ SED_OBJECT_FLAGS(gru)
 namespace {
 
 constexpr int GH = 256;                                // hidden size the kernels are built for
-constexpr int GRU_FLAG_INTS = 1024;                    // counters (one per (direction, row block) group) + error word
+constexpr int GRU_FLAG_INTS = 1024;                    // workspace ints: the error word lives at [GRU_MAX_GROUPS]
 constexpr int GRU_MAX_GROUPS = GRU_FLAG_INTS - 1;
 
 __device__ __forceinline__ float gru_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -40,7 +46,7 @@ __device__ __forceinline__ void st_coherent(float* ptr, float2 v) {
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // 16-byte coherent load (system-scope cache policy bits; atomicity is not needed: the data was completed before the
-// counter the reader waited on).  The result is valid only after ld_coherent_wait on the same registers.
+// sentinel disappeared -- each float is checked on its own).  The result is valid only after ld_coherent_wait on the same registers.
 typedef float f4r __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void ld_coherent4(f4r& dst, const float* ptr) {
     asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(dst) : "v"(ptr) : "memory");
@@ -52,26 +58,60 @@ __device__ __forceinline__ void ld_coherent_wait(f4r (&v)[N]) {
     for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));
 }
 
-// Group synchronisation.  arrive: every thread's coherent stores of the step are complete at the barrier (HIP's
-// __syncthreads waits for outstanding memory operations), then one thread bumps the
-// counter.  wait: one thread spins (bounded) until all `target` arrivals are visible, then releases the block.
-__device__ __forceinline__ void group_arrive(int* counter) {
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Hand-over through the data: every exchange buffer is pre-filled with this quiet NaN (a payload no arithmetic produces; a NaN
+// that training itself produces carries the default payload 0x7fc00000) and a consumer's operand block is complete when
+// none of its words is the sentinel.
+constexpr unsigned GRU_SENTINEL = 0x7fc0deadu;
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+// 8 fp32 values (already scaled) -> their (hi, lo) f16 halves as MFMA operands; element i of the operand = value i
+__device__ __forceinline__ void gru_split8(const f4r& u, const f4r& v, float s, half8& hi, half8& lo) {
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    sed_sf_split2(u[0] * s, u[1] * s, h0, l0);
+    sed_sf_split2(u[2] * s, u[3] * s, h1, l1);
+    sed_sf_split2(v[0] * s, v[1] * s, h2, l2);
+    sed_sf_split2(v[2] * s, v[3] * s, h3, l3);
+    const uintx4 h = {h0, h1, h2, h3}, l = {l0, l1, l2, l3};
+    hi = __builtin_bit_cast(half8, h);
+    lo = __builtin_bit_cast(half8, l);
 }
-__device__ __forceinline__ void group_wait(int* counter, int target, int* err, long spin_limit) {
-    if (threadIdx.x == 0) {
-        long spins = 0;
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
-            if ((++spins & 1023) == 0 &&
-                (spins > spin_limit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // give up everywhere, never hang
-                break;
+__device__ __forceinline__ float gru_amax4(const f4r& v) { return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))); }
+__device__ __forceinline__ bool gru_has_sentinel(const f4r& v) {
+    return __float_as_uint(v[0]) == GRU_SENTINEL || __float_as_uint(v[1]) == GRU_SENTINEL ||
+           __float_as_uint(v[2]) == GRU_SENTINEL || __float_as_uint(v[3]) == GRU_SENTINEL;
+}
+// the three exact partial products of one K = 16 slab, small terms first
+__device__ __forceinline__ void gru_mfma3(floatx16& acc, const half8& ahi, const half8& alo, const half8& bhi, const half8& blo) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc, 0, 0, 0);
+}
+
+// Poll this wave's operand block (N x 16 bytes per lane at `ap`) until it holds no sentinel.  Bounded: after `limit` polls,
+// or when another wave has given up, the error word is raised and the block is taken as it is (the launcher's check kernel
+// then overwrites the pass's output with NaN).  `dead` is sticky per wave: a pass that failed stops polling.
+template <int N>
+__device__ __forceinline__ void gru_poll(f4r (&a)[N], const float* ap, int* err, long limit, bool& dead) {
+    long polls = 0;
+    for (;;) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) ld_coherent4(a[q], ap + 4 * q);
+        ld_coherent_wait(a);
+        bool bad = false;
+#pragma unroll
+        for (int q = 0; q < N; ++q) bad |= gru_has_sentinel(a[q]);
+        if (dead || __builtin_amdgcn_ballot_w64(bad) == 0) return;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++polls & 63) == 0 || polls >= limit) {
+            if (polls >= limit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // give up everywhere, never hang
+                dead = true;
+                return;
             }
         }
     }
-    __syncthreads();
 }
 
 struct GruSeqFwdP {
@@ -81,7 +121,7 @@ struct GruSeqFwdP {
     float* hs;                 // [2][T][B][H]
     float* saves;              // [2][T][B][4H] = r, z, n, gh_n
     float* out;                // [B][T][2H]
-    int* flags;                // [ngroups] arrival counters (zeroed by the launcher) + error word at [GRU_MAX_GROUPS]
+    int* flags;                // workspace (zeroed by the launcher): the error word at [GRU_MAX_GROUPS]
     int B, T, ngroups;
     long spin_limit;
 };
@@ -94,17 +134,23 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_kernel(GruSeqFwdP p) {
     const int hf = lane >> 5, l31 = lane & 31;
     const int B = p.B, T = p.T;
     const long bh = (long)B * GH;
-    int* const counter = p.flags + group;
     int* const err = p.flags + GRU_MAX_GROUPS;
 
-    // this lane's part of the weight slice, resident for the whole sequence: gate g, hidden unit j0 + l31, 16 consecutive k
+    // this lane's part of the weight slice, resident for the whole sequence: gate g, hidden unit j0 + l31, 16 consecutive k,
+    // as split-f16 operands scaled by a power of two of the lane pair's own amax (the pair feeds one accumulator column)
     const int kb = wave * 32 + hf * 16;
-    float4 b[3][4];
+    half8 whi[3][2], wlo[3][2];
+    float winv[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
-        const float4* bp = reinterpret_cast<const float4*>(p.w[d] + (long)(g * GH + j0 + l31) * GH + kb);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) b[g][q] = bp[q];
+        const f4r* bp = reinterpret_cast<const f4r*>(p.w[d] + (long)(g * GH + j0 + l31) * GH + kb);
+        const f4r b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+        float am = fmaxf(fmaxf(gru_amax4(b0), gru_amax4(b1)), fmaxf(gru_amax4(b2), gru_amax4(b3)));
+        am = fmaxf(am, __shfl_xor(am, 32, 64));
+        const float sw = sed_sf_scale_of(am);
+        gru_split8(b0, b1, sw, whi[g][0], wlo[g][0]);
+        gru_split8(b2, b3, sw, whi[g][1], wlo[g][1]);
+        winv[g] = (1.0f / sw) * (1.0f / 8192.0f);       // h_prev is scaled by 2^13 (|h| <= 1)
     }
     const int arow = min(r0 + l31, B - 1);             // operand row of this lane (clamped: ragged last row block)
     // output role: accumulator register r = tid >> 5 of the lane pair (2q, 2q+1), q = tid & 31: two adjacent hidden units
@@ -118,6 +164,8 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_kernel(GruSeqFwdP p) {
     for (int g = 0; g < 3; ++g) bias[g] = *reinterpret_cast<const float2*>(p.bhh[d] + g * GH + j);
 
     float2 hlast = make_float2(0.f, 0.f);
+    bool dead = false;
+    const long poll_limit = p.spin_limit > 8 ? (p.spin_limit >> 3) : 1;
     for (int k = 0; k < T; ++k) {
         const int t = d ? T - 1 - k : k;
         const float* h_prev = p.hs + ((long)d * T + (d ? t + 1 : t - 1)) * bh;
@@ -129,27 +177,25 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_kernel(GruSeqFwdP p) {
         float2 gh[3] = {bias[0], bias[1], bias[2]};
         float2 hp = make_float2(0.f, 0.f);
         if (k > 0) {
-            group_wait(counter, 8 * k, err, p.spin_limit);
             f4r a[4];
-            const float* ap = h_prev + (long)arow * GH + kb;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ld_coherent4(a[q], ap + 4 * q);
-            ld_coherent_wait(a);
+            gru_poll(a, h_prev + (long)arow * GH + kb, err, poll_limit, dead);
             hp = hlast;                                // this thread wrote h_{t-1}[row][j, j+1] itself
+            half8 ahi[2], alo[2];
+            gru_split8(a[0], a[1], 8192.0f, ahi[0], alo[0]);
+            gru_split8(a[2], a[3], 8192.0f, ahi[1], alo[1]);
             floatx16 acc[3];
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, b[g][q].x, acc[g], 0, 0, 0);
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, b[g][q].y, acc[g], 0, 0, 0);
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, b[g][q].z, acc[g], 0, 0, 0);
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, b[g][q].w, acc[g], 0, 0, 0);
-                }
+                for (int g = 0; g < 3; ++g) gru_mfma3(acc[g], ahi[m], alo[m], whi[g][m], wlo[g][m]);
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[g][i] *= winv[g];
             // two-phase reduction over the 8 waves: 4..7 -> LDS -> added by 0..3 -> LDS -> summed by the output threads
             if (wave >= 4) {
 #pragma unroll
@@ -186,7 +232,7 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_kernel(GruSeqFwdP p) {
             zz.x = gru_sigmoid(gz.x + gh[1].x); zz.y = gru_sigmoid(gz.y + gh[1].y);
             nn.x = tanhf(gn.x + rr.x * gh[2].x); nn.y = tanhf(gn.y + rr.y * gh[2].y);
             hh.x = (1.0f - zz.x) * nn.x + zz.x * hp.x; hh.y = (1.0f - zz.y) * nn.y + zz.y * hp.y;
-            st_coherent(p.hs + ((long)d * T + t) * bh + (long)row * GH + j, hh);
+            st_coherent(p.hs + ((long)d * T + t) * bh + (long)row * GH + j, hh);      // the hand-over: replaces the sentinel
             hlast = hh;
             *reinterpret_cast<float2*>(p.out + ((long)row * T + t) * 2 * GH + d * GH + j) = hh;
             float* s = p.saves + ((long)d * T + t) * 4 * bh + (long)row * 4 * GH + j;
@@ -195,7 +241,7 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_kernel(GruSeqFwdP p) {
             *reinterpret_cast<float2*>(s + 2 * GH) = nn;
             *reinterpret_cast<float2*>(s + 3 * GH) = gh[2];
         }
-        if (k + 1 < T) group_arrive(counter);
+        if (k > 0 && k + 1 < T) __syncthreads();       // `red` is rewritten by the next step
     }
 }
 
@@ -220,17 +266,25 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqBwdP p) {
     const int hf = lane >> 5, l31 = lane & 31;
     const int B = p.B, T = p.T;
     const long bh = (long)B * GH;
-    int* const counter = p.flags + group;
     int* const err = p.flags + GRU_MAX_GROUPS;
 
     // dh_gemm[b][j] = sum_c dgh_later[b][c] * W_hh[c][j], c over 3H = 768: 96 per wave, 48 consecutive per lane;
-    // this lane's run of row j0 + l31 of W_hh^T is resident for the whole sequence
+    // this lane's run of row j0 + l31 of W_hh^T is resident for the whole sequence as split-f16 operands (scale: a power of two
+    // of the lane pair's own amax -- the pair feeds one accumulator column)
     const int kb = wave * 96 + hf * 48;
-    float4 b[12];
+    half8 whi[6], wlo[6];
+    float winv;
     {
-        const float4* bp = reinterpret_cast<const float4*>(p.wt[d] + (long)(j0 + l31) * 3 * GH + kb);
+        const f4r* bp = reinterpret_cast<const f4r*>(p.wt[d] + (long)(j0 + l31) * 3 * GH + kb);
+        f4r b[12];
+        float am = 0.f;
 #pragma unroll
-        for (int q = 0; q < 12; ++q) b[q] = bp[q];
+        for (int q = 0; q < 12; ++q) { b[q] = bp[q]; am = fmaxf(am, gru_amax4(b[q])); }
+        am = fmaxf(am, __shfl_xor(am, 32, 64));
+        const float sw = sed_sf_scale_of(am);
+#pragma unroll
+        for (int m = 0; m < 6; ++m) gru_split8(b[2 * m], b[2 * m + 1], sw, whi[m], wlo[m]);
+        winv = 1.0f / sw;
     }
     const int arow = min(r0 + l31, B - 1);
     const int r = tid >> 5, lp = (tid & 31) * 2;
@@ -242,6 +296,8 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqBwdP p) {
     // bias gradients (db_ih = column sums of dgi, db_hh = of dgh) accumulate here over the time steps: the two column-sum
     // passes over dgi / dgh (0.44 ms per step at B = 256) disappear
     float2 sb_r = make_float2(0.f, 0.f), sb_z = sb_r, sb_n = sb_r, sb_nr = sb_r;
+    bool dead = false;
+    const long poll_limit = p.spin_limit > 8 ? (p.spin_limit >> 3) : 1;
 
     for (int k = T - 1, done = 0; k >= 0; --k, ++done) {
         const int t = d ? T - 1 - k : k;
@@ -254,23 +310,26 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqBwdP p) {
         if (k > 0) hp = *reinterpret_cast<const float2*>(p.hs + ((long)d * T + (d ? t + 1 : t - 1)) * bh + (long)rowc * GH + j);
         dh.x += dhz.x; dh.y += dhz.y;
         if (done > 0) {
-            group_wait(counter, 8 * done, err, p.spin_limit);
             const float* dgh_later = p.dgh + ((long)d * T + (d ? t - 1 : t + 1)) * 3 * bh;
             f4r a[12];
-            const float* ap = dgh_later + (long)arow * 3 * GH + kb;
+            gru_poll(a, dgh_later + (long)arow * 3 * GH + kb, err, poll_limit, dead);
+            // gradients have no fixed range: one power-of-two scale per wave and step from the amax of its 32 x 96 block
+            float am = 0.f;
 #pragma unroll
-            for (int q = 0; q < 12; ++q) ld_coherent4(a[q], ap + 4 * q);
-            ld_coherent_wait(a);
+            for (int q = 0; q < 12; ++q) am = fmaxf(am, gru_amax4(a[q]));
+            const float sa = sed_sf_scale_of(wave_max(am));
             floatx16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-            for (int q = 0; q < 12; ++q) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, b[q].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, b[q].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, b[q].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, b[q].w, acc, 0, 0, 0);
+            for (int m = 0; m < 6; ++m) {
+                half8 ahi, alo;
+                gru_split8(a[2 * m], a[2 * m + 1], sa, ahi, alo);
+                gru_mfma3(acc, ahi, alo, whi[m], wlo[m]);
             }
+            const float unscale = winv * (1.0f / sa);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] *= unscale;
             if (wave >= 4) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) red[((wave - 4) * 16 + i) * 64 + lane] = acc[i];
@@ -292,7 +351,7 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqBwdP p) {
                 dh.x += v.x; dh.y += v.y;
             }
         }
-        float2 dr_pre, dz_pre, dn_pre, dn_r;
+    float2 dr_pre, dz_pre, dn_pre, dn_r;
 #define SED_GRU_BWD(c)                                                                                          \
     {                                                                                                           \
         const float dn = dh.c * (1.0f - zz.c);                                                                  \
@@ -318,7 +377,7 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqBwdP p) {
             sb_r.x += dr_pre.x; sb_r.y += dr_pre.y; sb_z.x += dz_pre.x; sb_z.y += dz_pre.y;
             sb_n.x += dn_pre.x; sb_n.y += dn_pre.y; sb_nr.x += dn_r.x; sb_nr.y += dn_r.y;
         }
-        if (k > 0) group_arrive(counter);
+        if (done > 0 && k > 0) __syncthreads();       // `red` is rewritten by the next step
     }
     if (p.dbias) {                                     // rows of the block: 16 r x 2 halves per hidden pair -> LDS -> 128 sums
         __syncthreads();
@@ -409,6 +468,9 @@ SED_API int sed_gru_seq_fwd(const float* gi, const float* w_hh_f, const float* w
     if (B <= 0 || T <= 0 || Hd != GH || ngroups > GRU_MAX_GROUPS || ngroups * (GH / 32) > 256) return SED_EINVAL;
     hipError_t e = hipMemsetAsync(ws, 0, GRU_FLAG_INTS * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
+    // the hand-over buffer starts out as sentinels; every word of it is replaced by the kernel
+    e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(hs), (int)GRU_SENTINEL, (size_t)2 * T * B * GH, stream);
+    if (e != hipSuccess) return (int)e;
     GruSeqFwdP p{gi, {w_hh_f, w_hh_b}, {b_hh_f, b_hh_b}, hs, saves, out, reinterpret_cast<int*>(ws), B, T, ngroups, g_spin_limit};
     hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3(ngroups * (GH / 32)), dim3(512), 0, stream, p);
     SED_LAUNCH_CHECK();
@@ -425,6 +487,8 @@ SED_API int sed_gru_seq_bwd(const float* g_out, const float* wt_f, const float* 
     const int ngroups = 2 * sed_cdiv(B, 32);
     if (B <= 0 || T <= 0 || Hd != GH || ngroups > GRU_MAX_GROUPS || ngroups * (GH / 32) > 256) return SED_EINVAL;
     hipError_t e = hipMemsetAsync(ws, 0, GRU_FLAG_INTS * sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(dgh), (int)GRU_SENTINEL, (size_t)2 * T * B * 3 * GH, stream);
     if (e != hipSuccess) return (int)e;
     GruSeqBwdP p{g_out, {wt_f, wt_b}, hs, saves, dgi, dgh, dbias_parts, reinterpret_cast<int*>(ws), B, T, ngroups, g_spin_limit};
     hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(ngroups * (GH / 32)), dim3(512), 0, stream, p);

@@ -21,9 +21,16 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
                                                           float* __restrict__ out, int accumulate) {
     int col = blockIdx.x * 256 + threadIdx.x;
     if (col >= K) return;
-    double s = 0.0;
-    for (long i = 0; i < n; ++i) s += (double)parts[i * ld + col];
-    out[col] = accumulate ? out[col] + (float)s : (float)s;
+    // eight independent fp64 chains (a single dependent chain over the 256 chunk rows of the two-level form took 40 us)
+    double s[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+    long i = 0;
+    for (; i + 8 <= n; i += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += (double)parts[(i + u) * ld + col];
+    }
+    for (int u = 0; i < n; ++i, ++u) s[u] += (double)parts[i * ld + col];
+    const double t = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    out[col] = accumulate ? out[col] + (float)t : (float)t;
 }
 
 // two-level variant for long columns: grid.y chunks -> ws, then the kernel above over ws

@@ -37,6 +37,32 @@ def main():
     w.sync()
     print("host enqueue, un-profiled: %.3f ms/step (B=%d, %s%s)" % (w.host_enqueue_ms(args.steps), args.batch_size, args.model_type,
                                                                    ", HIP graph" if args.hip_graph else ""))
+    # per-phase host time of un-throttled steps (drained device, <= 5 steps)
+    from sound_event_detection_dcase2017_task4_amd import ops
+    from sound_event_detection_dcase2017_task4_amd.pytorch.pytorch_utils import do_mixup
+    if w.graphed is None:
+        for nsteps in (1, 3, 5):
+            w.sync()
+            ph = [0.0] * 5
+            for i in range(nsteps):
+                wave, target = w.pool[i % len(w.pool)]
+                t0 = time.perf_counter()
+                lam = ops.upload_small(w.mixup.get_lambda(w.B2), w.dev, torch.float32)
+                t1 = time.perf_counter()
+                out = w.model(wave, lam)
+                t2 = time.perf_counter()
+                loss = w.loss_func(out, {"target": do_mixup(target, lam)})
+                w.opt.zero_grad()
+                t3 = time.perf_counter()
+                loss.backward()
+                t4 = time.perf_counter()
+                w.opt.step()
+                t5 = time.perf_counter()
+                for k, (a, b) in enumerate(((t0, t1), (t1, t2), (t2, t3), (t3, t4), (t4, t5))):
+                    ph[k] += (b - a) * 1e3 / nsteps
+            print("%d un-throttled step(s): lambda upload %.3f, forward %.3f, loss + zero_grad %.3f, backward %.3f, optimizer %.3f ms"
+                  % ((nsteps,) + tuple(ph)))
+        w.sync()
     dt, _, _ = w.run(40, 2)
     print("step time: %.3f ms (40 steps)" % (dt / 40 * 1e3))
     w.sync()
