@@ -16,7 +16,7 @@
 //  * a step of direction d / row block rb depends only on the 8 workgroups (hidden blocks) of the same (d, rb).  They hand
 //    over THROUGH THE DATA (round 4): the exchange buffers (h_t forward, dgh_t backward) are pre-filled with a sentinel NaN
 //    by the launcher, producers write their values with agent-scope atomic stores, and every consumer wave polls its own
-//    operand block with `sc0 sc1` loads until no sentinel is left.  Per step that is one store-to-load trip to the coherence
+//    operand block with `sc1` (agent-scope) loads until no sentinel is left.  Per step that is one store-to-load trip to the coherence
 //    point; the counter protocol of rounds 1-3 (stores -> wait -> barrier -> atomic add -> spin on the counter -> barrier ->
 //    loads) was three such trips in a row.  The members of a group have linear ids group + 16*jb, i.e. land on one XCD at B = 256;
 //  * everything a step needs that does NOT depend on the previous step (gi / g_out / saved gates) is loaded before
@@ -45,11 +45,11 @@ __device__ __forceinline__ void st_coherent(float* ptr, float2 v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(ptr), __builtin_bit_cast(unsigned long long, v),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// 16-byte coherent load (system-scope cache policy bits; atomicity is not needed: the data was completed before the
+// 16-byte coherent load (agent-scope cache policy: `sc1`, 3 % faster than `sc0 sc1` here; atomicity is not needed: the data was completed before the
 // sentinel disappeared -- each float is checked on its own).  The result is valid only after ld_coherent_wait on the same registers.
 typedef float f4r __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void ld_coherent4(f4r& dst, const float* ptr) {
-    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(dst) : "v"(ptr) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(ptr) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void ld_coherent_wait(f4r (&v)[N]) {
