@@ -136,3 +136,37 @@ def test_supported_asks_the_device(ops):
     assert L.sed_gru_seq_supported(256, 256) == 1 and L.sed_gru_seq_supported(512, 256) == 1
     assert L.sed_gru_seq_supported(513, 256) == 0          # 34 row blocks x 8 = 272 workgroups > 256 CUs
     assert L.sed_gru_seq_supported(256, 128) == 0          # kernels are built for hidden size 256
+
+
+@pytest.mark.parametrize("gscale,wscale", [(1e-8, 0.05), (1.0, 0.3), (1e4, 0.01)])
+def test_split_f16_recurrence_is_magnitude_safe(ops, gscale, wscale):
+    """The hidden projection of the fused recurrence multiplies split-f16 operands (round 4): W_hh with a power-of-two scale per
+    lane pair, h_prev with 2^13, the backward's dgh block with one scale per wave and step taken from its own amax.  Output
+    gradients of 1e-8 ... 1e+4 and small / large recurrent weights (saturating gates at 0.3) against torch.nn.GRU in FLOAT64:
+    forward to 2e-6 absolute, every gradient to 2e-5 relative -- or 1.5x what the fp32-MFMA per-step path measures on the same
+    inputs, where fp32 arithmetic itself is further away (saturating gates)."""
+    B, T = 40, 9
+    g = torch.Generator().manual_seed(11)
+    gru = torch.nn.GRU(512, 256, num_layers=1, bias=True, batch_first=True, bidirectional=True).double()
+    for p in gru.parameters():
+        p.data = (torch.randn(p.shape, generator=g) * wscale).double()
+    x = torch.randn(B, T, 512, generator=g)
+    gy = torch.randn(B, T, 512, generator=g) * gscale
+    xr = x.double().requires_grad_(True)
+    y, _ = gru(xr)
+    y.backward(gy.double())
+    ref = [y.detach(), xr.grad] + [getattr(gru, n).grad for n in NAMES]
+    gru32 = torch.nn.GRU(512, 256, num_layers=1, bias=True, batch_first=True, bidirectional=True)
+    for n in NAMES:
+        getattr(gru32, n).data = getattr(gru, n).data.float()
+    errs, fwd = {}, {}
+    for fused in (True, False):
+        got = run(ops, gru32, x, gy, fused=fused)
+        ops.check_device_errors(synchronize=True)
+        fwd[fused] = (got[0].cpu().double() - ref[0]).abs().max().item()
+        errs[fused] = [rel(a.cpu(), b) for a, b in zip(got[1:], ref[1:])]
+    # the yardstick is the fp32-MFMA per-step path on the same inputs (with 0.3-scale weights the pre-activations reach +-20 and
+    # fp32 arithmetic itself is 3e-5 from float64): the split-f16 recurrence must not be worse than fp32 arithmetic is
+    assert fwd[True] < max(2e-6, 1.5 * fwd[False]), (fwd[True], fwd[False])
+    for e_f, e_s, n in zip(errs[True], errs[False], ["dx"] + NAMES):
+        assert e_f < max(2e-5, 1.5 * e_s), ("fused vs float64", n, e_f, "per-step fp32 MFMA:", e_s)
