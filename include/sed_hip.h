@@ -310,6 +310,17 @@ int sed_gemm_nt(const float* x, const float* w, const float* bias, float* y, lon
                 sed_stream_t stream);
 int sed_gemm_tn(const float* x, const float* gy, float* dw, float* partial, long M, int N, int K,
                 sed_stream_t stream);
+/* The same NT GEMM on the f16 MFMA pipe with split-f16 operands (csrc/gemm_sf16.hip; the arithmetic of sed_conv3x3_sf16: exact
+ * products, fp32 accumulation -- the rounding error of an fp32 dot product): the nn.GRU input projections (models.py:529-530) and
+ * their input gradient.  wp / wscale = the weight matrix w [N][K] pre-split by sed_gemm_pack_sf16 (sed_gemm_pack_sf16_halfs(N, K)
+ * f16 values; wscale: float[sed_amax_slots() + 1] = its amax slots, then its power-of-two scale); x_amax: device amax vector of x
+ * (sed_amax); err_host / err_dev: the found-non-finite words (nullable); out_amax (nullable): amax slots of |y| as written.
+ * Needs N % 128 == 0, K % 32 == 0, M * K * 4 < 2^31 (sed_gemm_nt_sf16_supported); M may be ragged. */
+int sed_gemm_nt_sf16_supported(long M, int N, int K);
+long sed_gemm_pack_sf16_halfs(int N, int K);
+int sed_gemm_pack_sf16(const float* w, int N, int K, float* wscale, void* wp, sed_stream_t stream);
+int sed_gemm_nt_sf16(const float* x, const void* wp, const float* wscale, const float* bias, float* y, long M, int N, int K,
+                     const float* x_amax, int* err_host, int* err_dev, float* out_amax, sed_stream_t stream);
 /* two independent NT GEMMs of one shape in one launch (the two directions of a BiGRU recurrence step) */
 int sed_gemm_nt_pair(const float* x0, const float* x1, const float* w0, const float* w1, const float* bias0,
                      const float* bias1, float* y0, float* y1, long M, int N, int K, sed_stream_t stream);
@@ -353,15 +364,17 @@ int sed_gru_gate_bwd(const float* g_out0, const float* g_out1, long ld_go, const
                      sed_stream_t stream);
 
 /* ---- nn.GRU recurrence, fused (models.py:529-530, :565-567): ONE persistent launch per pass runs all T steps of both
- * directions -- hidden projection h_prev x W_hh^T on fp32 MFMA with the weight slice resident in registers, gate math,
- * and a per-(direction, 32-row block) counter in `ws` that orders the steps among the 8 workgroups sharing the rows
- * (bounded spin, no grid-wide barrier).  Built for Hd = 256 and B <= 512 (all workgroups must be co-resident):
+ * directions -- hidden projection h_prev x W_hh^T on the f16 MFMA pipe with split-f16 operands (the weight slice resident in
+ * registers; fp32-level error), gate math, and a hand-over THROUGH THE DATA among the 8 workgroups sharing a (direction, 32-row
+ * block): hs / dgh are pre-filled with a sentinel NaN by the call and every consumer wave polls its operand block until no
+ * sentinel is left (bounded spin, no grid-wide barrier).  Built for Hd = 256 and B <= 512 (all workgroups must be co-resident):
  * sed_gru_seq_supported; callers use the per-step GEMM + sed_gru_gate_* launches otherwise.
  * Layouts: gi [B][T][6H] (forward gates r,z,n then reverse gates, incl. b_ih), hs [2][T][B][H] hidden states,
  * saves [2][T][B][4H] = r,z,n,gh_n, out [B][T][2H] = concat(forward, reverse).  Backward: g_out [B][T][2H];
  * wt_* = W_hh^T [H][3H]; produces dgi [B][T][6H] and dgh [2][T][B][3H] (gate pre-activation gradients on the input /
  * hidden side; weight and bias gradients are plain GEMMs / column sums over them).
- * ws: sed_gru_seq_ws_floats() floats of scratch (counters; zeroed by the call).
+ * ws: sed_gru_seq_ws_floats() floats of scratch (the give-up word; zeroed by the call).  dgi_amax (nullable): amax slots of |dgi|,
+ * published by the backward recurrence (the operand scale of sed_gemm_nt_sf16 for the input gradient).
  * Run-time failure: the workgroups of a launch wait for each other, so all of them must be resident at once.
  * sed_gru_seq_supported also asks the CURRENT device (CU count, occupancy of both kernels) and answers 0 when they
  * cannot be; if a launch still cannot make progress (CU mask, co-tenant kernel), its bounded spin gives up and a
@@ -378,7 +391,7 @@ int sed_gru_seq_bwd(const float* g_out, const float* wt_f, const float* wt_b, co
                     int B, int T, int Hd, float* dgi, float* dgh,
                     float* dbias_parts /* nullable: [2 directions][ceil(B/32)][4: dr, dz, dn, dn*r][Hd] sums over time and the
                                           32 rows of a block: db_ih = (dr, dz, dn), db_hh = (dr, dz, dn*r) summed over blocks */,
-                    float* ws, int* err_host, sed_stream_t stream);
+                    float* ws, int* err_host, float* dgi_amax, sed_stream_t stream);
 int sed_gru_set_spin_limit(long spins);
 int sed_debug_occupy(int blocks, int lds_bytes, long microseconds, sed_stream_t stream);
 

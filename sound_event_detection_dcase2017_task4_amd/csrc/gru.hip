@@ -253,6 +253,7 @@ struct GruSeqBwdP {
     float* dgi;                // [B][T][6H]
     float* dgh;                // [2][T][B][3H]
     float* dbias;              // nullable: [2 directions][row blocks][4: dr, dz, dn, dn*r][H] sums over (t, the block's rows)
+    float* dgi_amax;           // nullable: amax slots of |dgi| (the operand scale of the split-f16 input-gradient GEMM)
     int* flags;
     int B, T, ngroups;
     long spin_limit;
@@ -296,6 +297,7 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqBwdP p) {
     // bias gradients (db_ih = column sums of dgi, db_hh = of dgh) accumulate here over the time steps: the two column-sum
     // passes over dgi / dgh (0.44 ms per step at B = 256) disappear
     float2 sb_r = make_float2(0.f, 0.f), sb_z = sb_r, sb_n = sb_r, sb_nr = sb_r;
+    float gmax = 0.f;                                  // max |dgi| this thread wrote
     bool dead = false;
     const long poll_limit = p.spin_limit > 8 ? (p.spin_limit >> 3) : 1;
 
@@ -376,9 +378,12 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqBwdP p) {
             st_coherent(gh_o + 2 * GH, dn_r);
             sb_r.x += dr_pre.x; sb_r.y += dr_pre.y; sb_z.x += dz_pre.x; sb_z.y += dz_pre.y;
             sb_n.x += dn_pre.x; sb_n.y += dn_pre.y; sb_nr.x += dn_r.x; sb_nr.y += dn_r.y;
+            gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(dr_pre.x), fabsf(dr_pre.y))),
+                         fmaxf(fmaxf(fabsf(dz_pre.x), fabsf(dz_pre.y)), fmaxf(fabsf(dn_pre.x), fabsf(dn_pre.y))));
         }
         if (done > 0 && k > 0) __syncthreads();       // `red` is rewritten by the next step
     }
+    if (p.dgi_amax) amax_publish_block(p.dgi_amax, gmax);
     if (p.dbias) {                                     // rows of the block: 16 r x 2 halves per hidden pair -> LDS -> 128 sums
         __syncthreads();
         float* o = red + tid * 8;
@@ -483,14 +488,18 @@ SED_API int sed_gru_seq_fwd(const float* gi, const float* w_hh_f, const float* w
 // Whole backward recurrence in one launch (reverse processing order).
 SED_API int sed_gru_seq_bwd(const float* g_out, const float* wt_f, const float* wt_b, const float* hs, const float* saves,
                             int B, int T, int Hd, float* dgi, float* dgh, float* dbias_parts, float* ws, int* err_host,
-                            hipStream_t stream) {
+                            float* dgi_amax, hipStream_t stream) {
     const int ngroups = 2 * sed_cdiv(B, 32);
     if (B <= 0 || T <= 0 || Hd != GH || ngroups > GRU_MAX_GROUPS || ngroups * (GH / 32) > 256) return SED_EINVAL;
     hipError_t e = hipMemsetAsync(ws, 0, GRU_FLAG_INTS * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
     e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(dgh), (int)GRU_SENTINEL, (size_t)2 * T * B * 3 * GH, stream);
     if (e != hipSuccess) return (int)e;
-    GruSeqBwdP p{g_out, {wt_f, wt_b}, hs, saves, dgi, dgh, dbias_parts, reinterpret_cast<int*>(ws), B, T, ngroups, g_spin_limit};
+    if (dgi_amax) {
+        e = sed_amax_clear(dgi_amax, stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    GruSeqBwdP p{g_out, {wt_f, wt_b}, hs, saves, dgi, dgh, dbias_parts, dgi_amax, reinterpret_cast<int*>(ws), B, T, ngroups, g_spin_limit};
     hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(ngroups * (GH / 32)), dim3(512), 0, stream, p);
     SED_LAUNCH_CHECK();
     hipLaunchKernelGGL(gru_seq_check_kernel, dim3(256), dim3(256), 0, stream, reinterpret_cast<const int*>(ws), err_host, 2, dgi,

@@ -1347,6 +1347,38 @@ def gemm_nt(x, w, bias=None):
     return y
 
 
+# Dense layers on the f16 MFMA pipe with split-f16 operands (csrc/gemm_sf16.hip): the nn.GRU input projections and their input
+# gradient.  Same arithmetic contract as the split-f16 convolutions (fp32-level error, scales from device-side amax values, a
+# non-finite operand raises the guard words); falls back to the fp32 MFMA GEMM for shapes it does not take or with USE_SF16 off.
+GEMM_SF16 = os.environ.get("SED_GEMM_SF16", "1") != "0"
+
+
+def gemm_pack_sf16(w):
+    """w [N][K] fp32 -> (split-f16 pack, wscale[65]) for gemm_nt_sf16 (two launches: amax, pack)."""
+    N, K = w.shape
+    wp = torch.empty((int(_lib.lib().sed_gemm_pack_sf16_halfs(N, K)),), dtype=torch.float16, device=w.device)
+    ws = _amax_buf(w.device, AMAX_SLOTS + 1)
+    _call("sed_gemm_pack_sf16", _ptr(w), N, K, _ptr(ws), _ptr(wp), _stream())
+    return wp, ws
+
+
+def gemm_nt_sf16_ok(M, N, K):
+    return bool(GEMM_SF16 and USE_SF16 and _lib.lib().sed_gemm_nt_sf16_supported(M, N, K))
+
+
+def gemm_nt_sf16(x, pack, N, bias=None, x_amax=None, out_amax=None):
+    """y[M][N] = x[M][K] w[N][K]^T (+bias) with w given as its split-f16 pack; x_amax: device amax vector of x (None: one pass)."""
+    M, K = x.shape
+    wp, ws = pack
+    if x_amax is None:
+        x_amax = amax_of(x)
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    with _timed("gemm_nt_sf16_mfma|%dx%dx%d", (M, N, K), 2.0 * M * N * K):
+        _call("sed_gemm_nt_sf16", _ptr(x), _ptr(wp), _ptr(ws), _ptr(bias), _ptr(y), M, N, K, _ptr(x_amax), _sf16_err_ptr(),
+              _sf16_err_dev_ptr(x.device), _ptr(out_amax), _stream())
+    return y
+
+
 def gemm_tn(x, gy, out=None):
     """dw[N][K] = sum_m gy[m][n] x[m][k]."""
     M, K = x.shape
@@ -1589,7 +1621,9 @@ class GruFn(torch.autograd.Function):
     gate launch for BOTH directions (forward at time s, reverse at time T-1-s)."""
 
     @staticmethod
-    def forward(ctx, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_b, w_hh_b, b_ih_b, b_hh_b):
+    def forward(ctx, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_b, w_hh_b, b_ih_b, b_hh_b, x_amax=None):
+        """x_amax (optional): device amax vector of x left by its producer (block 4's pool kernel): the split-f16 input projection
+        takes its operand scale from it instead of a pass over x."""
         _chk_dev(x, w_ih_f)
         x = _f32c(x)
         B, T, I = x.shape
@@ -1600,7 +1634,14 @@ class GruFn(torch.autograd.Function):
         # stacked / transposed weight operands: device copies, rebuilt only when a parameter changed
         w_ih, b_ih, w_ih_t = _cached("gru_ih", (w_ih_f, w_ih_b, b_ih_f, b_ih_b), lambda: _gru_ih_operands(
             w_ih_f, w_ih_b, b_ih_f, b_ih_b))
-        gi = gemm_nt(x.view(B * T, I), w_ih, b_ih).view(B, T, 6 * Hd)                  # (B, T, 6H)
+        sf_proj = gemm_nt_sf16_ok(B * T, 6 * Hd, I) and gemm_nt_sf16_ok(B * T, I, 6 * Hd)
+        if sf_proj:          # input projections of both directions on the f16 MFMA pipe (split-f16 operands); packs cached per step
+            pk_f, pk_t = _cached("gru_ih_sf16", (w_ih_f, w_ih_b), lambda: (gemm_pack_sf16(w_ih), gemm_pack_sf16(w_ih_t)))
+            gi = gemm_nt_sf16(x.view(B * T, I), pk_f, 6 * Hd, b_ih, x_amax=x_amax).view(B, T, 6 * Hd)
+            ctx.pk_t = pk_t
+        else:
+            gi = gemm_nt(x.view(B * T, I), w_ih, b_ih).view(B, T, 6 * Hd)              # (B, T, 6H)
+            ctx.pk_t = None
         hs = torch.empty((2, T, B, Hd), dtype=torch.float32, device=dev)
         saves = torch.empty((2, T, B, 4 * Hd), dtype=torch.float32, device=dev)
         whh = (_f32c(w_hh_f), _f32c(w_hh_b))
@@ -1646,12 +1687,14 @@ class GruFn(torch.autograd.Function):
             transpose_b(w_hh_f.view(1, 3 * Hd, Hd)).view(Hd, 3 * Hd), transpose_b(w_hh_b.view(1, 3 * Hd, Hd)).view(Hd, 3 * Hd)))
         fused = ctx.fused
         dbp = None
+        dgi_amax = None
         if fused:
             ws = torch.empty((_lib.lib().sed_gru_seq_ws_floats(),), dtype=torch.float32, device=dev)
             nrb = (B + 31) // 32
             dbp = torch.empty((2, nrb, 4 * Hd), dtype=torch.float32, device=dev)     # bias-gradient sums per row block
+            dgi_amax = _amax_buf(dev) if ctx.pk_t is not None else None      # amax of dgi, published by the recurrence itself
             _call("sed_gru_seq_bwd", _ptr(g_out), _ptr(wt[0]), _ptr(wt[1]), _ptr(hs), _ptr(saves), B, T, Hd,
-                  _ptr(dgi), _ptr(dgh), _ptr(dbp), _ptr(ws), _ptr(_err_flag()), s)
+                  _ptr(dgi), _ptr(dgh), _ptr(dbp), _ptr(ws), _ptr(_err_flag()), _ptr(dgi_amax), s)
         direct = [torch.empty((2, B, Hd), dtype=torch.float32, device=dev) for _ in range(2)]   # ping-pong
         rec = [torch.empty((2, B, Hd), dtype=torch.float32, device=dev) for _ in range(2)]
         have = False
@@ -1690,10 +1733,13 @@ class GruFn(torch.autograd.Function):
             db_hh_f = _ret(sk[3], col_sums(dgh[0].view(T * B, 3 * Hd), out=_dst(sk[3], (3 * Hd,), dev)))
             db_hh_b = _ret(sk[7], col_sums(dgh[1].view(T * B, 3 * Hd), out=_dst(sk[7], (3 * Hd,), dev)))
             db_ih = col_sums(dgi2)
-        gx = gemm_nt(dgi2, w_ih_t).view(B, T, I)
+        if ctx.pk_t is not None:
+            gx = gemm_nt_sf16(dgi2, ctx.pk_t, I, x_amax=dgi_amax).view(B, T, I)
+        else:
+            gx = gemm_nt(dgi2, w_ih_t).view(B, T, I)
         dw_ih = gemm_tn(x.view(B * T, I), dgi2)                                          # (6H, I)
         return (gx, _put(sk[0], dw_ih[:3 * Hd]), _ret(sk[1], dw_hh_f), _put(sk[2], db_ih[:3 * Hd]), db_hh_f,
-                _put(sk[4], dw_ih[3 * Hd:]), _ret(sk[5], dw_hh_b), _put(sk[6], db_ih[3 * Hd:]), db_hh_b)
+                _put(sk[4], dw_ih[3 * Hd:]), _ret(sk[5], dw_hh_b), _put(sk[6], db_ih[3 * Hd:]), db_hh_b, None)
 
 
 class ClipBceFn(torch.autograd.Function):

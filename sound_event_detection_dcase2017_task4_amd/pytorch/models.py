@@ -331,7 +331,9 @@ class _Cnn9Base(nn.Module):
         x = self.conv_block3(x, pool_size=(2, 2), pool_type='avg', pairs_out=True)
         # block 4: pool (1,1) followed by torch.mean(dim=3)  ==  one (1, W) average pool
         x = self.conv_block4(x, pool_size=(1, x.shape[2]), pool_type='avg')
-        return x.view(x.shape[0], x.shape[1], x.shape[3])               # (B, T', 512)
+        feat = x.view(x.shape[0], x.shape[1], x.shape[3])               # (B, T', 512)
+        feat._sed_amax = getattr(x, '_sed_amax', None)                  # block 4's pool left the amax of its output on the device
+        return feat
 
 
 class _FcHead(_Cnn9Base):
@@ -379,7 +381,8 @@ class _GruMixin(object):
     def _mid(self, feat, dropout_masks=None):
         g = self.gru
         return ops.GruFn.apply(feat, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0, g.weight_ih_l0_reverse,
-                               g.weight_hh_l0_reverse, g.bias_ih_l0_reverse, g.bias_hh_l0_reverse)
+                               g.weight_hh_l0_reverse, g.bias_ih_l0_reverse, g.bias_hh_l0_reverse,
+                               getattr(feat, '_sed_amax', None))
 
 
 class Cnn_9layers_Gru_FrameAvg(_GruMixin, _FcHead):

@@ -504,3 +504,42 @@ def test_operand_pair_dataflows_leave_a_training_step_unchanged(mt):
                 assert float((a - b).norm()) < 1e-6, (k, name)
                 continue
             assert float((a - b).norm() / a.norm()) < 5e-5, (k, name, float((a - b).norm() / a.norm()))
+
+
+@pytest.mark.parametrize("M,N,K,mag", [(1000, 128, 32, 1.0), (4099, 1536, 512, 1.0), (32000, 512, 1536, 1e-6), (777, 256, 96, 1e5)])
+def test_split_f16_gemm_vs_float64(M, N, K, mag):
+    """sed_gemm_nt_sf16 (csrc/gemm_sf16.hip: the GRU input projection and its input gradient) against a float64 matmul: ragged M,
+    one and many K stages, operand magnitudes 1e-6 ... 1e+5 (scales from device-side amax values), bias; relative L2 <= 1e-6 and
+    the worst output column within 2e-6 of its RMS -- the gate of the split-f16 convolutions.  The fp32-MFMA sed_gemm_nt measures
+    3e-7 on the same inputs."""
+    from sound_event_detection_dcase2017_task4_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) * mag).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05 * (1 + 10 * (torch.rand(N, 1, generator=g) < 0.02).float())).cuda()   # a few hot rows
+    bias = (torch.randn(N, generator=g) * mag).cuda()
+    assert ops.gemm_nt_sf16_ok(M, N, K)
+    pack = ops.gemm_pack_sf16(w)
+    out_amax = ops._amax_buf(x.device)
+    y = ops.gemm_nt_sf16(x, pack, N, bias, out_amax=out_amax)
+    ops.check_device_errors(synchronize=True)
+    ref = x.double() @ w.double().t() + bias.double()
+    err = (y.double() - ref)
+    assert float(err.norm() / ref.norm()) < 1e-6
+    col = err.pow(2).mean(0).sqrt() / ref.pow(2).mean(0).sqrt().clamp_min(1e-300)
+    assert float(col.max()) < 2e-6, float(col.max())
+    assert abs(float(out_amax.max()) - float(y.abs().max())) <= 1e-6 * float(y.abs().max())
+    y32 = ops.gemm_nt(x, w, bias) if (N % 64 == 0 and K % 32 == 0) else None
+    if y32 is not None:
+        assert float((y - y32).double().norm() / ref.norm()) < 2e-6
+
+
+def test_split_f16_gemm_reports_a_non_finite_operand():
+    from sound_event_detection_dcase2017_task4_amd import ops
+    x = torch.randn(512, 64).cuda()
+    x[17, 3] = float("nan")
+    w = torch.randn(128, 64).cuda()
+    ops.check_device_errors(synchronize=True)
+    ops.gemm_nt_sf16(x, ops.gemm_pack_sf16(w), 128)
+    with pytest.raises(ops.NonFiniteOperand):
+        ops.check_device_errors(synchronize=True)
+    ops.check_device_errors(synchronize=True)
