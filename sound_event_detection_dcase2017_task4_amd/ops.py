@@ -1379,6 +1379,25 @@ def gemm_nt_sf16(x, pack, N, bias=None, x_amax=None, out_amax=None):
     return y
 
 
+def linear_nt(x, w, bias=None, transposed=False, x_amax=None):
+    """y = x w^T (+ bias) of an nn.Linear weight w [N][K] -- or, transposed=True, y = x w: the input gradient of the same layer --
+    on the split-f16 GEMM where the shape allows it (the pack of w / w^T is cached per parameter and optimiser step like the
+    convolution packs), else on the fp32 MFMA GEMM."""
+    M, K = x.shape
+    N = w.shape[1] if transposed else w.shape[0]
+    if gemm_nt_sf16_ok(M, N, K):
+        def build():
+            wc = _f32c(w.detach())
+            if transposed:
+                wc = transpose_b(wc.view(1, wc.shape[0], wc.shape[1])).view(wc.shape[1], wc.shape[0])
+            return gemm_pack_sf16(wc)
+        return gemm_nt_sf16(x, _cached("lin_sf16_t" if transposed else "lin_sf16", (w,), build), N, bias, x_amax=x_amax)
+    wc = _f32c(w)
+    if transposed:
+        wc = transpose_b(wc.view(1, wc.shape[0], wc.shape[1])).view(wc.shape[1], wc.shape[0])
+    return gemm_nt(x, wc, bias)
+
+
 def gemm_tn(x, gy, out=None):
     """dw[N][K] = sum_m gy[m][n] x[m][k]."""
     M, K = x.shape
@@ -1555,7 +1574,8 @@ class MultiHeadFn(torch.autograd.Function):
         B, T, C = x.shape
         M = B * T
         x2 = x.view(M, C)
-        q, k, v = gemm_nt(x2, _f32c(wq), _f32c(bq)), gemm_nt(x2, _f32c(wk), _f32c(bk)), gemm_nt(x2, _f32c(wv), _f32c(bv))
+        xa = amax_of(x2) if gemm_nt_sf16_ok(M, C, C) else None         # one pass serves the three projections
+        q, k, v = (linear_nt(x2, w_, _f32c(b_), x_amax=xa) for w_, b_ in ((wq, bq), (wk, bk), (wv, bv)))
         o = torch.empty((M, C), dtype=torch.float32, device=x.device)
         stats = torch.empty((B, 8, T, 4), dtype=torch.float32, device=x.device)
         ka = keep_attn.contiguous() if keep_attn is not None else None
@@ -1565,7 +1585,7 @@ class MultiHeadFn(torch.autograd.Function):
         if kf is not None and (kf.dtype not in (torch.bool, torch.uint8) or kf.numel() != M * C):
             raise RuntimeError("fc keep mask must be bool/uint8 of shape (B, T, 512)")
         _call("sed_mha_fwd", _ptr(q), _ptr(k), _ptr(v), _ptr(ka), float(p_attn), B, T, _ptr(o), _ptr(stats), _stream())
-        y = gemm_nt(o, _f32c(wo), _f32c(bo))
+        y = linear_nt(o, wo, _f32c(bo))
         out = torch.empty_like(y)
         _call("sed_drop_relu_fwd", _ptr(y), _ptr(kf), float(p_fc), M * C, _ptr(out), _stream())
         ctx.save_for_backward(x2, q, k, v, o, stats, out, wq, wk, wv, wo, ka, kf)
@@ -1584,13 +1604,13 @@ class MultiHeadFn(torch.autograd.Function):
         sk = ctx.sinks                       # (wq, bq, wk, bk, wv, bv, wo, bo)
         dwo = _ret(sk[6], gemm_tn(o, gy, out=_dst(sk[6], (C, C), g.device)))
         dbo = _ret(sk[7], col_sums(gy, out=_dst(sk[7], (C,), g.device)))
-        go = gemm_nt(gy, transpose_b(_f32c(wo).view(1, C, C)).view(C, C))
+        go = linear_nt(gy, wo, transposed=True)
         gq, gk, gv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
         _call("sed_mha_bwd", _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(go), _ptr(ka), ctx.p[0], B, T, _ptr(stats), _ptr(gq),
               _ptr(gk), _ptr(gv), _stream())
-        gx = gemm_nt(gq, transpose_b(_f32c(wq).view(1, C, C)).view(C, C))
+        gx = linear_nt(gq, wq, transposed=True)
         for gt, w in ((gk, wk), (gv, wv)):
-            t = gemm_nt(gt, transpose_b(_f32c(w).view(1, C, C)).view(C, C))
+            t = linear_nt(gt, w, transposed=True)
             _call("sed_axpy", _ptr(gx), _ptr(t), M * C, _stream())
         grads = []
         for n, gt in enumerate((gq, gk, gv)):
