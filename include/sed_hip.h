@@ -321,6 +321,13 @@ long sed_gemm_pack_sf16_halfs(int N, int K);
 int sed_gemm_pack_sf16(const float* w, int N, int K, float* wscale, void* wp, sed_stream_t stream);
 int sed_gemm_nt_sf16(const float* x, const void* wp, const float* wscale, const float* bias, float* y, long M, int N, int K,
                      const float* x_amax, int* err_host, int* err_dev, float* out_amax, sed_stream_t stream);
+/* ... and the TN form for the weight gradients of those layers: dw[N][K] = sum_m gy[m][n] * x[m][k] with BOTH operands converted
+ * when staged (LDS transpose reads, as sed_conv3x3_wgrad_sf16); partial: sed_gemm_tn_sf16_partial_floats(M, N, K) floats of scratch
+ * (row slices, reduced in fp64).  N % 128 == 0, K % 128 == 0, M * max(N, K) * 4 < 2^31. */
+int sed_gemm_tn_sf16_supported(long M, int N, int K);
+long sed_gemm_tn_sf16_partial_floats(long M, int N, int K);
+int sed_gemm_tn_sf16(const float* x, const float* gy, float* dw, float* partial, long M, int N, int K, const float* x_amax,
+                     const float* gy_amax, int* err_host, int* err_dev, sed_stream_t stream);
 /* two independent NT GEMMs of one shape in one launch (the two directions of a BiGRU recurrence step) */
 int sed_gemm_nt_pair(const float* x0, const float* x1, const float* w0, const float* w1, const float* bias0,
                      const float* bias1, float* y0, float* y1, long M, int N, int K, sed_stream_t stream);

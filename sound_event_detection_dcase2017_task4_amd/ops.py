@@ -1398,10 +1398,35 @@ def linear_nt(x, w, bias=None, transposed=False, x_amax=None):
     return gemm_nt(x, wc, bias)
 
 
-def gemm_tn(x, gy, out=None):
-    """dw[N][K] = sum_m gy[m][n] x[m][k]."""
+_UNIT_AMAX = {}
+
+
+def unit_amax(device):
+    """Device amax vector holding 1.0: the operand scale of tensors that are bounded by construction (GRU hidden states)."""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    t = _UNIT_AMAX.get(key)
+    if t is None:
+        t = _UNIT_AMAX[key] = torch.ones((AMAX_SLOTS,), dtype=torch.float32, device=torch.device("cuda", key))
+    return t
+
+
+def gemm_tn(x, gy, out=None, x_amax=None, gy_amax=None):
+    """dw[N][K] = sum_m gy[m][n] x[m][k]: on the split-f16 TN GEMM where the shape allows it (x_amax / gy_amax: device amax
+    vectors or upper bounds of them; None = one pass each), else on the fp32 MFMA kernel."""
     M, K = x.shape
     N = gy.shape[1]
+    if GEMM_SF16 and USE_SF16 and x.is_contiguous() and gy.is_contiguous() and _lib.lib().sed_gemm_tn_sf16_supported(M, N, K):
+        if x_amax is None:
+            x_amax = amax_of(x)
+        if gy_amax is None:
+            gy_amax = amax_of(gy)
+        partial = torch.empty((int(_lib.lib().sed_gemm_tn_sf16_partial_floats(M, N, K)),), dtype=torch.float32, device=x.device)
+        dw = out if out is not None else torch.empty((N, K), dtype=torch.float32, device=x.device)
+        with _timed("gemm_tn_sf16_mfma|%dx%dx%d", (M, N, K), 2.0 * M * N * K):
+            _call("sed_gemm_tn_sf16", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), M, N, K, _ptr(x_amax), _ptr(gy_amax),
+                  _sf16_err_ptr(), _sf16_err_dev_ptr(x.device), _stream())
+        return dw
     ns, pps = ctypes.c_int(0), ctypes.c_int(0)
     nfl = _lib.lib().sed_wgrad_partial_floats(M, K, N, 1, ctypes.byref(ns), ctypes.byref(pps))
     partial = torch.empty((nfl,), dtype=torch.float32, device=x.device)
@@ -1590,6 +1615,7 @@ class MultiHeadFn(torch.autograd.Function):
         _call("sed_drop_relu_fwd", _ptr(y), _ptr(kf), float(p_fc), M * C, _ptr(out), _stream())
         ctx.save_for_backward(x2, q, k, v, o, stats, out, wq, wk, wv, wo, ka, kf)
         ctx.dims, ctx.p = (B, T, C), (float(p_attn), float(p_fc))
+        ctx.xa = xa
         ctx.sinks = _sinks(ctx, (wq, bq, wk, bk, wv, bv, wo, bo), 1)
         return out.view(B, T, C)
 
@@ -1602,19 +1628,22 @@ class MultiHeadFn(torch.autograd.Function):
         gy = torch.empty_like(g)
         _call("sed_drop_relu_bwd", _ptr(g), _ptr(out), _ptr(kf), ctx.p[1], M * C, _ptr(gy), _stream())
         sk = ctx.sinks                       # (wq, bq, wk, bk, wv, bv, wo, bo)
-        dwo = _ret(sk[6], gemm_tn(o, gy, out=_dst(sk[6], (C, C), g.device)))
+        sf = ctx.xa is not None
+        gya = amax_of(gy) if sf else None                  # one pass serves the weight gradient and the input gradient
+        dwo = _ret(sk[6], gemm_tn(o, gy, out=_dst(sk[6], (C, C), g.device), gy_amax=gya))
         dbo = _ret(sk[7], col_sums(gy, out=_dst(sk[7], (C,), g.device)))
-        go = linear_nt(gy, wo, transposed=True)
+        go = linear_nt(gy, wo, transposed=True, x_amax=gya)
         gq, gk, gv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
         _call("sed_mha_bwd", _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(go), _ptr(ka), ctx.p[0], B, T, _ptr(stats), _ptr(gq),
               _ptr(gk), _ptr(gv), _stream())
-        gx = linear_nt(gq, wq, transposed=True)
-        for gt, w in ((gk, wk), (gv, wv)):
-            t = linear_nt(gt, w, transposed=True)
+        gas = [amax_of(t_) if sf else None for t_ in (gq, gk, gv)]
+        gx = linear_nt(gq, wq, transposed=True, x_amax=gas[0])
+        for gt, w, ga in ((gk, wk, gas[1]), (gv, wv, gas[2])):
+            t = linear_nt(gt, w, transposed=True, x_amax=ga)
             _call("sed_axpy", _ptr(gx), _ptr(t), M * C, _stream())
         grads = []
         for n, gt in enumerate((gq, gk, gv)):
-            grads.append(_ret(sk[2 * n], gemm_tn(x2, gt, out=_dst(sk[2 * n], (C, C), g.device))))
+            grads.append(_ret(sk[2 * n], gemm_tn(x2, gt, out=_dst(sk[2 * n], (C, C), g.device), x_amax=ctx.xa, gy_amax=gas[n])))
             grads.append(_ret(sk[2 * n + 1], col_sums(gt, out=_dst(sk[2 * n + 1], (C,), g.device))))
         return (gx.view(B, T, C),) + tuple(grads) + (dwo, dbo, None, None, None, None)
 
@@ -1655,6 +1684,9 @@ class GruFn(torch.autograd.Function):
         w_ih, b_ih, w_ih_t = _cached("gru_ih", (w_ih_f, w_ih_b, b_ih_f, b_ih_b), lambda: _gru_ih_operands(
             w_ih_f, w_ih_b, b_ih_f, b_ih_b))
         sf_proj = gemm_nt_sf16_ok(B * T, 6 * Hd, I) and gemm_nt_sf16_ok(B * T, I, 6 * Hd)
+        if sf_proj and x_amax is None:
+            x_amax = amax_of(x)
+        ctx.x_amax = x_amax if sf_proj else None
         if sf_proj:          # input projections of both directions on the f16 MFMA pipe (split-f16 operands); packs cached per step
             pk_f, pk_t = _cached("gru_ih_sf16", (w_ih_f, w_ih_b), lambda: (gemm_pack_sf16(w_ih), gemm_pack_sf16(w_ih_t)))
             gi = gemm_nt_sf16(x.view(B * T, I), pk_f, 6 * Hd, b_ih, x_amax=x_amax).view(B, T, 6 * Hd)
@@ -1735,10 +1767,12 @@ class GruFn(torch.autograd.Function):
         # weight gradients of the recurrence: dW_hh = sum_t dgh_t^T h_{prev(t)}; h_prev is a shifted view of hs
         sk = ctx.sinks                       # (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_b, w_hh_b, b_ih_b, b_hh_b)
         if T > 1:
+            # |h| <= 1; |dgh| <= |dgi| element-wise (dgh's third gate is dgi's times r in (0, 1)): both operand scales are free
+            ha = unit_amax(dev) if dgi_amax is not None else None
             dw_hh_f = gemm_tn(hs[0, 0:T - 1].reshape((T - 1) * B, Hd), dgh[0, 1:T].reshape((T - 1) * B, 3 * Hd),
-                              out=_dst(sk[1], (3 * Hd, Hd), dev))
+                              out=_dst(sk[1], (3 * Hd, Hd), dev), x_amax=ha, gy_amax=dgi_amax)
             dw_hh_b = gemm_tn(hs[1, 1:T].reshape((T - 1) * B, Hd), dgh[1, 0:T - 1].reshape((T - 1) * B, 3 * Hd),
-                              out=_dst(sk[5], (3 * Hd, Hd), dev))
+                              out=_dst(sk[5], (3 * Hd, Hd), dev), x_amax=ha, gy_amax=dgi_amax)
         else:
             dw_hh_f, dw_hh_b = _dst(sk[1], (3 * Hd, Hd), dev).zero_(), _dst(sk[5], (3 * Hd, Hd), dev).zero_()
         dgi2 = dgi.view(B * T, 6 * Hd)
@@ -1757,7 +1791,7 @@ class GruFn(torch.autograd.Function):
             gx = gemm_nt_sf16(dgi2, ctx.pk_t, I, x_amax=dgi_amax).view(B, T, I)
         else:
             gx = gemm_nt(dgi2, w_ih_t).view(B, T, I)
-        dw_ih = gemm_tn(x.view(B * T, I), dgi2)                                          # (6H, I)
+        dw_ih = gemm_tn(x.view(B * T, I), dgi2, x_amax=ctx.x_amax if dgi_amax is not None else None, gy_amax=dgi_amax)   # (6H, I)
         return (gx, _put(sk[0], dw_ih[:3 * Hd]), _ret(sk[1], dw_hh_f), _put(sk[2], db_ih[:3 * Hd]), db_hh_f,
                 _put(sk[4], dw_ih[3 * Hd:]), _ret(sk[5], dw_hh_b), _put(sk[6], db_ih[3 * Hd:]), db_hh_b, None)
 

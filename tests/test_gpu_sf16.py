@@ -543,3 +543,23 @@ def test_split_f16_gemm_reports_a_non_finite_operand():
     with pytest.raises(ops.NonFiniteOperand):
         ops.check_device_errors(synchronize=True)
     ops.check_device_errors(synchronize=True)
+
+
+@pytest.mark.parametrize("M,N,K,mag", [(64, 128, 128, 1.0), (1000, 128, 256, 1.0), (31744, 768, 256, 1e-6), (32000, 1536, 512, 1e4),
+                                       (4099, 512, 512, 1.0)])
+def test_split_f16_tn_gemm_vs_float64(M, N, K, mag):
+    """sed_gemm_tn_sf16 (the weight gradients of the GRU / MultiHead dense layers: dw[n][k] = sum_m gy[m][n] x[m][k], both operands
+    converted when staged, LDS transpose reads, row slices reduced in fp64) against float64: ragged M (a partial last stage, fewer
+    stages than slices), gradient magnitudes 1e-6 ... 1e+4, one operand given by an upper BOUND of its amax; relative L2 <= 1e-6,
+    worst output row within 3e-6 of its RMS."""
+    from sound_event_detection_dcase2017_task4_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.tanh(torch.randn(M, K, generator=g)).cuda()                      # |x| <= 1 (hidden states)
+    gy = (torch.randn(M, N, generator=g) * mag * (1 + 5 * (torch.rand(1, N, generator=g) < 0.03).float())).cuda()
+    dw = ops.gemm_tn(x, gy, x_amax=ops.unit_amax("cuda"))                      # a bound of amax(x), amax(gy) by one pass
+    ops.check_device_errors(synchronize=True)
+    ref = gy.double().t() @ x.double()
+    err = dw.double() - ref
+    assert float(err.norm() / ref.norm()) < 1e-6
+    row = err.pow(2).mean(1).sqrt() / ref.pow(2).mean(1).sqrt().clamp_min(1e-300)
+    assert float(row.max()) < 3e-6, float(row.max())
