@@ -1423,7 +1423,7 @@ def gemm_tn(x, gy, out=None, x_amax=None, gy_amax=None):
             gy_amax = amax_of(gy)
         partial = torch.empty((int(_lib.lib().sed_gemm_tn_sf16_partial_floats(M, N, K)),), dtype=torch.float32, device=x.device)
         dw = out if out is not None else torch.empty((N, K), dtype=torch.float32, device=x.device)
-        with _timed("gemm_tn_sf16_mfma|%dx%dx%d", (M, N, K), 2.0 * M * N * K):
+        with _timed("gemm_tn_sf16_mfma(+slice reduce)|%dx%dx%d", (M, N, K), 2.0 * M * N * K):
             _call("sed_gemm_tn_sf16", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), M, N, K, _ptr(x_amax), _ptr(gy_amax),
                   _sf16_err_ptr(), _sf16_err_dev_ptr(x.device), _stream())
         return dw
