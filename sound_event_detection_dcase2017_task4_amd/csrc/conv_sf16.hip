@@ -898,7 +898,7 @@ SED_API int sed_conv3x3_sf16_dgrad_b1(const float* gy, const void* wp, const flo
 // the k halves are separate partial slices).  A stage = 64 pixels (64/W image rows): their gy rows are staged afresh, the
 // x rows go into a ring of RING >= 64/W + 2 image rows (power of two), of which every stage only loads the 64/W new ones;
 // rows -1 / H and the halo columns are zero.  A slice = a range of stages of one image or a range of whole images; the
-// partial sums [slice][k half][tap][co][ci] are reduced in fp64 by wgrad_sf16_reduce_kernel, which also unscales.
+// partial sums [slice][tap][co][ci] (the two k halves of a workgroup added in LDS) are reduced in fp64 by wgrad_sf16_reduce_kernel, which also unscales.
 // (Splitting the TAPS over six waves -- 2 co halves x 3 kernel rows, 3 accumulators and 120-160 VGPRs per wave, three to four
 // waves per SIMD -- measured 300-320 TFLOP/s against 335-360 for this layout: the gy fragments are then read three times.
 // Double-buffering gy and enlarging the ring to 2*64/W + 2 rows so that a stage needs ONE barrier instead of two measured
@@ -912,7 +912,7 @@ typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
 struct WSf16P {
     const float* x;            // [B][H][W][K]
     const float* gy;           // [B][H][W][N]
-    float* partial;            // [nslices * 2][9][N][K]
+    float* partial;            // [nslices][9][N][K]
     const float* in_scale;
     const float* in_shift;
     const float* g_amax;       // device: amax of gy
@@ -1141,8 +1141,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
         if (p.err_dev) __hip_atomic_store(p.err_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
-    // ---- partial sums of this (slice, k half): [tap][co][ci]
-    float* out = p.partial + ((long)(slice * 2 + wk) * 9) * p.N * p.K;
+    // ---- the two k halves of the workgroup meet in LDS (round 4: the staging buffers are free now; three accumulators per
+    // round = 24 KB), so a slice leaves ONE partial [tap][co][ci] instead of two: half the partial-sum bytes written here and
+    // read by the reduce kernel (300 -> 150 MB per launch on 512 -> 512 at batch 256)
+    float* const red = reinterpret_cast<float*>(smem);
+    static_assert(sizeof(smem) >= 2 * 3 * 16 * 64 * sizeof(float), "the k-half exchange needs 24 KB of LDS");
+    __syncthreads();
+#pragma unroll
+    for (int g3 = 0; g3 < 3; ++g3) {
+        if (wk == 1) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((wc * 3 + a) * 16 + r) * 64 + lane] = acc[3 * g3 + a][r];
+        }
+        __syncthreads();
+        if (wk == 0) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[3 * g3 + a][r] += red[((wc * 3 + a) * 16 + r) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wk != 0) return;
+    float* out = p.partial + ((long)slice * 9) * p.N * p.K;
 #pragma unroll
     for (int a = 0; a < 9; ++a)
 #pragma unroll
@@ -1218,7 +1241,7 @@ SED_API long sed_wgrad_sf16_partial_floats(int B, int H, int W, int Cin, int Cou
     if (!sed_wgrad_sf16_supported(H, W, Cin, Cout) || B <= 0) return 0;
     int spi, ips, g; long ns;
     wsf_slicing(B, H, W, Cin, Cout, &spi, &ips, &g, &ns);
-    return ns * 2 * 9 * Cin * Cout;
+    return ns * 9 * Cin * Cout;
 }
 
 SED_API int sed_conv3x3_wgrad_sf16(const float* x, const float* gy, float* dw_oihw, float* partial, int B, int H, int W,
@@ -1254,7 +1277,7 @@ SED_API int sed_conv3x3_wgrad_sf16(const float* x, const float* gy, float* dw_oi
 #undef WSF_LAUNCH
     SED_LAUNCH_CHECK();
     const long nk = 9L * Cin * Cout;
-    hipLaunchKernelGGL(wgrad_sf16_reduce_kernel, dim3((unsigned)(nk / 64)), dim3(256), 0, s, partial, (int)(ns * 2), Cout,
+    hipLaunchKernelGGL(wgrad_sf16_reduce_kernel, dim3((unsigned)(nk / 64)), dim3(256), 0, s, partial, (int)ns, Cout,
                        Cin, gy_amax, x_amax, dw_oihw);
     SED_LAUNCH_CHECK();
     return 0;
