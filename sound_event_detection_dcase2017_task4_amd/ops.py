@@ -52,7 +52,10 @@ GRAD_PAIRS = os.environ.get("SED_GRAD_PAIRS", "1") != "0"
 # ... and the pooled outputs of blocks 1-3 (read only by the next block's conv1, forward and weight gradient, and by the
 # block's own windowed backward pass): requested by the models' trunk (ConvBlock.forward(pairs_out=True))
 ACT_PAIRS = os.environ.get("SED_ACT_PAIRS", "1") != "0"
-_GRAD_AMAX = {}          # data_ptr of an input gradient a ConvBlock returned -> (its amax vector, numel): the next backward's bound
+# data_ptr of an input gradient a ConvBlock returned -> (its amax vector, numel): the bound of the NEXT ConvBlock backward of the
+# same backward pass.  Entries never outlive the pass that made them (an end-of-pass callback clears the table): an address is
+# not an identity, and a later tensor at the same address must never inherit a dead tensor's amax.
+_GRAD_AMAX = {}
 _SIDE = {}
 _PENDING = []            # [(event recorded on the side stream, sink or None)] of weight gradients not yet joined
 
@@ -1260,8 +1263,6 @@ class ConvBlockFn(torch.autograd.Function):
             amax2 = _amax_buf(dev) if sf2 else None
             _call("sed_bn_relu_pool_bwd_apply_mode", _ptr(y2), _ptr(g_out), B, H, W, Cout, ph, pw, ctx.pool_mode, _ptr(st2.scale),
                   _ptr(st2.shift), _ptr(coef2), _ptr(gy2), _ptr(amax2), _stream())
-        if len(_GRAD_AMAX) > 8:
-            _GRAD_AMAX.clear()
         # will gy1 (bn1's backward output) be written as pairs?  Its consumers: conv1's dgrad and weight gradient (Cin != 1)
         pair1 = (Cin != 1 and ctx.mm1 is not None and _wgrad_algo(H, W, Cin, Cout) == 3
                  and (not ctx.needs_input_grad[0] or _conv_algo(H, W, Cout, Cin) == 3))
@@ -1325,6 +1326,8 @@ class ConvBlockFn(torch.autograd.Function):
                 gx = _conv_fwd_like(gy1, w1, B, H, W, Cout, Cin, dgrad=True, epi=0, x_amax=amax1, packs=ctx.pk1, presplit=pair1,
                                     out_amax=gx_amax)
                 if gx_amax is not None:                  # the previous block's backward bounds ITS gradient with it
+                    if not _GRAD_AMAX:
+                        torch.autograd.Variable._execution_engine.queue_callback(_GRAD_AMAX.clear)     # end of this backward pass
                     _GRAD_AMAX[gx.data_ptr()] = (gx_amax, gx.numel())
             if fork and sk[0] is not None:
                 dw1 = _fork_wgrad(x, gy1, B, H, W, Cin, Cout, sink=sk[0], gy_amax=amax1, x_amax=ctx.xa, gy_presplit=pair1,
