@@ -83,7 +83,7 @@ int sed_bn_bwd_apply(float* dy_inout, const float* y, long nrows, int C, const f
 /* ---- bn0 + SpecAugmentation + mixup (models.py:287-296; do_mixup pytorch_utils.py:80-93) ----------------------
  * logmel [B2][T][64] -> out [B2 or B2/2][T][64].  stripes [B2][8] = {t_bgn0,t_len0,t_bgn1,t_len1,f_bgn0,f_len0,
  * f_bgn1,f_len1} (null: no SpecAugment, eval); lam [B2] (null: no mixup).  The backward only produces the
- * (sum dy, sum dy*xhat) partials [ceil(B2*T/1024)][2][64] for dgamma0/dbeta0 (the waveform takes no gradient). */
+ * (sum dy, sum dy*xhat) partials [ceil(B2*T/256)][2][64] for dgamma0/dbeta0 (the waveform takes no gradient). */
 int sed_bn0_aug_mix_fwd(const float* logmel, int B2, int T, const float* scale, const float* shift,
                         const int* stripes, const float* lam, float* out, sed_stream_t stream);
 int sed_bn0_aug_mix_bwd(const float* logmel, const float* g_out, int B2, int T, const float* mean,

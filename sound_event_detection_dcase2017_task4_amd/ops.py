@@ -688,7 +688,7 @@ class Bn0AugMix(torch.autograd.Function):
         st = ctx.st
         g = _f32c(g)
         B2, T, _ = lm.shape
-        nparts_max = (B2 * T + 1023) // 1024
+        nparts_max = (B2 * T + 255) // 256
         partials = torch.empty((nparts_max, 2, 64), dtype=torch.float32, device=lm.device)
         n = ctypes.c_int(0)
         _call("sed_bn0_aug_mix_bwd", _ptr(lm), _ptr(g), B2, T, _ptr(st.mean), _ptr(st.invstd), _ptr(stripes), _ptr(lam),
