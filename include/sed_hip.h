@@ -63,7 +63,10 @@ int sed_stats_rows_per_part(void);
 int sed_bn_finalize(const float* partials, int nparts, int rows_per_part, long N, int C, const float* gamma,
                     const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                     float* mean_out, float* invstd_out, float* scale_out, float* shift_out, double* ws,
-                    int* guard_dev, int* guard_host, float* cand, sed_stream_t stream);
+                    int* guard_dev, int* guard_host, float* cand,
+                    const float* y_amax /* nullable */, float* act_bound_out /* nullable [64]: what sed_act_bound computes, from
+                                                                                the same launch */,
+                    sed_stream_t stream);
 int sed_bn_commit(int n, const float* const* cand, float* const* running_mean, float* const* running_var, const int* C,
                   const int* guard_dev, sed_stream_t stream);
 int sed_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
@@ -74,6 +77,8 @@ int sed_bn_eval_affine(int C, const float* gamma, const float* beta, const float
  * through the batch mean/variance); 0: eval-mode BN (fixed affine: b = c = 0). */
 int sed_bn_bwd_finalize(const float* partials, int nparts, long N, int C, const float* mean, const float* invstd,
                         const float* scale, int batch_stats, float* dgamma, float* dbeta, float* coef, double* ws,
+                        const float* y_amax, const float* g_amax, float ginv,
+                        float* bound_out /* nullable [64]: sed_grad_bound(minmax = NULL, ..., y_amax) from the same launch */,
                         sed_stream_t stream);
 /* g_y = a*dy + b*y + c in place on dy [nrows][C].  amax_out (nullable, device): receives max |g_y| (the split-f16
  * convolution that consumes the tensor takes its scale from it; zeroed and accumulated in stream order). */

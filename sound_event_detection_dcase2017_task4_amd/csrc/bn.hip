@@ -101,11 +101,13 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, int nchunks, i
                                    float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                    float* __restrict__ scale_out, float* __restrict__ shift_out,
-                                   int* __restrict__ guard_dev, int* __restrict__ guard_host, float* __restrict__ cand) {
+                                   int* __restrict__ guard_dev, int* __restrict__ guard_host, float* __restrict__ cand,
+                                   const float* __restrict__ y_amax, float* __restrict__ act_bound_out) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), sub = threadIdx.x & 63;    // 256 threads = 4 channels x one wave
     if (c >= C) return;
     double s1, s2;
     chunk_sums16(ws, nchunks, C, c, sub, s1, s2);
+    const float A = act_bound_out ? amax_read(y_amax) : 0.f;       // (every lane of the wave takes part in the read)
     if (sub != 0) return;
     double mean = s1 / (double)N;
     double var = s2 / (double)N - mean * mean;
@@ -114,7 +116,13 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, int nchunks, i
     float meanf = (float)mean, invf = (float)invstd;
     float sc = gamma[c] * invf;
     mean_out[c] = meanf; invstd_out[c] = invf;
-    scale_out[c] = sc; shift_out[c] = fmaf(-meanf, sc, beta[c]);
+    const float shf = fmaf(-meanf, sc, beta[c]);
+    scale_out[c] = sc; shift_out[c] = shf;
+    // by-product for the split-f16 path (was the separate act_bound kernel): this channel's bound of the pooled activation
+    // relu(scale*y + shift) given |y| <= A, merged over the channels by one atomic per channel on the pre-zeroed slots
+    if (act_bound_out)
+        atomicMax(reinterpret_cast<unsigned*>(act_bound_out) + (c & (SED_AMAX_SLOTS - 1)),
+                  __float_as_uint(fmaxf(fmaf(fabsf(sc), A, shf), 0.f) * 1.0001f));
     if (guard_dev && !(fabs(mean) < 1e300 && var < 1e300)) {
         // found-non-finite guard (the split-f16 path): batch statistics that are NaN / inf raise the error words -- the Adam
         // kernel of this step refuses its update.  (guard_dev null: torch semantics, NaN flows into the buffers.)
@@ -151,11 +159,13 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int nchunk
                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                        const float* __restrict__ scale, int batch_stats,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ coef /*[3][C]*/) {
+                                       float* __restrict__ coef /*[3][C]*/, const float* __restrict__ y_amax,
+                                       const float* __restrict__ g_amax, float ginv, float* __restrict__ bound_out) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), sub = threadIdx.x & 63;
     if (c >= C) return;
     double s1, s2;
     chunk_sums16(ws, nchunks, C, c, sub, s1, s2);
+    const float A = bound_out ? amax_read(y_amax) : 0.f, G = bound_out ? amax_read(g_amax) * ginv : 0.f;
     if (sub != 0) return;
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
@@ -166,7 +176,12 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int nchunk
             b = -a * (double)invstd[c] * s2 / (double)N;
             cc = -a * s1 / (double)N - b * (double)mean[c];
         }
-        coef[c] = (float)a; coef[C + c] = (float)b; coef[2 * C + c] = (float)cc;
+        const float af = (float)a, bf = (float)b, cf = (float)cc;
+        coef[c] = af; coef[C + c] = bf; coef[2 * C + c] = cf;
+        // by-product (was grad_bound_kernel with the y_amax range): bound of |a*dy + b*y + c| for |dy| <= G, |y| <= A
+        if (bound_out)
+            atomicMax(reinterpret_cast<unsigned*>(bound_out) + (c & (SED_AMAX_SLOTS - 1)),
+                      __float_as_uint((fabsf(af) * G + fmaxf(fabsf(fmaf(bf, A, cf)), fabsf(fmaf(bf, -A, cf)))) * 1.0001f));
     }
 }
 
@@ -626,25 +641,33 @@ int reduce_chunks(int nparts) {          // parts per chunk: <= 1024 chunks (ws 
 // Partial statistics of x [N][C] in tiles of sed_stats_rows_per_part() rows.  partials must hold ceil(N/rows)*2*C floats.
 SED_API int sed_chan_stats(const float* x, long N, int C, float* partials, hipStream_t stream) {
     if (N <= 0 || C < 64 || C > 512 || (256 % (C / 4)) != 0) return SED_EINVAL;
-    // 256 rows per part (1024 until round 4: the 64 x 1001 log-mel rows of the metric's batch size made 63 workgroups on 256 CUs)
-    hipLaunchKernelGGL(chan_stats_kernel<256>, dim3(sed_cdiv(N, 256)), dim3(256), 0, stream, x, N, C, partials);
+    // (256-row parts would fill the chip at the metric's batch size -- 63 workgroups today, 21 -> 8 us -- but re-partitioning
+    // bn0's statistics moves their last bits, and with them a ReLU flip somewhere downstream: the bn0.weight gradient of the
+    // 6-clip fixtures went from < 2e-3 to 2.7e-3 of float64.  Not worth 0.15 % of the step.)
+    hipLaunchKernelGGL(chan_stats_kernel<1024>, dim3(sed_cdiv(N, 1024)), dim3(256), 0, stream, x, N, C, partials);
     SED_LAUNCH_CHECK();
     return 0;
 }
 
-SED_API int sed_stats_rows_per_part(void) { return 256; }
+SED_API int sed_stats_rows_per_part(void) { return 1024; }
 
 // ws: at least 1024*2*C doubles.
 SED_API int sed_bn_finalize(const float* partials, int nparts, int rows_per_part, long N, int C, const float* gamma,
                             const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                             float* mean_out, float* invstd_out, float* scale_out, float* shift_out, double* ws,
-                            int* guard_dev, int* guard_host, float* cand, hipStream_t stream) {
-    if (nparts <= 0 || C <= 0 || N <= 0) return SED_EINVAL;
+                            int* guard_dev, int* guard_host, float* cand, const float* y_amax, float* act_bound_out,
+                            hipStream_t stream) {
+    if (nparts <= 0 || C <= 0 || N <= 0 || (act_bound_out && !y_amax)) return SED_EINVAL;
+    if (act_bound_out) {
+        hipError_t e = sed_amax_clear(act_bound_out, stream);
+        if (e != hipSuccess) return (int)e;
+    }
     int ppc = reduce_chunks(nparts), nchunks = sed_cdiv(nparts, ppc), K = 2 * C;
     hipLaunchKernelGGL(reduce_parts_kernel<1>, dim3(nchunks, sed_cdiv(K, 256)), dim3(256), 0, stream, partials, nparts, K,
                        ppc, N, rows_per_part, ws);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(sed_cdiv(C, 4)), dim3(256), 0, stream, ws, nchunks, C, N, gamma, beta, eps,
-                       momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out, guard_dev, guard_host, cand);
+                       momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out, guard_dev, guard_host, cand,
+                       y_amax, act_bound_out);
     SED_LAUNCH_CHECK();
     return 0;
 }
@@ -696,13 +719,18 @@ SED_API int sed_bn_eval_affine(int C, const float* gamma, const float* beta, con
 // partials [nparts][2][C] = (sum dy, sum dy*xhat).  coef may be null (bn0: only dgamma/dbeta wanted).
 SED_API int sed_bn_bwd_finalize(const float* partials, int nparts, long N, int C, const float* mean,
                                 const float* invstd, const float* scale, int batch_stats, float* dgamma, float* dbeta,
-                                float* coef, double* ws, hipStream_t stream) {
-    if (nparts <= 0 || C <= 0 || N <= 0) return SED_EINVAL;
+                                float* coef, double* ws, const float* y_amax, const float* g_amax, float ginv, float* bound_out,
+                                hipStream_t stream) {
+    if (nparts <= 0 || C <= 0 || N <= 0 || (bound_out && (!coef || !y_amax || !g_amax))) return SED_EINVAL;
+    if (bound_out) {
+        hipError_t e = sed_amax_clear(bound_out, stream);
+        if (e != hipSuccess) return (int)e;
+    }
     int ppc = reduce_chunks(nparts), nchunks = sed_cdiv(nparts, ppc), K = 2 * C;
     hipLaunchKernelGGL(reduce_parts_kernel<0>, dim3(nchunks, sed_cdiv(K, 256)), dim3(256), 0, stream, partials, nparts, K,
                        ppc, N, 0, ws);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sed_cdiv(C, 4)), dim3(256), 0, stream, ws, nchunks, C, N, mean, invstd,
-                       scale, batch_stats, dgamma, dbeta, coef);
+                       scale, batch_stats, dgamma, dbeta, coef, y_amax, g_amax, ginv, bound_out);
     SED_LAUNCH_CHECK();
     return 0;
 }

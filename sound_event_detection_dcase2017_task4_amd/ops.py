@@ -576,7 +576,7 @@ def _ws(C, device):
     return torch.empty((2048 * C,), dtype=torch.float64, device=device)
 
 
-def bn_finalize(partials, nparts, rows_per_part, N, bn_w, bn_b, running_mean, running_var):
+def bn_finalize(partials, nparts, rows_per_part, N, bn_w, bn_b, running_mean, running_var, y_amax=None, act_bound_out=None):
     """Batch statistics -> folded affine + running-statistics update.  While the found-non-finite guard is on (USE_SF16)
     NaN / inf batch statistics raise the error words (the Adam kernel then refuses the step) and are NOT blended into
     running_mean / running_var: a refused step leaves the BatchNorm buffers intact like the parameters.  With
@@ -588,7 +588,7 @@ def bn_finalize(partials, nparts, rows_per_part, N, bn_w, bn_b, running_mean, ru
     _call("sed_bn_finalize", _ptr(partials), nparts, rows_per_part, N, C, _ptr(bn_w), _ptr(bn_b), BN_EPS, BN_MOMENTUM,
           _ptr(running_mean), _ptr(running_var), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale), _ptr(st.shift),
           _ptr(_ws(C, bn_w.device)), _sf16_err_dev_ptr(bn_w.device) if guard else None, _sf16_err_ptr() if guard else None,
-          _ptr(cand), _stream())
+          _ptr(cand), _ptr(y_amax) if act_bound_out is not None else None, _ptr(act_bound_out), _stream())
     if cand is not None:
         # the proposed running statistics are installed by ONE launch at the end of the forward pass (models' trunk:
         # begin_bn_commit / commit_bn) -- or right here for a BatchNorm used on its own -- unless the pass met NaN / inf
@@ -632,14 +632,18 @@ def bn_eval_affine(bn_w, bn_b, running_mean, running_var):
     return st
 
 
-def bn_bwd_finalize(partials, nparts, N, st, want_coef=True, batch_stats=True, sinks=(None, None)):
+def bn_bwd_finalize(partials, nparts, N, st, want_coef=True, batch_stats=True, sinks=(None, None), bound=None):
+    """bound (optional) = (y_amax, g_amax, ginv, bound_out): the finalize launch also leaves, in the zeroed amax vector bound_out,
+    an upper bound of max |a*dy + b*y + c| for |y| <= amax(y_amax), |dy| <= amax(g_amax) * ginv (what sed_grad_bound computes)."""
     C = st.mean.numel()
     dev = st.mean.device
     dgamma = _dst(sinks[0], (C,), dev)
     dbeta = _dst(sinks[1], (C,), dev)
     coef = torch.empty((3, C), dtype=torch.float32, device=dev) if want_coef else None
     _call("sed_bn_bwd_finalize", _ptr(partials), nparts, N, C, _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale),
-          1 if batch_stats else 0, _ptr(dgamma), _ptr(dbeta), _ptr(coef), _ptr(_ws(C, dev)), _stream())
+          1 if batch_stats else 0, _ptr(dgamma), _ptr(dbeta), _ptr(coef), _ptr(_ws(C, dev)),
+          _ptr(bound[0]) if bound else None, _ptr(bound[1]) if bound else None, float(bound[2]) if bound else 1.0,
+          _ptr(bound[3]) if bound else None, _stream())
     return _ret(sinks[0], dgamma), _ret(sinks[1], dbeta), coef
 
 
@@ -1182,9 +1186,13 @@ class ConvBlockFn(torch.autograd.Function):
             keep_mm2 = _amax_buf(dev)        # amax of y2, published by conv2's epilogue: bounds bn2's backward output
         y2 = _conv_fwd_like(y1, w2c, B, H, W, Cout, Cout, in_st=None if b1_pairs else st1, epi=1 if training else 0,
                             partials=part2, x_amax=a1, packs=pk2, presplit=b1_pairs, out_amax=keep_mm2)
-        st2 = bn_finalize(part2, np2, rpp2, M, g2, b2, rm2, rv2) if training else bn_eval_affine(g2, b2, rm2, rv2)
         out = torch.empty((B, H // ph, W // pw, Cout), dtype=torch.float32, device=dev)
         out_amax = _amax_buf(dev)
+        pairs_now = pool_mode == 0 and out_pairs and keep_mm2 is not None
+        # (pairs: the pooled output is scaled by a bound of its amax known before the pass -- from the amax of y2 and bn2's affine,
+        # computed by the finalize launch itself)
+        st2 = bn_finalize(part2, np2, rpp2, M, g2, b2, rm2, rv2, y_amax=keep_mm2 if pairs_now else None,
+                          act_bound_out=out_amax if pairs_now else None) if training else bn_eval_affine(g2, b2, rm2, rv2)
         cnt = None
         if pool_mode != 0:
             _call("sed_bn_relu_pool_fwd_mode", _ptr(y2), B, H, W, Cout, ph, pw, int(pool_mode), _ptr(st2.scale), _ptr(st2.shift),
@@ -1192,7 +1200,6 @@ class ConvBlockFn(torch.autograd.Function):
         elif out_pairs and keep_mm2 is not None:
             # the pooled output as split-f16 operand pairs, scaled by a bound of its amax known before the pass
             cnt = torch.empty((B, H // ph, W // pw, Cout), dtype=torch.uint8, device=dev)
-            _call("sed_act_bound", _ptr(keep_mm2), _ptr(st2.scale), _ptr(st2.shift), Cout, _ptr(out_amax), _stream())
             _call("sed_bn_relu_pool_fwd_cnt_pairs", _ptr(y2), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift), _ptr(out),
                   _ptr(cnt), _ptr(out_amax), _stream())
         elif training and POOL_BWD_WINDOWED and ph * pw > 1:
@@ -1246,8 +1253,6 @@ class ConvBlockFn(torch.autograd.Function):
             _call("sed_bn_relu_pool_bwd_reduce_mode", _ptr(y2), _ptr(g_out), B, H, W, Cout, ph, pw, ctx.pool_mode, _ptr(st2.scale),
                   _ptr(st2.shift), _ptr(st2.mean), _ptr(st2.invstd), _ptr(part), ctypes.byref(n), _stream())
         sk = ctx.sinks                                   # (w1, g1, b1, -, -, w2, g2, b2)
-        dg2, db2, coef2 = bn_bwd_finalize(part, n.value, M, st2, batch_stats=ctx.training, sinks=(sk[6], sk[7]))
-        gy2 = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
         sf2 = _conv_algo(H, W, Cout, Cout) == 3 or _wgrad_algo(H, W, Cout, Cout) == 3   # split-f16 consumers scale by the amax
         # gradients as operand pairs: both consumers of gy2 (conv2's dgrad and weight gradient) must be the split-f16 kernels
         pair2 = (ctx.mm2 is not None and ctx.pool_mode == 0 and _conv_algo(H, W, Cout, Cout) == 3
@@ -1255,8 +1260,13 @@ class ConvBlockFn(torch.autograd.Function):
         if pair2:
             ent = _GRAD_AMAX.pop(g_out.data_ptr(), None)
             g_amax = ent[0] if (ent is not None and ent[1] == g_out.numel()) else amax_of(g_out)
-            amax2 = _amax_buf(dev)                       # an upper BOUND of max |gy2|: the scale the pairs are written with
-            _call("sed_grad_bound", None, 0, Cout, _ptr(coef2), _ptr(g_amax), 1.0 / float(ph * pw), _ptr(amax2), _ptr(ctx.mm2), _stream())
+            amax2 = _amax_buf(dev)                       # an upper BOUND of max |gy2|: the scale the pairs are written with,
+            dg2, db2, coef2 = bn_bwd_finalize(part, n.value, M, st2, batch_stats=ctx.training, sinks=(sk[6], sk[7]),   # left by the
+                                              bound=(ctx.mm2, g_amax, 1.0 / float(ph * pw), amax2))                   # finalize launch
+        else:
+            dg2, db2, coef2 = bn_bwd_finalize(part, n.value, M, st2, batch_stats=ctx.training, sinks=(sk[6], sk[7]))
+        gy2 = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
+        if pair2:
             _call("sed_bn_relu_pool_bwd_apply_pairs", _ptr(y2), _ptr(g_out), B, H, W, Cout, ph, pw, _ptr(st2.scale), _ptr(st2.shift),
                   _ptr(coef2), _ptr(gy2), _ptr(amax2), _stream())
         else:

@@ -30,7 +30,7 @@ def test_host_only_entry_points():
     from sound_event_detection_dcase2017_task4_amd import _lib
     h = _lib.lib()
     assert h.sed_version().startswith(b"sed-hip")
-    assert h.sed_stats_rows_per_part() == 256 and h.sed_conv1_rows_per_part() == 256
+    assert h.sed_stats_rows_per_part() == 1024 and h.sed_conv1_rows_per_part() == 256
     assert h.sed_conv_rows_per_part(1000, 64) == 32 and h.sed_conv_rows_per_part(1000, 512) == 64
     assert h.sed_conv_rows_per_part(1 << 20, 64) == 32 and h.sed_conv_num_parts(1 << 20, 64) == 4 * 8192
     assert h.sed_conv_num_parts(1000, 128) == 16 and h.sed_conv_num_parts(1000, 64) == 32
