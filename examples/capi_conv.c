@@ -5,7 +5,8 @@
  *   gcc -O2 examples/capi_conv.c -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ \
  *       -Lsound_event_detection_dcase2017_task4_amd -lsed_hip -L/opt/rocm/lib -lamdhip64 -lm -o capi_conv
  *   (sound_event_detection_dcase2017_task4_amd/build.py builds it as build/capi_conv)
- * Exit code 0 = both kernels within 1e-4 of the CPU result. */
+ * ... and one dense layer (y = x w^T + b, dw = gy^T x) through the split-f16 GEMMs of the GRU / MultiHead heads.
+ * Exit code 0 = every kernel within tolerance of the CPU result. */
 #include <hip/hip_runtime_api.h>
 #include <math.h>
 #include <stdio.h>
@@ -98,6 +99,63 @@ int main(void) {
         }
         printf("%s: max |gpu - cpu| = %.3g\n", pass == 0 ? "sed_conv3x3_wino2" : (pass == 1 ? "sed_conv3x3_igemm" : "sed_conv3x3_sf16"), worst);
         if (!(worst < 1e-4)) rc = 1;
+    }
+    /* ---- the dense layers of the GRU / MultiHead heads (nn.GRU input projection, reference models.py:529-530): y = x w^T + b and
+     * dw = gy^T x on the split-f16 GEMMs, from the same plain-C host */
+    {
+        const int GM = 300, GN = 128, GK = 128;          /* ragged M on purpose */
+        float* gx = (float*)malloc(sizeof(float) * GM * GK);
+        float* gw = (float*)malloc(sizeof(float) * GN * GK);
+        float* gb = (float*)malloc(sizeof(float) * GN);
+        float* gyh = (float*)malloc(sizeof(float) * GM * GN);
+        float* gdw = (float*)malloc(sizeof(float) * GN * GK);
+        for (int i = 0; i < GM * GK; ++i) gx[i] = frand(&seed);
+        for (int i = 0; i < GN * GK; ++i) gw[i] = 0.1f * frand(&seed);
+        for (int i = 0; i < GN; ++i) gb[i] = frand(&seed);
+        float *dgx, *dgw, *dgb, *dgy, *dgdw, *dgws, *dgxa, *dgya, *dgpart;
+        void* dgwp;
+        CHECK_HIP(hipMalloc((void**)&dgx, sizeof(float) * GM * GK));
+        CHECK_HIP(hipMalloc((void**)&dgw, sizeof(float) * GN * GK));
+        CHECK_HIP(hipMalloc((void**)&dgb, sizeof(float) * GN));
+        CHECK_HIP(hipMalloc((void**)&dgy, sizeof(float) * GM * GN));
+        CHECK_HIP(hipMalloc((void**)&dgdw, sizeof(float) * GN * GK));
+        CHECK_HIP(hipMalloc(&dgwp, 2 * (size_t)sed_gemm_pack_sf16_halfs(GN, GK)));
+        CHECK_HIP(hipMalloc((void**)&dgws, sizeof(float) * (sed_amax_slots() + 1)));
+        CHECK_HIP(hipMalloc((void**)&dgxa, sizeof(float) * sed_amax_slots()));
+        CHECK_HIP(hipMalloc((void**)&dgya, sizeof(float) * sed_amax_slots()));
+        CHECK_HIP(hipMalloc((void**)&dgpart, sizeof(float) * (size_t)sed_gemm_tn_sf16_partial_floats(GM, GN, GK)));
+        CHECK_HIP(hipMemcpy(dgx, gx, sizeof(float) * GM * GK, hipMemcpyHostToDevice));
+        CHECK_HIP(hipMemcpy(dgw, gw, sizeof(float) * GN * GK, hipMemcpyHostToDevice));
+        CHECK_HIP(hipMemcpy(dgb, gb, sizeof(float) * GN, hipMemcpyHostToDevice));
+        if (!sed_gemm_nt_sf16_supported(GM, GN, GK) || !sed_gemm_tn_sf16_supported(GM, GN, GK)) { fprintf(stderr, "sf16 GEMM not supported?\n"); return 4; }
+        CHECK_SED(sed_gemm_pack_sf16(dgw, GN, GK, dgws, dgwp, (sed_stream_t)stream));
+        CHECK_SED(sed_amax(dgx, (long)GM * GK, dgxa, (sed_stream_t)stream));
+        CHECK_SED(sed_gemm_nt_sf16(dgx, dgwp, dgws, dgb, dgy, GM, GN, GK, dgxa, NULL, NULL, dgya /* amax of y, for the next call */,
+                                   (sed_stream_t)stream));
+        CHECK_SED(sed_gemm_tn_sf16(dgx, dgy, dgdw, dgpart, GM, GN, GK, dgxa, dgya, NULL, NULL, (sed_stream_t)stream));
+        CHECK_HIP(hipStreamSynchronize(stream));
+        CHECK_HIP(hipMemcpy(gyh, dgy, sizeof(float) * GM * GN, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(gdw, dgdw, sizeof(float) * GN * GK, hipMemcpyDeviceToHost));
+        double worst = 0.0, worst_dw = 0.0;
+        for (int m = 0; m < GM; ++m)
+            for (int n = 0; n < GN; ++n) {
+                double acc = gb[n];
+                for (int k = 0; k < GK; ++k) acc += (double)gx[m * GK + k] * gw[n * GK + k];
+                const double e = fabs(acc - (double)gyh[m * GN + n]);
+                if (e > worst) worst = e;
+            }
+        for (int n = 0; n < GN; ++n)
+            for (int k = 0; k < GK; ++k) {
+                double acc = 0.0;
+                for (int m = 0; m < GM; ++m) acc += (double)gyh[m * GN + n] * gx[m * GK + k];
+                const double e = fabs(acc - (double)gdw[n * GK + k]);
+                if (e > worst_dw) worst_dw = e;
+            }
+        printf("sed_gemm_nt_sf16: max |gpu - cpu| = %.3g\nsed_gemm_tn_sf16: max |gpu - cpu| = %.3g\n", worst, worst_dw);
+        if (!(worst < 1e-4) || !(worst_dw < 1e-3)) rc = 1;
+        hipFree(dgx); hipFree(dgw); hipFree(dgb); hipFree(dgy); hipFree(dgdw); hipFree(dgwp); hipFree(dgws); hipFree(dgxa);
+        hipFree(dgya); hipFree(dgpart);
+        free(gx); free(gw); free(gb); free(gyh); free(gdw);
     }
     /* bad arguments are reported, not executed */
     if (sed_conv3x3_wino2(dx, duf, dy, B, H, 7, Cin, Cout, NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL,
