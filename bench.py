@@ -288,7 +288,7 @@ class Workload(object):
                                   "copied into its static buffers and the Adam kernel is launched behind it, both inside the timed region"}
 
     def sync(self):
-        if self.world > 1:
+        if self.world > 1 or parallel.collectives_on():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -306,7 +306,7 @@ class Workload(object):
         dt = time.time() - t0
         tm, ops.TIMING, ops.TIMING_ONLY = ops.TIMING, None, None
         ops.check_device_errors()
-        if self.world > 1:
+        if self.world > 1 or parallel.collectives_on():
             t = torch.tensor([dt], device=self.dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = float(t.item())

@@ -30,7 +30,10 @@ def init_from_env(backend=None, timeout_minutes=60):
         # test / debug switch: all ranks use GPU 0 and talk over gloo, so that the N-rank code paths (CLI, bench) can run on
         # a 1-GPU box -- RCCL refuses two ranks on one device.  Never set in production.
         local_rank, backend = 0, "gloo"
-    if world > 1 and not dist.is_initialized():
+    # SED_FORCE_DIST=1 (tests): build the process group and issue every collective even with ONE rank, so that the RCCL code path
+    # (ProcessGroupNCCL with device_id, async all-reduce handles against our streams, broadcasts, barrier, shutdown) executes on
+    # a 1-GPU box.  (A one-rank all-reduce moves no bytes: it proves the plumbing, not the bandwidth.)
+    if (world > 1 or os.environ.get("SED_FORCE_DIST") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -88,25 +91,30 @@ def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+def collectives_on():
+    """Do the exchange steps run?  With more than one rank -- or with ONE rank when SED_FORCE_DIST=1 built a process group (tests)."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("SED_FORCE_DIST") == "1")
+
+
 def get_rank():
     return dist.get_rank() if dist.is_initialized() else 0
 
 
 def barrier():
-    if world_size() > 1:
+    if collectives_on():
         dist.barrier()
 
 
 def broadcast_flat(flat, src=0):
     """Rank `src`'s flat parameter buffer becomes everyone's (one-time, at start)."""
-    if world_size() > 1:
+    if collectives_on():
         dist.broadcast(flat, src=src)
     from . import ops                      # in-place write through the flat buffer: neither `_version` of the parameter
     ops.invalidate_weight_caches()         # views nor the optimiser generation saw it (padded head / stacked GRU operands)
 
 
 def broadcast_buffers(module, src=0):
-    if world_size() > 1:
+    if collectives_on():
         for b in module.buffers():
             dist.broadcast(b, src=src)
 
@@ -114,7 +122,7 @@ def broadcast_buffers(module, src=0):
 def broadcast_rng_state(src=0):
     """Every rank continues with rank `src`'s global torch CPU generator state: the SpecAugment positions of a global
     batch are drawn from it on every rank and must agree."""
-    if world_size() > 1:
+    if collectives_on():
         state = torch.get_rng_state()
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
         t = state.to(dev)
@@ -216,7 +224,7 @@ class GradBuckets(object):
             self.pre_fire_check(b, [i for i, bb in enumerate(self.bucket_of) if bb == b])
         self.fired[b] = True
         self.issue_order.append(b)
-        if world_size() > 1:
+        if collectives_on():
             lo, hi = self.ranges[b]
             last = all(self.fired)
             if last and self.publish_flag is not None and self.store is not None:

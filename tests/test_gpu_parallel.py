@@ -159,6 +159,31 @@ def test_bench_gpus_2_spawns_ranks_or_fails_loudly():
         assert "needs 2 GPUs" in (r.stderr + r.stdout) and '"n_gpus"' not in r.stdout
 
 
+def test_one_rank_over_rccl_runs_the_nccl_code_path():
+    """No box of the build pool has two GPUs, so RCCL has never carried this code between ranks.  What CAN run here: the same
+    bench.py under a ONE-rank process group on the `nccl` backend (SED_FORCE_DIST=1, a test-only switch): ProcessGroupNCCL is
+    built with device_id, the parameter / buffer broadcasts, the bucketed async all-reduces issued from inside backward against
+    the side-stream weight gradients, the stream-level waits in optimizer.step(), the barriers around the timed region, the MAX
+    all-reduce of the elapsed time and the orderly shutdown all execute.  (A one-rank all-reduce moves no bytes: this proves the
+    plumbing, not the bandwidth.)  The loss must equal the plain single-process run's bit for bit."""
+    from sound_event_detection_dcase2017_task4_amd import parallel
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    args = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch_size", "8",
+            "--seconds", "2", "--no_cpu_baseline", "--no_extra"]
+    plain = subprocess.run(args, capture_output=True, text=True, env=base, timeout=900)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    env = dict(base, SED_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(parallel.free_port()))
+    forced = subprocess.run(args, capture_output=True, text=True, env=env, timeout=900)
+    assert forced.returncode == 0, forced.stderr[-3000:]
+    a = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
+    b = json.loads([l for l in forced.stdout.splitlines() if l.startswith("{")][-1])
+    assert a["dist"]["backend"] is None and b["dist"]["backend"] == "nccl" and b["dist"]["world_size"] == 1
+    assert b["n_gpus"] == 1 and b["value"] > 0 and b["dist"]["allreduce_exposed_ms_per_step"] is not None
+    assert "from inside backward" in b["config"]["grad_allreduce"] and len(b["config"]["grad_allreduce"]) > 0
+    assert a["loss"] == b["loss"], (a["loss"], b["loss"])
+
+
 def test_bench_two_ranks_code_path_on_one_gpu():
     """The exact launch line the driver uses for N = 2 (torch.distributed.run, one process per rank), with the two ranks
     sharing GPU 0 over gloo (SED_SHARE_GPU=1, a test-only switch): barrier + synchronize around the timed region,
