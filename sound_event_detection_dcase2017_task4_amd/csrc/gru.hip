@@ -18,7 +18,13 @@
 //    by the launcher, producers write their values with agent-scope atomic stores, and every consumer wave polls its own
 //    operand block with `sc1` (agent-scope) loads until no sentinel is left.  Per step that is one store-to-load trip to the coherence
 //    point; the counter protocol of rounds 1-3 (stores -> wait -> barrier -> atomic add -> spin on the counter -> barrier ->
-//    loads) was three such trips in a row.  The members of a group have linear ids group + 16*jb, i.e. land on one XCD at B = 256;
+//    loads) was three such trips in a row.  The members of a group have workgroup ids x + 8 m (gru_group_of): the round-robin
+//    dispatcher puts them on ONE XCD, whose L2 is then the coherence point of the exchange: producers use PLAIN stores (they land in that L2, dirty) and the consumers' `sc1` loads -- which bypass the
+//    vector L1 -- find them there: 1.46 us per step of a bare 8 x 4 KB all-gather instead of 2.39 us with agent-scope stores
+//    that write through to the memory side (tools/xcd_exchange_probe.hip).  Dirty lines of one XCD's L2 are invisible to the
+//    other seven (the same probe with a group spread over the XCDs never completes), so the kernel does not ASSUME the
+//    placement: every workgroup publishes the XCC_ID hardware register it runs on, and a group whose eight members do not all
+//    report the same XCD falls back to the agent-scope stores;
 //  * everything a step needs that does NOT depend on the previous step (gi / g_out / saved gates) is loaded before
 //    the wait.
 // The spin is bounded: a wave that never sees its operands (which cannot happen while all workgroups are resident:
@@ -44,6 +50,13 @@ __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (
 __device__ __forceinline__ void st_coherent(float* ptr, float2 v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(ptr), __builtin_bit_cast(unsigned long long, v),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_xcd_local(float* ptr, float2 v) {       // lands in this XCD's L2; see gru_group_on_one_xcd
+    asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(ptr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st_exchange(float* ptr, float2 v, bool one_xcd) {
+    if (one_xcd) st_xcd_local(ptr, v);
+    else st_coherent(ptr, v);
 }
 // 16-byte coherent load (agent-scope cache policy: `sc1`, 3 % faster than `sc0 sc1` here; atomicity is not needed: the data was completed before the
 // sentinel disappeared -- each float is checked on its own).  The result is valid only after ld_coherent_wait on the same registers.
@@ -96,6 +109,22 @@ template <int N>
 __device__ __forceinline__ void gru_poll(f4r (&a)[N], const float* ap, int* err, long limit, bool& dead) {
     long polls = 0;
     for (;;) {
+        if (N > 4) {                                   // a wide block: watch ONE piece until it arrives, then fetch the block
+            for (;;) {
+                f4r one[1];
+                ld_coherent4(one[0], ap + 4 * (N - 1));
+                ld_coherent_wait(one);
+                if (dead || __builtin_amdgcn_ballot_w64(gru_has_sentinel(one[0])) == 0) break;
+                __builtin_amdgcn_s_sleep(1);
+                if ((++polls & 63) == 0 || polls >= limit) {
+                    if (polls >= limit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        dead = true;
+                        break;
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int q = 0; q < N; ++q) ld_coherent4(a[q], ap + 4 * q);
         ld_coherent_wait(a);
@@ -114,6 +143,45 @@ __device__ __forceinline__ void gru_poll(f4r (&a)[N], const float* ap, int* err,
     }
 }
 
+// Do the `members` workgroups of this group (linear ids group + ngroups * m) run on ONE XCD?  Each publishes the XCC_ID it reads
+// from the hardware register (+ 1; the launcher zeroed the table) with an agent-scope store and reads the others' the same way,
+// so every member sees the same eight values and takes the same decision.  Bounded like every wait of these kernels; a group
+// that cannot tell (or a failed pass) uses the agent-scope stores, which are right for any placement.
+// Workgroup id -> (group, member): the dispatcher deals workgroup i to XCD i % 8, so the 8 members of a group are the ids
+// x + 8 m (m = 0..7) of one block of 64 ids: group = x + 8 * (id / 64).  The grid is padded to whole blocks of 64; workgroups of
+// groups that do not exist leave at once.
+__host__ __device__ __forceinline__ int gru_group_of(int id) { return (id & 7) + 8 * (id >> 6); }
+__host__ __device__ __forceinline__ int gru_member_of(int id) { return (id >> 3) & 7; }
+__host__ __device__ __forceinline__ int gru_grid(int ngroups) { return 64 * ((ngroups + 7) / 8); }
+static_assert(GH / 32 == 8, "a group is 8 hidden blocks");
+constexpr int GRU_XCC_TABLE = 256;                     // flags[GRU_XCC_TABLE + workgroup id]
+__device__ __forceinline__ bool gru_group_on_one_xcd(int* flags, int group, long limit, int* lds_word) {
+    constexpr int members = GH / 32;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        if (lane == 0) {
+            unsigned id;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+            __hip_atomic_store(flags + GRU_XCC_TABLE + blockIdx.x, (int)(id & 0xf) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        int v = 0;
+        bool ok = false;
+        for (long polls = 0; polls < limit; ++polls) {
+            if (lane < members) v = __hip_atomic_load(flags + GRU_XCC_TABLE + (group & 7) + 8 * lane + 64 * (group >> 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = __builtin_amdgcn_ballot_w64(lane < members && v == 0) == 0;
+            if (ok) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const int v0 = __shfl(v, 0, 64);
+        const bool same = ok && __builtin_amdgcn_ballot_w64(lane < members && v != v0) == 0;
+        if (lane == 0) *lds_word = same ? 1 : 0;
+    }
+    __syncthreads();
+    const bool r = *lds_word != 0;
+    __syncthreads();
+    return r;
+}
+
 struct GruSeqFwdP {
     const float* gi;           // [B][T][6H]: input projections incl. b_ih, forward gates then reverse gates
     const float* w[2];         // W_hh [3H][H]
@@ -128,13 +196,15 @@ struct GruSeqFwdP {
 
 __global__ __launch_bounds__(512) void gru_seq_fwd_kernel(GruSeqFwdP p) {
     __shared__ __attribute__((aligned(16))) float red[4 * 3 * 16 * 64];      // 48 KB
-    const int group = blockIdx.x % p.ngroups, jb = blockIdx.x / p.ngroups;   // group members: ids group + ngroups*jb
+    const int group = gru_group_of(blockIdx.x), jb = gru_member_of(blockIdx.x);
+    if (group >= p.ngroups) return;                    // filler workgroups of the XCD-aligned grid (whole workgroup, before any barrier)
     const int d = group & 1, r0 = (group >> 1) * 32, j0 = jb * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hf = lane >> 5, l31 = lane & 31;
     const int B = p.B, T = p.T;
     const long bh = (long)B * GH;
     int* const err = p.flags + GRU_MAX_GROUPS;
+    const bool one_xcd = gru_group_on_one_xcd(p.flags, group, p.spin_limit > 8 ? (p.spin_limit >> 3) : 1, reinterpret_cast<int*>(red));
 
     // this lane's part of the weight slice, resident for the whole sequence: gate g, hidden unit j0 + l31, 16 consecutive k,
     // as split-f16 operands scaled by a power of two of the lane pair's own amax (the pair feeds one accumulator column)
@@ -232,7 +302,7 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_kernel(GruSeqFwdP p) {
             zz.x = gru_sigmoid(gz.x + gh[1].x); zz.y = gru_sigmoid(gz.y + gh[1].y);
             nn.x = tanhf(gn.x + rr.x * gh[2].x); nn.y = tanhf(gn.y + rr.y * gh[2].y);
             hh.x = (1.0f - zz.x) * nn.x + zz.x * hp.x; hh.y = (1.0f - zz.y) * nn.y + zz.y * hp.y;
-            st_coherent(p.hs + ((long)d * T + t) * bh + (long)row * GH + j, hh);      // the hand-over: replaces the sentinel
+            st_exchange(p.hs + ((long)d * T + t) * bh + (long)row * GH + j, hh, one_xcd);      // the hand-over: replaces the sentinel
             hlast = hh;
             *reinterpret_cast<float2*>(p.out + ((long)row * T + t) * 2 * GH + d * GH + j) = hh;
             float* s = p.saves + ((long)d * T + t) * 4 * bh + (long)row * 4 * GH + j;
@@ -261,7 +331,8 @@ struct GruSeqBwdP {
 
 __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqBwdP p) {
     __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];          // 16 KB
-    const int group = blockIdx.x % p.ngroups, jb = blockIdx.x / p.ngroups;
+    const int group = gru_group_of(blockIdx.x), jb = gru_member_of(blockIdx.x);
+    if (group >= p.ngroups) return;
     const int d = group & 1, r0 = (group >> 1) * 32, j0 = jb * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hf = lane >> 5, l31 = lane & 31;
@@ -370,12 +441,15 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqBwdP p) {
         if (live) {
             float* gi_o = p.dgi + ((long)row * T + t) * 6 * GH + d * 3 * GH + j;
             float* gh_o = p.dgh + ((long)d * T + t) * 3 * bh + (long)row * 3 * GH + j;
-            *reinterpret_cast<float2*>(gi_o) = dr_pre;
-            *reinterpret_cast<float2*>(gi_o + GH) = dz_pre;
-            *reinterpret_cast<float2*>(gi_o + 2 * GH) = dn_pre;
+            // the hand-over first: nothing else is queued in front of it.  Agent-scope stores here although the group shares an XCD:
+            // with three exchanged rows per thread and 48 KB polled per workgroup the XCD-local form measured 7 % SLOWER
+            // (1.04 vs 0.98 ms at B = 256), the forward pass 15 % faster (0.60 vs 0.71 ms)
             st_coherent(gh_o, dr_pre);
             st_coherent(gh_o + GH, dz_pre);
             st_coherent(gh_o + 2 * GH, dn_r);
+            *reinterpret_cast<float2*>(gi_o) = dr_pre;
+            *reinterpret_cast<float2*>(gi_o + GH) = dz_pre;
+            *reinterpret_cast<float2*>(gi_o + 2 * GH) = dn_pre;
             sb_r.x += dr_pre.x; sb_r.y += dr_pre.y; sb_z.x += dz_pre.x; sb_z.y += dz_pre.y;
             sb_n.x += dn_pre.x; sb_n.y += dn_pre.y; sb_nr.x += dn_r.x; sb_nr.y += dn_r.y;
             gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(dr_pre.x), fabsf(dr_pre.y))),
@@ -448,7 +522,7 @@ bool gru_device_fits(int grid) {
 
 SED_API int sed_gru_seq_supported(int B, int Hd) {
     if (!(Hd == GH && B > 0 && 2 * sed_cdiv(B, 32) * (GH / 32) <= 256)) return 0;
-    return gru_device_fits(2 * sed_cdiv(B, 32) * (GH / 32)) ? 1 : 0;
+    return gru_device_fits(gru_grid(2 * sed_cdiv(B, 32))) ? 1 : 0;
 }
 SED_API long sed_gru_seq_ws_floats(void) { return GRU_FLAG_INTS; }
 SED_API int sed_gru_set_spin_limit(long spins) {
@@ -477,7 +551,7 @@ SED_API int sed_gru_seq_fwd(const float* gi, const float* w_hh_f, const float* w
     e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(hs), (int)GRU_SENTINEL, (size_t)2 * T * B * GH, stream);
     if (e != hipSuccess) return (int)e;
     GruSeqFwdP p{gi, {w_hh_f, w_hh_b}, {b_hh_f, b_hh_b}, hs, saves, out, reinterpret_cast<int*>(ws), B, T, ngroups, g_spin_limit};
-    hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3(ngroups * (GH / 32)), dim3(512), 0, stream, p);
+    hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3(gru_grid(ngroups)), dim3(512), 0, stream, p);
     SED_LAUNCH_CHECK();
     hipLaunchKernelGGL(gru_seq_check_kernel, dim3(256), dim3(256), 0, stream, reinterpret_cast<const int*>(ws), err_host, 1, out,
                        (long)B * T * 2 * GH);
@@ -500,7 +574,7 @@ SED_API int sed_gru_seq_bwd(const float* g_out, const float* wt_f, const float* 
         if (e != hipSuccess) return (int)e;
     }
     GruSeqBwdP p{g_out, {wt_f, wt_b}, hs, saves, dgi, dgh, dbias_parts, dgi_amax, reinterpret_cast<int*>(ws), B, T, ngroups, g_spin_limit};
-    hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(ngroups * (GH / 32)), dim3(512), 0, stream, p);
+    hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(gru_grid(ngroups)), dim3(512), 0, stream, p);
     SED_LAUNCH_CHECK();
     hipLaunchKernelGGL(gru_seq_check_kernel, dim3(256), dim3(256), 0, stream, reinterpret_cast<const int*>(ws), err_host, 2, dgi,
                        (long)B * T * 6 * GH);

@@ -1717,8 +1717,9 @@ class GruFn(torch.autograd.Function):
             # fused recurrence: ONE persistent launch for all T steps of both directions (csrc/gru.hip); a launch that
             # cannot make progress poisons `out` with NaN and raises the host-mapped flag polled by check_device_errors
             ws = torch.empty((_lib.lib().sed_gru_seq_ws_floats(),), dtype=torch.float32, device=dev)
-            _call("sed_gru_seq_fwd", _ptr(gi), _ptr(whh[0]), _ptr(whh[1]), _ptr(bhh[0]), _ptr(bhh[1]), B, T, Hd,
-                  _ptr(hs), _ptr(saves), _ptr(out), _ptr(ws), _ptr(_err_flag()), _stream())
+            with _timed("gru_recurrence_fwd|B%d T%d", (B, T), 2.0 * 2 * B * T * 3 * Hd * Hd):
+                _call("sed_gru_seq_fwd", _ptr(gi), _ptr(whh[0]), _ptr(whh[1]), _ptr(bhh[0]), _ptr(bhh[1]), B, T, Hd,
+                      _ptr(hs), _ptr(saves), _ptr(out), _ptr(ws), _ptr(_err_flag()), _stream())
             ctx.save_for_backward(x, w_ih_t, whh[0], whh[1], hs, saves)
             return out
         gh0 = torch.stack([bhh[0].view(1, -1).expand(B, -1), bhh[1].view(1, -1).expand(B, -1)]).contiguous()  # h0 = 0
@@ -1758,8 +1759,9 @@ class GruFn(torch.autograd.Function):
             nrb = (B + 31) // 32
             dbp = torch.empty((2, nrb, 4 * Hd), dtype=torch.float32, device=dev)     # bias-gradient sums per row block
             dgi_amax = _amax_buf(dev) if ctx.pk_t is not None else None      # amax of dgi, published by the recurrence itself
-            _call("sed_gru_seq_bwd", _ptr(g_out), _ptr(wt[0]), _ptr(wt[1]), _ptr(hs), _ptr(saves), B, T, Hd,
-                  _ptr(dgi), _ptr(dgh), _ptr(dbp), _ptr(ws), _ptr(_err_flag()), _ptr(dgi_amax), s)
+            with _timed("gru_recurrence_bwd|B%d T%d", (B, T), 2.0 * 2 * B * T * 3 * Hd * Hd):
+                _call("sed_gru_seq_bwd", _ptr(g_out), _ptr(wt[0]), _ptr(wt[1]), _ptr(hs), _ptr(saves), B, T, Hd,
+                      _ptr(dgi), _ptr(dgh), _ptr(dbp), _ptr(ws), _ptr(_err_flag()), _ptr(dgi_amax), s)
         direct = [torch.empty((2, B, Hd), dtype=torch.float32, device=dev) for _ in range(2)]   # ping-pong
         rec = [torch.empty((2, B, Hd), dtype=torch.float32, device=dev) for _ in range(2)]
         have = False
