@@ -377,12 +377,13 @@ int sed_gru_gate_bwd(const float* g_out0, const float* g_out1, long ld_go, const
 
 /* ---- nn.GRU recurrence, fused (models.py:529-530, :565-567): ONE persistent launch per pass runs all T steps of both
  * directions -- hidden projection h_prev x W_hh^T on the f16 MFMA pipe with split-f16 operands (the weight slice resident in
- * registers; fp32-level error), gate math, and a hand-over THROUGH THE DATA among the 8 workgroups sharing a (direction, 32-row
- * block): hs / dgh are pre-filled with a sentinel NaN by the call and every consumer wave polls its operand block until no
+ * registers; fp32-level error), gate math, and a hand-over THROUGH THE DATA among the 4 workgroups sharing a (direction,
+ * sed_gru_seq_row_block()-row block): hs / dgh are pre-filled with a sentinel NaN by the call and every consumer wave polls its operand block until no
  * sentinel is left (bounded spin, no grid-wide barrier).  Built for Hd = 256 and B <= 512 (all workgroups must be co-resident):
  * sed_gru_seq_supported; callers use the per-step GEMM + sed_gru_gate_* launches otherwise.
  * Layouts: gi [B][T][6H] (forward gates r,z,n then reverse gates, incl. b_ih), hs [2][T][B][H] hidden states,
- * saves [2][T][B][4H] = r,z,n,gh_n, out [B][T][2H] = concat(forward, reverse).  Backward: g_out [B][T][2H];
+ * saves = r,z,n,gh_n: sed_gru_seq_saves_floats(B, T) floats in a layout private to the two recurrences (tile-major, so that a
+ * wave stores 1 KB runs), out [B][T][2H] = concat(forward, reverse).  Backward: g_out [B][T][2H];
  * wt_* = W_hh^T [H][3H]; produces dgi [B][T][6H] and dgh [2][T][B][3H] (gate pre-activation gradients on the input /
  * hidden side; weight and bias gradients are plain GEMMs / column sums over them).
  * ws: sed_gru_seq_ws_floats() floats of scratch (the give-up word; zeroed by the call).  dgi_amax (nullable): amax slots of |dgi|,
@@ -396,13 +397,15 @@ int sed_gru_gate_bwd(const float* g_out0, const float* g_out1, long ld_go, const
  * sed_debug_occupy (test hook): holds `blocks` CUs (one workgroup with lds_bytes of LDS each) for `microseconds`. */
 int sed_gru_seq_supported(int B, int Hd);
 long sed_gru_seq_ws_floats(void);
+int sed_gru_seq_row_block(void);      /* batch rows per workgroup (16): the granularity of dbias_parts */
+long sed_gru_seq_saves_floats(int B, int T);
 int sed_gru_seq_fwd(const float* gi, const float* w_hh_f, const float* w_hh_b, const float* b_hh_f,
                     const float* b_hh_b, int B, int T, int Hd, float* hs, float* saves, float* out, float* ws,
                     int* err_host, sed_stream_t stream);
 int sed_gru_seq_bwd(const float* g_out, const float* wt_f, const float* wt_b, const float* hs, const float* saves,
                     int B, int T, int Hd, float* dgi, float* dgh,
-                    float* dbias_parts /* nullable: [2 directions][ceil(B/32)][4: dr, dz, dn, dn*r][Hd] sums over time and the
-                                          32 rows of a block: db_ih = (dr, dz, dn), db_hh = (dr, dz, dn*r) summed over blocks */,
+                    float* dbias_parts /* nullable: [2 directions][ceil(B/row_block)][4: dr, dz, dn, dn*r][Hd] sums over time and
+                                          the rows of a block: db_ih = (dr, dz, dn), db_hh = (dr, dz, dn*r) summed over blocks */,
                     float* ws, int* err_host, float* dgi_amax, sed_stream_t stream);
 int sed_gru_set_spin_limit(long spins);
 int sed_debug_occupy(int blocks, int lds_bytes, long microseconds, sed_stream_t stream);

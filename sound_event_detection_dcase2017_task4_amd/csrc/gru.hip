@@ -4,31 +4,33 @@
 //
 // The recurrence is latency-bound (125 dependent steps of 0.1 GFLOP per direction), so the kernel is laid out for a
 // short per-step critical path, not for MFMA utilisation:
-//  * workgroup = 32 batch rows x 32 hidden units (x 3 gates) of one direction -> (H/32) x ceil(B/32) x 2 = 128
-//    workgroups at B=256, all co-resident (1 per CU); its 8 waves split the K reduction;
-//  * the workgroup's slice of W_hh (96 rows x 256) lives in REGISTERS for the whole sequence (48 VGPRs per lane) as
-//    split-f16 operands (round 4): w = (hi + lo) / s with a power-of-two scale per (gate, hidden unit, wave) taken from the
-//    lane pair's own 32 values; per step the 32 x 256 h_prev block is loaded, split the same way (|h| <= 1: fixed scale 2^13)
-//    and multiplied as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 -- exact products, fp32 accumulation, the error of an
-//    fp32 dot product (as in csrc/conv_sf16.hip) at 18 MFMAs of 32 cycles per wave and step instead of 48 fp32 MFMAs of 64
-//    (the MFMA k index is permuted consistently for both operands, which a dot product allows, so every lane reads
-//    contiguous float4 runs);
-//  * a step of direction d / row block rb depends only on the 8 workgroups (hidden blocks) of the same (d, rb).  They hand
+//  * workgroup = 16 batch rows x 64 hidden units (x 3 gates) of one direction -> (H/64) x ceil(B/16) x 2 = 128
+//    workgroups at B=256, all co-resident (1 per CU), 4 waves = 16 units each with the whole K reduction (see "the
+//    recurrences" below: no cross-wave sum, ONE barrier per step);
+//  * the wave's slice of W_hh (48 rows x 256) lives in REGISTERS for the whole sequence (192 VGPRs per lane) as
+//    split-f16 operands (round 4): w = (hi + lo) / s with a power-of-two scale per (gate, hidden unit) taken from the
+//    row's own amax; per step the 16 x 256 h_prev block is fetched once per workgroup, split the same way (|h| <= 1: fixed
+//    scale 2^13), shared through LDS and multiplied as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 -- exact products,
+//    fp32 accumulation, the error of an fp32 dot product (as in csrc/conv_sf16.hip) at 72 MFMAs of 16 cycles per wave and step
+//    (the K index is permuted consistently for both operands, which a dot product allows, so the polling loads are 64
+//    contiguous bytes per four lanes);
+//  * a step of direction d / row block rb depends only on the 4 workgroups (hidden blocks) of the same (d, rb).  They hand
 //    over THROUGH THE DATA (round 4): the exchange buffers (h_t forward, dgh_t backward) are pre-filled with a sentinel NaN
-//    by the launcher, producers write their values with agent-scope atomic stores, and every consumer wave polls its own
+//    by the launcher, producers write their values, and every consumer wave polls its own quarter of the
 //    operand block with `sc1` (agent-scope) loads until no sentinel is left.  Per step that is one store-to-load trip to the coherence
 //    point; the counter protocol of rounds 1-3 (stores -> wait -> barrier -> atomic add -> spin on the counter -> barrier ->
 //    loads) was three such trips in a row.  The members of a group have workgroup ids x + 8 m (gru_group_of): the round-robin
-//    dispatcher puts them on ONE XCD, whose L2 is then the coherence point of the exchange: producers use PLAIN stores (they land in that L2, dirty) and the consumers' `sc1` loads -- which bypass the
-//    vector L1 -- find them there: 1.46 us per step of a bare 8 x 4 KB all-gather instead of 2.39 us with agent-scope stores
+//    dispatcher puts them on ONE XCD, whose L2 is then the coherence point of the exchange:
+//    producers use PLAIN stores (they land in that L2, dirty) and the consumers' `sc1` loads -- which bypass the
+//    vector L1 -- find them there: 1.46 us per step of a bare 8 x 4 KB all-gather among 8 workgroups instead of 2.39 us with agent-scope stores
 //    that write through to the memory side (tools/xcd_exchange_probe.hip).  Dirty lines of one XCD's L2 are invisible to the
 //    other seven (the same probe with a group spread over the XCDs never completes), so the kernel does not ASSUME the
-//    placement: every workgroup publishes the XCC_ID hardware register it runs on, and a group whose eight members do not all
+//    placement: every workgroup publishes the XCC_ID hardware register it runs on, and a group whose four members do not all
 //    report the same XCD falls back to the agent-scope stores;
 //  * everything a step needs that does NOT depend on the previous step (gi / g_out / saved gates) is loaded before
 //    the wait.
 // The spin is bounded: a wave that never sees its operands (which cannot happen while all workgroups are resident:
-// 128 x 512 threads, 48 KB LDS) gives up after ~1 s and raises the error word instead of hanging the GPU.
+// 128 x 256 threads, 34 / 49 KB LDS) gives up after ~1 s and raises the error word instead of hanging the GPU.
 #include "common.h"
 #include "sed_hip.h"
 SED_OBJECT_FLAGS(gru)
@@ -40,9 +42,11 @@ constexpr int GRU_FLAG_INTS = 1024;                    // workspace ints: the er
 constexpr int GRU_MAX_GROUPS = GRU_FLAG_INTS - 1;
 
 __device__ __forceinline__ float gru_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-// accumulator register r of a 32x32 MFMA tile holds row (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), column lane & 31
-__device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+// The gate math sits on the critical path of every step of the persistent forward kernel (0.7 us of 4 per step with expf / tanhf /
+// IEEE division for the lane's four elements), so there it runs on the hardware exp2 and reciprocal (1 ulp each): absolute
+// error <= 1.5e-7 on values in [-1, 1], exact limits (exp -> inf gives rcp -> 0), NaN propagates.
+__device__ __forceinline__ float gru_sigmoid_hw(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float gru_tanh_hw(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
 // Data exchanged between workgroups DURING the kernel (h_t forward, dgh_t backward) is written and read with
 // agent-scope relaxed atomics (64-bit): they go to the coherence point, so the step synchronisation needs no L2
@@ -95,24 +99,17 @@ __device__ __forceinline__ bool gru_has_sentinel(const f4r& v) {
     return __float_as_uint(v[0]) == GRU_SENTINEL || __float_as_uint(v[1]) == GRU_SENTINEL ||
            __float_as_uint(v[2]) == GRU_SENTINEL || __float_as_uint(v[3]) == GRU_SENTINEL;
 }
-// the three exact partial products of one K = 16 slab, small terms first
-__device__ __forceinline__ void gru_mfma3(floatx16& acc, const half8& ahi, const half8& alo, const half8& bhi, const half8& blo) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc, 0, 0, 0);
-}
-
 // Poll this wave's operand block (N x 16 bytes per lane at `ap`) until it holds no sentinel.  Bounded: after `limit` polls,
 // or when another wave has given up, the error word is raised and the block is taken as it is (the launcher's check kernel
 // then overwrites the pass's output with NaN).  `dead` is sticky per wave: a pass that failed stops polling.
-template <int N>
+template <int N, int STRIDE>
 __device__ __forceinline__ void gru_poll(f4r (&a)[N], const float* ap, int* err, long limit, bool& dead) {
     long polls = 0;
     for (;;) {
         if (N > 4) {                                   // a wide block: watch ONE piece until it arrives, then fetch the block
             for (;;) {
                 f4r one[1];
-                ld_coherent4(one[0], ap + 4 * (N - 1));
+                ld_coherent4(one[0], ap + STRIDE * (N - 1));
                 ld_coherent_wait(one);
                 if (dead || __builtin_amdgcn_ballot_w64(gru_has_sentinel(one[0])) == 0) break;
                 __builtin_amdgcn_s_sleep(1);
@@ -126,7 +123,7 @@ __device__ __forceinline__ void gru_poll(f4r (&a)[N], const float* ap, int* err,
             }
         }
 #pragma unroll
-        for (int q = 0; q < N; ++q) ld_coherent4(a[q], ap + 4 * q);
+        for (int q = 0; q < N; ++q) ld_coherent4(a[q], ap + STRIDE * q);
         ld_coherent_wait(a);
         bool bad = false;
 #pragma unroll
@@ -148,15 +145,14 @@ __device__ __forceinline__ void gru_poll(f4r (&a)[N], const float* ap, int* err,
 // so every member sees the same eight values and takes the same decision.  Bounded like every wait of these kernels; a group
 // that cannot tell (or a failed pass) uses the agent-scope stores, which are right for any placement.
 // Workgroup id -> (group, member): the dispatcher deals workgroup i to XCD i % 8, so the 8 members of a group are the ids
-// x + 8 m (m = 0..7) of one block of 64 ids: group = x + 8 * (id / 64).  The grid is padded to whole blocks of 64; workgroups of
+// x + 8 m (m = 0..3) of one block of 32 ids: group = x + 8 * (id / 32).  The grid is padded to whole blocks of 32; workgroups of
 // groups that do not exist leave at once.
-__host__ __device__ __forceinline__ int gru_group_of(int id) { return (id & 7) + 8 * (id >> 6); }
-__host__ __device__ __forceinline__ int gru_member_of(int id) { return (id >> 3) & 7; }
-__host__ __device__ __forceinline__ int gru_grid(int ngroups) { return 64 * ((ngroups + 7) / 8); }
-static_assert(GH / 32 == 8, "a group is 8 hidden blocks");
+__host__ __device__ __forceinline__ int gru_group_of(int id) { return (id & 7) + 8 * (id >> 5); }
+__host__ __device__ __forceinline__ int gru_member_of(int id) { return (id >> 3) & 3; }
+__host__ __device__ __forceinline__ int gru_grid(int ngroups) { return 32 * ((ngroups + 7) / 8); }
 constexpr int GRU_XCC_TABLE = 256;                     // flags[GRU_XCC_TABLE + workgroup id]
 __device__ __forceinline__ bool gru_group_on_one_xcd(int* flags, int group, long limit, int* lds_word) {
-    constexpr int members = GH / 32;
+    constexpr int members = 4;
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         if (lane == 0) {
@@ -167,7 +163,7 @@ __device__ __forceinline__ bool gru_group_on_one_xcd(int* flags, int group, long
         int v = 0;
         bool ok = false;
         for (long polls = 0; polls < limit; ++polls) {
-            if (lane < members) v = __hip_atomic_load(flags + GRU_XCC_TABLE + (group & 7) + 8 * lane + 64 * (group >> 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane < members) v = __hip_atomic_load(flags + GRU_XCC_TABLE + (group & 7) + 8 * lane + 32 * (group >> 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ok = __builtin_amdgcn_ballot_w64(lane < members && v == 0) == 0;
             if (ok) break;
             __builtin_amdgcn_s_sleep(1);
@@ -182,144 +178,210 @@ __device__ __forceinline__ bool gru_group_on_one_xcd(int* flags, int group, long
     return r;
 }
 
+// ---- the recurrences --------------------------------------------------------------------------------------------------------
+// Workgroup = 16 batch rows x 64 hidden units of one direction, 4 waves; a wave owns 16 units for ALL gates and the WHOLE K
+// reduction, so the gate math follows the MFMAs in registers (rounds 1-3 split K over 8 waves and summed 48 accumulator
+// registers per wave through LDS behind three barriers).  Transposed product on v_mfma_f32_16x16x32_f16: A = the wave's
+// weight rows (resident: 192 VGPRs of split-f16 halves, 1 wave per SIMD), B = the exchanged operand block of the 16 batch
+// rows, so an accumulator lane holds 4 CONSECUTIVE units of one batch row: every global access of the gate math is 16 bytes.
+// The operand block is fetched ONCE per workgroup (each wave polls a quarter of it), split into f16 halves and shared
+// through LDS; positions along K are permuted (the same permutation on both operands) so that the polling loads are 64
+// contiguous bytes per four lanes and the LDS stores 16 bytes.
+constexpr int GRU_RB = 16;                             // batch rows per workgroup
+constexpr int GRU_UB = 64;                             // hidden units per workgroup
+constexpr int GRU_MEMBERS = GH / GRU_UB;               // workgroups per group
+constexpr int FROW = GH + 8;                           // LDS pitch of a staged row in halves: rows 4 banks apart
+constexpr int BROW = 3 * GH + 8;
+static_assert(GRU_MEMBERS == 4, "gru_group_of / gru_member_of are written for four members");
+
+// LDS position -> index along K.  Forward (K = 256): the staging lane (row, c) of wave w loads k = 64 w + 16 q + 4 c + i
+// (q = 0..3) and owns positions 64 w + 16 c + 4 q + i.  An aligned run of 8 positions is two runs of 4 consecutive k, 16 apart.
+__device__ __forceinline__ int gru_fwd_k_of(int p0) { return 64 * (p0 >> 6) + 16 * ((p0 >> 2) & 3) + 4 * ((p0 >> 4) & 3); }
+// Backward (K = 768): wave w loads c = 192 w + 16 q + 4 c4 + i (q = 0..11) and owns positions 192 w + 48 c4 + 4 q + i.
+__device__ __forceinline__ int gru_bwd_k_of(int p0) {
+    const int w = p0 / 192, rem = p0 % 192;
+    return 192 * w + 16 * ((rem % 48) >> 2) + 4 * (rem / 48);
+}
+
+// The saved gates (r, z, n, gh_n) travel from the forward to the backward recurrence only, and both kernels cut the work the
+// same way, so they are stored TILE-major: [direction][t][row block][16-unit block][gate][lane][4] -- a wave's store of one
+// gate is 1 KB contiguous (16 rows 4 KB apart cost 0.025 ms per store instruction and sequence at B = 256, contiguous 0.009:
+// every poll waits for the wave's earlier stores, vmcnt counts in order).  Rows past B in the last block are never written.
+__host__ __device__ __forceinline__ long gru_saves_tile(int d, int t, int T, int nrb, int rb, int ub) {
+    return ((((long)d * T + t) * nrb + rb) * (GH / 16) + ub) * (4 * 16 * 16);
+}
+
+__device__ __forceinline__ void st_exchange4(float* ptr, const f4r& v, bool one_xcd) {
+    if (one_xcd) {
+        asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(ptr), "v"(v) : "memory");
+    } else {
+        st_coherent(ptr, make_float2(v[0], v[1]));
+        st_coherent(ptr + 2, make_float2(v[2], v[3]));
+    }
+}
+__device__ __forceinline__ floatx4 gru_mfma16(const half8& a, const half8& b, const floatx4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
 struct GruSeqFwdP {
     const float* gi;           // [B][T][6H]: input projections incl. b_ih, forward gates then reverse gates
     const float* w[2];         // W_hh [3H][H]
     const float* bhh[2];       // [3H]
     float* hs;                 // [2][T][B][H]
-    float* saves;              // [2][T][B][4H] = r, z, n, gh_n
+    float* saves;              // r, z, n, gh_n in the tile layout of gru_saves_tile
     float* out;                // [B][T][2H]
     int* flags;                // workspace (zeroed by the launcher): the error word at [GRU_MAX_GROUPS]
     int B, T, ngroups;
     long spin_limit;
 };
 
-__global__ __launch_bounds__(512) void gru_seq_fwd_kernel(GruSeqFwdP p) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 3 * 16 * 64];      // 48 KB
-    const int group = gru_group_of(blockIdx.x), jb = gru_member_of(blockIdx.x);
+__global__ __launch_bounds__(256) void gru_seq_fwd_kernel(GruSeqFwdP p) {
+    __shared__ __attribute__((aligned(16))) _Float16 hb[2][2][GRU_RB * FROW];      // [step parity][hi, lo][row][position]: 33 KB
+    __shared__ float wsc[4][3][16];
+    __shared__ int xcd_word;
+    const int group = gru_group_of(blockIdx.x), mb = gru_member_of(blockIdx.x);
     if (group >= p.ngroups) return;                    // filler workgroups of the XCD-aligned grid (whole workgroup, before any barrier)
-    const int d = group & 1, r0 = (group >> 1) * 32, j0 = jb * 32;
+    const int d = group & 1, r0 = (group >> 1) * GRU_RB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int hf = lane >> 5, l31 = lane & 31;
+    const int c16 = lane & 15, q4 = lane >> 4;
+    const int j0 = mb * GRU_UB + wave * 16;            // the wave's 16 hidden units
     const int B = p.B, T = p.T;
     const long bh = (long)B * GH;
     int* const err = p.flags + GRU_MAX_GROUPS;
-    const bool one_xcd = gru_group_on_one_xcd(p.flags, group, p.spin_limit > 8 ? (p.spin_limit >> 3) : 1, reinterpret_cast<int*>(red));
+    const long poll_limit = p.spin_limit > 8 ? (p.spin_limit >> 3) : 1;
+    const bool one_xcd = gru_group_on_one_xcd(p.flags, group, poll_limit, &xcd_word);
 
-    // this lane's part of the weight slice, resident for the whole sequence: gate g, hidden unit j0 + l31, 16 consecutive k,
-    // as split-f16 operands scaled by a power of two of the lane pair's own amax (the pair feeds one accumulator column)
-    const int kb = wave * 32 + hf * 16;
-    half8 whi[3][2], wlo[3][2];
-    float winv[3];
+    // A operand, resident for the whole sequence: row = unit j0 + c16 of gate g, positions 32 ks + 8 q4 .. + 8, as split-f16
+    // halves scaled by a power of two of the ROW's own amax (the four lanes that share the row agree on it)
+    half8 whi[3][8], wlo[3][8];
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
-        const f4r* bp = reinterpret_cast<const f4r*>(p.w[d] + (long)(g * GH + j0 + l31) * GH + kb);
-        const f4r b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
-        float am = fmaxf(fmaxf(gru_amax4(b0), gru_amax4(b1)), fmaxf(gru_amax4(b2), gru_amax4(b3)));
+        const float* wr = p.w[d] + (long)(g * GH + j0 + c16) * GH;
+        f4r b[8][2];
+        float am = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int k0 = gru_fwd_k_of(32 * ks + 8 * q4);
+            b[ks][0] = *reinterpret_cast<const f4r*>(wr + k0);
+            b[ks][1] = *reinterpret_cast<const f4r*>(wr + k0 + 16);
+            am = fmaxf(am, fmaxf(gru_amax4(b[ks][0]), gru_amax4(b[ks][1])));
+        }
+        am = fmaxf(am, __shfl_xor(am, 16, 64));
         am = fmaxf(am, __shfl_xor(am, 32, 64));
         const float sw = sed_sf_scale_of(am);
-        gru_split8(b0, b1, sw, whi[g][0], wlo[g][0]);
-        gru_split8(b2, b3, sw, whi[g][1], wlo[g][1]);
-        winv[g] = (1.0f / sw) * (1.0f / 8192.0f);       // h_prev is scaled by 2^13 (|h| <= 1)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) gru_split8(b[ks][0], b[ks][1], sw, whi[g][ks], wlo[g][ks]);
+        if (q4 == 0) wsc[wave][g][c16] = (1.0f / sw) * (1.0f / 8192.0f);      // h_prev is scaled by 2^13 (|h| <= 1)
     }
-    const int arow = min(r0 + l31, B - 1);             // operand row of this lane (clamped: ragged last row block)
-    // output role: accumulator register r = tid >> 5 of the lane pair (2q, 2q+1), q = tid & 31: two adjacent hidden units
-    const int r = tid >> 5, lp = (tid & 31) * 2;
-    const int row = r0 + acc_row(r, lp >> 5);
+    __syncthreads();
+    // output role: batch row r0 + c16, units j .. j + 3 (accumulator register i = unit 4 q4 + i of the wave's 16)
+    float winv[3][4];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) winv[g][i] = wsc[wave][g][4 * q4 + i];
+    const int row = r0 + c16;
     const bool live = row < B;
     const int rowc = live ? row : B - 1;
-    const int j = j0 + (lp & 31);
-    float2 bias[3];
+    const int j = j0 + 4 * q4;
+    f4r bias[3];
 #pragma unroll
-    for (int g = 0; g < 3; ++g) bias[g] = *reinterpret_cast<const float2*>(p.bhh[d] + g * GH + j);
+    for (int g = 0; g < 3; ++g) bias[g] = *reinterpret_cast<const f4r*>(p.bhh[d] + g * GH + j);
+    // staging role: row r0 + (lane >> 2) of the operand block, k = 64 wave + 16 q + 4 (lane & 3) + i
+    const int srow = lane >> 2, sc = lane & 3;
+    const long soff = (long)min(r0 + srow, B - 1) * GH + 64 * wave + 4 * sc;
+    const int spos = srow * FROW + 64 * wave + 16 * sc;
+    const int fpos = c16 * FROW + 8 * q4;
 
-    float2 hlast = make_float2(0.f, 0.f);
+    f4r hlast = {0.f, 0.f, 0.f, 0.f};
     bool dead = false;
-    const long poll_limit = p.spin_limit > 8 ? (p.spin_limit >> 3) : 1;
+    // Software pipeline around the wait: a poll ends with s_waitcnt vmcnt(0), which also waits for every OTHER memory operation
+    // of the wave -- so the loads a step needs that do not depend on its predecessor (gi) are issued one step ahead, and the
+    // stores nobody waits for (out, saved gates) one step late, both right behind the barrier where the MFMAs hide them
+    // (stores in front of the poll cost 0.84 us per step, loads in front of it their full HBM latency).
+    f4r pre[3], keep[5];
+    int keep_t = -1;
+    {
+        const float* gir = p.gi + ((long)rowc * T + (d ? T - 1 : 0)) * 6 * GH + d * 3 * GH + j;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) pre[g] = *reinterpret_cast<const f4r*>(gir + g * GH);
+    }
+    auto flush = [&]() {                               // out / saves of step keep_t
+        if (live && keep_t >= 0) {
+            *reinterpret_cast<f4r*>(p.out + ((long)row * T + keep_t) * 2 * GH + d * GH + j) = keep[4];
+            float* s = p.saves + gru_saves_tile(d, keep_t, T, p.ngroups >> 1, group >> 1, mb * 4 + wave) + 4 * lane;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<f4r*>(s + 256 * g) = keep[g];
+        }
+    };
     for (int k = 0; k < T; ++k) {
         const int t = d ? T - 1 - k : k;
-        const float* h_prev = p.hs + ((long)d * T + (d ? t + 1 : t - 1)) * bh;
-        // independent of the previous step: this thread's input-projection values
-        const float* gir = p.gi + ((long)rowc * T + t) * 6 * GH + d * 3 * GH + j;
-        const float2 gr = *reinterpret_cast<const float2*>(gir);
-        const float2 gz = *reinterpret_cast<const float2*>(gir + GH);
-        const float2 gn = *reinterpret_cast<const float2*>(gir + 2 * GH);
-        float2 gh[3] = {bias[0], bias[1], bias[2]};
-        float2 hp = make_float2(0.f, 0.f);
+        const f4r gr = pre[0], gz = pre[1], gn = pre[2];
+        f4r gh[3] = {bias[0], bias[1], bias[2]};
         if (k > 0) {
+            const float* h_prev = p.hs + ((long)d * T + (d ? t + 1 : t - 1)) * bh;
             f4r a[4];
-            gru_poll(a, h_prev + (long)arow * GH + kb, err, poll_limit, dead);
-            hp = hlast;                                // this thread wrote h_{t-1}[row][j, j+1] itself
-            half8 ahi[2], alo[2];
-            gru_split8(a[0], a[1], 8192.0f, ahi[0], alo[0]);
-            gru_split8(a[2], a[3], 8192.0f, ahi[1], alo[1]);
-            floatx16 acc[3];
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int g = 0; g < 3; ++g) gru_mfma3(acc[g], ahi[m], alo[m], whi[g][m], wlo[g][m]);
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[g][i] *= winv[g];
-            // two-phase reduction over the 8 waves: 4..7 -> LDS -> added by 0..3 -> LDS -> summed by the output threads
-            if (wave >= 4) {
-#pragma unroll
-                for (int g = 0; g < 3; ++g)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) red[(((wave - 4) * 3 + g) * 16 + i) * 64 + lane] = acc[g][i];
-            }
-            __syncthreads();
-            if (wave < 4) {
-#pragma unroll
-                for (int g = 0; g < 3; ++g)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[g][i] += red[((wave * 3 + g) * 16 + i) * 64 + lane];
-            }
-            __syncthreads();
-            if (wave < 4) {
-#pragma unroll
-                for (int g = 0; g < 3; ++g)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) red[((wave * 3 + g) * 16 + i) * 64 + lane] = acc[g][i];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const float2 v = *reinterpret_cast<const float2*>(&red[((w * 3 + g) * 16 + r) * 64 + lp]);
-                    gh[g].x += v.x; gh[g].y += v.y;
-                }
+            gru_poll<4, 16>(a, h_prev + soff, err, poll_limit, dead);
+            half8 h0, l0, h1, l1;
+            gru_split8(a[0], a[1], 8192.0f, h0, l0);
+            gru_split8(a[2], a[3], 8192.0f, h1, l1);
+            _Float16* const sh = &hb[k & 1][0][spos];
+            _Float16* const sl = &hb[k & 1][1][spos];
+            *reinterpret_cast<half8*>(sh) = h0;
+            *reinterpret_cast<half8*>(sh + 8) = h1;
+            *reinterpret_cast<half8*>(sl) = l0;
+            *reinterpret_cast<half8*>(sl + 8) = l1;
+            __syncthreads();                           // the only barrier of a step: the block of step k + 2 goes to this buffer
+                                                       // after every wave has passed the barrier of step k + 1, i.e. has read it
         }
-        if (live) {
-            float2 rr, zz, nn, hh;
-            rr.x = gru_sigmoid(gr.x + gh[0].x); rr.y = gru_sigmoid(gr.y + gh[0].y);
-            zz.x = gru_sigmoid(gz.x + gh[1].x); zz.y = gru_sigmoid(gz.y + gh[1].y);
-            nn.x = tanhf(gn.x + rr.x * gh[2].x); nn.y = tanhf(gn.y + rr.y * gh[2].y);
-            hh.x = (1.0f - zz.x) * nn.x + zz.x * hp.x; hh.y = (1.0f - zz.y) * nn.y + zz.y * hp.y;
-            st_exchange(p.hs + ((long)d * T + t) * bh + (long)row * GH + j, hh, one_xcd);      // the hand-over: replaces the sentinel
-            hlast = hh;
-            *reinterpret_cast<float2*>(p.out + ((long)row * T + t) * 2 * GH + d * GH + j) = hh;
-            float* s = p.saves + ((long)d * T + t) * 4 * bh + (long)row * 4 * GH + j;
-            *reinterpret_cast<float2*>(s) = rr;
-            *reinterpret_cast<float2*>(s + GH) = zz;
-            *reinterpret_cast<float2*>(s + 2 * GH) = nn;
-            *reinterpret_cast<float2*>(s + 3 * GH) = gh[2];
+        if (k + 1 < T) {                               // next step's input projections
+            const float* gir = p.gi + ((long)rowc * T + (d ? t - 1 : t + 1)) * 6 * GH + d * 3 * GH + j;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) pre[g] = *reinterpret_cast<const f4r*>(gir + g * GH);
         }
-        if (k > 0 && k + 1 < T) __syncthreads();       // `red` is rewritten by the next step
+        flush();                                       // previous step's out / saves
+        if (k > 0) {
+            // nine independent accumulator chains (three exact partial products x three gates): no MFMA waits for its predecessor
+            floatx4 am[3], ac[3], ad[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) am[g] = ac[g] = ad[g] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const half8 ahi = *reinterpret_cast<const half8*>(&hb[k & 1][0][fpos + 32 * ks]);
+                const half8 alo = *reinterpret_cast<const half8*>(&hb[k & 1][1][fpos + 32 * ks]);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) ac[g] = gru_mfma16(wlo[g][ks], ahi, ac[g]);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) ad[g] = gru_mfma16(whi[g][ks], alo, ad[g]);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) am[g] = gru_mfma16(whi[g][ks], ahi, am[g]);
+            }
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gh[g][i] += (am[g][i] + (ac[g][i] + ad[g][i])) * winv[g][i];
+        }
+        f4r rr, zz, nn, hh;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rr[i] = gru_sigmoid_hw(gr[i] + gh[0][i]);
+            zz[i] = gru_sigmoid_hw(gz[i] + gh[1][i]);
+            nn[i] = gru_tanh_hw(gn[i] + rr[i] * gh[2][i]);
+            hh[i] = (1.0f - zz[i]) * nn[i] + zz[i] * hlast[i];     // this lane wrote h_{t-1}[row][j .. j+3] itself
+        }
+        if (live) st_exchange4(p.hs + ((long)d * T + t) * bh + (long)row * GH + j, hh, one_xcd);      // the hand-over: replaces the sentinel
+        hlast = hh;
+        keep[0] = rr; keep[1] = zz; keep[2] = nn; keep[3] = gh[2]; keep[4] = hh;
+        keep_t = t;
     }
+    flush();
 }
 
 struct GruSeqBwdP {
     const float* g_out;        // [B][T][2H]
     const float* wt[2];        // W_hh^T [H][3H]
     const float* hs;           // [2][T][B][H]
-    const float* saves;        // [2][T][B][4H]
+    const float* saves;        // gru_saves_tile layout
     float* dgi;                // [B][T][6H]
     float* dgh;                // [2][T][B][3H]
     float* dbias;              // nullable: [2 directions][row blocks][4: dr, dz, dn, dn*r][H] sums over (t, the block's rows)
@@ -329,149 +391,167 @@ struct GruSeqBwdP {
     long spin_limit;
 };
 
-__global__ __launch_bounds__(512) void gru_seq_bwd_kernel(GruSeqBwdP p) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];          // 16 KB
-    const int group = gru_group_of(blockIdx.x), jb = gru_member_of(blockIdx.x);
+__global__ __launch_bounds__(256) void gru_seq_bwd_kernel(GruSeqBwdP p) {
+    __shared__ __attribute__((aligned(16))) _Float16 gb[2][GRU_RB * BROW];         // [hi, lo][row][position]: 49 KB
+    __shared__ float qinv[2][4];                       // [step parity][quarter]: 1 / operand scale of the quarter a wave staged
+    __shared__ float wsc[4][16];
+    __shared__ int xcd_word;
+    const int group = gru_group_of(blockIdx.x), mb = gru_member_of(blockIdx.x);
     if (group >= p.ngroups) return;
-    const int d = group & 1, r0 = (group >> 1) * 32, j0 = jb * 32;
+    const int d = group & 1, r0 = (group >> 1) * GRU_RB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int hf = lane >> 5, l31 = lane & 31;
+    const int c16 = lane & 15, q4 = lane >> 4;
+    const int j0 = mb * GRU_UB + wave * 16;
     const int B = p.B, T = p.T;
     const long bh = (long)B * GH;
     int* const err = p.flags + GRU_MAX_GROUPS;
+    const long poll_limit = p.spin_limit > 8 ? (p.spin_limit >> 3) : 1;
+    const bool one_xcd = gru_group_on_one_xcd(p.flags, group, poll_limit, &xcd_word);
 
-    // dh_gemm[b][j] = sum_c dgh_later[b][c] * W_hh[c][j], c over 3H = 768: 96 per wave, 48 consecutive per lane;
-    // this lane's run of row j0 + l31 of W_hh^T is resident for the whole sequence as split-f16 operands (scale: a power of two
-    // of the lane pair's own amax -- the pair feeds one accumulator column)
-    const int kb = wave * 96 + hf * 48;
-    half8 whi[6], wlo[6];
-    float winv;
+    // dh_gemm[b][j] = sum_c dgh_later[b][c] * W_hh[c][j], c over 3H = 768.  A operand: row j0 + c16 of W_hh^T, resident
+    half8 whi[24], wlo[24];
     {
-        const f4r* bp = reinterpret_cast<const f4r*>(p.wt[d] + (long)(j0 + l31) * 3 * GH + kb);
-        f4r b[12];
+        const float* wr = p.wt[d] + (long)(j0 + c16) * 3 * GH;
         float am = 0.f;
 #pragma unroll
-        for (int q = 0; q < 12; ++q) { b[q] = bp[q]; am = fmaxf(am, gru_amax4(b[q])); }
+        for (int ks = 0; ks < 24; ++ks) {
+            const int k0 = gru_bwd_k_of(32 * ks + 8 * q4);
+            am = fmaxf(am, fmaxf(gru_amax4(*reinterpret_cast<const f4r*>(wr + k0)), gru_amax4(*reinterpret_cast<const f4r*>(wr + k0 + 16))));
+        }
+        am = fmaxf(am, __shfl_xor(am, 16, 64));
         am = fmaxf(am, __shfl_xor(am, 32, 64));
         const float sw = sed_sf_scale_of(am);
 #pragma unroll
-        for (int m = 0; m < 6; ++m) gru_split8(b[2 * m], b[2 * m + 1], sw, whi[m], wlo[m]);
-        winv = 1.0f / sw;
+        for (int ks = 0; ks < 24; ++ks) {
+            const int k0 = gru_bwd_k_of(32 * ks + 8 * q4);
+            gru_split8(*reinterpret_cast<const f4r*>(wr + k0), *reinterpret_cast<const f4r*>(wr + k0 + 16), sw, whi[ks], wlo[ks]);
+        }
+        if (q4 == 0) wsc[wave][c16] = 1.0f / sw;
     }
-    const int arow = min(r0 + l31, B - 1);
-    const int r = tid >> 5, lp = (tid & 31) * 2;
-    const int row = r0 + acc_row(r, lp >> 5);
+    __syncthreads();
+    float winv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) winv[i] = wsc[wave][4 * q4 + i];
+    const int row = r0 + c16;
     const bool live = row < B;
     const int rowc = live ? row : B - 1;
-    const int j = j0 + (lp & 31);
-    float2 dhz = make_float2(0.f, 0.f);                // dh * z of the step processed before (the later time step)
-    // bias gradients (db_ih = column sums of dgi, db_hh = of dgh) accumulate here over the time steps: the two column-sum
-    // passes over dgi / dgh (0.44 ms per step at B = 256) disappear
-    float2 sb_r = make_float2(0.f, 0.f), sb_z = sb_r, sb_n = sb_r, sb_nr = sb_r;
+    const int j = j0 + 4 * q4;
+    const int srow = lane >> 2, sc = lane & 3;
+    const long soff = (long)min(r0 + srow, B - 1) * 3 * GH + 192 * wave + 4 * sc;
+    const int spos = srow * BROW + 192 * wave + 48 * sc;
+    const int fpos = c16 * BROW + 8 * q4;
+
+    f4r dhz = {0.f, 0.f, 0.f, 0.f};                    // dh * z of the step processed before (the later time step)
+    // bias gradients (db_ih = column sums of dgi, db_hh = of dgh) accumulate here over the time steps
+    f4r sb_r = dhz, sb_z = dhz, sb_n = dhz, sb_nr = dhz;
     float gmax = 0.f;                                  // max |dgi| this thread wrote
     bool dead = false;
-    const long poll_limit = p.spin_limit > 8 ? (p.spin_limit >> 3) : 1;
 
+    // software pipeline around the wait, as in the forward kernel: the loads of a step that do not depend on the later step
+    // (output gradient, saved gates, previous hidden state) are issued one step ahead, the dgi stores one step late
+    f4r pre[6], keep[3];
+    int keep_t = -1;
+    auto prefetch = [&](int kk) {                      // step kk of the processing order
+        const int tt = d ? T - 1 - kk : kk;
+        pre[0] = *reinterpret_cast<const f4r*>(p.g_out + ((long)rowc * T + tt) * 2 * GH + d * GH + j);
+        const float* s = p.saves + gru_saves_tile(d, tt, T, p.ngroups >> 1, group >> 1, mb * 4 + wave) + 4 * lane;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre[1 + g] = *reinterpret_cast<const f4r*>(s + 256 * g);
+        pre[5] = f4r{0.f, 0.f, 0.f, 0.f};
+        if (kk > 0) pre[5] = *reinterpret_cast<const f4r*>(p.hs + ((long)d * T + (d ? tt + 1 : tt - 1)) * bh + (long)rowc * GH + j);
+    };
+    auto flush = [&]() {
+        if (live && keep_t >= 0) {
+            float* gi_o = p.dgi + ((long)row * T + keep_t) * 6 * GH + d * 3 * GH + j;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) *reinterpret_cast<f4r*>(gi_o + g * GH) = keep[g];
+        }
+    };
+    prefetch(T - 1);
     for (int k = T - 1, done = 0; k >= 0; --k, ++done) {
         const int t = d ? T - 1 - k : k;
-        // independent of the later step: output gradient, saved gates, previous hidden state
-        float2 dh = *reinterpret_cast<const float2*>(p.g_out + ((long)rowc * T + t) * 2 * GH + d * GH + j);
-        const float* s = p.saves + ((long)d * T + t) * 4 * bh + (long)rowc * 4 * GH + j;
-        const float2 rr = *reinterpret_cast<const float2*>(s), zz = *reinterpret_cast<const float2*>(s + GH);
-        const float2 nn = *reinterpret_cast<const float2*>(s + 2 * GH), ghn = *reinterpret_cast<const float2*>(s + 3 * GH);
-        float2 hp = make_float2(0.f, 0.f);
-        if (k > 0) hp = *reinterpret_cast<const float2*>(p.hs + ((long)d * T + (d ? t + 1 : t - 1)) * bh + (long)rowc * GH + j);
-        dh.x += dhz.x; dh.y += dhz.y;
+        f4r dh = pre[0];
+        const f4r rr = pre[1], zz = pre[2], nn = pre[3], ghn = pre[4], hp = pre[5];
+        dh += dhz;
         if (done > 0) {
             const float* dgh_later = p.dgh + ((long)d * T + (d ? t - 1 : t + 1)) * 3 * bh;
             f4r a[12];
-            gru_poll(a, dgh_later + (long)arow * 3 * GH + kb, err, poll_limit, dead);
-            // gradients have no fixed range: one power-of-two scale per wave and step from the amax of its 32 x 96 block
+            gru_poll<12, 16>(a, dgh_later + soff, err, poll_limit, dead);
+            // gradients have no fixed range: one power-of-two scale per staged quarter (16 rows x 192) and step from its amax
             float am = 0.f;
 #pragma unroll
             for (int q = 0; q < 12; ++q) am = fmaxf(am, gru_amax4(a[q]));
             const float sa = sed_sf_scale_of(wave_max(am));
-            floatx16 acc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            if (done > 1) __syncthreads();             // every wave has read the block of the step before: the buffer is free
 #pragma unroll
             for (int m = 0; m < 6; ++m) {
-                half8 ahi, alo;
-                gru_split8(a[2 * m], a[2 * m + 1], sa, ahi, alo);
-                gru_mfma3(acc, ahi, alo, whi[m], wlo[m]);
+                half8 hi, lo;
+                gru_split8(a[2 * m], a[2 * m + 1], sa, hi, lo);
+                *reinterpret_cast<half8*>(&gb[0][spos + 8 * m]) = hi;
+                *reinterpret_cast<half8*>(&gb[1][spos + 8 * m]) = lo;
             }
-            const float unscale = winv * (1.0f / sa);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] *= unscale;
-            if (wave >= 4) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) red[((wave - 4) * 16 + i) * 64 + lane] = acc[i];
-            }
+            if (lane == 0) qinv[done & 1][wave] = 1.0f / sa;
             __syncthreads();
-            if (wave < 4) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] += red[(wave * 16 + i) * 64 + lane];
-            }
-            __syncthreads();
-            if (wave < 4) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = acc[i];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const float2 v = *reinterpret_cast<const float2*>(&red[(w * 16 + r) * 64 + lp]);
-                dh.x += v.x; dh.y += v.y;
-            }
         }
-    float2 dr_pre, dz_pre, dn_pre, dn_r;
-#define SED_GRU_BWD(c)                                                                                          \
-    {                                                                                                           \
-        const float dn = dh.c * (1.0f - zz.c);                                                                  \
-        const float dz = dh.c * (hp.c - nn.c);                                                                  \
-        dn_pre.c = dn * (1.0f - nn.c * nn.c);                                                                   \
-        const float dr = dn_pre.c * ghn.c;                                                                      \
-        dr_pre.c = dr * rr.c * (1.0f - rr.c);                                                                   \
-        dz_pre.c = dz * zz.c * (1.0f - zz.c);                                                                   \
-        dn_r.c = dn_pre.c * rr.c;                                                                               \
-        dhz.c = dh.c * zz.c;                                                                                    \
-    }
-        SED_GRU_BWD(x) SED_GRU_BWD(y)
-#undef SED_GRU_BWD
+        if (k > 0) prefetch(k - 1);
+        flush();
+        if (done > 0) {
+            f4r g4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+                floatx4 am4 = {0.f, 0.f, 0.f, 0.f}, ac4 = am4, ad4 = am4;
+#pragma unroll
+                for (int m = 0; m < 6; ++m) {
+                    const int ks = 6 * qt + m;
+                    const half8 bhi = *reinterpret_cast<const half8*>(&gb[0][fpos + 32 * ks]);
+                    const half8 blo = *reinterpret_cast<const half8*>(&gb[1][fpos + 32 * ks]);
+                    ac4 = gru_mfma16(wlo[ks], bhi, ac4);
+                    ad4 = gru_mfma16(whi[ks], blo, ad4);
+                    am4 = gru_mfma16(whi[ks], bhi, am4);
+                }
+                const float u = qinv[done & 1][qt];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) g4[i] += (am4[i] + (ac4[i] + ad4[i])) * u;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dh[i] += g4[i] * winv[i];
+        }
+        f4r dr_pre, dz_pre, dn_pre, dn_r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float dn = dh[i] * (1.0f - zz[i]);
+            const float dz = dh[i] * (hp[i] - nn[i]);
+            dn_pre[i] = dn * (1.0f - nn[i] * nn[i]);
+            const float dr = dn_pre[i] * ghn[i];
+            dr_pre[i] = dr * rr[i] * (1.0f - rr[i]);
+            dz_pre[i] = dz * zz[i] * (1.0f - zz[i]);
+            dn_r[i] = dn_pre[i] * rr[i];
+            dhz[i] = dh[i] * zz[i];
+        }
         if (live) {
-            float* gi_o = p.dgi + ((long)row * T + t) * 6 * GH + d * 3 * GH + j;
             float* gh_o = p.dgh + ((long)d * T + t) * 3 * bh + (long)row * 3 * GH + j;
-            // the hand-over first: nothing else is queued in front of it.  Agent-scope stores here although the group shares an XCD:
-            // with three exchanged rows per thread and 48 KB polled per workgroup the XCD-local form measured 7 % SLOWER
-            // (1.04 vs 0.98 ms at B = 256), the forward pass 15 % faster (0.60 vs 0.71 ms)
-            st_coherent(gh_o, dr_pre);
-            st_coherent(gh_o + GH, dz_pre);
-            st_coherent(gh_o + 2 * GH, dn_r);
-            *reinterpret_cast<float2*>(gi_o) = dr_pre;
-            *reinterpret_cast<float2*>(gi_o + GH) = dz_pre;
-            *reinterpret_cast<float2*>(gi_o + 2 * GH) = dn_pre;
-            sb_r.x += dr_pre.x; sb_r.y += dr_pre.y; sb_z.x += dz_pre.x; sb_z.y += dz_pre.y;
-            sb_n.x += dn_pre.x; sb_n.y += dn_pre.y; sb_nr.x += dn_r.x; sb_nr.y += dn_r.y;
-            gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(dr_pre.x), fabsf(dr_pre.y))),
-                         fmaxf(fmaxf(fabsf(dz_pre.x), fabsf(dz_pre.y)), fmaxf(fabsf(dn_pre.x), fabsf(dn_pre.y))));
-        }
-        if (done > 0 && k > 0) __syncthreads();       // `red` is rewritten by the next step
-    }
-    if (p.dgi_amax) amax_publish_block(p.dgi_amax, gmax);
-    if (p.dbias) {                                     // rows of the block: 16 r x 2 halves per hidden pair -> LDS -> 128 sums
-        __syncthreads();
-        float* o = red + tid * 8;
-        o[0] = sb_r.x; o[1] = sb_r.y; o[2] = sb_z.x; o[3] = sb_z.y; o[4] = sb_n.x; o[5] = sb_n.y; o[6] = sb_nr.x; o[7] = sb_nr.y;
-        __syncthreads();
-        if (tid < 128) {
-            const int kind = tid >> 5, jj = tid & 31;              // hidden unit j0 + jj lives in the threads with (q & 15) == jj / 2
-            float acc = 0.f;
-#pragma unroll 4
-            for (int rr = 0; rr < 16; ++rr)
+            st_exchange4(gh_o, dr_pre, one_xcd);       // the hand-over
+            st_exchange4(gh_o + GH, dz_pre, one_xcd);
+            st_exchange4(gh_o + 2 * GH, dn_r, one_xcd);
+            sb_r += dr_pre; sb_z += dz_pre; sb_n += dn_pre; sb_nr += dn_r;
 #pragma unroll
-                for (int half = 0; half < 2; ++half)
-                    acc += red[(rr * 32 + half * 16 + (jj >> 1)) * 8 + kind * 2 + (jj & 1)];
-            p.dbias[(((long)d * (p.ngroups >> 1) + (group >> 1)) * 4 + kind) * GH + j0 + jj] = acc;
+            for (int i = 0; i < 4; ++i) gmax = fmaxf(gmax, fmaxf(fabsf(dr_pre[i]), fmaxf(fabsf(dz_pre[i]), fabsf(dn_pre[i]))));
+        }
+        keep[0] = dr_pre; keep[1] = dz_pre; keep[2] = dn_pre;
+        keep_t = t;
+    }
+    flush();
+    if (p.dgi_amax) amax_publish_block(p.dgi_amax, gmax);
+    if (p.dbias) {                                     // sum over the 16 batch rows of the block: the lanes with equal q4
+        f4r* const sums[4] = {&sb_r, &sb_z, &sb_n, &sb_nr};
+#pragma unroll
+        for (int kind = 0; kind < 4; ++kind) {
+            f4r v = *sums[kind];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] += __shfl_xor(v[i], o, 64);
+            if (c16 == 0) *reinterpret_cast<f4r*>(p.dbias + (((long)d * (p.ngroups >> 1) + (group >> 1)) * 4 + kind) * GH + j) = v;
         }
     }
 }
@@ -508,8 +588,8 @@ bool gru_device_fits(int grid) {
     if (dev != cached_dev) {
         int cus = 0, per_f = 0, per_b = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_f, gru_seq_fwd_kernel, 512, 0) != hipSuccess) return false;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_b, gru_seq_bwd_kernel, 512, 0) != hipSuccess) return false;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_f, gru_seq_fwd_kernel, 256, 0) != hipSuccess) return false;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_b, gru_seq_bwd_kernel, 256, 0) != hipSuccess) return false;
         // one workgroup per CU is what the kernels are laid out for; the occupancy API may over-report by one block per CU
         // (MI355X_MICROARCH.md), so only its ">= 1" answer is used
         cached_cap = (per_f >= 1 && per_b >= 1) ? cus : 0;
@@ -521,10 +601,12 @@ bool gru_device_fits(int grid) {
 }  // namespace
 
 SED_API int sed_gru_seq_supported(int B, int Hd) {
-    if (!(Hd == GH && B > 0 && 2 * sed_cdiv(B, 32) * (GH / 32) <= 256)) return 0;
-    return gru_device_fits(gru_grid(2 * sed_cdiv(B, 32))) ? 1 : 0;
+    if (!(Hd == GH && B > 0 && gru_grid(2 * sed_cdiv(B, GRU_RB)) <= 256)) return 0;
+    return gru_device_fits(gru_grid(2 * sed_cdiv(B, GRU_RB))) ? 1 : 0;
 }
 SED_API long sed_gru_seq_ws_floats(void) { return GRU_FLAG_INTS; }
+SED_API int sed_gru_seq_row_block(void) { return GRU_RB; }
+SED_API long sed_gru_seq_saves_floats(int B, int T) { return B > 0 && T > 0 ? 2L * T * sed_cdiv(B, GRU_RB) * GRU_RB * 4 * GH : 0; }
 SED_API int sed_gru_set_spin_limit(long spins) {
     g_spin_limit = spins > 0 ? spins : (1L << 23);
     return 0;
@@ -543,15 +625,15 @@ SED_API int sed_debug_occupy(int blocks, int lds_bytes, long microseconds, hipSt
 SED_API int sed_gru_seq_fwd(const float* gi, const float* w_hh_f, const float* w_hh_b, const float* b_hh_f,
                             const float* b_hh_b, int B, int T, int Hd, float* hs, float* saves, float* out, float* ws,
                             int* err_host, hipStream_t stream) {
-    const int ngroups = 2 * sed_cdiv(B, 32);
-    if (B <= 0 || T <= 0 || Hd != GH || ngroups > GRU_MAX_GROUPS || ngroups * (GH / 32) > 256) return SED_EINVAL;
+    const int ngroups = 2 * sed_cdiv(B, GRU_RB);
+    if (B <= 0 || T <= 0 || Hd != GH || gru_grid(ngroups) > 256) return SED_EINVAL;
     hipError_t e = hipMemsetAsync(ws, 0, GRU_FLAG_INTS * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
     // the hand-over buffer starts out as sentinels; every word of it is replaced by the kernel
     e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(hs), (int)GRU_SENTINEL, (size_t)2 * T * B * GH, stream);
     if (e != hipSuccess) return (int)e;
     GruSeqFwdP p{gi, {w_hh_f, w_hh_b}, {b_hh_f, b_hh_b}, hs, saves, out, reinterpret_cast<int*>(ws), B, T, ngroups, g_spin_limit};
-    hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3(gru_grid(ngroups)), dim3(512), 0, stream, p);
+    hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3(gru_grid(ngroups)), dim3(256), 0, stream, p);
     SED_LAUNCH_CHECK();
     hipLaunchKernelGGL(gru_seq_check_kernel, dim3(256), dim3(256), 0, stream, reinterpret_cast<const int*>(ws), err_host, 1, out,
                        (long)B * T * 2 * GH);
@@ -563,8 +645,8 @@ SED_API int sed_gru_seq_fwd(const float* gi, const float* w_hh_f, const float* w
 SED_API int sed_gru_seq_bwd(const float* g_out, const float* wt_f, const float* wt_b, const float* hs, const float* saves,
                             int B, int T, int Hd, float* dgi, float* dgh, float* dbias_parts, float* ws, int* err_host,
                             float* dgi_amax, hipStream_t stream) {
-    const int ngroups = 2 * sed_cdiv(B, 32);
-    if (B <= 0 || T <= 0 || Hd != GH || ngroups > GRU_MAX_GROUPS || ngroups * (GH / 32) > 256) return SED_EINVAL;
+    const int ngroups = 2 * sed_cdiv(B, GRU_RB);
+    if (B <= 0 || T <= 0 || Hd != GH || gru_grid(ngroups) > 256) return SED_EINVAL;
     hipError_t e = hipMemsetAsync(ws, 0, GRU_FLAG_INTS * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
     e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(dgh), (int)GRU_SENTINEL, (size_t)2 * T * B * 3 * GH, stream);
@@ -574,7 +656,7 @@ SED_API int sed_gru_seq_bwd(const float* g_out, const float* wt_f, const float* 
         if (e != hipSuccess) return (int)e;
     }
     GruSeqBwdP p{g_out, {wt_f, wt_b}, hs, saves, dgi, dgh, dbias_parts, dgi_amax, reinterpret_cast<int*>(ws), B, T, ngroups, g_spin_limit};
-    hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(gru_grid(ngroups)), dim3(512), 0, stream, p);
+    hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(gru_grid(ngroups)), dim3(256), 0, stream, p);
     SED_LAUNCH_CHECK();
     hipLaunchKernelGGL(gru_seq_check_kernel, dim3(256), dim3(256), 0, stream, reinterpret_cast<const int*>(ws), err_host, 2, dgi,
                        (long)B * T * 6 * GH);

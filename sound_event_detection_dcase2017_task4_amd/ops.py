@@ -1708,11 +1708,13 @@ class GruFn(torch.autograd.Function):
             gi = gemm_nt(x.view(B * T, I), w_ih, b_ih).view(B, T, 6 * Hd)              # (B, T, 6H)
             ctx.pk_t = None
         hs = torch.empty((2, T, B, Hd), dtype=torch.float32, device=dev)
-        saves = torch.empty((2, T, B, 4 * Hd), dtype=torch.float32, device=dev)
         whh = (_f32c(w_hh_f), _f32c(w_hh_b))
         bhh = (_f32c(b_hh_f), _f32c(b_hh_b))
         ctx.sinks = _sinks(ctx, (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_b, w_hh_b, b_ih_b, b_hh_b), 1)
         ctx.fused = bool(USE_FUSED_GRU and _lib.lib().sed_gru_seq_supported(B, Hd))
+        # saved gates r, z, n, gh_n: the fused pair of recurrences keeps them in a private tile layout (rows padded to its row block)
+        saves = (torch.empty((_lib.lib().sed_gru_seq_saves_floats(B, T),), dtype=torch.float32, device=dev) if ctx.fused
+                 else torch.empty((2, T, B, 4 * Hd), dtype=torch.float32, device=dev))
         if ctx.fused:
             # fused recurrence: ONE persistent launch for all T steps of both directions (csrc/gru.hip); a launch that
             # cannot make progress poisons `out` with NaN and raises the host-mapped flag polled by check_device_errors
@@ -1756,7 +1758,8 @@ class GruFn(torch.autograd.Function):
         dgi_amax = None
         if fused:
             ws = torch.empty((_lib.lib().sed_gru_seq_ws_floats(),), dtype=torch.float32, device=dev)
-            nrb = (B + 31) // 32
+            rb = _lib.lib().sed_gru_seq_row_block()
+            nrb = (B + rb - 1) // rb
             dbp = torch.empty((2, nrb, 4 * Hd), dtype=torch.float32, device=dev)     # bias-gradient sums per row block
             dgi_amax = _amax_buf(dev) if ctx.pk_t is not None else None      # amax of dgi, published by the recurrence itself
             with _timed("gru_recurrence_bwd|B%d T%d", (B, T), 2.0 * 2 * B * T * 3 * Hd * Hd):

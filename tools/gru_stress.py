@@ -31,24 +31,3 @@ for it in range(200):
             break
 torch.cuda.synchronize()
 print("nondeterministic iterations:", bad, "of 200")
-# kernel time of the two recurrences (HIP events around the C-ABI calls, ops.TIMING)
-for Bt in (256, 32):
-    xt = torch.randn(Bt, T, 512, device="cuda")
-    gt = torch.randn(Bt, T, 512, device="cuda")
-    ops.USE_FUSED_GRU = True
-    def once():
-        ps = [getattr(gru, n).detach().clone().requires_grad_(True) for n in names]
-        xd = xt.clone().requires_grad_(True)
-        ops.GruFn.apply(xd, *ps).backward(gt)
-    for _ in range(3):
-        once()
-    torch.cuda.synchronize()
-    ops.TIMING, ops.TIMING_ONLY = {}, None
-    for _ in range(10):
-        once()
-    torch.cuda.synchronize()
-    tm, ops.TIMING = ops.TIMING, None
-    for k, v in sorted(tm.items()):
-        if "gru" in k:
-            ms = [a.elapsed_time(b) for a, b, _ in v]
-            print("B=%d  %-28s %.3f ms avg over %d launches (min %.3f)" % (Bt, k, sum(ms) / len(ms), len(ms), min(ms)))
