@@ -416,11 +416,17 @@ int sed_debug_occupy(int blocks, int lds_bytes, long microseconds, sed_stream_t 
  * :651-657), or null in eval mode; p_drop = 0.1 (:590).  stats: [B][8][T][4] floats (row max, row sum, D, -) written by
  * the forward and completed / consumed by the backward.
  *   sed_mha_fwd: O = dropout(softmax(Q K^T / 8)) V            sed_mha_bwd: g_q, g_k, g_v from g_o
+ * T <= 128 runs on fp32-MFMA kernels (the whole score tile of a (clip, head) at once), longer sequences on vector kernels.
+ * keep_bits: scratch of sed_mha_mask_words(B, T) 32-bit words (0 words for T > 128: pass null), required with a non-null keep
+ * for T <= 128: sed_mha_fwd packs the mask into it (dropped bits per query over the keys and per key over the queries),
+ * sed_mha_bwd of the SAME mask reads it back -- hand in the buffer the forward call filled.
  * sed_drop_relu_*: y = relu(dropout(x)) of the output projection (:664), keep bytes [n] or null, p_drop = 0.2. */
+long sed_mha_mask_words(int B, int T);
 int sed_mha_fwd(const float* q, const float* k, const float* v, const unsigned char* keep, float p_drop, int B, int T,
-                float* o, float* stats, sed_stream_t stream);
+                float* o, float* stats, unsigned* keep_bits, sed_stream_t stream);
 int sed_mha_bwd(const float* q, const float* k, const float* v, const float* o, const float* g_o, const unsigned char* keep,
-                float p_drop, int B, int T, float* stats, float* g_q, float* g_k, float* g_v, sed_stream_t stream);
+                float p_drop, int B, int T, float* stats, float* g_q, float* g_k, float* g_v, const unsigned* keep_bits,
+                sed_stream_t stream);
 int sed_drop_relu_fwd(const float* x, const unsigned char* keep, float p_drop, long n, float* y, sed_stream_t stream);
 int sed_drop_relu_bwd(const float* g_y, const float* y, const unsigned char* keep, float p_drop, long n, float* g_x,
                       sed_stream_t stream);

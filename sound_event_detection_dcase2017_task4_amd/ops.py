@@ -1622,7 +1622,10 @@ class MultiHeadFn(torch.autograd.Function):
             raise RuntimeError("attention keep mask must be bool/uint8 of shape (8*B, T, T)")
         if kf is not None and (kf.dtype not in (torch.bool, torch.uint8) or kf.numel() != M * C):
             raise RuntimeError("fc keep mask must be bool/uint8 of shape (B, T, 512)")
-        _call("sed_mha_fwd", _ptr(q), _ptr(k), _ptr(v), _ptr(ka), float(p_attn), B, T, _ptr(o), _ptr(stats), _stream())
+        nbits = _lib.lib().sed_mha_mask_words(B, T) if ka is not None else 0
+        kbits = torch.empty((nbits,), dtype=torch.int32, device=x.device) if nbits else None      # the mask as bits (MFMA kernels)
+        _call("sed_mha_fwd", _ptr(q), _ptr(k), _ptr(v), _ptr(ka), float(p_attn), B, T, _ptr(o), _ptr(stats), _ptr(kbits), _stream())
+        ctx.kbits = kbits
         y = linear_nt(o, wo, _f32c(bo))
         out = torch.empty_like(y)
         _call("sed_drop_relu_fwd", _ptr(y), _ptr(kf), float(p_fc), M * C, _ptr(out), _stream())
@@ -1648,7 +1651,7 @@ class MultiHeadFn(torch.autograd.Function):
         go = linear_nt(gy, wo, transposed=True, x_amax=gya)
         gq, gk, gv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
         _call("sed_mha_bwd", _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(go), _ptr(ka), ctx.p[0], B, T, _ptr(stats), _ptr(gq),
-              _ptr(gk), _ptr(gv), _stream())
+              _ptr(gk), _ptr(gv), _ptr(ctx.kbits), _stream())
         gas = [amax_of(t_) if sf else None for t_ in (gq, gk, gv)]
         gx = linear_nt(gq, wq, transposed=True, x_amax=gas[0])
         for gt, w, ga in ((gk, wk, gas[1]), (gv, wv, gas[2])):
