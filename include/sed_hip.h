@@ -394,6 +394,8 @@ int sed_gru_gate_bwd(const float* g_out0, const float* g_out1, long ld_go, const
  * follow-up kernel overwrites `out` / `dgi` with NaN and stores 1 (forward) / 2 (backward) into *err_host, a
  * DEVICE-VISIBLE HOST int (hipHostMalloc / pinned; may be null) that the host can poll without synchronising.
  * sed_gru_set_spin_limit (test hook): polls before giving up (default 2^23, about 1 s; <= 0 restores the default).
+ * sed_gru_force_agent_scope (test hook): the workgroups of a group normally find themselves on one XCD (they check the XCC_ID
+ * register) and exchange through its L2 with plain stores; 1 makes them use the agent-scope stores of the fallback path.
  * sed_debug_occupy (test hook): holds `blocks` CUs (one workgroup with lds_bytes of LDS each) for `microseconds`. */
 int sed_gru_seq_supported(int B, int Hd);
 long sed_gru_seq_ws_floats(void);
@@ -408,6 +410,7 @@ int sed_gru_seq_bwd(const float* g_out, const float* wt_f, const float* wt_b, co
                                           the rows of a block: db_ih = (dr, dz, dn), db_hh = (dr, dz, dn*r) summed over blocks */,
                     float* ws, int* err_host, float* dgi_amax, sed_stream_t stream);
 int sed_gru_set_spin_limit(long spins);
+int sed_gru_force_agent_scope(int on);
 int sed_debug_occupy(int blocks, int lds_bytes, long microseconds, sed_stream_t stream);
 
 /* ---- multi-head self-attention of the Transformer heads (models.py:587-665; 8 heads x 64) ----------------------

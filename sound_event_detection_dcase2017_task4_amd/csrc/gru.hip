@@ -233,6 +233,7 @@ struct GruSeqFwdP {
     int* flags;                // workspace (zeroed by the launcher): the error word at [GRU_MAX_GROUPS]
     int B, T, ngroups;
     long spin_limit;
+    int agent_scope;           // test hook: exchange with agent-scope stores although the group shares an XCD
 };
 
 __global__ __launch_bounds__(256) void gru_seq_fwd_kernel(GruSeqFwdP p) {
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(256) void gru_seq_fwd_kernel(GruSeqFwdP p) {
     const long bh = (long)B * GH;
     int* const err = p.flags + GRU_MAX_GROUPS;
     const long poll_limit = p.spin_limit > 8 ? (p.spin_limit >> 3) : 1;
-    const bool one_xcd = gru_group_on_one_xcd(p.flags, group, poll_limit, &xcd_word);
+    const bool one_xcd = gru_group_on_one_xcd(p.flags, group, poll_limit, &xcd_word) && !p.agent_scope;
 
     // A operand, resident for the whole sequence: row = unit j0 + c16 of gate g, positions 32 ks + 8 q4 .. + 8, as split-f16
     // halves scaled by a power of two of the ROW's own amax (the four lanes that share the row agree on it)
@@ -389,6 +390,7 @@ struct GruSeqBwdP {
     int* flags;
     int B, T, ngroups;
     long spin_limit;
+    int agent_scope;           // test hook: exchange with agent-scope stores although the group shares an XCD
 };
 
 __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(GruSeqBwdP p) {
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(GruSeqBwdP p) {
     const long bh = (long)B * GH;
     int* const err = p.flags + GRU_MAX_GROUPS;
     const long poll_limit = p.spin_limit > 8 ? (p.spin_limit >> 3) : 1;
-    const bool one_xcd = gru_group_on_one_xcd(p.flags, group, poll_limit, &xcd_word);
+    const bool one_xcd = gru_group_on_one_xcd(p.flags, group, poll_limit, &xcd_word) && !p.agent_scope;
 
     // dh_gemm[b][j] = sum_c dgh_later[b][c] * W_hh[c][j], c over 3H = 768.  A operand: row j0 + c16 of W_hh^T, resident
     half8 whi[24], wlo[24];
@@ -579,6 +581,7 @@ __global__ __launch_bounds__(256) void occupy_kernel(long ticks) {
 }
 
 long g_spin_limit = 1L << 23;          // ~1 s of polling
+int g_agent_scope = 0;
 
 // all workgroups of the persistent kernels fit on the current device at once?  (cached per device)
 bool gru_device_fits(int grid) {
@@ -611,6 +614,10 @@ SED_API int sed_gru_set_spin_limit(long spins) {
     g_spin_limit = spins > 0 ? spins : (1L << 23);
     return 0;
 }
+SED_API int sed_gru_force_agent_scope(int on) {
+    g_agent_scope = on ? 1 : 0;
+    return 0;
+}
 SED_API int sed_debug_occupy(int blocks, int lds_bytes, long microseconds, hipStream_t stream) {
     if (blocks <= 0 || lds_bytes < 1024 || lds_bytes > 160 * 1024 || microseconds < 0 || microseconds > 2000000) return SED_EINVAL;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -632,7 +639,7 @@ SED_API int sed_gru_seq_fwd(const float* gi, const float* w_hh_f, const float* w
     // the hand-over buffer starts out as sentinels; every word of it is replaced by the kernel
     e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(hs), (int)GRU_SENTINEL, (size_t)2 * T * B * GH, stream);
     if (e != hipSuccess) return (int)e;
-    GruSeqFwdP p{gi, {w_hh_f, w_hh_b}, {b_hh_f, b_hh_b}, hs, saves, out, reinterpret_cast<int*>(ws), B, T, ngroups, g_spin_limit};
+    GruSeqFwdP p{gi, {w_hh_f, w_hh_b}, {b_hh_f, b_hh_b}, hs, saves, out, reinterpret_cast<int*>(ws), B, T, ngroups, g_spin_limit, g_agent_scope};
     hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3(gru_grid(ngroups)), dim3(256), 0, stream, p);
     SED_LAUNCH_CHECK();
     hipLaunchKernelGGL(gru_seq_check_kernel, dim3(256), dim3(256), 0, stream, reinterpret_cast<const int*>(ws), err_host, 1, out,
@@ -655,7 +662,7 @@ SED_API int sed_gru_seq_bwd(const float* g_out, const float* wt_f, const float* 
         e = sed_amax_clear(dgi_amax, stream);
         if (e != hipSuccess) return (int)e;
     }
-    GruSeqBwdP p{g_out, {wt_f, wt_b}, hs, saves, dgi, dgh, dbias_parts, dgi_amax, reinterpret_cast<int*>(ws), B, T, ngroups, g_spin_limit};
+    GruSeqBwdP p{g_out, {wt_f, wt_b}, hs, saves, dgi, dgh, dbias_parts, dgi_amax, reinterpret_cast<int*>(ws), B, T, ngroups, g_spin_limit, g_agent_scope};
     hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(gru_grid(ngroups)), dim3(256), 0, stream, p);
     SED_LAUNCH_CHECK();
     hipLaunchKernelGGL(gru_seq_check_kernel, dim3(256), dim3(256), 0, stream, reinterpret_cast<const int*>(ws), err_host, 2, dgi,

@@ -234,8 +234,9 @@ class MultiHead(nn.Module):
         if self.training:
             B, T, C = x_btc.shape
             if dropout_masks is None:
-                keep_attn = torch.rand((self.n_head * B, T, T), device=x_btc.device) >= self.attn_dropout_p
-                keep_fc = torch.rand((B, T, C), device=x_btc.device) >= self.dropout_p
+                # keep masks drawn as bytes in ONE kernel each (a float draw + a compare wrote and re-read 4 bytes per element)
+                keep_attn = torch.empty((self.n_head * B, T, T), dtype=torch.uint8, device=x_btc.device).bernoulli_(1.0 - self.attn_dropout_p)
+                keep_fc = torch.empty((B, T, C), dtype=torch.uint8, device=x_btc.device).bernoulli_(1.0 - self.dropout_p)
             else:
                 keep_attn, keep_fc = (m.to(device=x_btc.device, dtype=torch.bool) for m in dropout_masks)
         return ops.MultiHeadFn.apply(x_btc, self.w_qs.weight, self.w_qs.bias, self.w_ks.weight, self.w_ks.bias,

@@ -70,6 +70,25 @@ def test_production_shape_fused_vs_per_step_vs_torch(ops):
     ops.check_device_errors(synchronize=True)
 
 
+@pytest.mark.parametrize("B", [256, 40])
+def test_xcd_local_and_agent_scope_exchange_agree(ops, B):
+    """The four workgroups of a (direction, row block) sit on one XCD and hand h_t / dgh_t over with plain stores through its L2;
+    a group that does not find itself co-located (XCC_ID register) uses agent-scope stores.  The dispatcher of this part always
+    co-locates them, so the fallback is forced through the test hook: both forms must give the same bits."""
+    T = 60
+    gru, x, gy = make(B, T)
+    L = ops._lib.lib()
+    try:
+        local = run(ops, gru, x, gy, fused=True)
+        L.sed_gru_force_agent_scope(1)
+        agent = run(ops, gru, x, gy, fused=True)
+    finally:
+        L.sed_gru_force_agent_scope(0)
+    ops.check_device_errors(synchronize=True)
+    for a, b, n in zip(local, agent, ["y", "dx"] + NAMES):
+        assert torch.equal(a, b), (n, (a - b).abs().max().item())
+
+
 def test_fused_gru_beside_a_co_tenant_kernel(ops):
     """A second stream holds 64 whole CUs (one 160 KB-LDS workgroup each) while the fused recurrence is launched: the 128
     persistent workgroups still find CUs, and the results equal the undisturbed run bit for bit -- or, if the device
