@@ -431,9 +431,21 @@ def _cache_fresh(kind, srcs):
     return hit is not None and hit[0] == _cache_stamp(srcs) and all(r() is t for r, t in zip(hit[2], srcs))
 
 
-def _cache_put(kind, srcs, val):
-    if len(_WCACHE) > 64:
+def _cache_trim():
+    """Keep the table small WITHOUT touching live entries of the current parameter generation: entries whose tensors are gone or
+    that belong to an older generation go first; only a table that is still large after that is dropped.  (Clearing everything at a
+    fixed size could wipe entries that the very same prepack_sf16 call had just put -- found as a test that failed once in five
+    runs, whenever earlier tests had left the table near the limit.)"""
+    if len(_WCACHE) <= 64:
+        return
+    for k in [k for k, (stamp, _, refs) in _WCACHE.items() if stamp[0] != PARAM_GENERATION or any(r() is None for r in refs)]:
+        del _WCACHE[k]
+    if len(_WCACHE) > 512:
         _WCACHE.clear()
+
+
+def _cache_put(kind, srcs, val):
+    _cache_trim()
     _WCACHE[(kind,) + tuple(id(t) for t in srcs)] = (_cache_stamp(srcs), val, [weakref.ref(t) for t in srcs])
 
 
@@ -447,8 +459,7 @@ def _cached(kind, srcs, build):
     if hit is not None and hit[0] == stamp and all(r() is t for r, t in zip(hit[2], srcs)):
         return hit[1]
     val = build()
-    if len(_WCACHE) > 64:
-        _WCACHE.clear()
+    _cache_trim()
     _WCACHE[key] = (stamp, val, [weakref.ref(t) for t in srcs])
     return val
 

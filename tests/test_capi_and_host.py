@@ -327,3 +327,31 @@ def test_pinned_batch_loader_hold_keeps_earlier_batches_valid():
             for wave, copy in seen[-(hold + 1):]:
                 assert torch.equal(wave, copy)
         assert len(seen) == 12
+
+
+def test_weight_cache_trim_keeps_live_entries_of_the_current_generation():
+    """ops._WCACHE is trimmed, not cleared: entries of dead tensors / older parameter generations go, live ones of the current
+    generation stay -- a prepack call must never wipe what it has just put (CPU tensors suffice: the table only looks at object
+    identity, data_ptr and the version counter)."""
+    from sound_event_detection_dcase2017_task4_amd import ops
+    saved, gen = dict(ops._WCACHE), ops.PARAM_GENERATION
+    try:
+        ops._WCACHE.clear()
+        dead = [torch.zeros(1) for _ in range(70)]
+        for t in dead:
+            ops._cache_put("k", (t,), 1)
+        live = [torch.zeros(1) for _ in range(10)]
+        del dead
+        for t in live:
+            ops._cache_put("k", (t,), 2)
+        assert all(ops._cache_fresh("k", (t,)) for t in live)          # the first puts of this batch survived the later ones
+        ops.invalidate_weight_caches()
+        assert not any(ops._cache_fresh("k", (t,)) for t in live)
+        more = [torch.zeros(1) for _ in range(70)]
+        for t in more:
+            ops._cache_put("k", (t,), 3)
+        assert all(ops._cache_fresh("k", (t,)) for t in more) and len(ops._WCACHE) <= 80
+    finally:
+        ops._WCACHE.clear()
+        ops._WCACHE.update(saved)
+        ops.PARAM_GENERATION = gen
