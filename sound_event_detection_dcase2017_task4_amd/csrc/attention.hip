@@ -562,12 +562,14 @@ SED_API int sed_mha_bwd(const float* q, const float* k, const float* v, const fl
         if (keep && !keep_bits) return SED_EINVAL;
         const unsigned* bits = keep ? keep_bits : nullptr;
         constexpr int kv_lds = (2 * MT * MHA_D + 3 * MT) * (int)sizeof(float);      // 65.5 KB: above the static limit
-        static bool raised = false;
-        if (!raised) {
+        static int raised_dev = -1;                    // the attribute belongs to (function, device)
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return SED_EINVAL;
+        if (dev != raised_dev) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mha_bwd_kv_mfma_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, kv_lds);
             if (e != hipSuccess) return (int)e;
-            raised = true;
+            raised_dev = dev;
         }
         hipLaunchKernelGGL(mha_bwd_q_mfma_kernel, dim3(B * MHA_H), dim3(256), 0, stream, q, k, v, o, g_o, bits, ik, B, T, stats, g_q);
         hipLaunchKernelGGL(mha_bwd_kv_mfma_kernel, dim3(B * MHA_H), dim3(256), kv_lds, stream, q, k, v, g_o, bits, ik, B, T, stats,
