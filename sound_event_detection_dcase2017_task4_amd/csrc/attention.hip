@@ -259,14 +259,17 @@ __device__ __forceinline__ void mha_dot(floatx16& acc, const float* __restrict__
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, own[4 * c + 3], acc, 0, 0, 0);
     }
 }
-// out[dt] += w^T-as-A . tile rows:  out[own row][d] += sum over the 32 tile rows of w[r] * tile[trow0 + row(r, half)][d]
+// out[dt] += w^T-as-A . tile rows:  out[own row][d] += sum over the 32 tile rows of w[r] * tile[trow0 + row(r, half)][d];
+// the two output tiles INTERLEAVE the columns (lane l31 of tile dt owns column 2 l31 + dt), so one 8-byte LDS read feeds both
+// MFMAs of a k-step and the epilogues store float2
 __device__ __forceinline__ void mha_apply(floatx16 (&out)[2], const floatx16& w, const float* __restrict__ tile, int trow0, int half, int l31) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = trow0 + mha_acc_row(r, half);
+        const float2 b = *reinterpret_cast<const float2*>(tile + mha_at(row, 2 * l31));      // columns 2 l31 and 2 l31 + 1: one read for both tiles
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
-            out[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], tile[mha_at(row, 32 * dt + l31)], out[dt], 0, 0, 0);
+            out[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], dt ? b.y : b.x, out[dt], 0, 0, 0);
     }
 }
 __device__ __forceinline__ float mha_xor32(float v) { return __shfl_xor(v, 32, 64); }
@@ -377,9 +380,7 @@ __global__ __launch_bounds__(256, 2) void mha_fwd_mfma_kernel(const float* __res
         const int qr = mha_acc_row(r, half);
         const float sc = __shfl(rl, qr, 64);
         if (32 * wave + qr < T) {
-            float* op = o + (row0 + 32 * wave + qr) * MHA_LD + h * MHA_D + l31;
-            op[0] = acc[0][r] * sc;
-            op[32] = acc[1][r] * sc;
+            *reinterpret_cast<float2*>(o + (row0 + 32 * wave + qr) * MHA_LD + h * MHA_D + 2 * l31) = make_float2(acc[0][r] * sc, acc[1][r] * sc);
         }
     }
     if (stats && half == 0 && qi < T) {
@@ -447,9 +448,7 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_q_mfma_kernel(const float* __r
     for (int r = 0; r < 16; ++r) {
         const int qr = 32 * wave + mha_acc_row(r, half);
         if (qr < T) {
-            float* op = gq + (row0 + qr) * MHA_LD + h * MHA_D + l31;
-            op[0] = acc[0][r];
-            op[32] = acc[1][r];
+            *reinterpret_cast<float2*>(gq + (row0 + qr) * MHA_LD + h * MHA_D + 2 * l31) = make_float2(acc[0][r], acc[1][r]);
         }
     }
 }
@@ -513,9 +512,9 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kv_mfma_kernel(const float* __
     for (int r = 0; r < 16; ++r) {
         const int kr = 32 * wave + mha_acc_row(r, half);
         if (kr < T) {
-            const long off = (row0 + kr) * MHA_LD + h * MHA_D + l31;
-            gk[off] = ak[0][r]; gk[off + 32] = ak[1][r];
-            gv[off] = av[0][r]; gv[off + 32] = av[1][r];
+            const long off = (row0 + kr) * MHA_LD + h * MHA_D + 2 * l31;
+            *reinterpret_cast<float2*>(gk + off) = make_float2(ak[0][r], ak[1][r]);
+            *reinterpret_cast<float2*>(gv + off) = make_float2(av[0][r], av[1][r]);
         }
     }
 }
