@@ -403,6 +403,7 @@ def extra_configs(rank, world, dev, steps=5, warmup=2, hip_graph="off"):
     for tag, mt, B, mix, inf in (
             ("configs[2] Cnn_9layers_FrameAtt B=256 mixup", "Cnn_9layers_FrameAtt", 256, True, False),
             ("configs[3] Cnn_9layers_Gru_FrameAtt B=256 mixup", "Cnn_9layers_Gru_FrameAtt", 256, True, False),
+            ("SURVEY 8(f)4 Transformer heads: Cnn_9layers_Transformer_FrameAvg B=256 mixup", "Cnn_9layers_Transformer_FrameAvg", 256, True, False),
             ("configs[0] shape on the GPU: Cnn_9layers_FrameAvg B=32 no mixup", "Cnn_9layers_FrameAvg", 32, False, False),
             ("small per-GPU batch (--batch_size 32 over 8 GPUs in the CLI): Cnn_9layers_FrameAvg B=4 mixup", "Cnn_9layers_FrameAvg", 4, True, False),
             ("inference (eval-mode forward) Cnn_9layers_FrameAvg 256 clips/step", "Cnn_9layers_FrameAvg", 256, False, True)):
