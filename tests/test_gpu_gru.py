@@ -70,6 +70,28 @@ def test_production_shape_fused_vs_per_step_vs_torch(ops):
     ops.check_device_errors(synchronize=True)
 
 
+@pytest.mark.parametrize("B,T", [(1, 1), (1, 9), (17, 3), (33, 7), (48, 2), (512, 2)])
+def test_fused_recurrence_on_ragged_and_extreme_shapes(ops, B, T):
+    """Row blocks of 16: a single row, one row past a block, the largest batch the persistent kernels take (512 = 256
+    workgroups), sequences of one step (no hand-over at all) and of two -- fused vs per-step launches vs torch.nn.GRU."""
+    gru, x, gy = make(B, T, seed=B + T)
+    assert ops._lib.lib().sed_gru_seq_supported(B, 256) == 1
+    xr = x.clone().requires_grad_(True)
+    y, _ = gru(xr)
+    y.backward(gy)
+    ref = [y.detach(), xr.grad] + [getattr(gru, n).grad for n in NAMES]
+    step = run(ops, gru, x, gy, fused=False)
+    fused = run(ops, gru, x, gy, fused=True)
+    ops.check_device_errors(synchronize=True)
+    for a, b_, c, n in zip(fused, step, ref, ["y", "dx"] + NAMES):
+        scale = max(c.abs().max().item(), 1e-30)
+        if T == 1 and n in ("weight_hh_l0", "weight_hh_l0_reverse"):      # no previous state: the gradient is exactly zero
+            assert a.abs().max().item() == 0.0
+            continue
+        assert (a - b_).abs().max().item() <= 2e-6 * scale, ("fused vs per-step", n)
+        assert (a.cpu() - c).abs().max().item() <= 2e-4 * scale, ("fused vs torch", n)
+
+
 @pytest.mark.parametrize("B", [256, 40])
 def test_xcd_local_and_agent_scope_exchange_agree(ops, B):
     """The four workgroups of a (direction, row block) sit on one XCD and hand h_t / dgh_t over with plain stores through its L2;

@@ -562,7 +562,8 @@ def test_conv3x3_winograd_wgrad(ops, B, H, W, Cin, Cout, inT):
     assert rel(dw, dwd) < 1e-5
 
 
-@pytest.mark.parametrize("B,T,train", [(3, 12, False), (2, 125, True), (1, 130, True), (4, 12, True)])
+@pytest.mark.parametrize("B,T,train", [(3, 12, False), (2, 125, True), (1, 130, True), (4, 12, True), (1, 128, True), (2, 33, True),
+                                       (2, 2, False), (1, 97, False)])
 def test_multihead_attention_forward_backward(ops, B, T, train):
     """MultiHeadFn (q/k/v projections, scaled dot-product attention with dropout, output projection, dropout, ReLU) vs
     the same computation in torch autograd (models.py:641-665), incl. T > 128 (two row chunks) and T not a multiple of
