@@ -6,7 +6,7 @@
 // short per-step critical path, not for MFMA utilisation:
 //  * workgroup = 16 batch rows x 64 hidden units (x 3 gates) of one direction -> (H/64) x ceil(B/16) x 2 = 128
 //    workgroups at B=256, all co-resident (1 per CU), 4 waves = 16 units each with the whole K reduction (see "the
-//    recurrences" below: no cross-wave sum, ONE barrier per step);
+//    recurrences" below: no cross-wave sum, ONE barrier per step: the shared operand block is double-buffered);
 //  * the wave's slice of W_hh (48 rows x 256) lives in REGISTERS for the whole sequence (192 VGPRs per lane) as
 //    split-f16 operands (round 4): w = (hi + lo) / s with a power-of-two scale per (gate, hidden unit) taken from the
 //    row's own amax; per step the 16 x 256 h_prev block is fetched once per workgroup, split the same way (|h| <= 1: fixed
@@ -30,7 +30,7 @@
 //  * everything a step needs that does NOT depend on the previous step (gi / g_out / saved gates) is loaded before
 //    the wait.
 // The spin is bounded: a wave that never sees its operands (which cannot happen while all workgroups are resident:
-// 128 x 256 threads, 34 / 49 KB LDS) gives up after ~1 s and raises the error word instead of hanging the GPU.
+// 128 x 256 threads, 34 / 98 KB LDS) gives up after ~1 s and raises the error word instead of hanging the GPU.
 #include "common.h"
 #include "sed_hip.h"
 SED_OBJECT_FLAGS(gru)
@@ -102,11 +102,13 @@ __device__ __forceinline__ bool gru_has_sentinel(const f4r& v) {
 // Poll this wave's operand block (N x 16 bytes per lane at `ap`) until it holds no sentinel.  Bounded: after `limit` polls,
 // or when another wave has given up, the error word is raised and the block is taken as it is (the launcher's check kernel
 // then overwrites the pass's output with NaN).  `dead` is sticky per wave: a pass that failed stops polling.
+// watch_one: poll ONE piece of a wide block until it arrives and fetch the block then -- pays behind agent-scope stores (0.84 ->
+// 0.81 ms for the backward pass at B = 256), costs behind XCD-local ones (0.71 -> 0.75 ms): on only in the fallback.
 template <int N, int STRIDE>
-__device__ __forceinline__ void gru_poll(f4r (&a)[N], const float* ap, int* err, long limit, bool& dead) {
+__device__ __forceinline__ void gru_poll(f4r (&a)[N], const float* ap, int* err, long limit, bool& dead, bool watch_one) {
     long polls = 0;
     for (;;) {
-        if (N > 4) {                                   // a wide block: watch ONE piece until it arrives, then fetch the block
+        if (N > 4 && watch_one) {                      // a wide block behind agent-scope stores: watch ONE piece until it arrives, then fetch the block
             for (;;) {
                 f4r one[1];
                 ld_coherent4(one[0], ap + STRIDE * (N - 1));
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(256) void gru_seq_fwd_kernel(GruSeqFwdP p) {
         if (k > 0) {
             const float* h_prev = p.hs + ((long)d * T + (d ? t + 1 : t - 1)) * bh;
             f4r a[4];
-            gru_poll<4, 16>(a, h_prev + soff, err, poll_limit, dead);
+            gru_poll<4, 16>(a, h_prev + soff, err, poll_limit, dead, false);
             half8 h0, l0, h1, l1;
             gru_split8(a[0], a[1], 8192.0f, h0, l0);
             gru_split8(a[2], a[3], 8192.0f, h1, l1);
@@ -394,7 +396,8 @@ struct GruSeqBwdP {
 };
 
 __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(GruSeqBwdP p) {
-    __shared__ __attribute__((aligned(16))) _Float16 gb[2][GRU_RB * BROW];         // [hi, lo][row][position]: 49 KB
+    extern __shared__ __attribute__((aligned(16))) _Float16 gb_dyn[];             // [step parity][hi, lo][row][position]: 2 x 49 KB
+    constexpr int GPLANE = GRU_RB * BROW;
     __shared__ float qinv[2][4];                       // [step parity][quarter]: 1 / operand scale of the quarter a wave staged
     __shared__ float wsc[4][16];
     __shared__ int xcd_word;
@@ -478,19 +481,20 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(GruSeqBwdP p) {
         if (done > 0) {
             const float* dgh_later = p.dgh + ((long)d * T + (d ? t - 1 : t + 1)) * 3 * bh;
             f4r a[12];
-            gru_poll<12, 16>(a, dgh_later + soff, err, poll_limit, dead);
+            gru_poll<12, 16>(a, dgh_later + soff, err, poll_limit, dead, !one_xcd);
             // gradients have no fixed range: one power-of-two scale per staged quarter (16 rows x 192) and step from its amax
             float am = 0.f;
 #pragma unroll
             for (int q = 0; q < 12; ++q) am = fmaxf(am, gru_amax4(a[q]));
             const float sa = sed_sf_scale_of(wave_max(am));
-            if (done > 1) __syncthreads();             // every wave has read the block of the step before: the buffer is free
+            _Float16* const gb = gb_dyn + (done & 1) * 2 * GPLANE;      // the block of step n + 2 goes here after every wave has
+                                                                       // passed the barrier of step n + 1, i.e. has read this one
 #pragma unroll
             for (int m = 0; m < 6; ++m) {
                 half8 hi, lo;
                 gru_split8(a[2 * m], a[2 * m + 1], sa, hi, lo);
-                *reinterpret_cast<half8*>(&gb[0][spos + 8 * m]) = hi;
-                *reinterpret_cast<half8*>(&gb[1][spos + 8 * m]) = lo;
+                *reinterpret_cast<half8*>(&gb[spos + 8 * m]) = hi;
+                *reinterpret_cast<half8*>(&gb[GPLANE + spos + 8 * m]) = lo;
             }
             if (lane == 0) qinv[done & 1][wave] = 1.0f / sa;
             __syncthreads();
@@ -498,6 +502,7 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(GruSeqBwdP p) {
         if (k > 0) prefetch(k - 1);
         flush();
         if (done > 0) {
+            const _Float16* const gb = gb_dyn + (done & 1) * 2 * GPLANE;
             f4r g4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int qt = 0; qt < 4; ++qt) {
@@ -505,8 +510,8 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(GruSeqBwdP p) {
 #pragma unroll
                 for (int m = 0; m < 6; ++m) {
                     const int ks = 6 * qt + m;
-                    const half8 bhi = *reinterpret_cast<const half8*>(&gb[0][fpos + 32 * ks]);
-                    const half8 blo = *reinterpret_cast<const half8*>(&gb[1][fpos + 32 * ks]);
+                    const half8 bhi = *reinterpret_cast<const half8*>(&gb[fpos + 32 * ks]);
+                    const half8 blo = *reinterpret_cast<const half8*>(&gb[GPLANE + fpos + 32 * ks]);
                     ac4 = gru_mfma16(wlo[ks], bhi, ac4);
                     ad4 = gru_mfma16(whi[ks], blo, ad4);
                     am4 = gru_mfma16(whi[ks], bhi, am4);
@@ -580,6 +585,20 @@ __global__ __launch_bounds__(256) void occupy_kernel(long ticks) {
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
 }
 
+// the backward kernel double-buffers its 49 KB operand block: dynamic LDS above the 64 KB static limit, raised per device
+constexpr int GRU_BWD_LDS = 2 * 2 * GRU_RB * BROW * (int)sizeof(_Float16);
+bool gru_bwd_lds_raised() {
+    static int raised_dev = -1;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (dev != raised_dev) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_seq_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GRU_BWD_LDS) != hipSuccess) return false;
+        raised_dev = dev;
+    }
+    return true;
+}
+
 long g_spin_limit = 1L << 23;          // ~1 s of polling
 int g_agent_scope = 0;
 
@@ -592,7 +611,7 @@ bool gru_device_fits(int grid) {
         int cus = 0, per_f = 0, per_b = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_f, gru_seq_fwd_kernel, 256, 0) != hipSuccess) return false;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_b, gru_seq_bwd_kernel, 256, 0) != hipSuccess) return false;
+        if (!gru_bwd_lds_raised() || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_b, gru_seq_bwd_kernel, 256, GRU_BWD_LDS) != hipSuccess) return false;
         // one workgroup per CU is what the kernels are laid out for; the occupancy API may over-report by one block per CU
         // (MI355X_MICROARCH.md), so only its ">= 1" answer is used
         cached_cap = (per_f >= 1 && per_b >= 1) ? cus : 0;
@@ -663,7 +682,8 @@ SED_API int sed_gru_seq_bwd(const float* g_out, const float* wt_f, const float* 
         if (e != hipSuccess) return (int)e;
     }
     GruSeqBwdP p{g_out, {wt_f, wt_b}, hs, saves, dgi, dgh, dbias_parts, dgi_amax, reinterpret_cast<int*>(ws), B, T, ngroups, g_spin_limit, g_agent_scope};
-    hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(gru_grid(ngroups)), dim3(256), 0, stream, p);
+    if (!gru_bwd_lds_raised()) return SED_EINVAL;
+    hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(gru_grid(ngroups)), dim3(256), GRU_BWD_LDS, stream, p);
     SED_LAUNCH_CHECK();
     hipLaunchKernelGGL(gru_seq_check_kernel, dim3(256), dim3(256), 0, stream, reinterpret_cast<const int*>(ws), err_host, 2, dgi,
                        (long)B * T * 6 * GH);
