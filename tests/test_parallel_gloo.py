@@ -146,6 +146,41 @@ def test_grad_buckets_world_size_2_gloo(tmp_path):
     assert open(out).read() == "ok"
 
 
+def _forced_one_rank_worker(rank, world, port, out):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SED_FORCE_DIST="1")
+    from sound_event_detection_dcase2017_task4_amd import parallel
+    r, w, lr = parallel.init_from_env(backend="gloo")
+    assert (r, w) == (0, 1) and dist.is_initialized() and parallel.collectives_on()
+    flat = torch.arange(50, dtype=torch.float32)
+    parallel.broadcast_flat(flat)                                 # a real broadcast among one rank: values unchanged
+    assert torch.equal(flat, torch.arange(50, dtype=torch.float32))
+    numels = [10, 15, 25]
+    offsets = [0, 10, 25]
+    gb = parallel.GradBuckets(flat, offsets, numels, cuts=[offsets[1]])
+    for i in range(3):
+        gb.expect(i)
+    gb.new_gradients()
+    for i in (2, 1, 0):
+        gb.ready(i)
+    assert gb.issue_order == [1] or gb.issue_order == [1, 0]     # the tail bucket went to the backend from inside "backward"
+    gb.finish()
+    assert gb.issue_order == [1, 0] and torch.equal(flat, torch.arange(50, dtype=torch.float32))   # sum over one rank
+    gb.begin_step()
+    parallel.broadcast_rng_state()
+    parallel.barrier()
+    parallel.shutdown()
+    open(out, "w").write("ok")
+
+
+def test_forced_one_rank_group_runs_every_exchange_step(tmp_path):
+    """SED_FORCE_DIST=1 (tests only): a ONE-rank job builds its process group and sends every broadcast, bucket and barrier
+    through it -- the switch that lets the RCCL branch execute on the 1-GPU boxes (tests/test_gpu_parallel.py); here over gloo."""
+    out = str(tmp_path / "ok.txt")
+    mp.spawn(_forced_one_rank_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    assert open(out).read() == "ok"
+
+
 def test_shard_rows_keeps_mixup_pairs_together():
     sys.path.insert(0, REPO)
     from sound_event_detection_dcase2017_task4_amd import parallel
