@@ -1241,8 +1241,14 @@ static void wsf_slicing(int B, int H, int W, int Cin, int Cout, int* spi, int* i
     const int g = (H + trs - 1) / trs;
     const long tiles = (long)(Cin / 32) * (Cout / 64);
     long want = 2048 / tiles;                        // workgroups ~ 2048: four rounds of the 512 resident ones
-    const long most = ((long)B * g) / 64;            // ... but at least 64 stages per slice (the 74 KB partial write per
-    if (want > most) want = most;                    // workgroup and k half must stay small next to its K loop)
+    long most = ((long)B * g) / 64;                  // ... but at least 64 stages per slice (the 74 KB partial write per
+                                                     // workgroup and k half must stay small next to its K loop)
+    const long fill = (512 + tiles - 1) / tiles;     // ... unless that leaves resident slots empty: 128 -> 256 @ 250 x 16 at batch
+    if (most < fill) {                               // 32 ran on 256 workgroups (one per CU instead of two): down to 32 stages
+        most = fill;
+        if (most > ((long)B * g) / 32) most = ((long)B * g) / 32;
+    }
+    if (want > most) want = most;
     const long least = ((long)B * g + 255) / 256;    // ... and at most 256 stages (16384 pixels) per fp32 accumulation chain
     if (want < least) want = least;                  // (7e-7 relative at 125 stages, tests/test_gpu_sf16.py); beyond a slice
                                                      // the sums continue in fp64 (reduce kernel)
