@@ -680,7 +680,18 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 // backward of the Cin=1 conv: one pass over gy produces (i) per-block dW partials [nblk][9][64] and
 // (ii) t[p][tap] = <gy[p][:], w[:, tap]> (the scatter form of dgrad); conv1_dgrad_gather then sums 9 neighbours.
-constexpr int C1B_ROWS = 4096;      // rows per workgroup (scratch sized for 1024 by the callers: an upper bound)
+constexpr int C1B_ROWS = 4096;      // rows per workgroup at most (scratch sized for 1024 by the callers: an upper bound)
+// Rows per workgroup of a launch: 4096 while that gives at least three rounds of the 768 resident workgroups (three per CU), else
+// what gives ~two rounds, never fewer than 1024 (the callers' scratch).  At the metric's batch size 4096 rows meant 501
+// workgroups on 768 slots.
+static int c1b_rows_for(long M) {
+    if (M / C1B_ROWS >= 3 * 768) return C1B_ROWS;
+    long rows = (M + 2 * 768 - 1) / (2 * 768);
+    rows = (rows + 15) / 16 * 16;
+    if (rows < 1024) rows = 1024;
+    if (rows > C1B_ROWS) rows = C1B_ROWS;
+    return (int)rows;
+}
 // AFF: gy is the masked dgrad output dz of the NEXT conv and the BatchNorm backward g = a*dz + b*y + c (coef [3][64])
 // is applied on load, which saves the separate sed_bn_bwd_apply pass over the two largest tensors of the model.
 // yraw null (round 4): y = conv1(x0) is RECOMPUTED from the nine taps the kernel loads anyway (36 FMAs per lane and row, the
@@ -689,7 +700,7 @@ template <bool AFF>
 __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict__ x0, const float* __restrict__ w,
                                                         const float* __restrict__ gy, const float* __restrict__ yraw,
                                                         const float* __restrict__ coef, long M, int H, int W,
-                                                        float* __restrict__ dw_partials, float* __restrict__ tbuf) {
+                                                        float* __restrict__ dw_partials, float* __restrict__ tbuf, int rows_per_wg) {
     __shared__ float red[16][9 * 64 + 4];
     const int c4 = threadIdx.x & 15, pl = threadIdx.x >> 4;
     float wr[9][4];
@@ -707,8 +718,8 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
         ca = reinterpret_cast<const float4*>(coef)[c4]; cb = reinterpret_cast<const float4*>(coef)[16 + c4];
         cc = reinterpret_cast<const float4*>(coef)[32 + c4];
     }
-    const long base = (long)blockIdx.x * C1B_ROWS;
-    const long nrows = min((long)C1B_ROWS, M - base);
+    const long base = (long)blockIdx.x * rows_per_wg;
+    const long nrows = min((long)rows_per_wg, M - base);
     C1Walk pos(base + pl, H, W);
     for (int r = pl; r < nrows; r += 16, pos.advance(16, H, W)) {
         long pm = base + r;
@@ -782,8 +793,15 @@ __global__ __launch_bounds__(1024) void conv1_wgrad_reduce_kernel(const float* _
                                                                   float* __restrict__ dw) {
     __shared__ double red[1024];
     const int i = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
-    double s = 0.0;
-    for (int b = sl; b < nblk; b += 16) s += (double)parts[(long)b * 576 + i];
+    double s = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;        // four loads in flight: one per dependent iteration cost a round trip each
+    int b = sl;
+    for (; b + 48 < nblk; b += 64) {
+        const float v0 = parts[(long)b * 576 + i], v1 = parts[(long)(b + 16) * 576 + i];
+        const float v2 = parts[(long)(b + 32) * 576 + i], v3 = parts[(long)(b + 48) * 576 + i];
+        s += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
+    }
+    for (; b < nblk; b += 16) s += (double)parts[(long)b * 576 + i];
+    s = (s + s1) + (s2 + s3);
     red[threadIdx.x] = s;
     __syncthreads();
     if (sl == 0) {
@@ -980,13 +998,14 @@ SED_API int sed_conv1_bwd(const float* x0, const float* w_oihw, const float* gy,
                           int B, int H, int W, float* dw, float* gx0, float* dw_partials, float* tbuf, hipStream_t stream) {
     long M = (long)B * H * W;
     if (M <= 0 || M >= (1L << 31) / 9 || (bn_y != nullptr && bn_coef == nullptr)) return SED_EINVAL;
-    int nblk = sed_cdiv(M, C1B_ROWS);
+    const int rows = c1b_rows_for(M);
+    int nblk = sed_cdiv(M, rows);
     if (bn_coef)
         hipLaunchKernelGGL(conv1_bwd_kernel<true>, dim3(nblk), dim3(256), 0, stream, x0, w_oihw, gy, bn_y, bn_coef, M, H, W,
-                           dw_partials, gx0 ? tbuf : (float*)nullptr);
+                           dw_partials, gx0 ? tbuf : (float*)nullptr, rows);
     else
         hipLaunchKernelGGL(conv1_bwd_kernel<false>, dim3(nblk), dim3(256), 0, stream, x0, w_oihw, gy, bn_y, bn_coef, M, H, W,
-                           dw_partials, gx0 ? tbuf : (float*)nullptr);
+                           dw_partials, gx0 ? tbuf : (float*)nullptr, rows);
     hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(9), dim3(1024), 0, stream, dw_partials, nblk, dw);
     if (gx0) {
         int g = sed_cdiv(M, 256);

@@ -1238,31 +1238,32 @@ __global__ __launch_bounds__(256) void wgrad_sf16_reduce_kernel(const float* __r
 
 static void wsf_slicing(int B, int H, int W, int Cin, int Cout, int* spi, int* ips, int* spimg, long* nslices) {
     const int trs = 64 / W;
-    const int g = (H + trs - 1) / trs;
+    const int g = (H + trs - 1) / trs;               // stages (64 pixels) per image
     const long tiles = (long)(Cin / 32) * (Cout / 64);
-    long want = 2048 / tiles;                        // workgroups ~ 2048: four rounds of the 512 resident ones
-    long most = ((long)B * g) / 64;                  // ... but at least 64 stages per slice (the 74 KB partial write per
-                                                     // workgroup and k half must stay small next to its K loop)
-    const long fill = (512 + tiles - 1) / tiles;     // ... unless that leaves resident slots empty: 128 -> 256 @ 250 x 16 at batch
-    if (most < fill) {                               // 32 ran on 256 workgroups (one per CU instead of two): down to 32 stages
-        most = fill;
-        if (most > ((long)B * g) / 32) most = ((long)B * g) / 32;
-    }
-    if (want > most) want = most;
-    const long least = ((long)B * g + 255) / 256;    // ... and at most 256 stages (16384 pixels) per fp32 accumulation chain
-    if (want < least) want = least;                  // (7e-7 relative at 125 stages, tests/test_gpu_sf16.py); beyond a slice
-                                                     // the sums continue in fp64 (reduce kernel)
-    if (want < 1) want = 1;
     *spimg = g;
-    if (want >= B) {
-        int s = (int)(want / B);
-        if (s > g / 8) s = g / 8 > 0 ? g / 8 : 1;   // at least 8 stages per slice
-        if (s < 1) s = 1;
-        *spi = s; *ips = 0; *nslices = (long)B * s;
-    } else {
-        int i = (int)((B + want - 1) / want);
-        *spi = 0; *ips = i; *nslices = (B + i - 1) / i;
-    }
+    // A slice is 1/s of an image (s = 1 .. g/8: at least 8 stages) or i whole images.  512 workgroups are resident at a time (two
+    // per CU), so a launch costs  rounds(workgroups / 512) x (stages per slice + c)  with c ~ 4 stages for a workgroup's prologue
+    // and its 74 KB partial write: take the cheapest cut with at most 256 stages (16384 pixels) per fp32 accumulation chain
+    // (7e-7 relative at 125 stages, tests/test_gpu_sf16.py; beyond a slice the sums continue in fp64 in the reduce kernel).
+    // (Until late round 4: ~2048 workgroups, at least 64 stages, rounded DOWN -- 384 / 768 / 960 workgroups at the metric's batch
+    // size, i.e. half-empty last rounds, and 256 for 128 -> 256 @ 250 x 16.)
+    long best_cost = -1, best_blk = 0;
+    int best_s = 1, best_i = 0;
+    auto consider = [&](int s, int i) {
+        const long nsl = s ? (long)B * s : (B + i - 1) / i;
+        const long stages = s ? (g + s - 1) / s : (long)i * g;
+        if (stages > 256 && !(s && s == (g / 8 > 0 ? g / 8 : 1))) return;      // too long a chain (unless nothing shorter exists)
+        const long blk = nsl * tiles;
+        const long cost = ((blk + 511) / 512) * (stages + 4);
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && blk < best_blk)) {
+            best_cost = cost; best_blk = blk; best_s = s; best_i = i;
+        }
+    };
+    const int smax = g / 8 > 0 ? g / 8 : 1;
+    for (int s = 1; s <= smax; ++s) consider(s, 0);
+    for (int i = 2; i <= B; ++i) consider(0, i);
+    *spi = best_s; *ips = best_i;
+    *nslices = best_s ? (long)B * best_s : (B + best_i - 1) / best_i;
 }
 
 }  // namespace
