@@ -671,7 +671,25 @@ __global__ __launch_bounds__(256) void amax_multi_kernel(SfMultiP p) {
     const float* __restrict__ x = p.w[t];
     const long n = 9L * p.cout[t] * p.cin[t];
     float m = 0.f;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[e]));
+    const long stride = (long)gridDim.x * 256;
+    long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if ((reinterpret_cast<unsigned long long>(x) & 15) == 0) {     // 16-byte loads, four in flight (one dependent 4-byte load per
+        const float4* x4 = reinterpret_cast<const float4*>(x);    // trip walked the 2.4 M floats of a 512 x 512 weight in 35 us)
+        const long n4 = n >> 2;
+        for (; e + 3 * stride < n4; e += 4 * stride) {
+            const float4 a = x4[e], b = x4[e + stride], c = x4[e + 2 * stride], d = x4[e + 3 * stride];
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                               fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w))),
+                               fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)))));
+        }
+        for (; e < n4; e += stride) {
+            const float4 a = x4[e];
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+        }
+        e = 4 * n4 + (long)blockIdx.x * 256 + threadIdx.x;
+    }
+    for (; e < n; e += stride) m = fmaxf(m, fabsf(x[e]));
     amax_publish_block(p.wscale[t], m);
 }
 
