@@ -716,17 +716,15 @@ __global__ __launch_bounds__(256) void pack_sf16_multi_kernel(SfMultiP p) {
 static int sf_log2w(int W) { return W == 64 ? 6 : W == 32 ? 5 : W == 16 ? 4 : 3; }
 // tile choice: 256 px x 64 co (MW = 4: 50 KB LDS, <= 160 VGPRs, THREE workgroups per CU) for every layer -- 5 % faster than
 // 128 px x 128 co (MW = 2: 66 KB, two per CU) on the >= 128-channel layers although it converts each patch twice as
-// often: the third wave per SIMD hides more than the reuse saves.  SED_SF16_MW2=1 selects MW = 2 where Cout % 128 == 0.
+// often: the third wave per SIMD hides more than the reuse saves (re-measured at the metric's batch size at the end of round 4, where
+// MW = 2 would balance 1000 workgroups better over its 512 slots than MW = 4 over 768: 8.65 vs 8.44 ms per step; the run-time switch
+// of rounds 2-4 is gone, the kernel template still takes MW).
 // (Round 3 also built 192 px x 128 co with SIX waves -- three per SIMD AND the 128-channel reuse, 69 KB, two workgroups per CU;
 // parity-green: 323-339 TFLOP/s against 408-420 for MW = 4 and 384-390 for MW = 2 over the six >= 128-channel layers,
 // profiles/r03/experiment_tile_192x128_six_waves.txt -- six waves do not spread evenly over four SIMDs and only two barrier
 // domains share a CU.  And 256 px x 128 co with EIGHT waves at four waves per SIMD (128 VGPRs: 9-41 spilled registers): the
 // dgrad variant (11 spills) +0.7 %, the fused-input variants -10 %, experiment_tile_256x128_eight_waves.txt.  Removed again.)
-static int sf_mw(int Cout) {
-    static int mw2 = -1;
-    if (mw2 < 0) { const char* e = getenv("SED_SF16_MW2"); mw2 = (e && e[0] == '1') ? 1 : 0; }
-    return (Cout % 128 == 0 && mw2) ? 2 : 4;
-}
+static int sf_mw(int) { return 4; }
 
 }  // namespace
 
@@ -881,10 +879,6 @@ SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale
         if (epi == 0) hipLaunchKernelGGL((conv_sf16_kernel<4, false, 0, true>), g, blk, 0, s, p);
         else if (epi == 1) hipLaunchKernelGGL((conv_sf16_kernel<4, false, 1, true>), g, blk, 0, s, p);
         else hipLaunchKernelGGL((conv_sf16_kernel<4, false, 2, true>), g, blk, 0, s, p);
-    } else if (mw == 2) {
-        if (epi == 0) { if (it) SF_LAUNCH(2, true, 0); else SF_LAUNCH(2, false, 0); }
-        else if (epi == 1) { if (it) SF_LAUNCH(2, true, 1); else SF_LAUNCH(2, false, 1); }
-        else SF_LAUNCH(2, false, 2);
     } else {
         if (epi == 0) { if (it) SF_LAUNCH(4, true, 0); else SF_LAUNCH(4, false, 0); }
         else if (epi == 1) { if (it) SF_LAUNCH(4, true, 1); else SF_LAUNCH(4, false, 1); }

@@ -3,9 +3,9 @@
 register-file room for it?  The side-stream schedule gains only 1-1.6 % of the step because the weight-gradient
 kernel allocates 2 x 248 of a SIMD's 512 VGPRs and the convolution 3 x 168: a 36-53-VGPR streaming wave cannot co-reside and only
 gets the slots retiring workgroups free.  Here the SAME convolution runs as MW = 4 (3 waves / SIMD, 504 VGPRs held) and as MW = 2
-(SED_SF16_MW2=1: 2 waves / SIMD, ~330 held, 180 free) beside bn_bwd_apply / the pool backward apply on a second stream.
+(the MW = 2 tile of rounds 2-4, selected by SED_SF16_MW2=1 until that switch was removed: 2 waves / SIMD, ~330 held, 180 free) beside bn_bwd_apply / the pool backward apply on a second stream.
 
-    python tools/coresident_overlap_probe.py            (run twice: with and without SED_SF16_MW2=1)"""
+    python tools/coresident_overlap_probe.py            (was run twice: with and without SED_SF16_MW2=1; the switch is gone, the record is profiles/r04)"""
 import os
 import sys
 import time
