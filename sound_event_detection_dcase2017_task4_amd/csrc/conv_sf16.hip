@@ -619,23 +619,30 @@ __global__ __launch_bounds__(256) void amax_big_kernel(const float* __restrict__
     amax_publish_block(out, m);
 }
 
-__device__ __forceinline__ void pack_sf16_one(const float* __restrict__ w, int Cout, int Cin, int dgrad, float sw, long e,
-                                              _Float16* __restrict__ wp) {
+// Nine elements -- one (output channel, input channel) pair -- per task: task q = (ks * No + o) * 16 + il reads the 36
+// contiguous bytes of its 3 x 3 filter and writes its 18 halves (a wave's stores of one tap and plane are 128 contiguous bytes).
+// One element per trip with three divisions each made the per-step pack of the seven conv weights cost 50 us.
+__device__ __forceinline__ void pack_sf16_nine(const float* __restrict__ w, int Cout, int Cin, int dgrad, float sw, long q,
+                                               _Float16* __restrict__ wp) {
     const int No = dgrad ? Cin : Cout;
-    const int il = (int)(e & 15);
-    long q = e >> 4;
-    const int o = (int)(q % No); q /= No;
-    const int dx = (int)(q % 3); q /= 3;
-    const int dy = (int)(q % 3); q /= 3;
-    const int ks = (int)q;
+    const int il = (int)(q & 15);
+    const long t = q >> 4;
+    const int o = (int)(t % No), ks = (int)(t / No);
     const int i = ks * 16 + il;
-    const float v = (dgrad ? w[(((long)i * Cin + o) * 3 + (2 - dy)) * 3 + (2 - dx)]
-                           : w[(((long)o * Cin + i) * 3 + dy) * 3 + dx]) * sw;
-    const _Float16 hi = (_Float16)v;
-    const _Float16 lo = (_Float16)(v - (float)hi);
-    const long base = ((long)(ks * 3 + dy) * 2) * 3 * No * 16;
-    wp[base + ((long)dx * No + o) * 16 + il] = hi;
-    wp[base + 3L * No * 16 + ((long)dx * No + o) * 16 + il] = lo;
+    const float* src = w + (dgrad ? ((long)i * Cin + o) : ((long)o * Cin + i)) * 9;
+    float r[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r[k] = src[k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int dy = k / 3, dx = k % 3;
+        const float v = r[dgrad ? 8 - k : k] * sw;
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        const long base = ((long)(ks * 3 + dy) * 2) * 3 * No * 16;
+        wp[base + ((long)dx * No + o) * 16 + il] = hi;
+        wp[base + 3L * No * 16 + ((long)dx * No + o) * 16 + il] = lo;
+    }
 }
 
 // mode 0 / 1: the forward / dgrad layout into wp; mode 2: BOTH, the forward pack followed by the dgrad pack (18*Cin*Cout
@@ -645,13 +652,14 @@ __global__ __launch_bounds__(256) void pack_sf16_kernel(const float* __restrict_
     const float sw = sf_scale_of(amax_read(wscale));
     if (blockIdx.x == 0 && threadIdx.x == 0) wscale[SED_AMAX_SLOTS] = sw;
     const long total = 9L * Cout * Cin;
-    const long n = mode == 2 ? 2 * total : total;
+    const long pairs = (long)Cout * Cin;
+    const long n = mode == 2 ? 2 * pairs : pairs;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
         if (mode == 2) {
-            if (e < total) pack_sf16_one(w, Cout, Cin, 0, sw, e, wp);
-            else pack_sf16_one(w, Cout, Cin, 1, sw, e - total, wp + 2 * total);
+            if (e < pairs) pack_sf16_nine(w, Cout, Cin, 0, sw, e, wp);
+            else pack_sf16_nine(w, Cout, Cin, 1, sw, e - pairs, wp + 2 * total);
         } else {
-            pack_sf16_one(w, Cout, Cin, mode, sw, e, wp);
+            pack_sf16_nine(w, Cout, Cin, mode, sw, e, wp);
         }
     }
 }
@@ -702,13 +710,14 @@ __global__ __launch_bounds__(256) void pack_sf16_multi_kernel(SfMultiP p) {
     const float sw = sf_scale_of(amax_read(wscale));
     if (blockIdx.x == 0 && threadIdx.x == 0) wscale[SED_AMAX_SLOTS] = sw;
     const long total = 9L * Cout * Cin;
-    const long n = mode == 2 ? 2 * total : total;
+    const long pairs = (long)Cout * Cin;
+    const long n = mode == 2 ? 2 * pairs : pairs;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
         if (mode == 2) {
-            if (e < total) pack_sf16_one(w, Cout, Cin, 0, sw, e, wp);
-            else pack_sf16_one(w, Cout, Cin, 1, sw, e - total, wp + 2 * total);
+            if (e < pairs) pack_sf16_nine(w, Cout, Cin, 0, sw, e, wp);
+            else pack_sf16_nine(w, Cout, Cin, 1, sw, e - pairs, wp + 2 * total);
         } else {
-            pack_sf16_one(w, Cout, Cin, mode, sw, e, wp);
+            pack_sf16_nine(w, Cout, Cin, mode, sw, e, wp);
         }
     }
 }
@@ -768,7 +777,7 @@ SED_API int sed_pack_conv_weights_sf16(const float* w_oihw, int Cout, int Cin, i
         int rc = sed_amax(w_oihw, total, wscale, stream);
         if (rc) return rc;
     }
-    const long nb = ((both ? 2 : 1) * total + 255) / 256;
+    const long nb = ((both ? 2 : 1) * (total / 9) + 255) / 256;
     hipLaunchKernelGGL(pack_sf16_kernel, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, (hipStream_t)stream, w_oihw,
                        Cout, Cin, both ? 2 : dg, wscale, (_Float16*)wp);
     SED_LAUNCH_CHECK();
@@ -794,7 +803,7 @@ SED_API int sed_pack_conv_weights_sf16_multi(int n, const float* const* w_oihw, 
             if (e != hipSuccess) return (int)e;
         }
     }
-    const long nb_a = (most / 2 + 1023) / 1024, nb_p = (most + 255) / 256;
+    const long nb_a = (most / 2 + 1023) / 1024, nb_p = (most / 9 + 255) / 256;
     hipLaunchKernelGGL(amax_multi_kernel, dim3((unsigned)(nb_a > 64 ? 64 : (nb_a < 1 ? 1 : nb_a)), n), dim3(256), 0,
                        (hipStream_t)stream, p);
     hipLaunchKernelGGL(pack_sf16_multi_kernel, dim3((unsigned)(nb_p > 1024 ? 1024 : nb_p), n), dim3(256), 0, (hipStream_t)stream, p);
