@@ -34,7 +34,7 @@ python $R/tools/timeline_overlap.py $OUT/timeline/t_kernel_trace.csv > $OUT/time
 rm -rf $OUT/timeline
 # the metric's own batch size (bs=32): serial kernel trace + per-step gap digest + by-shape table
 SED_WGRAD_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_b32 -o bench -- $B32 --steps 6 --warmup 3 > $OUT/bench_line_b32_under_rocprofv3_main_stream_only.json 2> $OUT/stats_b32.err
-python $R/tools/step_gaps.py $(find $OUT/stats_b32 -name "*kernel_trace.csv") 5 > $OUT/step_digest_b32_main_stream_only.txt 2>&1
+python $R/tools/step_gaps.py $(find $OUT/stats_b32 -name "*kernel_trace.csv") 4 > $OUT/step_digest_b32_main_stream_only.txt 2>&1
 python $R/tools/step_gaps.py $(find $OUT/stats_serial -name "*kernel_trace.csv") 4 > $OUT/step_digest_b256_main_stream_only.txt 2>&1
 $B32 --steps 40 --warmup 5 --by_shape > $OUT/bench_line_b32.json 2> $OUT/by_shape_b32.txt
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE"; do
