@@ -56,7 +56,10 @@ int sed_logmel_i16(const short* wave, int B2, int L, const float* window, const 
  * guard_dev / guard_host (nullable; the found-non-finite words of the split-f16 path, see sed_adam_amsgrad): batch
  * statistics that are NaN / inf raise them; null = torch semantics.  cand (nullable, [2][C]): the new running statistics
  * are written THERE instead of in place, and sed_bn_commit (n <= 16 BatchNorms per launch) installs them unless
- * *guard_dev != 0: a forward pass that met a non-finite value anywhere leaves every BatchNorm buffer untouched.
+ * *guard_dev != 0: a forward pass that met a non-finite value anywhere leaves every BatchNorm buffer untouched.  Either way
+ * `cand` then holds the statistics from BEFORE the step, and sed_bn_restore (same arguments, launched behind the optimiser
+ * step) copies them back when *guard_dev != 0 by then: a step refused because of its backward pass, its all-reduced
+ * gradient or another rank's flag leaves the BatchNorm buffers as intact as the parameters.
  * sed_bn_eval_affine: eval mode, fold the running statistics instead. */
 int sed_chan_stats(const float* x, long N, int C, float* partials, sed_stream_t stream);
 int sed_stats_rows_per_part(void);
@@ -67,8 +70,10 @@ int sed_bn_finalize(const float* partials, int nparts, int rows_per_part, long N
                     const float* y_amax /* nullable */, float* act_bound_out /* nullable [64]: what sed_act_bound computes, from
                                                                                 the same launch */,
                     sed_stream_t stream);
-int sed_bn_commit(int n, const float* const* cand, float* const* running_mean, float* const* running_var, const int* C,
+int sed_bn_commit(int n, float* const* cand, float* const* running_mean, float* const* running_var, const int* C,
                   const int* guard_dev, sed_stream_t stream);
+int sed_bn_restore(int n, float* const* cand, float* const* running_mean, float* const* running_var, const int* C,
+                   const int* guard_dev, sed_stream_t stream);
 int sed_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* mean_out, float* invstd_out, float* scale_out,
                        float* shift_out, sed_stream_t stream);

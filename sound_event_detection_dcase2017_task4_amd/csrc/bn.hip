@@ -675,25 +675,33 @@ SED_API int sed_bn_finalize(const float* partials, int nparts, int rows_per_part
 namespace {
 constexpr int SED_BN_COMMIT_MAX = 16;
 struct BnCommitP {
-    const float* cand[SED_BN_COMMIT_MAX];
+    float* cand[SED_BN_COMMIT_MAX];
     float* rm[SED_BN_COMMIT_MAX];
     float* rv[SED_BN_COMMIT_MAX];
     int C[SED_BN_COMMIT_MAX];
 };
+// RESTORE = false (end of the forward pass): install the proposed statistics and keep the ones they replace in `cand` --
+// unless the found-non-finite word is already up: then nothing is installed and `cand` takes a copy of the untouched buffers.
+// RESTORE = true (behind the optimiser step, whose finite check has folded in the backward pass, the all-reduced gradient and
+// the other ranks' flags): a refused step puts the old statistics back.  Either way `cand` holds "before this step".
+template <bool RESTORE>
 __global__ __launch_bounds__(256) void bn_commit_kernel(BnCommitP p, const int* __restrict__ guard_dev) {
-    if (guard_dev && __hip_atomic_load(guard_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    const bool up = guard_dev && __hip_atomic_load(guard_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    if (RESTORE && !up) return;
     const int t = blockIdx.y, C = p.C[t];
     for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
-        p.rm[t][c] = p.cand[t][c];
-        p.rv[t][c] = p.cand[t][C + c];
+        const float om = p.rm[t][c], ov = p.rv[t][c];
+        if (RESTORE) { p.rm[t][c] = p.cand[t][c]; p.rv[t][c] = p.cand[t][C + c]; }
+        else {
+            if (!up) { p.rm[t][c] = p.cand[t][c]; p.rv[t][c] = p.cand[t][C + c]; }
+            p.cand[t][c] = om; p.cand[t][C + c] = ov;
+        }
     }
 }
-}  // namespace
 
-// Install the running statistics proposed by n <= 16 sed_bn_finalize(..., cand) calls -- unless *guard_dev != 0.
-SED_API int sed_bn_commit(int n, const float* const* cand, float* const* running_mean, float* const* running_var, const int* C,
-                          const int* guard_dev, hipStream_t stream) {
-    if (n <= 0 || n > SED_BN_COMMIT_MAX || !cand || !running_mean || !running_var || !C) return SED_EINVAL;
+int bn_commit_launch(bool restore, int n, float* const* cand, float* const* running_mean, float* const* running_var, const int* C,
+                     const int* guard_dev, hipStream_t stream) {
+    if (n <= 0 || n > SED_BN_COMMIT_MAX || !cand || !running_mean || !running_var || !C || (restore && !guard_dev)) return SED_EINVAL;
     BnCommitP p;
     int most = 0;
     for (int t = 0; t < SED_BN_COMMIT_MAX; ++t) {
@@ -702,9 +710,24 @@ SED_API int sed_bn_commit(int n, const float* const* cand, float* const* running
         p.cand[t] = cand[s]; p.rm[t] = running_mean[s]; p.rv[t] = running_var[s]; p.C[t] = C[s];
         if (t < n && C[s] > most) most = C[s];
     }
-    hipLaunchKernelGGL(bn_commit_kernel, dim3(sed_cdiv(most, 256), n), dim3(256), 0, stream, p, guard_dev);
+    if (restore) hipLaunchKernelGGL(bn_commit_kernel<true>, dim3(sed_cdiv(most, 256), n), dim3(256), 0, stream, p, guard_dev);
+    else hipLaunchKernelGGL(bn_commit_kernel<false>, dim3(sed_cdiv(most, 256), n), dim3(256), 0, stream, p, guard_dev);
     SED_LAUNCH_CHECK();
     return 0;
+}
+}  // namespace
+
+// Install the running statistics proposed by n <= 16 sed_bn_finalize(..., cand) calls -- unless *guard_dev != 0 -- and leave
+// the statistics from before the step in `cand`; sed_bn_restore puts those back when *guard_dev != 0 (a step refused later:
+// non-finite backward pass, non-finite all-reduced gradient, another rank's flag).
+SED_API int sed_bn_commit(int n, float* const* cand, float* const* running_mean, float* const* running_var, const int* C,
+                          const int* guard_dev, hipStream_t stream) {
+    return bn_commit_launch(false, n, cand, running_mean, running_var, C, guard_dev, stream);
+}
+
+SED_API int sed_bn_restore(int n, float* const* cand, float* const* running_mean, float* const* running_var, const int* C,
+                           const int* guard_dev, hipStream_t stream) {
+    return bn_commit_launch(true, n, cand, running_mean, running_var, C, guard_dev, stream);
 }
 
 SED_API int sed_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,

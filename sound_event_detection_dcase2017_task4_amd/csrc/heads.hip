@@ -531,14 +531,14 @@ SED_API int sed_axpy(float* out, const float* a, long n, hipStream_t stream) {
 // "sed-hip <abi> (gfx950) flags:<hash>": the hash identifies the hipcc flags EVERY object of this library was compiled with
 // ("mixed:..." when they disagree); build.py defines it, the loader refuses a library whose flags are not the default ones
 // unless SED_ALLOW_EXPERIMENT=1.
+// SED_OBJECTS (common.h) lists every object of the library; tests/test_capi_and_host.py holds it equal to build.SOURCES.
 #define SED_WEAK_FLAGS(name) extern "C" __attribute__((weak, visibility("hidden"))) const char sed_objflags_##name[];
-SED_WEAK_FLAGS(logmel) SED_WEAK_FLAGS(bn) SED_WEAK_FLAGS(conv) SED_WEAK_FLAGS(conv_wino) SED_WEAK_FLAGS(conv_wino2)
-SED_WEAK_FLAGS(conv_sf16) SED_WEAK_FLAGS(attention) SED_WEAK_FLAGS(gru)
+SED_OBJECTS(SED_WEAK_FLAGS)
+#define SED_FLAGS_ENTRY(name) sed_objflags_##name,
 SED_API const char* sed_version(void) {
-    static char buf[512];
+    static char buf[768];
     if (!buf[0]) {
-        const char* objs[] = {sed_objflags_heads,     sed_objflags_logmel,    sed_objflags_bn,        sed_objflags_conv, sed_objflags_conv_wino,
-                              sed_objflags_conv_wino2, sed_objflags_conv_sf16, sed_objflags_attention, sed_objflags_gru};
+        const char* objs[] = {sed_objflags_heads, SED_OBJECTS(SED_FLAGS_ENTRY)};
         bool same = true;
         for (const char* o : objs) same = same && (!o || strcmp(o, objs[0]) == 0);
         if (same) {

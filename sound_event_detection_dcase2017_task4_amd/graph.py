@@ -36,6 +36,7 @@ class GraphedTrainStep(object):
         self.graph = None
         self.loss = None
         self._written = set()
+        self._bn_last = None
         self.calls = 0
         self.replays = 0
         self._key = None
@@ -96,6 +97,8 @@ class GraphedTrainStep(object):
         # take a `p.grad is None` parameter (model.zero_grad(set_to_none=True) between replays) for one that received
         # nothing and ZERO the slice the graph has just filled
         self._written = set(buckets.written)
+        # ... and likewise the BatchNorm entries of the captured forward pass (ops.restore_bn_if_refused() after every replay)
+        self._bn_last = ops._BN_LAST
 
     def __call__(self, wave, target, lam=None, stripes=None):
         if self.mixup and lam is None:
@@ -119,6 +122,7 @@ class GraphedTrainStep(object):
             self.graph.replay()
             self.replays += 1
             self.opt.buckets.written |= self._written
+            ops._BN_LAST = self._bn_last
             loss = self.loss
         self.opt.step()
         return loss

@@ -611,6 +611,7 @@ def bn_finalize(partials, nparts, rows_per_part, N, bn_w, bn_b, running_mean, ru
 
 
 _BN_COMMIT = None        # [(cand, running_mean, running_var, C)] while a forward pass collects its BatchNorm updates
+_BN_LAST = None          # the entries the newest forward pass installed; their `cand` now hold the statistics from before it
 
 
 def begin_bn_commit():
@@ -620,17 +621,31 @@ def begin_bn_commit():
 
 def commit_bn(drop=False):
     """End of a forward pass: install the running statistics its BatchNorms proposed (one launch; skipped on the device when
-    the found-non-finite word is set).  drop=True: the pass raised -- forget them."""
-    global _BN_COMMIT
+    the found-non-finite word is set) and keep the ones they replace until the optimiser step has settled
+    (restore_bn_if_refused).  drop=True: the pass raised -- forget them."""
+    global _BN_COMMIT, _BN_LAST
     entries, _BN_COMMIT = _BN_COMMIT, None
     if entries and not drop:
         for i in range(0, len(entries), 16):
             _commit_bn_entries(entries[i:i + 16])
+        _BN_LAST = entries
 
 
-def _commit_bn_entries(entries):
+def restore_bn_if_refused():
+    """Behind the Adam launch of optim.FusedAdamAmsgrad.step(): when that step was refused for a reason that arose AFTER the
+    forward pass (a split-f16 dgrad / wgrad met NaN, the all-reduced gradient is non-finite, another rank raised its flag) the
+    running statistics the forward pass installed are taken back on the device -- the found-non-finite word decides, no
+    synchronisation.  A refused step leaves the BatchNorm buffers as intact as parameters and moments, on every rank."""
+    global _BN_LAST
+    entries, _BN_LAST = _BN_LAST, None
+    if entries and USE_SF16:
+        for i in range(0, len(entries), 16):
+            _commit_bn_entries(entries[i:i + 16], restore=True)
+
+
+def _commit_bn_entries(entries, restore=False):
     n = len(entries)
-    _call("sed_bn_commit", n, (ctypes.c_void_p * n)(*[e[0].data_ptr() for e in entries]),
+    _call("sed_bn_restore" if restore else "sed_bn_commit", n, (ctypes.c_void_p * n)(*[e[0].data_ptr() for e in entries]),
           (ctypes.c_void_p * n)(*[e[1].data_ptr() for e in entries]), (ctypes.c_void_p * n)(*[e[2].data_ptr() for e in entries]),
           (ctypes.c_int * n)(*[e[3] for e in entries]), _sf16_err_dev_ptr(entries[0][1].device), _stream())
 

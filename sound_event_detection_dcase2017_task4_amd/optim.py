@@ -195,6 +195,7 @@ class FusedAdamAmsgrad(object):
                           self.lr, self.betas[0], self.betas[1], self.eps, 1.0 / float(self.world_size), skipped=self._skipped,
                           status_ptr=(self._status.data_ptr() + 4 * (self._issued % POLL_RING)) if lagged else None,
                           rank_flag=self._grad_store if self.world_size > 1 else None)
+        ops.restore_bn_if_refused()        # a step refused after its forward pass takes the BatchNorm statistics back too
         if lagged:
             ev = torch.cuda.Event()
             ev.record()

@@ -62,6 +62,7 @@ def _build_model(model_type):
 
 
 POLL_LAG = 2          # optimiser steps between a step and the (rank-consistent) poll of its found-non-finite status
+RECOVERIES = []       # one {'iteration', 'skipped', 'rank'} per recover() call of this process (what tests / wrappers inspect)
 
 
 def train(args):
@@ -164,6 +165,7 @@ def train(args):
         no guard (main.py:245-258: NaN flows into the weights); here the run continues on the fp32 MFMA kernels, which carry
         non-finite values exactly like the reference's torch ops, and the refused batches are run again on them, in order."""
         k = err.skipped_steps
+        RECOVERIES.append({'iteration': iteration, 'skipped': k, 'rank': rank})
         logging.warning('iteration %d: %s', iteration, err)
         logging.warning('%d optimiser step(s) were refused on all %d rank(s); switching to the fp32 MFMA kernels '
                         '(ops.USE_SF16 = False) and re-running their batches', k, world)

@@ -355,3 +355,33 @@ def test_weight_cache_trim_keeps_live_entries_of_the_current_generation():
         ops._WCACHE.clear()
         ops._WCACHE.update(saved)
         ops.PARAM_GENERATION = gen
+
+
+def test_flags_hash_check_covers_every_object_of_the_library():
+    """sed_version() compares the flags hash of EVERY object: the list it walks (SED_OBJECTS in csrc/common.h, plus heads.hip
+    itself) must be build.SOURCES, and every source must publish its hash under its own name (round 4: gemm_sf16.o was built
+    and linked but missing from the list, so an experiment build of it alone would have gone unnoticed)."""
+    from sound_event_detection_dcase2017_task4_amd import build
+    common = open(os.path.join(build.CSRC, "common.h")).read()
+    listed = re.findall(r"X\((\w+)\)", re.search(r"#define SED_OBJECTS\(X\)(.*)", common).group(1))
+    names = [s[:-len(".hip")] for s in build.SOURCES]
+    assert sorted(listed + ["heads"]) == sorted(names) and len(set(listed)) == len(listed)
+    for n in names:
+        src = open(os.path.join(build.CSRC, n + ".hip")).read()
+        assert re.search(r"^SED_OBJECT_FLAGS\(%s\)" % n, src, flags=re.M), n
+    heads = open(os.path.join(build.CSRC, "heads.hip")).read()
+    assert "SED_OBJECTS(SED_WEAK_FLAGS)" in heads and "SED_OBJECTS(SED_FLAGS_ENTRY)" in heads
+
+
+def test_gpu_tier_collection_order_puts_parity_first_and_spawned_ranks_last():
+    """tests/conftest.py orders the `-m gpu` tier (the driver runs it with -x): oracle / golden parity, then the float64 checks
+    of the split-f16 kernels, then the rest; CLI subprocesses and multi-rank tests come last, so a process-level failure can
+    never hide the numerics evidence again (round 4: test_gpu_parallel sat in front of test_gpu_sf16)."""
+    import conftest
+    ids = ["tests/test_gpu_parallel.py::a", "tests/test_gpu_cli.py::b", "tests/test_gpu_sf16.py::c", "tests/test_gpu_optim.py::d",
+           "tests/test_gpu_model.py::e", "tests/test_gpu_frontend.py::f", "tests/test_gpu_graph.py::g", "tests/test_gpu_ops.py::h",
+           "tests/test_gpu_gru.py::i"]
+    order = sorted(ids, key=conftest.collection_rank)
+    pos = {i.split("::")[1]: k for k, i in enumerate(order)}
+    assert max(pos[k] for k in "efhi") < pos["c"] < min(pos["d"], pos["g"]) and max(pos["d"], pos["g"]) < pos["b"] < pos["a"]
+    assert order[-1].startswith("tests/test_gpu_parallel.py")

@@ -403,3 +403,51 @@ def test_lagged_poll_reports_refused_steps_at_a_deterministic_step():
         opt.poll(0)
     assert ei.value.skipped_steps == 1 and opt.step_count == 6
     ops.check_device_errors(synchronize=True, nonfinite=True)
+
+
+@pytest.mark.parametrize("graphed", [False, True])
+def test_step_refused_after_its_forward_pass_takes_the_batchnorm_statistics_back(graphed):
+    """The forward pass of a step is clean and installs its BatchNorm running statistics; the NaN arrives afterwards (here: a
+    non-finite loss gradient, which is what a poisoned backward pass, a non-finite all-reduced gradient or another rank's
+    flag look like to this rank).  The Adam kernel refuses the step -- and the running statistics the forward pass had
+    already blended in are taken back behind it (sed_bn_restore), so a refused step leaves the buffers exactly as they were
+    and the re-run of the same batch does not blend it twice.  Eager and under the HIP graph (replays run no Python)."""
+    from sound_event_detection_dcase2017_task4_amd import ops
+    from sound_event_detection_dcase2017_task4_amd.graph import GraphedTrainStep
+    from sound_event_detection_dcase2017_task4_amd.optim import FusedAdamAmsgrad
+    from sound_event_detection_dcase2017_task4_amd.pytorch.losses import clip_bce
+    m = _build("Cnn_9layers_FrameAvg")
+    opt = FusedAdamAmsgrad(m, lr=1e-3)
+    x, y, lam, stripes = _batch(rows=4)
+    poison = torch.ones((), device="cuda")
+
+    def loss_func(out, tgt):
+        return clip_bce(out, tgt) * poison                   # poison = NaN: finite forward pass, NaN gradient everywhere
+
+    ops.check_device_errors(synchronize=True)
+    if graphed:
+        stepper = GraphedTrainStep(m, opt, loss_func, mixup=False, eager_steps=1)
+        step = lambda: stepper(x, y, None, stripes)
+    else:
+        def step():
+            loss = loss_func(m(x, None, specaug_stripes=stripes), {"target": y})
+            opt.zero_grad(); loss.backward(); opt.step()
+    for _ in range(3):
+        step()                                               # clean steps (the third one replays the graph)
+    ops.check_device_errors(synchronize=True)
+    assert opt.step_count == 3 and (not graphed or stepper.replays >= 1)
+    before = opt.flat.clone()
+    bufs = {k: v.clone() for k, v in m.named_buffers() if not k.endswith("num_batches_tracked")}
+    poison.fill_(float("nan"))
+    with pytest.raises(ops.NonFiniteOperand):
+        step()
+        ops.check_device_errors(synchronize=True)
+    assert torch.equal(opt.flat, before) and opt.step_count == 3
+    for k, v in m.named_buffers():
+        if not k.endswith("num_batches_tracked"):
+            assert torch.equal(v, bufs[k]), k                # restored bit for bit
+    ops.rollback_bn_counters(m, 1)
+    poison.fill_(1.0)
+    step()                                                   # the run goes on, and now the statistics DO move
+    ops.check_device_errors(synchronize=True)
+    assert opt.step_count == 4 and not torch.equal(m.bn0.running_mean, bufs["bn0.running_mean"])
