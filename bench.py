@@ -114,14 +114,12 @@ def pmc_traffic(substrings, name="pmc_traffic.json"):
     return (round(tot / n) if n else None), "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes/launch)" % os.path.relpath(path, REPO)
 
 
-FAMILY_KERNELS = {"gemm_nt_sf16_mfma": ["gemm_sf16_kernel"], "gemm_tn_sf16_mfma(+slice reduce)": ["gemm_tn_sf16_"], "conv3x3_sf16_mfma(fwd+dgrad)": ["conv_sf16_kernel"], "conv3x3_wgrad_sf16_mfma(+slice reduce)": ["wgrad_sf16_"], "conv3x3_wino_mfma(fwd+dgrad)": ["conv_wino_kernel"], "conv3x3_wino2d_mfma(fwd+dgrad)": ["conv_wino2_kernel"],
-                  "conv3x3_wgrad_wino2d_mfma(+slice reduce)": ["wgrad_wino2_"], "conv3x3_wgrad_wino_mfma(+slice reduce)": ["wgrad_wino_"],
+FAMILY_KERNELS = {"gemm_nt_sf16_mfma": ["gemm_sf16_kernel"], "gemm_tn_sf16_mfma(+slice reduce)": ["gemm_tn_sf16_"], "conv3x3_sf16_mfma(fwd+dgrad)": ["conv_sf16_kernel"], "conv3x3_wgrad_sf16_mfma(+slice reduce)": ["wgrad_sf16_"], "conv3x3_wino2d_mfma(fwd+dgrad)": ["conv_wino2_kernel"],
+                  "conv3x3_wgrad_wino2d_mfma(+slice reduce)": ["wgrad_wino2_"],
                   "conv3x3_igemm_mfma(fwd+dgrad)": ["conv_igemm_kernel"], "conv3x3_wgrad_mfma(+slice reduce)": ["wgrad_kernel"]}
 
 
-NOTES = {"conv3x3_wino_mfma(fwd+dgrad)": ("fused 1-D Winograd F(2,3) implicit GEMM on fp32 MFMA", 1 / 1.5, FP32_MFMA_PEAK_TFLOPS),
-         "conv3x3_wino2d_mfma(fwd+dgrad)": ("fused 2-D Winograd F(2x2,3x3) implicit GEMM on fp32 MFMA", 1 / 2.25, FP32_MFMA_PEAK_TFLOPS),
-         "conv3x3_wgrad_wino_mfma(+slice reduce)": ("Winograd-domain F(2,3) weight gradient on fp32 MFMA", 1 / 1.5, FP32_MFMA_PEAK_TFLOPS),
+NOTES = {"conv3x3_wino2d_mfma(fwd+dgrad)": ("fused 2-D Winograd F(2x2,3x3) implicit GEMM on fp32 MFMA", 1 / 2.25, FP32_MFMA_PEAK_TFLOPS),
          "conv3x3_wgrad_wino2d_mfma(+slice reduce)": ("Winograd-domain F(2x2,3x3) weight gradient on fp32 MFMA", 1 / 2.25, FP32_MFMA_PEAK_TFLOPS),
          "conv3x3_wgrad_sf16_mfma(+slice reduce)": ("weight gradient with split-f16 operands (LDS transpose reads) on the f16 MFMA pipe",
                                                     3.0, F16_MFMA_PEAK_TFLOPS),
@@ -355,7 +353,7 @@ def graph_eager_steps(mode, B, world, warmup, inference=False, h2d=False):
     return min(3, warmup - 1)
 
 
-DOMINANT = ("conv3x3_sf16_mfma(fwd+dgrad)", "conv3x3_wino2d_mfma(fwd+dgrad)", "conv3x3_wino_mfma(fwd+dgrad)",
+DOMINANT = ("conv3x3_sf16_mfma(fwd+dgrad)", "conv3x3_wino2d_mfma(fwd+dgrad)",
             "conv3x3_igemm_mfma(fwd+dgrad)", "logmel_frontend")     # families bracketed by HIP events inside the headline region
 
 

@@ -198,16 +198,6 @@ int sed_conv3x3_igemm(const float* x, const float* w_packed, float* y, int B, in
                       const float* in_scale, const float* in_shift, int epi, float* partials, const float* yprev,
                       const float* p_scale, const float* p_shift, const float* p_mean, const float* p_invstd,
                       sed_stream_t stream);
-/* Fused 1-D Winograd F(2,3) (along W) variant of sed_conv3x3_igemm: 1.5x fewer MFMA flops, same fusions and the same
- * contract, with w_wino = the Winograd pack [3 ky][4 xi][Cout][Cin] from sed_pack_conv_weights_wino (uf: forward,
- * ud: dgrad with Cin/Cout swapped).  Statistics partials: [ceil(M/128)*2][2][Cout], 64 rows per part.  Needs W even,
- * W | 128, Cin % 16 == 0, Cout % 64 == 0 (sed_conv3x3_wino_supported). */
-int sed_conv3x3_wino_supported(int H, int W, int Cin, int Cout);
-int sed_pack_conv_weights_wino(const float* w_oihw, int Cout, int Cin, float* uf, float* ud, sed_stream_t stream);
-int sed_conv3x3_wino(const float* x, const float* w_wino, float* y, int B, int H, int W, int Cin, int Cout,
-                     const float* in_scale, const float* in_shift, int epi, float* partials, const float* yprev,
-                     const float* p_scale, const float* p_shift, const float* p_mean, const float* p_invstd,
-                     sed_stream_t stream);
 /* Fused 2-D Winograd F(2x2,3x3) variant (16 instead of 36 MACs per 2x2 output tile): same fusions and contract, with
  * w_wino2 = the k-step-major pack [Cin/8][16][Cout][8] from sed_pack_conv_weights_wino2 (uf: forward, ud: dgrad with
  * Cin/Cout swapped).  Statistics parts: P = sed_conv_wino2_num_parts(B,H,W), one per wave (<= 64 pixels);
@@ -297,11 +287,6 @@ long sed_wgrad_sf16_partial_floats(int B, int H, int W, int Cin, int Cout);
 int sed_conv3x3_wgrad_sf16(const float* x, const float* gy, float* dw_oihw, float* partial, int B, int H, int W,
                            int Cin, int Cout, const float* in_scale, const float* in_shift, const float* gy_amax,
                            const float* x_amax, int* err_host, int* err_dev, int flags, sed_stream_t stream);
-/* Winograd-domain weight gradient (12 instead of 18 MACs per output pair); same contract as sed_conv3x3_wgrad.
- * Needs W a power of two <= 64 and Cin, Cout % 64 == 0; partial: sed_wgrad_wino_partial_floats(...) floats. */
-long sed_wgrad_wino_partial_floats(long M, int Cin, int Cout, int* nslices_out, int* pix_per_slice_out);
-int sed_conv3x3_wgrad_wino(const float* x, const float* gy, float* dw_oihw, float* partial, int B, int H, int W, int Cin,
-                           int Cout, const float* in_scale, const float* in_shift, sed_stream_t stream);
 long sed_wgrad_partial_floats(long M, int Cin, int Cout, int ntaps, int* nslices_out, int* pix_per_slice_out);
 int sed_conv3x3_wgrad(const float* x, const float* gy, float* dw_oihw, float* partial, int B, int H, int W, int Cin,
                       int Cout, const float* in_scale, const float* in_shift, sed_stream_t stream);
@@ -398,10 +383,7 @@ int sed_gru_gate_bwd(const float* g_out0, const float* g_out1, long ld_go, const
  * cannot be; if a launch still cannot make progress (CU mask, co-tenant kernel), its bounded spin gives up and a
  * follow-up kernel overwrites `out` / `dgi` with NaN and stores 1 (forward) / 2 (backward) into *err_host, a
  * DEVICE-VISIBLE HOST int (hipHostMalloc / pinned; may be null) that the host can poll without synchronising.
- * sed_gru_set_spin_limit (test hook): polls before giving up (default 2^23, about 1 s; <= 0 restores the default).
- * sed_gru_force_agent_scope (test hook): the workgroups of a group normally find themselves on one XCD (they check the XCC_ID
- * register) and exchange through its L2 with plain stores; 1 makes them use the agent-scope stores of the fallback path.
- * sed_debug_occupy (test hook): holds `blocks` CUs (one workgroup with lds_bytes of LDS each) for `microseconds`. */
+ * (The give-up path and the agent-scope fallback are exercised through the test hooks of include/sed_hip_test.h.) */
 int sed_gru_seq_supported(int B, int Hd);
 long sed_gru_seq_ws_floats(void);
 int sed_gru_seq_row_block(void);      /* batch rows per workgroup (16): the granularity of dbias_parts */
@@ -414,9 +396,6 @@ int sed_gru_seq_bwd(const float* g_out, const float* wt_f, const float* wt_b, co
                     float* dbias_parts /* nullable: [2 directions][ceil(B/row_block)][4: dr, dz, dn, dn*r][Hd] sums over time and
                                           the rows of a block: db_ih = (dr, dz, dn), db_hh = (dr, dz, dn*r) summed over blocks */,
                     float* ws, int* err_host, float* dgi_amax, sed_stream_t stream);
-int sed_gru_set_spin_limit(long spins);
-int sed_gru_force_agent_scope(int on);
-int sed_debug_occupy(int blocks, int lds_bytes, long microseconds, sed_stream_t stream);
 
 /* ---- multi-head self-attention of the Transformer heads (models.py:587-665; 8 heads x 64) ----------------------
  * q, k, v, o, g_*: [B*T][512] fp32, head h in columns 64h..64h+63 (the Linear outputs of w_qs / w_ks / w_vs, no

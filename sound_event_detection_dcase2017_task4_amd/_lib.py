@@ -8,6 +8,7 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "sed_hip.h")
+TEST_HEADER = os.path.join(os.path.dirname(HERE), "include", "sed_hip_test.h")       # test hooks: not the product ABI
 LIB_PATH = os.path.join(HERE, "libsed_hip.so")
 
 _CTYPES = {
@@ -76,6 +77,16 @@ def lib():
         verify_flags(h)
         _LIB = h
     return _LIB
+
+
+def test_hooks():
+    """The library handle with the prototypes of include/sed_hip_test.h installed as well (tests and tools only)."""
+    h = lib()
+    for name, (ret, argtypes) in parse_header(TEST_HEADER).items():
+        fn = getattr(h, name)
+        fn.restype = ret
+        fn.argtypes = argtypes
+    return h
 
 
 def verify_flags(h):

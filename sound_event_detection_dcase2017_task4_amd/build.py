@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsed_hip.so")
-SOURCES = ["logmel.hip", "bn.hip", "conv.hip", "conv_wino.hip", "conv_wino2.hip", "conv_sf16.hip", "gemm_sf16.hip", "heads.hip", "attention.hip", "gru.hip"]
+SOURCES = ["logmel.hip", "bn.hip", "conv.hip", "conv_wino2.hip", "conv_sf16.hip", "gemm_sf16.hip", "heads.hip", "attention.hip", "gru.hip"]
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-I", INCLUDE]
 # SED_HIPCC_FLAGS: extra flags for kernel experiments (tools/ablate.sh, tools/experiment_*.patch).  A library built with them

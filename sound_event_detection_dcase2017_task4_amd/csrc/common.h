@@ -22,7 +22,7 @@
 #define SED_OBJECT_FLAGS(name) extern "C" __attribute__((visibility("hidden"))) const char sed_objflags_##name[] = SED_BUILD_FLAGS_HASH;
 // every translation unit of libsed_hip.so besides heads.hip, which holds sed_version() and compares their flags hashes with
 // its own (= build.SOURCES without the suffix, minus heads: tests/test_capi_and_host.py keeps the two lists equal)
-#define SED_OBJECTS(X) X(logmel) X(bn) X(conv) X(conv_wino) X(conv_wino2) X(conv_sf16) X(gemm_sf16) X(attention) X(gru)
+#define SED_OBJECTS(X) X(logmel) X(bn) X(conv) X(conv_wino2) X(conv_sf16) X(gemm_sf16) X(attention) X(gru)
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));

@@ -1,5 +1,5 @@
 // 3x3 convolution with a FUSED 2-D Winograd F(2x2,3x3), fp32 MFMA: 16 multiplies per 2x2 output tile and (ci, co)
-// pair instead of 36 (the 1-D kernel in conv_wino.hip needs 24).
+// pair instead of 36.
 //
 //     U = G g G^T (4x4 per (co, ci), packed once per step),   V = B^T d B (4x4 input patch, formed in registers),
 //     M[eta][xi] = sum_ci V[eta][xi] * U[eta][xi],            Y = A^T M A (2x2 outputs)
@@ -17,7 +17,7 @@
 // ds_read_b128 quarter-wave conflict-free.  B stage: U[16][32 co][8 ci] by LDS-DMA from the k-step-major pack
 // (16 KB contiguous per (k-step, co block)), same swizzle applied on the source side.
 //
-// Fusions as in conv_wino.hip: input relu(scale*x+shift); epilogue 1 = BN statistics (sum, M2) per wave (64 pixels)
+// Fusions as in the direct kernel (conv.hip): input relu(scale*x+shift); epilogue 1 = BN statistics (sum, M2) per wave (64 pixels)
 // + the per-part pixel count (tiles past the image edge are not counted); epilogue 2 = ReLU mask + BN-backward sums.
 #include "common.h"
 #include "sed_hip.h"

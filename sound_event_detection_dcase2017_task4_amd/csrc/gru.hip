@@ -33,6 +33,7 @@
 // 128 x 256 threads, 34 / 98 KB LDS) gives up after ~1 s and raises the error word instead of hanging the GPU.
 #include "common.h"
 #include "sed_hip.h"
+#include "sed_hip_test.h"
 SED_OBJECT_FLAGS(gru)
 
 namespace {

@@ -17,10 +17,8 @@ from . import _lib
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
-# The fused 1-D Winograd F(2,3) kernels (csrc/conv_wino.hip) do the same convolutions with 1.5x fewer MFMA flops; they are
-# used for forward, dgrad and wgrad whenever the layer shape allows.  False = direct implicit GEMM everywhere.
 USE_SF16 = os.environ.get("SED_USE_SF16", "1") != "0"   # split-f16 MFMA convolution (forward / dgrad) where supported; 0: fp32 Winograd kernels
-USE_WINOGRAD = 2          # 2: 2-D F(2x2,3x3) where supported, else 1-D F(2,3), else direct; 1: 1-D; 0: direct only
+USE_WINOGRAD = 2          # fp32-MFMA path (USE_SF16 off): 2 = fused 2-D Winograd F(2x2,3x3) where supported, else the direct implicit GEMM; 0: direct only
 # ConvBlock backward: BN2's (sum dy, sum dy*xhat) from the pooled output + per-window ReLU counts instead of a pass over
 # the full-resolution conv output.  The identity divides by gamma, so the kernels themselves fall back to the exact pass
 # (on the device, from this step's weights) whenever some |gamma| < POOL_BWD_GAMMA_MIN.
@@ -743,27 +741,6 @@ def _conv_igemm(x, w_packed, B, H, W, Cin, Cout, in_st=None, epi=0, partials=Non
     return y
 
 
-def _pack_wino(w, want_f=True, want_d=False):
-    """OIHW -> Winograd-domain packs uf [3][4][Cout][Cin] / ud [3][4][Cin][Cout]."""
-    Cout, Cin = w.shape[0], w.shape[1]
-    uf = torch.empty((3, 4, Cout, Cin), dtype=torch.float32, device=w.device) if want_f else None
-    ud = torch.empty((3, 4, Cin, Cout), dtype=torch.float32, device=w.device) if want_d else None
-    _call("sed_pack_conv_weights_wino", _ptr(w), Cout, Cin, _ptr(uf), _ptr(ud), _stream())
-    return uf, ud
-
-
-def _conv_wino(x, w_wino, B, H, W, Cin, Cout, in_st=None, epi=0, partials=None, yprev=None, p_st=None):
-    y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
-    with _timed("conv3x3_wino_mfma(fwd+dgrad)|%d->%d@%dx%d epi%d%s", (Cin, Cout, H, W, epi, "+inT" if in_st is not None else ""),
-                2.0 * 9 * B * H * W * Cin * Cout):
-        _call("sed_conv3x3_wino", _ptr(x), _ptr(w_wino), _ptr(y), B, H, W, Cin, Cout,
-              _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, epi,
-              _ptr(partials), _ptr(yprev), _ptr(p_st.scale) if p_st is not None else None,
-              _ptr(p_st.shift) if p_st is not None else None, _ptr(p_st.mean) if p_st is not None else None,
-              _ptr(p_st.invstd) if p_st is not None else None, _stream())
-    return y
-
-
 def _pack_wino2(w, want_f=True, want_d=False):
     """OIHW -> 2-D Winograd packs uf [Cin/8][16][Cout][8] / ud [Cout/8][16][Cin][8]."""
     Cout, Cin = w.shape[0], w.shape[1]
@@ -797,24 +774,6 @@ def _pack(w, want_f=True, want_d=False):
     wd = torch.empty((9, Cin, Cout), dtype=torch.float32, device=w.device) if want_d else None
     _call("sed_pack_conv_weights", _ptr(w), Cout, Cin, _ptr(wf), _ptr(wd), _stream())
     return wf, wd
-
-
-def _wgrad_wino_ok(W, Cin, Cout):
-    return W in (8, 16, 32, 64) and Cin % 64 == 0 and Cout % 64 == 0
-
-
-def _wgrad_wino(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, keep=None):
-    ns, pps = ctypes.c_int(0), ctypes.c_int(0)
-    nfl = _lib.lib().sed_wgrad_wino_partial_floats(B * H * W, Cin, Cout, ctypes.byref(ns), ctypes.byref(pps))
-    partial = torch.empty((nfl,), dtype=torch.float32, device=x.device)
-    dw = _dst(sink, (Cout, Cin, 3, 3), x.device)
-    if keep is not None:
-        keep.extend((partial, dw))                   # alive until the side stream has been joined
-    with _timed("conv3x3_wgrad_wino_mfma(+slice reduce)|%d->%d@%dx%d%s", (Cin, Cout, H, W, "+inT" if in_st is not None else ""),
-                2.0 * 9 * B * H * W * Cin * Cout):
-        _call("sed_conv3x3_wgrad_wino", _ptr(x), _ptr(gy), _ptr(dw), _ptr(partial), B, H, W, Cin, Cout,
-              _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, _stream())
-    return _ret(sink, dw) if signal else (None if sink is not None else dw)
 
 
 def _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, keep=None):
@@ -879,8 +838,6 @@ def _wgrad(x, gy, B, H, W, Cin, Cout, in_st=None, sink=None, signal=True, gy_ama
         raise RuntimeError("split-f16 operand pairs can only feed the split-f16 weight-gradient kernel")
     if USE_WINOGRAD >= 2 and W in (8, 16, 32, 64) and Cin % 32 == 0 and Cout % 64 == 0:
         return _wgrad_wino2(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=signal, keep=keep)
-    if USE_WINOGRAD and _wgrad_wino_ok(W, Cin, Cout):
-        return _wgrad_wino(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=signal, keep=keep)
     return _wgrad_direct(x, gy, B, H, W, Cin, Cout, in_st=in_st, sink=sink, signal=signal, keep=keep)
 
 
@@ -1050,14 +1007,12 @@ def conv3x3_sf16(x, pack, B, H, W, Cin, Cout, in_st=None, epi=0, partials=None, 
 
 
 def _conv_algo(H, W, Cin, Cout):
-    """2 = fused 2-D Winograd F(2x2,3x3), 1 = fused 1-D Winograd F(2,3), 0 = direct implicit GEMM."""
+    """3 = split-f16 direct, 2 = fused 2-D Winograd F(2x2,3x3) on fp32 MFMA, 0 = direct fp32 implicit GEMM."""
     L = _lib.lib()
     if USE_SF16 and L.sed_conv3x3_sf16_supported(H, W, Cin, Cout):
         return 3
     if USE_WINOGRAD >= 2 and L.sed_conv3x3_wino2_supported(H, W, Cin, Cout):
         return 2
-    if USE_WINOGRAD >= 1 and L.sed_conv3x3_wino_supported(H, W, Cin, Cout):
-        return 1
     return 0
 
 
@@ -1080,9 +1035,6 @@ def _conv_fwd_like(x, w_oihw, B, H, W, Cin, Cout, dgrad=False, **kw):
     if algo == 2:
         uf, ud = _pack_wino2(w_oihw, want_f=not dgrad, want_d=dgrad)
         return _conv_wino2(x, ud if dgrad else uf, B, H, W, Cin, Cout, **kw)
-    if algo == 1:
-        uf, ud = _pack_wino(w_oihw, want_f=not dgrad, want_d=dgrad)
-        return _conv_wino(x, ud if dgrad else uf, B, H, W, Cin, Cout, **kw)
     wf, wd = _pack(w_oihw, want_f=not dgrad, want_d=dgrad)
     return _conv_igemm(x, wd if dgrad else wf, B, H, W, Cin, Cout, **kw)
 
@@ -1099,9 +1051,6 @@ def _conv_parts(B, H, W, Cin, Cout):
     if algo == 2:
         P = int(L.sed_conv_wino2_num_parts(B, H, W))
         return P, -1, P * 2 * Cout + P
-    if algo == 1:
-        P = ((M + 127) // 128) * 2
-        return P, 64, P * 2 * Cout
     P = L.sed_conv_num_parts(M, Cout)
     return P, L.sed_conv_rows_per_part(M, Cout), P * 2 * Cout
 

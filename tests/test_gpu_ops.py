@@ -406,60 +406,6 @@ def test_bce_mixup_adam(ops, golden_dir):
     assert (wd.cpu() - w.detach()).abs().max().item() < 2e-7
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 13, 8, 64, 64), (1, 25, 16, 64, 128), (3, 12, 32, 128, 128),
-                                            (2, 9, 64, 64, 64), (2, 101, 64, 64, 64), (5, 7, 8, 256, 512)])
-def test_conv3x3_winograd_forward_dgrad(ops, B, H, W, Cin, Cout):
-    """Fused 1-D Winograd F(2,3) kernel vs torch conv2d (forward and dgrad), incl. tiles that straddle clips and a
-    ragged last tile (B*H*W not a multiple of 128)."""
-    g = torch.Generator().manual_seed(B * 100 + W)
-    x = torch.randn(B, Cin, H, W, generator=g)
-    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
-    gy = torch.randn(B, Cout, H, W, generator=g)
-    xr = x.clone().requires_grad_(True)
-    y_ref = F.conv2d(xr, w, padding=1)
-    y_ref.backward(gy)
-    wdev, xd, gyd = w.cuda(), nhwc(x), nhwc(gy)
-    uf, ud = ops._pack_wino(wdev, True, True)
-    y = ops._conv_wino(xd, uf, B, H, W, Cin, Cout)
-    assert rel(nchw(y), y_ref.detach()) < 5e-6
-    gx = ops._conv_wino(gyd, ud, B, H, W, Cout, Cin)
-    assert rel(nchw(gx), xr.grad) < 5e-6
-
-
-def test_conv3x3_winograd_fusions_match_direct_kernel(ops):
-    """Input BN+ReLU transform, statistics epilogue and the dgrad mask/sums epilogue give the same results as the
-    direct implicit-GEMM kernel."""
-    B, H, W, C, Co = 2, 21, 16, 64, 128
-    g = torch.Generator().manual_seed(5)
-    yprev = (torch.randn(B, H, W, C, generator=g) * 2 + 0.5).cuda()
-    w = (torch.randn(Co, C, 3, 3, generator=g) * 0.05).cuda()
-    st = ops.BnStats(C, "cuda")
-    st.scale.copy_(torch.rand(C, generator=g) + 0.5); st.shift.copy_(torch.randn(C, generator=g) * 0.3)
-    st.mean.copy_(torch.randn(C, generator=g) * 0.1); st.invstd.copy_(torch.rand(C, generator=g) + 0.5)
-    from sound_event_detection_dcase2017_task4_amd import _lib
-    L = _lib.lib()
-    M = B * H * W
-    wf, wd = ops._pack(w, True, True)
-    uf, ud = ops._pack_wino(w, True, True)
-    npd, rppd = L.sed_conv_num_parts(M, Co), L.sed_conv_rows_per_part(M, Co)
-    npw = ((M + 127) // 128) * 2
-    pd = torch.zeros((npd, 2, Co), device="cuda"); pw = torch.zeros((npw, 2, Co), device="cuda")
-    yd = ops._conv_igemm(yprev, wf, B, H, W, C, Co, in_st=st, epi=1, partials=pd)
-    yw = ops._conv_wino(yprev, uf, B, H, W, C, Co, in_st=st, epi=1, partials=pw)
-    assert rel(yw.cpu(), yd.cpu()) < 5e-6
-    one, zero = torch.ones(Co).cuda(), torch.zeros(Co).cuda()
-    sd = ops.bn_finalize(pd, npd, rppd, M, one, zero, None, None)
-    sw = ops.bn_finalize(pw, npw, 64, M, one, zero, None, None)
-    assert (sd.mean - sw.mean).abs().max().item() < 1e-5 and rel(sw.invstd.cpu(), sd.invstd.cpu()) < 1e-5
-    gy = torch.randn(B, H, W, Co, generator=g).cuda()
-    npd2 = L.sed_conv_num_parts(M, C); npw2 = ((M + 127) // 128) * 2
-    pd2 = torch.zeros((npd2, 2, C), device="cuda"); pw2 = torch.zeros((npw2, 2, C), device="cuda")
-    dd = ops._conv_igemm(gy, wd, B, H, W, Co, C, epi=2, partials=pd2, yprev=yprev, p_st=st)
-    dw_ = ops._conv_wino(gy, ud, B, H, W, Co, C, epi=2, partials=pw2, yprev=yprev, p_st=st)
-    assert rel(dw_.cpu(), dd.cpu()) < 5e-6
-    assert rel(pw2.sum(0).cpu(), pd2.sum(0).cpu()) < 1e-4
-
-
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 13, 8, 64, 64), (1, 25, 16, 64, 128), (3, 12, 32, 128, 128), (2, 9, 64, 64, 64),
                                             (2, 101, 64, 64, 64), (5, 7, 8, 256, 512), (2, 125, 8, 64, 32), (1, 1, 8, 8, 32)])
 def test_conv3x3_winograd2d_forward_dgrad(ops, B, H, W, Cin, Cout):
@@ -537,28 +483,6 @@ def test_conv3x3_winograd2d_wgrad(ops, B, H, W, Cin, Cout, inT):
     dw = ops._wgrad_wino2(xd, gyd, B, H, W, Cin, Cout, in_st=st).cpu()
     assert rel(dw, w.grad) < 1e-5
     dwd = ops._wgrad_direct(xd, gyd, B, H, W, Cin, Cout, in_st=st).cpu() if Cin % 64 == 0 else w.grad
-    assert rel(dw, dwd) < 1e-5
-
-
-@pytest.mark.parametrize("B,H,W,Cin,Cout,inT", [(2, 13, 8, 64, 64, False), (1, 25, 16, 64, 128, True), (3, 12, 32, 128, 128, False),
-                                                (2, 101, 64, 64, 64, True), (5, 7, 8, 256, 512, False), (2, 300, 32, 128, 64, False)])
-def test_conv3x3_winograd_wgrad(ops, B, H, W, Cin, Cout, inT):
-    """Winograd-domain weight gradient vs torch autograd (incl. the on-the-fly BN+ReLU input transform, ragged slices)."""
-    g = torch.Generator().manual_seed(B * 10 + W)
-    x = torch.randn(B, Cin, H, W, generator=g)
-    gy = torch.randn(B, Cout, H, W, generator=g)
-    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).requires_grad_(True)
-    st = None
-    a = x
-    if inT:
-        sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
-        a = F.relu(x * sc[None, :, None, None] + sh[None, :, None, None])
-        st = ops.BnStats(Cin, "cuda"); st.scale.copy_(sc); st.shift.copy_(sh)
-    F.conv2d(a, w, padding=1).backward(gy)
-    xd, gyd = nhwc(x), nhwc(gy)
-    dw = ops._wgrad_wino(xd, gyd, B, H, W, Cin, Cout, in_st=st).cpu()
-    assert rel(dw, w.grad) < 1e-5
-    dwd = ops._wgrad_direct(xd, gyd, B, H, W, Cin, Cout, in_st=st).cpu()
     assert rel(dw, dwd) < 1e-5
 
 

@@ -70,13 +70,6 @@ def main():
                      ("igemm fwd epi0+inT", lambda: ops._conv_igemm(x, wf, B, H, W, ci, co, in_st=st)),
                      ("igemm fwd epi1    ", lambda: ops._conv_igemm(x, wf, B, H, W, ci, co, epi=1, partials=part)),
                      ("igemm dgrad epi2  ", lambda: ops._conv_igemm(gy, wd, B, H, W, co, ci, epi=2, partials=partb, yprev=x, p_st=sto))]
-        if args.only in ("", "wino") and L.sed_conv3x3_wino_supported(H, W, ci, co):
-            uf, ud = ops._pack_wino(w, True, True)
-            npw = ((M + 127) // 128) * 2
-            pw = torch.empty((npw, 2, co), device="cuda"); pwb = torch.empty((npw, 2, ci), device="cuda")
-            runs += [("wino  fwd epi1+inT", lambda: ops._conv_wino(x, uf, B, H, W, ci, co, in_st=st, epi=1, partials=pw)),
-                     ("wino  fwd epi0    ", lambda: ops._conv_wino(x, uf, B, H, W, ci, co)),
-                     ("wino  dgrad epi2  ", lambda: ops._conv_wino(gy, ud, B, H, W, co, ci, epi=2, partials=pwb, yprev=x, p_st=sto))]
         if args.only in ("", "wino2") and L.sed_conv3x3_wino2_supported(H, W, ci, co):
             uf2, ud2 = ops._pack_wino2(w, True, True)
             pw2, _ = ops._wino2_partials(B, H, W, co, "cuda")
@@ -106,9 +99,7 @@ def main():
             runs += [("wgrad +inT        ", lambda: ops._wgrad_direct(x, gy, B, H, W, ci, co, in_st=st)),
                      ("wgrad             ", lambda: ops._wgrad_direct(x, gy, B, H, W, ci, co)),
                      ("wgrad wino2 +inT  ", lambda: ops._wgrad_wino2(x, gy, B, H, W, ci, co, in_st=st)),
-                     ("wgrad wino2       ", lambda: ops._wgrad_wino2(x, gy, B, H, W, ci, co)),
-                     ("wgrad wino +inT   ", lambda: ops._wgrad_wino(x, gy, B, H, W, ci, co, in_st=st)),
-                     ("wgrad wino        ", lambda: ops._wgrad_wino(x, gy, B, H, W, ci, co))]
+                     ("wgrad wino2       ", lambda: ops._wgrad_wino2(x, gy, B, H, W, ci, co))]
         for name, fn in runs:
             ms = timeit(fn, args.reps)
             print("%4d->%-4d %4dx%-3d %s %8.3f ms  %6.1f TFLOP/s" % (ci, co, H, W, name, ms, fl / ms / 1e9))
