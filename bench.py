@@ -98,17 +98,47 @@ def latest_profile(name):
     return cands[-1] if cands else None
 
 
+# which kernel sources a kernel family is compiled from: a committed PMC figure is quoted only while THESE files are the ones it
+# was collected on (`_meta.sources` of the digest, written on the GPU box at collection time by tools/collect_profiles.sh)
+KERNEL_SOURCES = {"conv_sf16_kernel": ["conv_sf16.hip", "common.h"], "wgrad_sf16_": ["conv_sf16.hip", "common.h"],
+                  "logmel32_kernel": ["logmel.hip", "common.h"], "conv_wino2_kernel": ["conv_wino2.hip", "common.h"],
+                  "wgrad_wino2_": ["conv_wino2.hip", "common.h"], "conv_igemm_kernel": ["conv.hip", "common.h"],
+                  "wgrad_kernel": ["conv.hip", "common.h"], "gemm_sf16_kernel": ["gemm_sf16.hip", "common.h"],
+                  "gemm_tn_sf16_": ["gemm_sf16.hip", "common.h"]}
+
+
+def pmc_fresh(meta, substrings, current=None):
+    """None when the digest's recorded kernel sources equal the current ones for every kernel in `substrings`, else the reason
+    it must not be quoted (no record at all counts as stale)."""
+    if current is None:
+        from sound_event_detection_dcase2017_task4_amd import build
+        current = build.source_hashes()
+    rec = (meta or {}).get("sources")
+    if not rec:
+        return "no kernel-source record (`_meta.sources`) in the digest"
+    for sub in substrings:
+        for f in KERNEL_SOURCES.get(sub, sorted(current)):
+            if rec.get(f) != current.get(f):
+                return "csrc/%s changed since the counters were collected (%s then, %s now)" % (f, rec.get(f), current.get(f))
+    return None
+
+
 def pmc_traffic(substrings, name="pmc_traffic.json"):
     """HBM bytes per launch of a timed kernel family, from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
     gfx950 correction + WRITE_SIZE; tools/pmc_digest.py).  PMC collection needs rocprofv3 around the process, so it cannot
     be sampled live: the figure is valid for the workload the file was collected on (pmc_traffic_b32.json: the headline
-    bs=32; pmc_traffic.json: configs[1], B=256), otherwise null."""
+    bs=32; pmc_traffic.json: configs[1], B=256) AND for the kernel sources it was collected on (pmc_fresh), otherwise null
+    with the reason as the source."""
     path = latest_profile(name)
     if not substrings or path is None:
         return None, None
+    data = json.load(open(path))
+    stale = pmc_fresh(data.get("_meta"), substrings)
+    if stale:
+        return None, "%s NOT quoted: %s" % (os.path.relpath(path, REPO), stale)
     tot, n = 0.0, 0
-    for k, v in json.load(open(path)).items():
-        if any(sub in k for sub in substrings):
+    for k, v in data.items():
+        if k != "_meta" and any(sub in k for sub in substrings):
             tot += (v["fetch_bytes_x2_per_launch"] + v["write_bytes_per_launch"]) * v["launches"]
             n += v["launches"] if "reduce" not in k else 0
     return (round(tot / n) if n else None), "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes/launch)" % os.path.relpath(path, REPO)
@@ -134,6 +164,7 @@ def kernel_report(timing, steps, B2, default_workload, by_shape=False, frames=10
     collected inside a timed region.  'achieved' always counts the ALGORITHMIC direct-convolution flops:
     Winograd kernels execute fewer MACs than that on the fp32 MFMA pipe, the split-f16 kernels THREE f16 MACs per
     algorithmic MAC on the f16 MFMA pipe (`executed_*`)."""
+    busy_file = "pmc_mfma_busy_b32.json" if pmc_file == "pmc_traffic_b32.json" else "pmc_mfma_busy.json"
     timing = dict(timing or {})
 
     def summarise(groups):
@@ -159,7 +190,8 @@ def kernel_report(timing, steps, B2, default_workload, by_shape=False, frames=10
         # VALU-only floor of 2300 = 0.25 ms per 512 waveforms, tools/valu_ubench.hip); HBM traffic is 1.06x algorithmic
         valu_floor_ms = 0.25 * (B2 * frames) / (512.0 * 1001.0)
         frontend = {"kernel": "logmel32_kernel (STFT+mel+log, K1)", "bound": "valu", "achieved": round(gbps, 1),
-                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": tr,
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                    "target_frac": 0.6, "met": bool(gbps / HBM_PEAK_GBPS >= 0.6), "traffic": tr,
                     "traffic_source": src, "avg_launch_ms": round(ms / len(fe), 4),
                     "bytes_per_waveform": int(fe[0][2] / B2),
                     "valu_floor_ms": round(valu_floor_ms, 4), "frac_of_valu_floor": round(valu_floor_ms / (ms / len(fe)), 4),
@@ -192,14 +224,18 @@ def kernel_report(timing, steps, B2, default_workload, by_shape=False, frames=10
             roofline["traffic"], src = pmc_traffic(FAMILY_KERNELS.get(dom), pmc_file)
             if src:
                 roofline["traffic_source"] = src
-        busy = latest_profile("pmc_mfma_busy.json")
+        busy = latest_profile(busy_file) if default_workload else None
         if busy:                                    # committed PMC evidence: share of GPU cycles the MFMA pipe is executing
-            for key, sub in FAMILY_KERNELS.items():
-                if key == dom:
-                    for fam, v in json.load(open(busy)).items():
-                        if any(fam.startswith(x.rstrip("_")) or x.rstrip("_") in fam for x in sub):
-                            roofline["mfma_pipe_busy_frac"] = [v["mfma_busy_frac_min"], v["mfma_busy_frac_max"]]
-                            roofline["mfma_pipe_busy_source"] = "%s (%s)" % (os.path.relpath(busy, REPO), v["definition"])
+            data = json.load(open(busy))
+            stale = pmc_fresh(data.get("_meta"), FAMILY_KERNELS.get(dom, []))
+            if stale:
+                roofline["mfma_pipe_busy_frac"] = None
+                roofline["mfma_pipe_busy_source"] = "%s NOT quoted: %s" % (os.path.relpath(busy, REPO), stale)
+            else:
+                for fam, v in data.items():
+                    if fam != "_meta" and any(fam.startswith(x.rstrip("_")) or x.rstrip("_") in fam for x in FAMILY_KERNELS.get(dom, [])):
+                        roofline["mfma_pipe_busy_frac"] = [v["mfma_busy_frac_min"], v["mfma_busy_frac_max"]]
+                        roofline["mfma_pipe_busy_source"] = "%s (%s)" % (os.path.relpath(busy, REPO), v["definition"])
     # every MFMA kernel family of the step, same accounting (the dominant one above is the `roofline` object)
     for tag, v in kern.items():
         what, executed_per_alg, peak = NOTES.get(tag, ("fp32 MFMA implicit GEMM", 1.0, FP32_MFMA_PEAK_TFLOPS))
@@ -292,9 +328,12 @@ class Workload(object):
 
     def run(self, steps, warmup, timing=False, timing_only=None):
         """W untimed steps, then exactly K timed ones bracketed by barrier + synchronize; MAX over ranks."""
+        ev0 = len(self.opt.buckets.wait_events) if self.opt.buckets.wait_events is not None else 0
         for i in range(warmup):
             self.step(i)
         self.sync()
+        if getattr(self, "first_run_steps", None) is None:        # where the timed steps of the FIRST run sit in wait_events
+            self.first_run_steps = (ev0 + warmup, steps)
         if timing:
             ops.TIMING, ops.TIMING_ONLY = {}, timing_only
         t0 = time.time()
@@ -450,6 +489,64 @@ def strict_fp32(mt, B, mix, rank, world, dev, steps=5, warmup=2):
         torch.cuda.empty_cache()
 
 
+def ranks_seen(dev):
+    """Proof that the backend really spans the ranks the line claims: all-reduce (sum) of a 1 from every rank."""
+    if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        return 1
+    t = torch.ones((1,), device=dev, dtype=torch.float32)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+    return int(round(float(t.item())))
+
+
+def dist_report(wl, steps):
+    """`dist` object of a row: backend, ranks the backend saw, exposed all-reduce time of the TIMED steps, bucket bytes."""
+    b = wl.opt.buckets
+    # wait_events collects one pair per optimiser step from the first warm-up step on: the timed region is the last `steps`
+    # entries of the first run() (later passes -- kernel table, un-evented rerun -- append behind them)
+    waits = (b.wait_events or [])
+    first = getattr(wl, "first_run_steps", None)
+    waits = waits[first[0]:first[0] + first[1]] if first else waits[-steps:]
+    init = torch.distributed.is_available() and torch.distributed.is_initialized()
+    return {"backend": torch.distributed.get_backend() if init else None,
+            "world_size": torch.distributed.get_world_size() if init else 1,
+            "n_ranks_seen": ranks_seen(wl.dev),
+            # time the compute stream sat behind the bucketed all-reduces in optimizer.step() = the EXPOSED part of the
+            # gradient exchange (the rest ran beside the backward pass), averaged over the timed steps; null at 1 rank
+            "allreduce_exposed_ms_per_step": (round(sum(a.elapsed_time(c) for a, c in waits) / max(len(waits), 1), 4)
+                                              if waits else None),
+            "allreduce_exposed_steps_averaged": len(waits),
+            # SED_ALLREDUCE_OVERLAP=0: every bucket goes out behind the backward pass instead of from inside it
+            "allreduce_overlap": not (b.deferred or wl.graphed is not None),
+            "nonfinite_poll_lag_steps": wl.opt.poll_lag,
+            "flat_gradient_bytes": int(wl.opt.flat_grad.numel() * 4),
+            "bucket_bytes": [int(4 * (hi - lo)) for lo, hi in b.ranges]}
+
+
+def strong_row(mt, B_local, mix, rank, world, dev, steps, warmup, seconds=10, int16=False):
+    """Strong-scaling reading of the metric at N ranks: the reference's `--batch_size 32` is the GLOBAL batch that
+    nn.DataParallel scatters (pytorch/main.py:138, :160-166), i.e. 32 / N clips per GPU.  Small per-GPU batches are launch-bound,
+    so forward + loss + backward replay as one HIP graph per step (graph.GraphedTrainStep; the bucketed all-reduce then goes out
+    behind the graph, in optimizer.step())."""
+    try:
+        wu = max(warmup, 4)
+        w = Workload(mt, B_local, mix, rank, world, dev, seconds=seconds, int16=int16, hip_graph=min(3, wu - 1))
+        w.opt.buckets.wait_events = []
+        dt, loss, _ = w.run(steps, wu)
+        row = {"metric": "training clips/sec (10s@32kHz) %s GLOBAL bs=%d at %d GPU (%d clips per GPU)" % (mt, B_local * world, world, B_local),
+               "scaling": "strong", "value": round(B_local * world * steps / dt, 2), "unit": "clips/s", "steps": steps, "warmup": wu,
+               "ms_per_step": round(dt / steps * 1e3, 3), "per_gpu_batch": B_local, "global_batch": B_local * world,
+               "workload": w.describe(seconds, int16), "loss": round(loss, 5), "dist": dist_report(w, steps)}
+        row.update(w.graph_info())
+        w.opt.buckets.wait_events = None
+        del w
+        return row
+    except Exception as e:                 # a side row must never lose the headline line -- but every rank must get here together
+        return {"scaling": "strong", "value": None, "error": repr(e)}
+    finally:
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -462,6 +559,7 @@ def main():
     ap.add_argument("--no_mixup", action="store_true")
     ap.add_argument("--seconds", type=int, default=10)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_strong", action="store_true", help="skip the strong-scaling row of a --gpus N > 1 run")
     ap.add_argument("--no_extra", action="store_true", help="skip the extra_configs runs (other BASELINE.json configurations)")
     ap.add_argument("--int16", action="store_true", help="feed int16 waveforms (the HDF5 storage dtype)")
     ap.add_argument("--by_shape", action="store_true", help="print a per-layer MFMA kernel table to stderr")
@@ -519,18 +617,13 @@ def main():
                           events_in_region=not args.no_kernel_events)
         loss = row["loss"]
     bucket_order = list(wl.opt.buckets.last_issue_order)
-    waits = wl.opt.buckets.wait_events[:args.steps]
-    dist_info = {"backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
-                 "world_size": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
-                 # time the compute stream sat behind the bucketed all-reduces in optimizer.step() = the EXPOSED part of the
-                 # gradient exchange (the rest ran beside the backward pass); null at 1 rank
-                 "allreduce_exposed_ms_per_step": (round(sum(a.elapsed_time(b) for a, b in waits) / max(len(waits), 1), 4)
-                                                   if waits else None),
-                 # SED_ALLREDUCE_OVERLAP=0: every bucket goes out behind the backward pass instead of from inside it
-                 "allreduce_overlap": not wl.opt.buckets.deferred,
-                 "nonfinite_poll_lag_steps": wl.opt.poll_lag,
-                 "flat_gradient_bytes": int(wl.opt.flat_grad.numel() * 4)}
+    dist_info = dist_report(wl, args.steps)
     wl.opt.buckets.wait_events = None
+    strong = None
+    if world > 1 and B == 32 and mix and not args.inference and not args.h2d and 32 % world == 0 and not args.no_strong:
+        # the OTHER reading of the metric: --batch_size 32 is the GLOBAL batch the reference's DataParallel scatters
+        # (pytorch/main.py:138, :160-166): 32 / N clips per GPU.  Every rank runs it (collectives), rank 0 reports it.
+        strong = strong_row(args.model_type, 32 // world, mix, rank, world, dev, args.steps, args.warmup, args.seconds, args.int16)
     parallel.shutdown()               # all ranks: barrier + destroy the process group; rank 0 then reports alone
     if rank != 0:
         return
@@ -543,7 +636,8 @@ def main():
                   ("training clips/sec (10s@32kHz) %s bs=%d at %d GPU" % (args.model_type, B, world)),
         "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None,
+        "dtype": "f32 (split-f16x3 MFMA products, fp32 accumulate)" if ops.USE_SF16 else "f32", "data": "synthetic",
         "arithmetic": ("fp32 storage and accumulation throughout; 3x3 convolution products (forward, dgrad, weight gradients) as "
                        "three split-f16 MFMAs with fp32 accumulation, operand scales from device-side amax values -- the "
                        "rounding error of a direct fp32 convolution at any magnitude (tests/test_gpu_sf16.py vs float64); "
@@ -566,12 +660,15 @@ def main():
         if k not in ("value", "unit", "steps", "warmup", "ms_per_step", "loss"):
             line[k] = v
     line.setdefault("hip_graph", False)
+    if strong is not None:
+        line["strong"] = strong
     del wl
     gc.collect()
     torch.cuda.empty_cache()
     if world == 1 and default_workload and not args.no_extra:
         if ops.USE_SF16:
             line["strict_fp32"] = strict_fp32(args.model_type, B, mix, rank, world, dev, steps=20, warmup=3)
+            line["value_strict_fp32"] = line["strict_fp32"].get("value")    # the figure with no precision question, top level
         line["extra_configs"] = extra_configs(rank, world, dev, hip_graph=args.hip_graph)
     if world == 1 and not args.no_cpu_baseline:
         try:
@@ -580,7 +677,10 @@ def main():
             line["cpu_baseline"] = {"value": None, "unit": "clips/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
     else:
         line["cpu_baseline"] = None
-    print(json.dumps(line))
+    # N > 1: the ranks share this stdout with the native collectives library, which writes unbuffered fragments into it
+    # (profiles/r05/two_rank_stdout_diag.txt): start on a fresh line so that the JSON line is a line of its own
+    sys.stdout.write(("\n" if world > 1 else "") + json.dumps(line) + "\n")
+    sys.stdout.flush()
 
 
 if __name__ == "__main__":

@@ -102,6 +102,24 @@ def recipe_state(model_type, seed=0):
     return st
 
 
+def flipfree_state(model_type, seed=0, beta=24.0):
+    """recipe_state with every ConvBlock BatchNorm bias at +beta (gamma keeps its ~1): the normalised pre-activations
+    (min xhat = -17 on the fixtures' data: the zero padding makes border pixels outliers in proportion to beta) never reach zero, so no ReLU mask (models.py:102-103) can differ between two evaluations of the same
+    step -- what is left of a gradient difference is arithmetic alone.  The trunk's features then sit around +beta, so the
+    first weights behind them are scaled down to keep the head out of saturation (fc / AttBlock: x 0.16/beta, GRU and
+    MultiHead input projections: x 0.4/beta).  Used by the flip-free whole-model gradient fixtures (tests/golden/make_golden.py --flipfree)."""
+    st = recipe_state(model_type, seed)
+    for key in list(st.keys()):
+        if key.startswith("conv_block") and ".bn" in key and key.endswith(".bias"):
+            st[key] = torch.full_like(st[key], float(beta))
+        elif key == "fc.weight" or (key in ("att_block.att.weight", "att_block.cla.weight") and "Gru" not in model_type
+                                    and "Transformer" not in model_type):
+            st[key] = st[key] * (0.16 / beta)
+        elif key.startswith("gru.weight_ih") or key in ("multihead.w_qs.weight", "multihead.w_ks.weight", "multihead.w_vs.weight"):
+            st[key] = st[key] * (0.4 / beta)
+    return st
+
+
 # --------------------------------------------------------------------------------------------
 # forward pieces
 

@@ -37,6 +37,17 @@ def flags_hash(flags=None):
     return hashlib.sha1(" ".join(keep).encode()).hexdigest()[:12]
 
 
+def source_hashes():
+    """{file name: sha1[:12]} of every kernel source (csrc/*.hip, csrc/common.h).  Profile digests under profiles/ record it
+    (tools/pmc_digest.py `_meta`), and bench.py quotes a committed PMC figure only while the sources of THAT kernel are the
+    ones it was collected on."""
+    out = {}
+    for name in sorted(SOURCES + ["common.h"]):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            out[name] = hashlib.sha1(f.read()).hexdigest()[:12]
+    return out
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True

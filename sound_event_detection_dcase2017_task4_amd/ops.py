@@ -113,6 +113,7 @@ def drop_pending_wgrads():
         for ev, sink, keep in _PENDING:
             main.wait_event(ev)
         del _PENDING[:]
+    _GRAD_AMAX.clear()          # amax hand-overs of a backward pass that raised (the engine callback clears them otherwise)
 
 
 _STREAM_OVERRIDE = None     # set while kernels are being enqueued on the side stream (see _fork_wgrad)
@@ -882,8 +883,11 @@ def _amax_buf(device, n=AMAX_SLOTS):
     ent = _AMAX_POOL.get(key)
     if ent is None or ent[1] >= ent[0].shape[0]:
         pool = torch.zeros((64, _POOL_ROW), dtype=torch.float32, device=torch.device("cuda", key))
-        _lib.check(_lib.lib().sed_amax_prezeroed_range(ctypes.c_void_p(pool.data_ptr()), pool.numel(), 1), "sed_amax_prezeroed_range")
-        weakref.finalize(pool, _unregister_pool, pool.data_ptr(), pool.numel())     # views keep `pool` (their _base) alive
+        # the registry is a fixed table (64 live pools): when it is full -- many forward passes before one backward, retained
+        # autograd graphs keep rows and hence pools alive -- the pool simply stays unregistered and the library zeroes its
+        # rows itself, as it does for any other amax buffer (registration only SKIPS a memset, it is never needed)
+        if _lib.lib().sed_amax_prezeroed_range(ctypes.c_void_p(pool.data_ptr()), pool.numel(), 1) == 0:
+            weakref.finalize(pool, _unregister_pool, pool.data_ptr(), pool.numel())     # views keep `pool` (their _base) alive
         ent = _AMAX_POOL[key] = [pool, 0]
     v = ent[0][ent[1]][:n]
     ent[1] += 1

@@ -280,6 +280,60 @@ def big_fixture(model_type, seed):
     return out
 
 
+FF_ROWS, FF_L = 8, 64000              # the flip-free fixture: 8 waveforms -> 4 clips of 2 s (T = 201)
+
+
+def flipfree_fixture(model_type, seed):
+    """One training step of the genuine reference in FLOAT64 (and in float32, to record the reference's own error) from
+    `oracle.model.flipfree_state`: every ConvBlock BatchNorm bias = +24, so no ReLU mask can flip between evaluations and a
+    gradient difference is arithmetic alone -- the SURVEY 8(d) gate (relative error <= 1e-3) then holds for EVERY trainable
+    tensor without an allow-list.  The generator asserts the premise: the smallest ConvBlock pre-activation of the step is
+    far above zero.  Every gradient is stored as a deterministic subsample plus its norms."""
+    out = {}
+    T = FF_L // 320 + 1
+    loss_func = ref_losses.get_loss_func('clip_bce')
+    xw64 = torch.from_numpy(waves(2700 + seed, FF_ROWS, FF_L))
+    tg64 = torch.from_numpy(targets(2800 + seed, FF_ROWS))
+    lam = ofe.mixup_lambdas(FF_ROWS, np.random.RandomState(1234)).astype(np.float32)
+    torch.manual_seed(2900 + seed)
+    stripes = ofe.draw_specaug_stripes(FF_ROWS, T, 64)
+    out["ff_stripes"], out["ff_lambda"] = stripes, lam
+    grads, losses, outs = {}, {}, {}
+    for tag, dtype in (("f64", torch.float64), ("f32", torch.float32)):
+        m = getattr(ref_models, model_type)(*CTOR)
+        m.load_state_dict(om.flipfree_state(model_type, seed))
+        if dtype == torch.float64:
+            m = m.double()
+        m.train()
+        low = [float("inf")]
+        hooks = [bn.register_forward_hook(lambda mod, i, o: low.__setitem__(0, min(low[0], float(o.min()))))
+                 for blk in (m.conv_block1, m.conv_block2, m.conv_block3, m.conv_block4) for bn in (blk.bn1, blk.bn2)]
+        torch.manual_seed(2900 + seed)
+        o = m(xw64.to(dtype), torch.from_numpy(lam).to(dtype))
+        for h in hooks:
+            h.remove()
+        assert low[0] > 1.0, "a ConvBlock pre-activation came within reach of zero (%g): not flip-free" % low[0]
+        loss = loss_func(o, {'target': ref_utils.do_mixup(tg64.to(dtype), torch.from_numpy(lam).to(dtype)).clamp(max=1.0)})
+        loss.backward()
+        grads[tag] = {k: p.grad.detach().double().numpy().copy() for k, p in m.named_parameters() if p.grad is not None}
+        losses[tag], outs[tag] = loss.item(), o["clipwise_output"].detach().double().numpy()
+        out["ff_min_preact_" + tag] = np.array(low[0])
+    out["ff_loss64"], out["ff_loss32"], out["ff_clip64"] = np.array(losses["f64"]), np.array(losses["f32"]), outs["f64"]
+    worst = (0.0, None)
+    for k, g in grads["f64"].items():
+        out["ff_g64/" + k] = g.reshape(-1)[sample_index(g.size)].astype(np.float32)
+        out["ff_g64n/" + k] = np.array([np.sqrt((g ** 2).sum()), g.sum(), np.abs(g).sum(), np.abs(g).max()])
+        e32 = float(np.sqrt(((grads["f32"][k] - g) ** 2).sum()) / max(np.sqrt((g ** 2).sum()), 1e-300))
+        out["ff_ref32err/" + k] = np.array(e32)
+        if e32 > worst[0]:
+            worst = (e32, k)
+    print(model_type, "flip-free fixture: loss64 %.6f loss32 %.6f, smallest pre-activation %.2f | reference fp32 vs fp64 gradient, "
+          "worst relative L2: %.2e (%s); gradient norms %.2e .. %.2e" % (
+              losses["f64"], losses["f32"], float(out["ff_min_preact_f64"]), worst[0], worst[1],
+              min(v[0] for k, v in out.items() if k.startswith("ff_g64n/")), max(v[0] for k, v in out.items() if k.startswith("ff_g64n/"))))
+    return out
+
+
 def misc_fixture():
     out = {"mixup_lambda64": ofe.mixup_lambdas(64, np.random.RandomState(1234))}
     torch.manual_seed(7)
@@ -303,6 +357,12 @@ if __name__ == "__main__":
                 continue
             np.savez_compressed(os.path.join(HERE, mt + "__big.npz"), **big_fixture(mt, seed=i + 1))
             print(mt + "__big.npz", os.path.getsize(os.path.join(HERE, mt + "__big.npz")))
+        sys.exit(0)
+    if only and only[0] == "--flipfree":    # only the <model>__flipfree.npz files (whole-model gradients without ReLU flips)
+        for i, mt in enumerate(om.MODEL_TYPES):
+            if mt in (only[1:] or ("Cnn_9layers_FrameAvg", "Cnn_9layers_Gru_FrameAtt")):
+                np.savez_compressed(os.path.join(HERE, mt + "__flipfree.npz"), **flipfree_fixture(mt, seed=i + 1))
+                print(mt + "__flipfree.npz", os.path.getsize(os.path.join(HERE, mt + "__flipfree.npz")))
         sys.exit(0)
     if not only:
         np.savez_compressed(os.path.join(HERE, "frontend.npz"), **frontend_fixture())

@@ -394,3 +394,34 @@ def test_gpu_tier_collection_order_puts_parity_first_and_spawned_ranks_last():
     pos = {i.split("::")[1]: k for k, i in enumerate(order)}
     assert max(pos[k] for k in "efhi") < pos["c"] < min(pos["d"], pos["g"]) and max(pos["d"], pos["g"]) < pos["b"] < pos["a"]
     assert order[-1].startswith("tests/test_gpu_parallel.py")
+
+
+def test_bench_refuses_to_quote_stale_pmc_figures(tmp_path, monkeypatch):
+    """bench.py quotes `roofline.traffic` / `mfma_pipe_busy_frac` from committed rocprofv3 PMC digests.  A digest carries the
+    hashes of the kernel sources it was collected on (`_meta.sources`); once the sources of the kernel in question differ -- or
+    the digest has no record at all -- the figure is NOT quoted (null + the reason), instead of silently describing another
+    binary (round-4 review)."""
+    import json
+    import bench
+    from sound_event_detection_dcase2017_task4_amd import build
+    cur = build.source_hashes()
+    assert set(cur) == set(build.SOURCES) | {"common.h"} and all(len(v) == 12 for v in cur.values())
+    assert bench.pmc_fresh({"sources": dict(cur)}, ["conv_sf16_kernel"]) is None
+    assert "no kernel-source record" in bench.pmc_fresh(None, ["conv_sf16_kernel"])
+    other = dict(cur, **{"conv_sf16.hip": "0" * 12})
+    assert "csrc/conv_sf16.hip changed" in bench.pmc_fresh({"sources": other}, ["conv_sf16_kernel"])
+    assert bench.pmc_fresh({"sources": other}, ["logmel32_kernel"]) is None            # another kernel's sources: still valid
+    for fam, files in bench.KERNEL_SOURCES.items():
+        assert all(f in cur for f in files), fam
+    # end to end through pmc_traffic(): a fresh digest is quoted, the same digest with a changed source is not
+    prof = tmp_path / "profiles" / "r99"
+    prof.mkdir(parents=True)
+    body = {"void conv_sf16_kernel<4>(Sf16P)": {"launches": 2, "fetch_bytes_raw_per_launch": 50, "fetch_bytes_x2_per_launch": 100,
+                                                 "write_bytes_per_launch": 11}}
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    (prof / "pmc_traffic_b32.json").write_text(json.dumps(dict(body, _meta={"sources": cur})))
+    val, src = bench.pmc_traffic(["conv_sf16_kernel"], "pmc_traffic_b32.json")
+    assert val == 111 and "pmc_traffic_b32.json" in src
+    (prof / "pmc_traffic_b32.json").write_text(json.dumps(dict(body, _meta={"sources": other})))
+    val, src = bench.pmc_traffic(["conv_sf16_kernel"], "pmc_traffic_b32.json")
+    assert val is None and "NOT quoted" in src

@@ -515,6 +515,67 @@ def test_low_noise_training_fixture_vs_float64_reference(mt, golden_dir, conv_pa
     print("after three steps, worst over tensors (gates: 1e-2, 0.05, 0.10, 0.10):", worst)
 
 
+FF_ROWS, FF_L = 8, 64000
+
+
+@pytest.mark.parametrize("mt", ["Cnn_9layers_FrameAvg", "Cnn_9layers_Gru_FrameAtt"])
+def test_flip_free_whole_model_gradients_vs_float64_reference(mt, golden_dir, conv_path):
+    """The SURVEY 8(d) gradient gate (relative error <= 1e-3) on a WHOLE-MODEL training step in which no ReLU mask can flip:
+    `oracle.model.flipfree_state` puts every ConvBlock BatchNorm bias at +24 (the generator asserts that the smallest
+    pre-activation of the step is > 6), so what separates this path from the genuine reference evaluated in float64
+    (tests/golden/<model>__flipfree.npz, make_golden.py --flipfree) is arithmetic alone -- the measurement behind the "the
+    other fixtures' gate is loose because of flips" argument.  Every trainable tensor is checked, no allow-list:
+      * Gru_FrameAtt: relative L2 <= 1e-3 on every tensor (the reference's own float32 run reads <= 3.5e-4 there);
+      * FrameAvg: with the ReLUs linear the trunk is an affine map followed by a mean over frames, the clip-level loss
+        gradient is CONSTANT over the frames of a clip, and a BatchNorm backward (g - mean(g) - xhat * mean(g * xhat))
+        annihilates a constant: the trunk gradients are 1e-9 .. 1e-11 of the head's (pure cancellation residue) and the
+        reference's own float32 run is 2e-3 .. 3e-2 from float64 on them (`ff_ref32err/*`).  There the gate is 3x the
+        reference's own float32 error (or 1e-3 where that is larger), and 1e-3 flat on every tensor the reference itself
+        gets to 1e-4.
+    Tensors whose true gradient is structurally zero (attention shift invariance) are checked absolutely."""
+    from sound_event_detection_dcase2017_task4_amd.pytorch import models
+    from sound_event_detection_dcase2017_task4_amd.pytorch.losses import get_loss_func
+    from sound_event_detection_dcase2017_task4_amd.pytorch.pytorch_utils import do_mixup
+    from sound_event_detection_dcase2017_task4_amd.optim import FusedAdamAmsgrad
+    fx = np.load(os.path.join(golden_dir, mt + "__flipfree.npz"))
+    seed = SEEDS[mt]
+    assert float(fx["ff_min_preact_f64"]) > 6.0 and float(fx["ff_min_preact_f32"]) > 6.0       # the premise: no mask can flip
+    m = getattr(models, mt)(*CTOR)
+    m.load_state_dict(om.flipfree_state(mt, seed))
+    m = m.to("cuda").train()
+    opt = FusedAdamAmsgrad(m, lr=1e-3)
+    xw = torch.from_numpy(waves(2700 + seed, FF_ROWS, FF_L)).cuda()
+    tg = torch.from_numpy(targets(2800 + seed, FF_ROWS)).cuda()
+    lam = torch.from_numpy(fx["ff_lambda"]).cuda()
+    o = m(xw, lam, specaug_stripes=fx["ff_stripes"])
+    loss = get_loss_func("clip_bce")(o, {"target": do_mixup(tg, lam)})
+    assert abs(loss.item() - float(fx["ff_loss64"])) < 2e-5, (loss.item(), float(fx["ff_loss64"]))
+    assert np.abs(o["clipwise_output"].detach().cpu().numpy() - fx["ff_clip64"]).max() < 1e-4
+    opt.zero_grad()
+    loss.backward()
+    report, bad = {}, {}
+    for k, p in m.named_parameters():
+        if ("ff_g64/" + k) not in fx.files:
+            continue
+        want = fx["ff_g64/" + k].astype(np.float64)
+        l2, _, _, mx = fx["ff_g64n/" + k]
+        g = p.grad.detach().double().reshape(-1).cpu().numpy()
+        ref = float(fx["ff_ref32err/" + k])
+        if ref > 1.0:                                            # structurally zero in exact arithmetic (the reference's fp32 run
+            assert np.abs(g).max() < 1e-6, (k, np.abs(g).max())  # is pure noise there): absolute check
+            continue
+        got = g[sample_index(g.size)]
+        err = float(np.sqrt(((got - want) ** 2).sum() / max((want ** 2).sum(), 1e-300)))
+        gate = 1e-3 if (mt != "Cnn_9layers_FrameAvg" or ref <= 1e-4) else max(1e-3, 3.0 * ref)
+        report[k] = (err, ref, gate)
+        if err > gate:
+            bad[k] = (err, ref, gate)
+    print("flip-free gradient relative L2 vs float64 (ours, reference-fp32, gate), worst five:",
+          sorted(report.items(), key=lambda kv: -kv[1][0] / kv[1][2])[:5])
+    print("FLIPFREE_REPORT", mt, conv_path, {k: ("%.2e" % v[0], "%.2e" % v[1]) for k, v in report.items()})
+    assert len(report) >= 26 and not bad, bad
+
+
 @pytest.mark.parametrize("mt", ["Cnn_9layers_FrameAvg", "Cnn_9layers_Gru_FrameAtt"])
 def test_twenty_step_loss_trajectory_vs_oracle(mt):
     """Training dynamics, not just one step: 20 optimiser steps on one fixed batch of 8 waveforms (fresh mixup lambdas and

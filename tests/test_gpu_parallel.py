@@ -193,16 +193,29 @@ def test_bench_two_ranks_code_path_on_one_gpu():
     env["SED_SHARE_GPU"] = "1"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", str(parallel.free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2",
-                        "--steps", "3", "--warmup", "1", "--batch_size", "16", "--seconds", "2"],
+                        "--steps", "3", "--warmup", "1", "--batch_size", "32", "--seconds", "2"],
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, lines
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["config"]["global_batch"] == 32
+    # headline row: weak reading (32 clips per GPU)
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["config"]["global_batch"] == 64
     assert line["scaling"] == "weak" and line["cpu_baseline"] is None and "extra_configs" not in line
-    assert abs(line["value"] - 32 * 3 / (line["ms_per_step"] * 3e-3)) < 0.02 * line["value"]
+    assert abs(line["value"] - 64 * 3 / (line["ms_per_step"] * 3e-3)) < 0.02 * line["value"]
     assert line["roofline"]["kernel"].startswith("conv3x3")
+    d = line["dist"]
+    assert d["backend"] == "gloo" and d["world_size"] == 2 and d["n_ranks_seen"] == 2
+    assert d["allreduce_exposed_ms_per_step"] is not None and d["allreduce_exposed_steps_averaged"] == 3
+    assert sum(d["bucket_bytes"]) == d["flat_gradient_bytes"] and len(d["bucket_bytes"]) >= 2
+    # strong reading in the same line: the reference's --batch_size 32 is the GLOBAL batch (main.py:138) = 16 clips per GPU
+    st = line["strong"]
+    assert st["scaling"] == "strong" and st["global_batch"] == 32 and st["per_gpu_batch"] == 16 and st["value"] > 0, st
+    assert abs(st["value"] - 32 * 3 / (st["ms_per_step"] * 3e-3)) < 0.02 * st["value"]
+    assert st["hip_graph"] is True and st["hip_graph_replays"] >= 3
+    sd = st["dist"]
+    assert sd["n_ranks_seen"] == 2 and sd["allreduce_exposed_ms_per_step"] is not None and sd["allreduce_exposed_steps_averaged"] == 3
+    assert sd["allreduce_overlap"] is False and sum(sd["bucket_bytes"]) == sd["flat_gradient_bytes"]
 
 
 def test_train_cli_two_ranks_global_batch(tmp_path):

@@ -140,6 +140,30 @@ def _bucket_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _ranks_seen_worker(rank, world, port, out):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from sound_event_detection_dcase2017_task4_amd import parallel
+    import bench
+    parallel.init_from_env(backend="gloo")
+    seen = bench.ranks_seen(torch.device("cpu"))          # all-reduce of a 1 from every rank: what the bench rows report
+    assert seen == world, seen
+    dist.barrier()
+    if rank == 0:
+        open(out, "w").write("ok %d" % seen)
+    dist.destroy_process_group()
+
+
+def test_bench_rows_prove_the_rank_count_by_an_all_reduce(tmp_path):
+    """`dist.n_ranks_seen` of the weak and strong rows of `bench.py --gpus N` (bench.ranks_seen): the sum over ranks of 1."""
+    import bench
+    assert bench.ranks_seen(torch.device("cpu")) == 1      # no process group: one rank
+    out = str(tmp_path / "ok.txt")
+    mp.spawn(_ranks_seen_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read() == "ok 2"
+
+
 def test_grad_buckets_world_size_2_gloo(tmp_path):
     out = str(tmp_path / "ok.txt")
     mp.spawn(_bucket_worker, args=(2, _free_port(), out), nprocs=2, join=True)
@@ -244,10 +268,12 @@ def test_bench_roofline_traffic_lookup_matches_the_kernels_that_exist():
     front = re.search(r'pmc_traffic\(\["([a-z0-9_]+)"\]', text).group(1)
     for sub in [front] + [s for subs in bench.FAMILY_KERNELS.values() for s in subs]:
         assert sub in source, sub
+    # a digest is quoted only while the kernel's sources are the ones it was collected on (bench.pmc_fresh); otherwise the
+    # figure is null and the source string says why
     tr, src = bench.pmc_traffic([front])
-    assert tr and tr > 786e6 and src.startswith("profiles/r"), (tr, src)       # >= the algorithmic 786.6 MB per launch
-    tr, _ = bench.pmc_traffic(bench.FAMILY_KERNELS["conv3x3_sf16_mfma(fwd+dgrad)"])      # the default convolution path
-    assert tr and tr > 1e9
+    assert (tr and tr > 786e6 and src.startswith("profiles/r")) or (tr is None and "NOT quoted" in src), (tr, src)   # >= the algorithmic 786.6 MB per launch
+    tr, src = bench.pmc_traffic(bench.FAMILY_KERNELS["conv3x3_sf16_mfma(fwd+dgrad)"])      # the default convolution path
+    assert (tr and tr > 1e9) or (tr is None and "NOT quoted" in src), (tr, src)
 
 
 def test_bucket_refuses_to_fire_before_its_side_stream_gradients_are_joined():

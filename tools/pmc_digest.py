@@ -4,7 +4,10 @@ Usage (GPU box; separate passes because FETCH_SIZE and WRITE_SIZE do not fit one
     cd /tmp; export TMPDIR=/tmp
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -o p -- python $R/bench.py --steps 1 --warmup 1 --no_cpu_baseline
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -o p -- python $R/bench.py --steps 1 --warmup 1 --no_cpu_baseline
-    python tools/pmc_digest.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/r01/pmc_traffic.json
+    python tools/pmc_digest.py gpurun_out/pmc_fetch gpurun_out/pmc_write [meta.json] > profiles/r01/pmc_traffic.json
+
+meta.json (written ON THE GPU BOX by tools/collect_profiles.sh at collection time: kernel source hashes, workload) becomes the
+`_meta` entry; bench.py refuses to quote a figure whose kernel sources have changed since (bench.pmc_traffic).
 
 FETCH_SIZE / WRITE_SIZE are reported in KB.  On gfx950 FETCH_SIZE counts a wide (16 B/lane) coalesced read at half its
 bytes (same guide), so 'fetch_bytes_x2' doubles it; every kernel here reads through 16-B loads or 16-B LDS-DMA.
@@ -39,6 +42,8 @@ def main():
         out[k] = {"launches": nf, "fetch_bytes_raw_per_launch": round(f * 1024 / nf),
                   "fetch_bytes_x2_per_launch": round(2 * f * 1024 / nf),
                   "write_bytes_per_launch": round(w * 1024 / max(nw, 1))}
+    if len(sys.argv) > 3:
+        out["_meta"] = json.load(open(sys.argv[3]))
     json.dump(out, sys.stdout, indent=1)
 
 
