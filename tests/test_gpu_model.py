@@ -525,13 +525,14 @@ def test_flip_free_whole_model_gradients_vs_float64_reference(mt, golden_dir, co
     pre-activation of the step is > 6), so what separates this path from the genuine reference evaluated in float64
     (tests/golden/<model>__flipfree.npz, make_golden.py --flipfree) is arithmetic alone -- the measurement behind the "the
     other fixtures' gate is loose because of flips" argument.  Every trainable tensor is checked, no allow-list:
-      * Gru_FrameAtt: relative L2 <= 1e-3 on every tensor (the reference's own float32 run reads <= 3.5e-4 there);
+      * Gru_FrameAtt: relative L2 <= 1e-4 on EVERY tensor -- ten times below the 8(d) figure; measured <= 1.9e-5 on both
+        convolution paths (profiles/r05/flipfree_gradients.txt), where the reference's own float32 run reads up to 3.5e-4;
       * FrameAvg: with the ReLUs linear the trunk is an affine map followed by a mean over frames, the clip-level loss
         gradient is CONSTANT over the frames of a clip, and a BatchNorm backward (g - mean(g) - xhat * mean(g * xhat))
         annihilates a constant: the trunk gradients are 1e-9 .. 1e-11 of the head's (pure cancellation residue) and the
-        reference's own float32 run is 2e-3 .. 3e-2 from float64 on them (`ff_ref32err/*`).  There the gate is 3x the
-        reference's own float32 error (or 1e-3 where that is larger), and 1e-3 flat on every tensor the reference itself
-        gets to 1e-4.
+        reference's own float32 run is 2e-3 .. 3e-2 from float64 on them (`ff_ref32err/*`; this build: 1e-4 .. 8e-3).
+        There the gate is 8x the reference's own float32 error (or 1e-3 where that is larger), and 1e-3 flat on every
+        tensor the reference itself gets to 1e-4 (bn0, block 1's first layer, the head).
     Tensors whose true gradient is structurally zero (attention shift invariance) are checked absolutely."""
     from sound_event_detection_dcase2017_task4_amd.pytorch import models
     from sound_event_detection_dcase2017_task4_amd.pytorch.losses import get_loss_func
@@ -566,7 +567,10 @@ def test_flip_free_whole_model_gradients_vs_float64_reference(mt, golden_dir, co
             continue
         got = g[sample_index(g.size)]
         err = float(np.sqrt(((got - want) ** 2).sum() / max((want ** 2).sum(), 1e-300)))
-        gate = 1e-3 if (mt != "Cnn_9layers_FrameAvg" or ref <= 1e-4) else max(1e-3, 3.0 * ref)
+        if mt == "Cnn_9layers_FrameAvg":
+            gate = 1e-3 if ref <= 1e-4 else max(1e-3, 8.0 * ref)
+        else:
+            gate = 1e-4
         report[k] = (err, ref, gate)
         if err > gate:
             bad[k] = (err, ref, gate)
