@@ -62,6 +62,7 @@ def _build_model(model_type):
 
 
 POLL_LAG = 2          # optimiser steps between a step and the (rank-consistent) poll of its found-non-finite status
+HIP_GRAPH_AUTO_MAX_CLIPS = 8       # --hip_graph auto: replay the step as one HIP graph when a rank trains on <= 8 clips per step
 RECOVERIES = []       # one {'iteration', 'skipped', 'rank'} per recover() call of this process (what tests / wrappers inspect)
 
 
@@ -116,7 +117,15 @@ def train(args):
     # hold: a batch stays valid while POLL_LAG + 1 later ones are requested -- the batches of refused steps are re-run
     train_loader = PinnedBatchLoader(train_path, train_sampler, device=device, hold=POLL_LAG + 1)
     mixup_augmenter = Mixup(mixup_alpha=1., random_seed=1234) if mix else None
-    graphed = GraphedTrainStep(model, optimizer, loss_func, mixup=mix) if getattr(args, 'hip_graph', False) else None
+    # small per-GPU batches are launch-bound (--batch_size 32 over 8 GPUs = 4 clips each: ~140 kernels of 5-100 us): the step is
+    # then replayed as ONE HIP graph unless --hip_graph off; larger batches keep the eager loop (no gain there)
+    per_rank_clips = global_batch // world
+    mode = getattr(args, 'hip_graph', 'auto')
+    mode = {True: 'on', False: 'auto', None: 'auto'}.get(mode, mode)
+    use_graph = mode == 'on' or (mode == 'auto' and per_rank_clips <= HIP_GRAPH_AUTO_MAX_CLIPS)
+    graphed = GraphedTrainStep(model, optimizer, loss_func, mixup=mix) if use_graph else None
+    if rank == 0:
+        logging.info('HIP graph replay of forward + loss + backward: {} ({} clips per GPU)'.format('on' if use_graph else 'off', per_rank_clips))
     train_bgn_time = time.time()
 
     # evaluation sets of the every-1000-iterations branch (main.py:78-89, :150-176): used when present
@@ -277,9 +286,10 @@ def build_parser():
     p.add_argument('--mini_data', action='store_true', default=False)
     p.add_argument('--synthetic', type=int, default=0, help='(extension) train on N synthetic clips')
     p.add_argument('--print_every', type=int, default=100, help='(extension) loss print cadence; 1 = reference')
-    p.add_argument('--hip_graph', action='store_true', default=False,
+    p.add_argument('--hip_graph', nargs='?', const='on', default='auto', choices=['on', 'off', 'auto'],
                    help='(extension) replay forward + loss + backward as ONE HIP graph per step (graph.GraphedTrainStep): '
-                        'frees the host from enqueueing ~140 kernels per step; the device time is unchanged')
+                        'frees the host from enqueueing ~140 kernels per step.  auto (default): on when a rank trains on '
+                        '<= 8 clips per step (the launch-bound regime, e.g. --batch_size 32 over 8 GPUs), off otherwise')
     p.add_argument('--per_gpu_batch', action='store_true', default=False,
                    help='(extension) --batch_size is per GPU (global batch = ranks x batch_size) instead of the global batch')
     q = subparsers.add_parser('inference_prob')

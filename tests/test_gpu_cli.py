@@ -159,12 +159,12 @@ def test_train_cli_survives_a_non_finite_batch(tmp_path, monkeypatch, caplog):
 
 
 def test_train_cli_with_hip_graph_prints_the_same_losses(tmp_path, capsys):
-    """`train --hip_graph`: three eager iterations, then forward + loss + backward replayed as one HIP graph per iteration;
-    the loss series is the eager run's."""
+    """`train --hip_graph` (and the default `auto` at <= 8 clips per GPU): three eager iterations, then forward + loss + backward
+    replayed as one HIP graph per iteration; the loss series is the eager run's (`--hip_graph off`)."""
     from sound_event_detection_dcase2017_task4_amd.pytorch import main as cli
     series = []
-    for extra in ([], ["--hip_graph"]):
-        ws = str(tmp_path / ("g" if extra else "e"))
+    for extra in (["--hip_graph", "off"], ["--hip_graph"], []):
+        ws = str(tmp_path / ("run%d" % len(series)))
         os.makedirs(ws)
         torch.manual_seed(4321)
         cli.main(["train", "--dataset_dir", ws, "--workspace", ws, "--holdout_fold", "1", "--model_type", "Cnn_9layers_FrameAvg",
@@ -172,5 +172,6 @@ def test_train_cli_with_hip_graph_prints_the_same_losses(tmp_path, capsys):
                   "--learning_rate", "1e-3", "--resume_iteration", "0", "--stop_iteration", "7", "--print_every", "1"] + extra)
         out = capsys.readouterr().out
         series.append([float(l.split()[1]) for l in out.splitlines() if len(l.split()) == 2 and l.split()[0].isdigit()])
-    assert len(series[0]) == len(series[1]) == 8
+    assert len(series[0]) == len(series[1]) == len(series[2]) == 8
     np.testing.assert_allclose(series[1], series[0], rtol=5e-6, atol=0)
+    assert series[2] == series[1]                      # auto = on at 4 clips per GPU: the very same replayed kernels
