@@ -24,7 +24,7 @@ def golden_dir():
 #   0  oracle / golden parity of the product path        1  kernel-vs-float64 numerics of the split-f16 kernels
 #   2  remaining single-process op / optimiser / graph    3  CLI subprocesses     4  multi-rank (spawned ranks, torchrun)
 _ORDER = {"test_gpu_frontend": 0, "test_gpu_model": 0, "test_gpu_ops": 0, "test_gpu_gru": 0,
-          "test_gpu_sf16": 1, "test_gpu_wino_sf16": 1,
+          "test_gpu_sf16": 1,
           "test_gpu_optim": 2, "test_gpu_graph": 2,
           "test_gpu_cli": 3,
           "test_gpu_parallel": 4}
