@@ -9,6 +9,16 @@ ROUND=${1:-r02}
 R=$PWD
 OUT=$R/gpurun_out/prof_$ROUND
 mkdir -p $OUT
+# what the counters are collected ON: the hashes of the kernel sources of THIS snapshot (bench.py quotes a PMC figure only while
+# the sources of the kernel in question are unchanged: bench.pmc_fresh) + the workload of each digest
+python - > $OUT/meta_b32.json <<PY
+import json, sys
+sys.path.insert(0, "$R")
+from sound_event_detection_dcase2017_task4_amd import build
+json.dump({"sources": build.source_hashes(), "round": "$ROUND",
+           "workload": "bench.py default: Cnn_9layers_FrameAvg bs=32 mixup (the metric's configuration), --steps 1 --warmup 1, SED_WGRAD_SIDE_STREAM=0"}, sys.stdout)
+PY
+sed 's/bs=32 mixup (the metric.s configuration)/B=256 mixup (BASELINE.json configs[1])/; s/bench.py default/bench.py --batch_size 256/' $OUT/meta_b32.json > $OUT/meta_b256.json
 cd /tmp; export TMPDIR=/tmp
 # Since round 4 bench.py's default workload is the metric's own configuration (bs=32); configs[1] needs --batch_size 256.
 B="python $R/bench.py --no_cpu_baseline --no_extra --batch_size 256"
@@ -37,7 +47,7 @@ SED_WGRAD_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d 
 python $R/tools/step_gaps.py $(find $OUT/stats_b32 -name "*kernel_trace.csv") 4 > $OUT/step_digest_b32_main_stream_only.txt 2>&1
 python $R/tools/step_gaps.py $(find $OUT/stats_serial -name "*kernel_trace.csv") 4 > $OUT/step_digest_b256_main_stream_only.txt 2>&1
 $B32 --steps 40 --warmup 5 --by_shape > $OUT/bench_line_b32.json 2> $OUT/by_shape_b32.txt
-for pass in "fetch FETCH_SIZE" "write WRITE_SIZE"; do
+for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sqD MfmaUtil" "sqB SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "sqF GRBM_GUI_ACTIVE"; do
   set -- $pass; name=$1; shift
   SED_WGRAD_SIDE_STREAM=0 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_b32_$name -o p -- $B32 --steps 1 --warmup 1 > /dev/null 2> $OUT/pmc_b32_$name.err
 done

@@ -6,8 +6,11 @@ ROUND=${1:-r04}
 EXTRA=${2:-}
 P=profiles/$ROUND; G=gpurun_out/prof_$ROUND
 mkdir -p $P
-python tools/pmc_digest.py $G/pmc_fetch $G/pmc_write > $P/pmc_traffic.json
-python tools/pmc_digest.py $G/pmc_b32_fetch $G/pmc_b32_write > $P/pmc_traffic_b32.json
+python tools/pmc_digest.py $G/pmc_fetch $G/pmc_write $G/meta_b256.json > $P/pmc_traffic.json
+python tools/pmc_digest.py $G/pmc_b32_fetch $G/pmc_b32_write $G/meta_b32.json > $P/pmc_traffic_b32.json
+python tools/pmc_mfma_busy.py $G/pmc_sqD "B=256 training step (configs[1])" $G/meta_b256.json > $P/pmc_mfma_busy.json
+python tools/pmc_mfma_busy.py $G/pmc_b32_sqD "bs=32 training step (the metric's configuration)" $G/meta_b32.json > $P/pmc_mfma_busy_b32.json
+python tools/pmc_sq_digest.py $G/pmc_b32_sqD $G/pmc_b32_sqB $G/pmc_b32_sqF > $P/rocprofv3_pmc_summaries_b32.txt 2>&1
 python tools/pmc_sq_digest.py $G/pmc_sqA $G/pmc_sqB $G/pmc_sqC $G/pmc_sqD $G/pmc_sqE $G/pmc_sqF > $P/rocprofv3_pmc_summaries.txt 2>&1
 cp $G/stats/bench_kernel_stats.csv $P/rocprofv3_kernel_stats__b256_steps5_warmup2.csv
 cp $G/stats_serial/bench_kernel_stats.csv $P/rocprofv3_kernel_stats__main_stream_only__b256_steps5_warmup2.csv
