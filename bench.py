@@ -489,6 +489,30 @@ def strict_fp32(mt, B, mix, rank, world, dev, steps=5, warmup=2):
         torch.cuda.empty_cache()
 
 
+class StrongRowWatchdog(object):
+    """Started on EVERY rank right before the strong-scaling row of an N > 1 run, cancelled when the row is back.  If it is not back
+    after `seconds` (a collective that never completes): rank 0 prints the finished headline line with `strong.error`, and every
+    rank ends the process with exit code 0 -- the headline measurement is never lost to a side row."""
+
+    def __init__(self, line, seconds):
+        import threading
+        self.line, self.seconds = line, seconds
+        self.timer = threading.Timer(seconds + (0.0 if line is not None else 3.0), self.fire)     # rank 0 first, the others 3 s later
+        self.timer.daemon = True
+        self.timer.start()
+
+    def cancel(self):
+        self.timer.cancel()
+
+    def fire(self):
+        if self.line is not None:
+            self.line["strong"] = {"scaling": "strong", "value": None,
+                                   "error": "watchdog: the strong-scaling row did not finish within %g s" % self.seconds}
+            sys.stdout.write("\n" + json.dumps(self.line) + "\n")
+            sys.stdout.flush()
+        os._exit(0)
+
+
 def ranks_seen(dev):
     """Proof that the backend really spans the ranks the line claims: all-reduce (sum) of a 1 from every rank."""
     if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
@@ -619,14 +643,6 @@ def main():
     bucket_order = list(wl.opt.buckets.last_issue_order)
     dist_info = dist_report(wl, args.steps)
     wl.opt.buckets.wait_events = None
-    strong = None
-    if world > 1 and B == 32 and mix and not args.inference and not args.h2d and 32 % world == 0 and not args.no_strong:
-        # the OTHER reading of the metric: --batch_size 32 is the GLOBAL batch the reference's DataParallel scatters
-        # (pytorch/main.py:138, :160-166): 32 / N clips per GPU.  Every rank runs it (collectives), rank 0 reports it.
-        strong = strong_row(args.model_type, 32 // world, mix, rank, world, dev, args.steps, args.warmup, args.seconds, args.int16)
-    parallel.shutdown()               # all ranks: barrier + destroy the process group; rank 0 then reports alone
-    if rank != 0:
-        return
     bucket_ranges = [[lo, hi] for lo, hi in wl.opt.buckets.ranges]
     clips_per_s = B * world * args.steps / dt
     line = {
@@ -660,8 +676,19 @@ def main():
         if k not in ("value", "unit", "steps", "warmup", "ms_per_step", "loss"):
             line[k] = v
     line.setdefault("hip_graph", False)
-    if strong is not None:
-        line["strong"] = strong
+    # ---- N > 1 only: the strong-scaling row.  The headline line is COMPLETE before it starts, and a watchdog on every rank
+    # guarantees that a row that does not come back (a collective that never completes on hardware this code has not seen)
+    # costs the row, not the line: rank 0 prints the headline with `strong.error`, every rank leaves with exit code 0
+    if world > 1 and B == 32 and mix and not args.inference and not args.h2d and 32 % world == 0 and not args.no_strong:
+        # the OTHER reading of the metric: --batch_size 32 is the GLOBAL batch the reference's DataParallel scatters
+        # (pytorch/main.py:138, :160-166): 32 / N clips per GPU.  Every rank runs it (collectives), rank 0 reports it.
+        line["cpu_baseline"] = None
+        guard = StrongRowWatchdog(line if rank == 0 else None, float(os.environ.get("SED_BENCH_STRONG_TIMEOUT_S", "300")))
+        line["strong"] = strong_row(args.model_type, 32 // world, mix, rank, world, dev, args.steps, args.warmup, args.seconds, args.int16)
+        guard.cancel()
+    parallel.shutdown()               # all ranks: barrier + destroy the process group; rank 0 then reports alone
+    if rank != 0:
+        return
     del wl
     gc.collect()
     torch.cuda.empty_cache()

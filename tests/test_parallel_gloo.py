@@ -360,3 +360,31 @@ def test_rank_flag_rides_on_the_last_bucket(tmp_path, overlap):
     out = str(tmp_path / "ok.txt")
     mp.spawn(_flag_worker, args=(2, _free_port(), out, overlap), nprocs=2, join=True)
     assert open(out).read() == "ok"
+
+
+def test_bench_strong_row_watchdog_keeps_the_headline_line():
+    """`bench.py --gpus N`: the strong-scaling row runs AFTER the headline line is complete, under a watchdog on every rank.  A
+    row that never comes back (a stuck collective) must cost the row only: rank 0 prints the headline with `strong.error`, every
+    rank leaves with exit code 0 (bench.StrongRowWatchdog)."""
+    import json
+    import subprocess
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "line = {'metric': 'm', 'value': 1.0, 'n_gpus': 2}\n"
+            "w = bench.StrongRowWatchdog(line if sys.argv[1] == '0' else None, 0.5)\n"
+            "time.sleep(30)\n"
+            "print('never')\n" % REPO)
+    for rank in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code, rank], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "never" not in r.stdout, (r.returncode, r.stdout, r.stderr[-500:])
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if rank == "0":
+            assert len(lines) == 1
+            d = json.loads(lines[0])
+            assert d["value"] == 1.0 and d["strong"]["value"] is None and "watchdog" in d["strong"]["error"]
+        else:
+            assert lines == []
+    # cancelled in time: nothing happens
+    code2 = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+             "w = bench.StrongRowWatchdog({'a': 1}, 0.5); w.cancel(); time.sleep(1.5); print('done')\n" % REPO)
+    r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "done"
