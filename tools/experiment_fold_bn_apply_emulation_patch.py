@@ -1,7 +1,7 @@
 # experiment patch (round 3): bn_bwd_apply folded into the staging of the dgrad / weight-gradient kernels (second tensor + per-channel affine;
 # timing only, results wrong): rebuild and run tools/conv_bench.py --only sf16 / --only sf16w
 # Applies to csrc/conv_sf16.hip as of commit 59f285e (git show 59f285e:sound_event_detection_dcase2017_task4_amd/csrc/conv_sf16.hip);
-# the string anchors below fail loudly on any other revision.  Result: DESIGN.md section 9, profiles/r03/experiment_*.txt.
+# the string anchors below fail loudly on any other revision.  Result: docs/HISTORY.md (round 3), profiles/r03/experiment_*.txt.
 p='/root/repo/sound_event_detection_dcase2017_task4_amd/csrc/conv_sf16.hip'
 s=open(p).read()
 def rep(a,b,cnt=1):

@@ -1,7 +1,7 @@
 # experiment patch (round 3): operands already stored as (hi, lo) f16 pairs: staging = plain copies (-DSF_EMU_PRESPLIT; results correct with
 # tools/conv_bench.py --presplit)
 # Applies to csrc/conv_sf16.hip as of commit 61e77b9 (git show 61e77b9:sound_event_detection_dcase2017_task4_amd/csrc/conv_sf16.hip);
-# the string anchors below fail loudly on any other revision.  Result: DESIGN.md section 9, profiles/r03/experiment_*.txt.
+# the string anchors below fail loudly on any other revision.  Result: docs/HISTORY.md (round 3), profiles/r03/experiment_*.txt.
 p='/root/repo/sound_event_detection_dcase2017_task4_amd/csrc/conv_sf16.hip'
 s=open(p).read()
 def rep(a,b,cnt=1):

@@ -1,7 +1,7 @@
 # experiment patch (round 3): Winograd F(2,3) along W emulated inside conv_sf16_kernel (timing only, results wrong): build with -DSF_EMU_WINO;
 # bash tools/ablate.sh conv_sf16.hip "--batch 128 --reps 5 --only sf16" base DSF_EMU_WINO
 # Applies to csrc/conv_sf16.hip as of commit 09bea50 (git show 09bea50:sound_event_detection_dcase2017_task4_amd/csrc/conv_sf16.hip);
-# the string anchors below fail loudly on any other revision.  Result: DESIGN.md section 9, profiles/r03/experiment_*.txt.
+# the string anchors below fail loudly on any other revision.  Result: docs/HISTORY.md (round 3), profiles/r03/experiment_*.txt.
 p='/root/repo/sound_event_detection_dcase2017_task4_amd/csrc/conv_sf16.hip'
 s=open(p).read()
 def rep(a,b,cnt=1):
