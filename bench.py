@@ -506,8 +506,11 @@ class StrongRowWatchdog(object):
 
     def fire(self):
         if self.line is not None:
-            self.line["strong"] = {"scaling": "strong", "value": None,
-                                   "error": "watchdog: the strong-scaling row did not finish within %g s" % self.seconds}
+            if "strong" not in self.line:          # (a row that DID come back is kept: then it is the shutdown that hangs)
+                self.line["strong"] = {"scaling": "strong", "value": None,
+                                       "error": "watchdog: the strong-scaling row did not finish within %g s" % self.seconds}
+            else:
+                self.line["dist"]["shutdown_error"] = "watchdog: the process group did not shut down within %g s" % self.seconds
             sys.stdout.write("\n" + json.dumps(self.line) + "\n")
             sys.stdout.flush()
         os._exit(0)
@@ -685,8 +688,13 @@ def main():
         line["cpu_baseline"] = None
         guard = StrongRowWatchdog(line if rank == 0 else None, float(os.environ.get("SED_BENCH_STRONG_TIMEOUT_S", "300")))
         line["strong"] = strong_row(args.model_type, 32 // world, mix, rank, world, dev, args.steps, args.warmup, args.seconds, args.int16)
+        try:
+            parallel.shutdown()       # under the same watchdog: a side row that left the backend in a bad state must not cost the line
+        except Exception as e:
+            line["dist"]["shutdown_error"] = repr(e)
         guard.cancel()
-    parallel.shutdown()               # all ranks: barrier + destroy the process group; rank 0 then reports alone
+    else:
+        parallel.shutdown()           # all ranks: barrier + destroy the process group; rank 0 then reports alone
     if rank != 0:
         return
     del wl

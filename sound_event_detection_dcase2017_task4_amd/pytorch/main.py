@@ -154,10 +154,21 @@ def train(args):
 
     recent = collections.deque(maxlen=POLL_LAG + 1)      # (wave, target, lam, stripes) of the newest steps, oldest first
 
+    graph_box = [graphed]
+
     def one_step(wave, target, lam, stripes):
         model.train()
-        if graphed is not None:                      # same body, captured once per input shape and replayed
-            return graphed(wave, target, lam, stripes)
+        if graph_box[0] is not None:                 # same body, captured once per input shape and replayed
+            try:
+                return graph_box[0](wave, target, lam, stripes)
+            except ops.NonFiniteOperand:
+                raise
+            except Exception as err:                 # the capture was refused (nothing of this step has run yet)
+                if mode == 'on':
+                    raise                            # asked for explicitly: fail loudly
+                logging.warning('--hip_graph auto: the HIP graph capture failed (%r); continuing with the eager loop', err)
+                graph_box[0] = None
+                torch.cuda.synchronize()
         batch_output_dict = model(wave, lam, specaug_stripes=stripes)
         batch_target_dict = {'target': do_mixup(target, lam) if mix else target}
         step_loss = loss_func(batch_output_dict, batch_target_dict)

@@ -175,3 +175,40 @@ def test_train_cli_with_hip_graph_prints_the_same_losses(tmp_path, capsys):
     assert len(series[0]) == len(series[1]) == len(series[2]) == 8
     np.testing.assert_allclose(series[1], series[0], rtol=5e-6, atol=0)
     assert series[2] == series[1]                      # auto = on at 4 clips per GPU: the very same replayed kernels
+
+
+def test_train_cli_auto_graph_falls_back_to_the_eager_loop_when_capture_fails(tmp_path, capsys, monkeypatch, caplog):
+    """`--hip_graph auto` is a default, not a request: a refused capture (a runtime this code has not seen) must cost the graph, not
+    the run -- the CLI logs it and continues kernel by kernel with the same losses; `--hip_graph on` fails loudly."""
+    import logging
+    from sound_event_detection_dcase2017_task4_amd import graph
+    from sound_event_detection_dcase2017_task4_amd.pytorch import main as cli
+
+    def args(ws, *extra):
+        return ["train", "--dataset_dir", ws, "--workspace", ws, "--holdout_fold", "1", "--model_type", "Cnn_9layers_FrameAvg",
+                "--loss_type", "clip_bce", "--augmentation", "mixup", "--batch_size", "4", "--cuda", "--synthetic", "12",
+                "--learning_rate", "1e-3", "--resume_iteration", "0", "--stop_iteration", "5", "--print_every", "1"] + list(extra)
+
+    def losses():
+        out = capsys.readouterr().out
+        return [float(l.split()[1]) for l in out.splitlines() if len(l.split()) == 2 and l.split()[0].isdigit()]
+
+    ws = str(tmp_path / "off"); os.makedirs(ws)
+    torch.manual_seed(99)
+    cli.main(args(ws, "--hip_graph", "off"))
+    want = losses()
+
+    def refuse(self):
+        raise RuntimeError("capture refused (test)")
+    monkeypatch.setattr(graph.GraphedTrainStep, "_capture", refuse)
+    ws = str(tmp_path / "auto"); os.makedirs(ws)
+    torch.manual_seed(99)
+    with caplog.at_level(logging.WARNING):
+        cli.main(args(ws))
+    got = losses()
+    assert len(got) == len(want) == 6
+    np.testing.assert_allclose(got, want, rtol=5e-6, atol=0)
+    assert any("HIP graph capture failed" in r.getMessage() for r in caplog.records)
+    ws = str(tmp_path / "on"); os.makedirs(ws)
+    with pytest.raises(RuntimeError, match="capture refused"):
+        cli.main(args(ws, "--hip_graph", "on"))
