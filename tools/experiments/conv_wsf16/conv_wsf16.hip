@@ -369,6 +369,263 @@ __global__ __launch_bounds__(256, 1) void conv_wsf16_kernel(WsfP p) {
     }
 }
 
+// =====================================================================================================================
+// Second cut (v2, "eta halves"): the same workgroup tile (128 tiles x 32 channels) on EIGHT waves = two per SIMD, so that one
+// wave's MFMAs run under the other's transform / split / LDS traffic (what the direct kernel gets from three workgroups per CU).
+// A wave owns 32 tiles x 32 channels x EIGHT positions (two eta rows: 8 accumulators = 128 registers); waves 0-3 take eta = 0, 1
+// (patch rows 0, 1, 2), waves 4-7 eta = 2, 3 (rows 1, 2, 3); the rows are combined FIRST (w_a = A - B, w_b = B +- C: the eta
+// transform commutes with the column transform), four channels at a time, so that a K-step holds at most 48 raw registers; the
+// eta halves meet once, in the epilogue, through LDS (half 0 finishes output row 2t, half 1 row 2t + 1).  Raw patch by LDS-DMA
+// only (no fused operand transform in this cut).
+template <int ABL = 0, bool ROT = false>
+__global__ __launch_bounds__(512, 1) void conv_wsf16h_kernel(WsfP p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WSF_RAWBYTES + 2 * WSF_USTAGE];
+    unsigned char* const Raw = smem;
+    unsigned char* const Us = smem + 2 * WSF_RAWBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tbk = wv & 3, hf = wv >> 2;
+    const int W = p.W, logW = p.logW, OR = p.OR, PW = p.PW;
+    const int KT = p.K >> 4;
+    const int nb = p.N >> 5;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    int cb, tb;
+    if (nb >= 8) { const int cpx = nb >> 3; cb = xcd * cpx + j % cpx; tb = j / cpx; }
+    else { const int share = 8 / nb; cb = xcd % nb; tb = j * share + xcd / nb; }
+    if (tb >= p.ntb) return;
+    const int n0 = cb * 32;
+    const int b = tb / p.nrb, h0 = (tb % p.nrb) * OR;
+
+    const float sa = sed_sf_scale_of(amax_read(p.x_amax)) * 0.25f;
+    const float inv = 1.0f / (sa * p.wscale[SED_AMAX_SLOTS]);
+
+    constexpr int OOB = (int)0x80000000;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x) + (long)b * p.H * W * p.K, 0, (int)((unsigned)p.H * W * p.K * 4u), 0x00020000);
+
+    // ---- U by LDS-DMA: 32 slabs of 1 KB per stage, 4 per wave
+    const int brow = lane >> 1;
+    const int boff = (n0 + brow) * 32 + ((((lane & 1) ^ ((brow >> 3) & 1))) << 4);
+    const unsigned us_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)Us);
+    const long slab_stride = (long)p.N * 32;
+    auto udma = [&](int ks, int st) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int slab = wv * 4 + jj;
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(p.up) + ((long)ks * 32 + slab) * slab_stride;
+            unsigned keep_;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep_)
+                         : "v"(boff), "s"(us_base + (unsigned)(st * WSF_USTAGE + slab * 1024)), "s"(src)
+                         : "memory");
+        }
+    };
+    // ---- raw patch by LDS-DMA: 16-row blocks, block wv + 8 n of a stage (n < 6)
+    constexpr int NRD = 6;
+    int voff[NRD];
+    const int rows_used = (OR + 2) * 2 * PW;
+#pragma unroll
+    for (int n = 0; n < NRD; ++n) {
+        const int R = 16 * (wv + 8 * n) + (lane >> 2);
+        const int prow = R / (2 * PW), rem = R - prow * 2 * PW;
+        const int plane = rem >= PW ? 1 : 0, idx = rem - plane * PW;
+        const int pc = 2 * idx + plane, h = h0 - 1 + prow;
+        const int q = (lane & 3) ^ ((R >> 2) & 3);
+        const bool ok = R < rows_used && pc >= 1 && pc <= W && (unsigned)h < (unsigned)p.H;
+        voff[n] = ok ? ((h * W + pc - 1) * p.K + q * 4) * 4 : OOB;
+    }
+    const unsigned raw_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)Raw);
+    auto rdma = [&](int ks, int buf) {
+#pragma unroll
+        for (int n = 0; n < NRD; ++n) {
+            if (16 * (wv + 8 * n) < rows_used) {                 // wave-uniform
+                unsigned keep_;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep_)
+                             : "v"(voff[n]), "s"(raw_base + (unsigned)(buf * WSF_RAWBYTES + (wv + 8 * n) * 1024)), "s"(xrs), "s"(ks * 64)
+                             : "memory");
+            }
+        }
+    };
+    udma(0, 0);
+    rdma(0, 0);
+    if (ABL & 1) { udma(1, 1); rdma(1, 1); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- fragment addressing: this lane's tile, its half of the K-step, this wave's three patch rows
+    const int kh = lane >> 5;
+    const int t = 32 * tbk + (lane & 31);
+    const int tx = t & ((W >> 1) - 1), ty = t >> (logW - 1);
+    const int rA = hf ? 2 : 0, rB = hf ? 1 : 2, rC = hf ? 3 : 1;
+    const float sgn = hf ? -1.0f : 1.0f;             // w_b = B + sgn * C
+    int roff[3][4];                                   // chunk 2 kh (channels 8 kh .. + 3); chunk 2 kh + 1 sits at roff ^ 16
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        roff[0][c] = wsf_raw(((2 * ty + rA) * 2 + (c & 1)) * PW + tx + (c >> 1), 2 * kh);
+        roff[1][c] = wsf_raw(((2 * ty + rB) * 2 + (c & 1)) * PW + tx + (c >> 1), 2 * kh);
+        roff[2][c] = wsf_raw(((2 * ty + rC) * 2 + (c & 1)) * PW + tx + (c >> 1), 2 * kh);
+    }
+    const int uoff = wsf_usw(lane & 31, kh) + hf * 8 * 2048;     // this half's positions start at 8 hf
+
+    floatx16 acc[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 sgn2 = {sgn, sgn};
+    // A workgroup barrier per K-step puts all eight waves into the SAME phase: with "transform, then MFMAs" both waves of a SIMD
+    // transform together and then queue for the matrix pipe together (ablation: removing the MFMAs removed their whole pipe time --
+    // nothing had overlapped them).  ROT = true (measured SLOWER, kept for the record: WSF_V2=2): the two waves of a SIMD are waves
+    // w and w + 4 = the two eta halves of one tile block, so the eta-half-1 waves run their loop ROTATED by half a K-step against
+    // two barriers per K-step:
+    //     first half :  half 0 transforms K-step ks      ||  half 1 issues the MFMAs of K-step ks - 1
+    //     second half:  half 0 issues the MFMAs of ks    ||  half 1 transforms ks
+    // -- one wave's VALU / LDS work under the other's MFMAs on every SIMD, with no more registers than the un-rotated loop (a
+    // wave still transforms, then multiplies; only the barriers moved).  Buffer lifetimes: raw[st] is read until the second half
+    // of its K-step, U[st] until the first half of the next one: the raw DMA of ks + 1 goes out at the top of ks, the U DMA of
+    // ks + 1 behind the first barrier of ks.
+#define WSFH_T(ST)                                                                                                      \
+    {                                                                                                                   \
+        const unsigned char* const Rb = Raw + (ST) * WSF_RAWBYTES;                                                      \
+        _Pragma("unroll") for (int cq = 0; cq < 2; ++cq) {                                                              \
+            f2 wa[4][2], wb[4][2];     /* row-combined patch, [column][channel pair]: packed fp32 throughout */            \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                             \
+                const float4 A = *reinterpret_cast<const float4*>(Rb + (roff[0][c] ^ (cq << 4)));                       \
+                const float4 B = *reinterpret_cast<const float4*>(Rb + (roff[1][c] ^ (cq << 4)));                       \
+                const float4 C = *reinterpret_cast<const float4*>(Rb + (roff[2][c] ^ (cq << 4)));                       \
+                const f2 A0 = {A.x, A.y}, A1 = {A.z, A.w}, B0 = {B.x, B.y}, B1 = {B.z, B.w}, C0 = {C.x, C.y}, C1 = {C.z, C.w}; \
+                wa[c][0] = A0 - B0; wa[c][1] = A1 - B1;                                                                 \
+                wb[c][0] = __builtin_elementwise_fma(sgn2, C0, B0); wb[c][1] = __builtin_elementwise_fma(sgn2, C1, B1); \
+            }                                                                                                           \
+            _Pragma("unroll") for (int ab = 0; ab < 2; ++ab) {                                                          \
+                _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                         \
+                    const f2 w0 = ab ? wb[0][e] : wa[0][e], w1 = ab ? wb[1][e] : wa[1][e];                              \
+                    const f2 w2 = ab ? wb[2][e] : wa[2][e], w3 = ab ? wb[3][e] : wa[3][e];                              \
+                    const f2 V0 = w0 - w2, V1 = w1 + w2, V2 = w2 - w1, V3 = w1 - w3;                                    \
+                    if (ABL & 2) {                                                                                      \
+                        fh[ab * 4 + 0][2 * cq + e] = __float_as_uint(V0[0]); fl[ab * 4 + 0][2 * cq + e] = __float_as_uint(V0[1]); \
+                        fh[ab * 4 + 1][2 * cq + e] = __float_as_uint(V1[0]); fl[ab * 4 + 1][2 * cq + e] = __float_as_uint(V1[1]); \
+                        fh[ab * 4 + 2][2 * cq + e] = __float_as_uint(V2[0]); fl[ab * 4 + 2][2 * cq + e] = __float_as_uint(V2[1]); \
+                        fh[ab * 4 + 3][2 * cq + e] = __float_as_uint(V3[0]); fl[ab * 4 + 3][2 * cq + e] = __float_as_uint(V3[1]); \
+                    } else {                                                                                            \
+                        wsf_split2s(V0[0], V0[1], sa, fh[ab * 4 + 0][2 * cq + e], fl[ab * 4 + 0][2 * cq + e]);          \
+                        wsf_split2s(V1[0], V1[1], sa, fh[ab * 4 + 1][2 * cq + e], fl[ab * 4 + 1][2 * cq + e]);          \
+                        wsf_split2s(V2[0], V2[1], sa, fh[ab * 4 + 2][2 * cq + e], fl[ab * 4 + 2][2 * cq + e]);          \
+                        wsf_split2s(V3[0], V3[1], sa, fh[ab * 4 + 3][2 * cq + e], fl[ab * 4 + 3][2 * cq + e]);          \
+                    }                                                                                                   \
+                }                                                                                                       \
+            }                                                                                                           \
+        }                                                                                                               \
+    }
+#define WSFH_M(ST)                                                                                                      \
+    {                                                                                                                   \
+        const unsigned char* const Ub = Us + (ST) * WSF_USTAGE;                                                         \
+        _Pragma("unroll") for (int pos = 0; pos < 8; ++pos) {                                                           \
+            const uintx4 hv = {fh[pos][0], fh[pos][1], fh[pos][2], fh[pos][3]}, lv = {fl[pos][0], fl[pos][1], fl[pos][2], fl[pos][3]}; \
+            const half8 ah = __builtin_bit_cast(half8, hv), al = __builtin_bit_cast(half8, lv);                         \
+            const half8 bh = *reinterpret_cast<const half8*>(Ub + (pos * 2) * 1024 + uoff);                             \
+            const half8 bl = *reinterpret_cast<const half8*>(Ub + (pos * 2 + 1) * 1024 + uoff);                         \
+            if (ABL & 4) { acc[pos][0] += (float)al[0] * (float)bh[0] + (float)ah[1] * (float)bl[1]; continue; }         \
+            acc[pos] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[pos], 0, 0, 0);                               \
+            acc[pos] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[pos], 0, 0, 0);                               \
+            acc[pos] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[pos], 0, 0, 0);                               \
+        }                                                                                                               \
+    }
+    // K-step KS on stage ST (compile-time stage: every LDS offset is lane base + immediate) as seen by eta half HF (compile-time:
+    // the two halves run two SEPARATE loops -- one scalar branch at the top, no control-flow merges inside)
+#define WSFH_STEP(KS, ST, HF)                                                                                           \
+    {                                                                                                                   \
+        if ((KS) + 1 < KT && !(ABL & 1)) rdma((KS) + 1, (ST) ^ 1);                                                      \
+        if ((HF) == 0) WSFH_T(ST) else if ((KS) > 0) WSFH_M((ST) ^ 1)                                                   \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                \
+        __syncthreads();                                                                                                \
+        if ((KS) + 1 < KT && !(ABL & 1)) udma((KS) + 1, (ST) ^ 1);                                                      \
+        if ((HF) == 0) WSFH_M(ST) else WSFH_T(ST)                                                                       \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                \
+        __syncthreads();                                                                                                \
+    }
+    // un-rotated K-step (ROT = false, the faster form: see README): every wave transforms, then multiplies; one barrier
+#define WSFH_STEP1(KS, ST)                                                                                              \
+    {                                                                                                                   \
+        if ((KS) + 1 < KT && !(ABL & 1)) { udma((KS) + 1, (ST) ^ 1); rdma((KS) + 1, (ST) ^ 1); }                        \
+        WSFH_T(ST)                                                                                                      \
+        WSFH_M(ST)                                                                                                      \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                \
+        __syncthreads();                                                                                                \
+    }
+    if (!ROT) {
+        unsigned fh[8][4], fl[8][4];                  // (hi, lo) fragment words of the 8 positions: words 0, 1 <- channel quad 0; 2, 3 <- quad 1
+        for (int ks = 0; ks < KT; ks += 2) {          // K % 32 == 0 for every layer this cut is run on: two K-steps per trip
+            WSFH_STEP1(ks, 0)
+            WSFH_STEP1(ks + 1, 1)
+        }
+    } else if (hf == 0) {
+        unsigned fh[8][4], fl[8][4];
+        for (int ks = 0; ks < KT; ks += 2) {
+            WSFH_STEP(ks, 0, 0)
+            WSFH_STEP(ks + 1, 1, 0)
+        }
+    } else {
+        unsigned fh[8][4], fl[8][4];
+#pragma unroll
+        for (int a_ = 0; a_ < 8; ++a_)
+#pragma unroll
+            for (int b_ = 0; b_ < 4; ++b_) { fh[a_][b_] = 0u; fl[a_][b_] = 0u; }
+        for (int ks = 0; ks < KT; ks += 2) {
+            WSFH_STEP(ks, 0, 1)
+            WSFH_STEP(ks + 1, 1, 1)
+        }
+        WSFH_M(1)                                     // the rotated half's last K-step (KT is even: stage 1)
+    }
+#undef WSFH_STEP
+#undef WSFH_STEP1
+#undef WSFH_M
+#undef WSFH_T
+
+    // ---- output transform.  Row direction first, per half: half 0 holds M0, M1 -> P = M0 + M1 (its share of output row 0) and
+    // Q = M1 (its share of row 1); half 1 holds M2, M3 -> P = M2, Q = -(M2 + M3).  Columns: y[.][0] = v0 + v1 + v2, y[.][1] = v1 - v2 - v3.
+    // Half 0 finishes row 0 (needs the other half's P), half 1 row 1 (needs the other half's Q): 32 floats per lane each way, through LDS.
+    float* const red = reinterpret_cast<float*>(smem);           // [pair 4][direction 2][32][64 lanes]
+    float mine[16][2], give[16][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float P[4], Q[4];
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+            if (hf == 0) { P[xi] = acc[xi][r] + acc[4 + xi][r]; Q[xi] = acc[4 + xi][r]; }
+            else { P[xi] = acc[xi][r]; Q[xi] = -(acc[xi][r] + acc[4 + xi][r]); }
+        }
+        const float p0 = (P[0] + P[1]) + P[2], p1 = (P[1] - P[2]) - P[3];
+        const float q0 = (Q[0] + Q[1]) + Q[2], q1 = (Q[1] - Q[2]) - Q[3];
+        if (hf == 0) { mine[r][0] = p0; mine[r][1] = p1; give[r][0] = q0; give[r][1] = q1; }
+        else { mine[r][0] = q0; mine[r][1] = q1; give[r][0] = p0; give[r][1] = p1; }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        red[((tbk * 2 + hf) * 32 + 2 * r) * 64 + lane] = give[r][0];
+        red[((tbk * 2 + hf) * 32 + 2 * r + 1) * 64 + lane] = give[r][1];
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y + (long)b * p.H * W * p.N, 0,
+                                                                         (int)((unsigned)p.H * W * p.N * 4u), 0x00020000);
+    const int col = n0 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float y0 = (mine[r][0] + red[((tbk * 2 + (hf ^ 1)) * 32 + 2 * r) * 64 + lane]) * inv;
+        const float y1 = (mine[r][1] + red[((tbk * 2 + (hf ^ 1)) * 32 + 2 * r + 1) * 64 + lane]) * inv;
+        const int ti = 32 * tbk + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int otx = ti & ((W >> 1) - 1), oty = ti >> (logW - 1);
+        const int h = h0 + 2 * oty + hf, w = 2 * otx;
+        const int o0 = h < p.H ? ((h * W + w) * p.N + col) * 4 : OOB;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y0), yrs, o0, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y1), yrs, o0 == OOB ? OOB : o0 + p.N * 4, 0, 0);
+    }
+}
+
 // ---- weights: U = G g G^T per (output channel, input channel) pair; amax of U -> power-of-two scale; (hi, lo) planes.
 // dgrad = 1: the operand of the transposed convolution (channel roles swapped, taps flipped).
 __device__ __forceinline__ void wsf_u_of(const float* __restrict__ w, int Cout, int Cin, int dgrad, int o, int i, float (&U)[16]) {
@@ -471,6 +728,21 @@ SED_API int sed_conv3x3_wsf16(const float* x, const void* up, const float* wscal
     const int nb = Cout / 32;
     const long grid = nb >= 8 ? (long)p.ntb * nb : 8L * ((p.ntb + 8 / nb - 1) / (8 / nb));
     if (grid >= (1L << 31)) return SED_EINVAL;
+    { const char* e = getenv("WSF_V2"); if (e && atoi(e) == 2 && !in_scale && Cin % 32 == 0) {
+        hipLaunchKernelGGL((conv_wsf16h_kernel<0, true>), dim3((unsigned)grid), dim3(512), 0, stream, p);
+        SED_LAUNCH_CHECK();
+        return 0;
+    }
+    if (e && atoi(e) == 1 && !in_scale && Cin % 32 == 0) {
+        if (p.abl == 1) hipLaunchKernelGGL(conv_wsf16h_kernel<1>, dim3((unsigned)grid), dim3(512), 0, stream, p);
+        else if (p.abl == 2) hipLaunchKernelGGL(conv_wsf16h_kernel<2>, dim3((unsigned)grid), dim3(512), 0, stream, p);
+        else if (p.abl == 4) hipLaunchKernelGGL(conv_wsf16h_kernel<4>, dim3((unsigned)grid), dim3(512), 0, stream, p);
+        else if (p.abl == 6) hipLaunchKernelGGL(conv_wsf16h_kernel<6>, dim3((unsigned)grid), dim3(512), 0, stream, p);
+        else if (p.abl == 7) hipLaunchKernelGGL(conv_wsf16h_kernel<7>, dim3((unsigned)grid), dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL(conv_wsf16h_kernel<0>, dim3((unsigned)grid), dim3(512), 0, stream, p);
+        SED_LAUNCH_CHECK();
+        return 0;
+    } }
     if (in_scale) hipLaunchKernelGGL((conv_wsf16_kernel<true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     else if (p.abl == 1) hipLaunchKernelGGL((conv_wsf16_kernel<false, 1>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     else if (p.abl == 2) hipLaunchKernelGGL((conv_wsf16_kernel<false, 2>), dim3((unsigned)grid), dim3(256), 0, stream, p);

@@ -36,10 +36,11 @@ def load():
     usage, keep = [], False
     for l in r.stderr.splitlines():                    # the resource blocks of the two un-ablated convolution kernels
         if "Function Name" in l:
-            keep = "conv_wsf16_kernel" in l and "Li0E" in l
+            keep = ("conv_wsf16_kernel" in l or "conv_wsf16h_kernel" in l) and "Li0E" in l
         if keep and any(k in l for k in ("Function Name", "VGPRs:", "AGPRs:", "ScratchSize", "VGPRs Spill", "LDS Size", "Occupancy")):
-            usage.append(l.split("remark: ")[-1].split(" [-Rpass")[0].split(": ", 1)[-1] if "Function Name" not in l else
-                         "conv_wsf16_kernel<INT = %s>" % ("true" if "ILb1" in l else "false"))
+            usage.append(l.split("remark: ")[-1].split(" [-Rpass")[0].strip() if "Function Name" not in l else
+                         ("conv_wsf16h_kernel<ROT = %s> (v2, eta halves)" % ("true" if "Lb1E" in l else "false") if "wsf16h" in l else
+                          "conv_wsf16_kernel<INT = %s> (v1)" % ("true" if "ILb1" in l else "false")))
     subprocess.run([os.environ.get("CXX", "g++"), "-shared", "-fPIC", "-o", so, obj], check=True)
     _lib.lib()                                          # loads torch's HIP runtime RTLD_GLOBAL first
     h = ctypes.CDLL(so)
@@ -101,7 +102,7 @@ def bench(args):
         print("#   " + l.strip())
     B = args.batch
     tot = {}
-    for (ci, co, H, W) in LAYERS:
+    for (ci, co, H, W) in ([LAYERS[int(i)] for i in args.layers.split(",")] if args.layers else LAYERS):
         g = torch.Generator(device="cuda").manual_seed(1)
         x = torch.randn((B, H, W, ci), device="cuda", generator=g)
         gy = torch.randn((B, H, W, co), device="cuda", generator=g)
@@ -118,6 +119,8 @@ def bench(args):
                 ("winograd sf16 fwd +inT", lambda: k.conv(x, ups, B, H, W, ci, co, in_st=st, x_amax=xamT)),
                 ("winograd sf16 dgrad   ", lambda: k.conv(gy, upd, B, H, W, co, ci, x_amax=gam))]
         for name, fn in runs:
+            if args.only_wino and not name.startswith("winograd sf16 dgrad"):
+                continue
             ms = timeit(fn, args.reps)
             print("%4d->%-4d %4dx%-3d B=%-3d %s %8.3f ms  %6.1f TFLOP/s (algorithmic)" % (ci, co, H, W, B, name, ms, fl / ms / 1e9))
             t = tot.setdefault(name, [0.0, 0.0]); t[0] += ms; t[1] += fl
@@ -151,6 +154,8 @@ if __name__ == "__main__":
     ap.add_argument("mode", choices=["check", "bench"])
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--layers", type=str, default="", help="comma-separated indices into LAYERS")
+    ap.add_argument("--only_wino", action="store_true")
     ap.add_argument("--abl", type=int, default=0, help="timing ablation (results wrong): 1 no DMA after the prologue, 2 no operand split, "
                                                       "4 no MFMA; sums allowed (3, 6, 7)")
     a = ap.parse_args()
