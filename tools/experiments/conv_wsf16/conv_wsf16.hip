@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256, 1) void conv_wsf16_kernel(WsfP p) {
 // transform commutes with the column transform), four channels at a time, so that a K-step holds at most 48 raw registers; the
 // eta halves meet once, in the epilogue, through LDS (half 0 finishes output row 2t, half 1 row 2t + 1).  Raw patch by LDS-DMA
 // only (no fused operand transform in this cut).
-template <int ABL = 0, bool ROT = false>
+template <int ABL = 0, int ROT = 0>      // ROT: 0 plain, 1 rotated eta halves, 2 group-b transform interleaved with group-a MFMAs
 __global__ __launch_bounds__(512, 1) void conv_wsf16h_kernel(WsfP p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WSF_RAWBYTES + 2 * WSF_USTAGE];
     unsigned char* const Raw = smem;
@@ -548,7 +548,112 @@ __global__ __launch_bounds__(512, 1) void conv_wsf16h_kernel(WsfP p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                \
         __syncthreads();                                                                                                \
     }
-    // un-rotated K-step (ROT = false, the faster form: see README): every wave transforms, then multiplies; one barrier
+    // ROT = 2: inside a wave, the transform of eta row b runs BETWEEN the MFMAs of eta row a (program order pinned by scheduling
+    // barriers: one MFMA, then a twelfth of the row-b work), no loop-carried state: T_a ; [M_a || T_b] ; M_b
+#define WSFH_SB() __builtin_amdgcn_sched_barrier(0);
+    // group-a transform of channel quad CQ: rows A, B -> w_a -> V -> fragment words 2 CQ, 2 CQ + 1 of positions 0..3
+#define WSFH_TA(RB, CQ)                                                                                                 \
+    {                                                                                                                   \
+        f2 w_[4][2];                                                                                                    \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                                 \
+            const float4 A = *reinterpret_cast<const float4*>((RB) + (roff[0][c] ^ ((CQ) << 4)));                       \
+            const float4 B = *reinterpret_cast<const float4*>((RB) + (roff[1][c] ^ ((CQ) << 4)));                       \
+            const f2 A0 = {A.x, A.y}, A1 = {A.z, A.w}, B0 = {B.x, B.y}, B1 = {B.z, B.w};                                \
+            w_[c][0] = A0 - B0; w_[c][1] = A1 - B1;                                                                     \
+        }                                                                                                               \
+        _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                                 \
+            const f2 V0 = w_[0][e] - w_[2][e], V1 = w_[1][e] + w_[2][e], V2 = w_[2][e] - w_[1][e], V3 = w_[1][e] - w_[3][e]; \
+            wsf_split2s(V0[0], V0[1], sa, fh[0][2 * (CQ) + e], fl[0][2 * (CQ) + e]);                                    \
+            wsf_split2s(V1[0], V1[1], sa, fh[1][2 * (CQ) + e], fl[1][2 * (CQ) + e]);                                    \
+            wsf_split2s(V2[0], V2[1], sa, fh[2][2 * (CQ) + e], fl[2][2 * (CQ) + e]);                                    \
+            wsf_split2s(V3[0], V3[1], sa, fh[3][2 * (CQ) + e], fl[3][2 * (CQ) + e]);                                    \
+        }                                                                                                               \
+    }
+    // one MFMA of position POS: product PR (0: lo*hi, 1: hi*lo, 2: hi*hi) with fragments AH / AL and U fragments BH / BL
+#define WSFH_MF(POS, PR, AH, AL, BH, BL)                                                                                \
+    acc[POS] = __builtin_amdgcn_mfma_f32_32x32x16_f16((PR) == 0 ? AL : AH, (PR) == 1 ? BL : BH, acc[POS], 0, 0, 0);
+#define WSFH_FRAG(POS, AH, AL)                                                                                          \
+    const uintx4 hv##POS = {fh[POS][0], fh[POS][1], fh[POS][2], fh[POS][3]}, lv##POS = {fl[POS][0], fl[POS][1], fl[POS][2], fl[POS][3]}; \
+    const half8 AH = __builtin_bit_cast(half8, hv##POS), AL = __builtin_bit_cast(half8, lv##POS);
+#define WSFH_UB(UB, POS, BH, BL)                                                                                        \
+    const half8 BH = *reinterpret_cast<const half8*>((UB) + ((POS) * 2) * 1024 + uoff);                                 \
+    const half8 BL = *reinterpret_cast<const half8*>((UB) + ((POS) * 2 + 1) * 1024 + uoff);
+    // group-b work of channel quad CQ in six slices, one behind each of six group-a MFMAs
+#define WSFH_STEP2(KS, ST)                                                                                              \
+    {                                                                                                                   \
+        if ((KS) + 1 < KT && !(ABL & 1)) { udma((KS) + 1, (ST) ^ 1); rdma((KS) + 1, (ST) ^ 1); }                        \
+        const unsigned char* const Rb = Raw + (ST) * WSF_RAWBYTES;                                                      \
+        const unsigned char* const Ub = Us + (ST) * WSF_USTAGE;                                                         \
+        WSFH_TA(Rb, 0) WSFH_TA(Rb, 1)                                                                                   \
+        WSFH_UB(Ub, 0, bh0, bl0) WSFH_UB(Ub, 1, bh1, bl1)                                                               \
+        WSFH_FRAG(0, ah0, al0) WSFH_FRAG(1, ah1, al1) WSFH_FRAG(2, ah2, al2) WSFH_FRAG(3, ah3, al3)                     \
+        WSFH_SB()                                                                                                       \
+        f2 wq[4][2];                                                                                                    \
+        /* ---- channel quad 0 of group b under the MFMAs of positions 0, 1 */                                          \
+        float4 Bq[4], Cq[4];                                                                                            \
+        WSFH_MF(0, 0, ah0, al0, bh0, bl0)                                                                               \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) { Bq[c] = *reinterpret_cast<const float4*>(Rb + roff[1][c]); Cq[c] = *reinterpret_cast<const float4*>(Rb + roff[2][c]); } \
+        WSFH_SB()                                                                                                       \
+        WSFH_MF(0, 1, ah0, al0, bh0, bl0)                                                                               \
+        WSFH_UB(Ub, 2, bh2, bl2) WSFH_UB(Ub, 3, bh3, bl3)                                                               \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                                 \
+            const f2 B0 = {Bq[c].x, Bq[c].y}, B1 = {Bq[c].z, Bq[c].w}, C0 = {Cq[c].x, Cq[c].y}, C1 = {Cq[c].z, Cq[c].w}; \
+            wq[c][0] = __builtin_elementwise_fma(sgn2, C0, B0); wq[c][1] = __builtin_elementwise_fma(sgn2, C1, B1);     \
+        }                                                                                                               \
+        WSFH_SB()                                                                                                       \
+        WSFH_MF(0, 2, ah0, al0, bh0, bl0)                                                                               \
+        { const f2 V0 = wq[0][0] - wq[2][0], V1 = wq[1][0] + wq[2][0];                                                  \
+          wsf_split2s(V0[0], V0[1], sa, fh[4][0], fl[4][0]); wsf_split2s(V1[0], V1[1], sa, fh[5][0], fl[5][0]); }       \
+        WSFH_SB()                                                                                                       \
+        WSFH_MF(1, 0, ah1, al1, bh1, bl1)                                                                               \
+        { const f2 V2 = wq[2][0] - wq[1][0], V3 = wq[1][0] - wq[3][0];                                                  \
+          wsf_split2s(V2[0], V2[1], sa, fh[6][0], fl[6][0]); wsf_split2s(V3[0], V3[1], sa, fh[7][0], fl[7][0]); }       \
+        WSFH_SB()                                                                                                       \
+        WSFH_MF(1, 1, ah1, al1, bh1, bl1)                                                                               \
+        { const f2 V0 = wq[0][1] - wq[2][1], V1 = wq[1][1] + wq[2][1];                                                  \
+          wsf_split2s(V0[0], V0[1], sa, fh[4][1], fl[4][1]); wsf_split2s(V1[0], V1[1], sa, fh[5][1], fl[5][1]); }       \
+        WSFH_SB()                                                                                                       \
+        WSFH_MF(1, 2, ah1, al1, bh1, bl1)                                                                               \
+        { const f2 V2 = wq[2][1] - wq[1][1], V3 = wq[1][1] - wq[3][1];                                                  \
+          wsf_split2s(V2[0], V2[1], sa, fh[6][1], fl[6][1]); wsf_split2s(V3[0], V3[1], sa, fh[7][1], fl[7][1]); }       \
+        WSFH_SB()                                                                                                       \
+        /* ---- channel quad 1 of group b under the MFMAs of positions 2, 3 */                                          \
+        WSFH_MF(2, 0, ah2, al2, bh2, bl2)                                                                               \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) { Bq[c] = *reinterpret_cast<const float4*>(Rb + (roff[1][c] ^ 16)); Cq[c] = *reinterpret_cast<const float4*>(Rb + (roff[2][c] ^ 16)); } \
+        WSFH_SB()                                                                                                       \
+        WSFH_MF(2, 1, ah2, al2, bh2, bl2)                                                                               \
+        WSFH_UB(Ub, 4, bh4, bl4) WSFH_UB(Ub, 5, bh5, bl5)                                                               \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                                 \
+            const f2 B0 = {Bq[c].x, Bq[c].y}, B1 = {Bq[c].z, Bq[c].w}, C0 = {Cq[c].x, Cq[c].y}, C1 = {Cq[c].z, Cq[c].w}; \
+            wq[c][0] = __builtin_elementwise_fma(sgn2, C0, B0); wq[c][1] = __builtin_elementwise_fma(sgn2, C1, B1);     \
+        }                                                                                                               \
+        WSFH_SB()                                                                                                       \
+        WSFH_MF(2, 2, ah2, al2, bh2, bl2)                                                                               \
+        { const f2 V0 = wq[0][0] - wq[2][0], V1 = wq[1][0] + wq[2][0];                                                  \
+          wsf_split2s(V0[0], V0[1], sa, fh[4][2], fl[4][2]); wsf_split2s(V1[0], V1[1], sa, fh[5][2], fl[5][2]); }       \
+        WSFH_SB()                                                                                                       \
+        WSFH_MF(3, 0, ah3, al3, bh3, bl3)                                                                               \
+        { const f2 V2 = wq[2][0] - wq[1][0], V3 = wq[1][0] - wq[3][0];                                                  \
+          wsf_split2s(V2[0], V2[1], sa, fh[6][2], fl[6][2]); wsf_split2s(V3[0], V3[1], sa, fh[7][2], fl[7][2]); }       \
+        WSFH_SB()                                                                                                       \
+        WSFH_MF(3, 1, ah3, al3, bh3, bl3)                                                                               \
+        { const f2 V0 = wq[0][1] - wq[2][1], V1 = wq[1][1] + wq[2][1];                                                  \
+          wsf_split2s(V0[0], V0[1], sa, fh[4][3], fl[4][3]); wsf_split2s(V1[0], V1[1], sa, fh[5][3], fl[5][3]); }       \
+        WSFH_SB()                                                                                                       \
+        WSFH_MF(3, 2, ah3, al3, bh3, bl3)                                                                               \
+        { const f2 V2 = wq[2][1] - wq[1][1], V3 = wq[1][1] - wq[3][1];                                                  \
+          wsf_split2s(V2[0], V2[1], sa, fh[6][3], fl[6][3]); wsf_split2s(V3[0], V3[1], sa, fh[7][3], fl[7][3]); }       \
+        WSFH_SB()                                                                                                       \
+        /* ---- group b */                                                                                              \
+        WSFH_UB(Ub, 6, bh6, bl6) WSFH_UB(Ub, 7, bh7, bl7)                                                               \
+        WSFH_FRAG(4, ah4, al4) WSFH_FRAG(5, ah5, al5) WSFH_FRAG(6, ah6, al6) WSFH_FRAG(7, ah7, al7)                     \
+        WSFH_MF(4, 0, ah4, al4, bh4, bl4) WSFH_MF(5, 0, ah5, al5, bh5, bl5) WSFH_MF(6, 0, ah6, al6, bh6, bl6) WSFH_MF(7, 0, ah7, al7, bh7, bl7) \
+        WSFH_MF(4, 1, ah4, al4, bh4, bl4) WSFH_MF(5, 1, ah5, al5, bh5, bl5) WSFH_MF(6, 1, ah6, al6, bh6, bl6) WSFH_MF(7, 1, ah7, al7, bh7, bl7) \
+        WSFH_MF(4, 2, ah4, al4, bh4, bl4) WSFH_MF(5, 2, ah5, al5, bh5, bl5) WSFH_MF(6, 2, ah6, al6, bh6, bl6) WSFH_MF(7, 2, ah7, al7, bh7, bl7) \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                \
+        __syncthreads();                                                                                                \
+    }
+    // un-rotated K-step (ROT = 0): every wave transforms, then multiplies; one barrier
 #define WSFH_STEP1(KS, ST)                                                                                              \
     {                                                                                                                   \
         if ((KS) + 1 < KT && !(ABL & 1)) { udma((KS) + 1, (ST) ^ 1); rdma((KS) + 1, (ST) ^ 1); }                        \
@@ -557,7 +662,13 @@ __global__ __launch_bounds__(512, 1) void conv_wsf16h_kernel(WsfP p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                \
         __syncthreads();                                                                                                \
     }
-    if (!ROT) {
+    if (ROT == 2) {
+        unsigned fh[8][4], fl[8][4];
+        for (int ks = 0; ks < KT; ks += 2) {
+            WSFH_STEP2(ks, 0)
+            WSFH_STEP2(ks + 1, 1)
+        }
+    } else if (ROT == 0) {
         unsigned fh[8][4], fl[8][4];                  // (hi, lo) fragment words of the 8 positions: words 0, 1 <- channel quad 0; 2, 3 <- quad 1
         for (int ks = 0; ks < KT; ks += 2) {          // K % 32 == 0 for every layer this cut is run on: two K-steps per trip
             WSFH_STEP1(ks, 0)
@@ -583,6 +694,7 @@ __global__ __launch_bounds__(512, 1) void conv_wsf16h_kernel(WsfP p) {
     }
 #undef WSFH_STEP
 #undef WSFH_STEP1
+#undef WSFH_STEP2
 #undef WSFH_M
 #undef WSFH_T
 
@@ -728,8 +840,13 @@ SED_API int sed_conv3x3_wsf16(const float* x, const void* up, const float* wscal
     const int nb = Cout / 32;
     const long grid = nb >= 8 ? (long)p.ntb * nb : 8L * ((p.ntb + 8 / nb - 1) / (8 / nb));
     if (grid >= (1L << 31)) return SED_EINVAL;
-    { const char* e = getenv("WSF_V2"); if (e && atoi(e) == 2 && !in_scale && Cin % 32 == 0) {
-        hipLaunchKernelGGL((conv_wsf16h_kernel<0, true>), dim3((unsigned)grid), dim3(512), 0, stream, p);
+    { const char* e = getenv("WSF_V2"); if (e && atoi(e) == 3 && !in_scale && Cin % 32 == 0) {
+        hipLaunchKernelGGL((conv_wsf16h_kernel<0, 2>), dim3((unsigned)grid), dim3(512), 0, stream, p);
+        SED_LAUNCH_CHECK();
+        return 0;
+    }
+    if (e && atoi(e) == 2 && !in_scale && Cin % 32 == 0) {
+        hipLaunchKernelGGL((conv_wsf16h_kernel<0, 1>), dim3((unsigned)grid), dim3(512), 0, stream, p);
         SED_LAUNCH_CHECK();
         return 0;
     }
