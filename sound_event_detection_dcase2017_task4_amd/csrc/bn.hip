@@ -8,6 +8,7 @@
 // Statistics are carried as per-tile partials (sum, M2 = sum((x - tile_mean)^2)) in fp32 and merged in fp64
 // (raw moments S1, S2 = M2 + sum^2/n), so var = S2/N - mean^2 is immune to cancellation.
 #include "common.h"
+#include <stdlib.h>
 #include <mutex>
 #include "sed_hip.h"
 SED_OBJECT_FLAGS(bn)
@@ -96,7 +97,36 @@ __device__ __forceinline__ void chunk_sums16(const double* __restrict__ ws, int 
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ ws, int nchunks, int C, long N,
+// The same sums straight from the partials (no reduce_parts pass: one launch instead of two) for the part counts where one wave
+// per channel walks them in a few trips -- blocks 3 and 4 and bn0 at the metric's batch size, every BatchNorm but block 1's at 4
+// clips per GPU.  MODE as in reduce_parts_kernel.
+struct BnDirectP {
+    const float* parts;        // null: the sums come from ws (two-launch form)
+    int nparts, rows_per_part;
+};
+template <int MODE>
+__device__ __forceinline__ void direct_sums(const BnDirectP& dp, int C, long N, int c, int sub, double& s1, double& s2) {
+    const int K = 2 * C;
+    s1 = 0.0; s2 = 0.0;
+    for (int p = sub; p < dp.nparts; p += 64) {
+        const double a = (double)dp.parts[(long)p * K + c], b = (double)dp.parts[(long)p * K + C + c];
+        if (MODE == 0) { s1 += a; s2 += b; }
+        else {
+            const double n = dp.rows_per_part < 0 ? (double)dp.parts[(long)dp.nparts * K + p]
+                                                  : (double)min((long)dp.rows_per_part, N - (long)p * dp.rows_per_part);
+            s1 += a;
+            if (n > 0.0) s2 += b + a * a / n;          // (tile rows past the end of the tensor: no rows, as in reduce_parts_kernel)
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+}
+// A/B on one box (round 5; 60 steps, twice): two launches 2.12 / 8.068 ms per step (4 clips per GPU under the HIP graph / the
+// metric's bs=32), direct up to 512 parts 2.075 / 8.05, up to 2048 parts 2.09 / 8.07, up to 8192 parts 2.085 / 8.19 -- one wave per
+// channel walking more than ~8 trips of strided loads is slower than the chunked pass it replaces
+constexpr int SED_BN_DIRECT_MAX_PARTS = 512;
+
+__global__ void bn_finalize_kernel(const double* __restrict__ ws, int nchunks, BnDirectP dp, int C, long N,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out,
@@ -106,7 +136,8 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, int nchunks, i
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), sub = threadIdx.x & 63;    // 256 threads = 4 channels x one wave
     if (c >= C) return;
     double s1, s2;
-    chunk_sums16(ws, nchunks, C, c, sub, s1, s2);
+    if (dp.parts) direct_sums<1>(dp, C, N, c, sub, s1, s2);
+    else chunk_sums16(ws, nchunks, C, c, sub, s1, s2);
     const float A = act_bound_out ? amax_read(y_amax) : 0.f;       // (every lane of the wave takes part in the read)
     if (sub != 0) return;
     double mean = s1 / (double)N;
@@ -155,7 +186,7 @@ __global__ void bn_eval_affine_kernel(int C, const float* __restrict__ gamma, co
 }
 
 // stage 2 (backward): dbeta = sum dy, dgamma = sum dy*xhat; coefficients of g_y = a*dy + b*y + c.
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int nchunks, int C, long N,
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int nchunks, BnDirectP dp, int C, long N,
                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                        const float* __restrict__ scale, int batch_stats,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -164,7 +195,8 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int nchunk
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), sub = threadIdx.x & 63;
     if (c >= C) return;
     double s1, s2;
-    chunk_sums16(ws, nchunks, C, c, sub, s1, s2);
+    if (dp.parts) direct_sums<0>(dp, C, N, c, sub, s1, s2);
+    else chunk_sums16(ws, nchunks, C, c, sub, s1, s2);
     const float A = bound_out ? amax_read(y_amax) : 0.f, G = bound_out ? amax_read(g_amax) * ginv : 0.f;
     if (sub != 0) return;
     dbeta[c] = (float)s1;
@@ -663,9 +695,12 @@ SED_API int sed_bn_finalize(const float* partials, int nparts, int rows_per_part
         if (e != hipSuccess) return (int)e;
     }
     int ppc = reduce_chunks(nparts), nchunks = sed_cdiv(nparts, ppc), K = 2 * C;
-    hipLaunchKernelGGL(reduce_parts_kernel<1>, dim3(nchunks, sed_cdiv(K, 256)), dim3(256), 0, stream, partials, nparts, K,
-                       ppc, N, rows_per_part, ws);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(sed_cdiv(C, 4)), dim3(256), 0, stream, ws, nchunks, C, N, gamma, beta, eps,
+    const bool direct = nparts <= SED_BN_DIRECT_MAX_PARTS;
+    const BnDirectP dp{direct ? partials : nullptr, nparts, rows_per_part};
+    if (!direct)
+        hipLaunchKernelGGL(reduce_parts_kernel<1>, dim3(nchunks, sed_cdiv(K, 256)), dim3(256), 0, stream, partials, nparts, K,
+                           ppc, N, rows_per_part, ws);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(sed_cdiv(C, 4)), dim3(256), 0, stream, ws, nchunks, dp, C, N, gamma, beta, eps,
                        momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out, guard_dev, guard_host, cand,
                        y_amax, act_bound_out);
     SED_LAUNCH_CHECK();
@@ -750,9 +785,12 @@ SED_API int sed_bn_bwd_finalize(const float* partials, int nparts, long N, int C
         if (e != hipSuccess) return (int)e;
     }
     int ppc = reduce_chunks(nparts), nchunks = sed_cdiv(nparts, ppc), K = 2 * C;
-    hipLaunchKernelGGL(reduce_parts_kernel<0>, dim3(nchunks, sed_cdiv(K, 256)), dim3(256), 0, stream, partials, nparts, K,
-                       ppc, N, 0, ws);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sed_cdiv(C, 4)), dim3(256), 0, stream, ws, nchunks, C, N, mean, invstd,
+    const bool direct = nparts <= SED_BN_DIRECT_MAX_PARTS;
+    const BnDirectP dp{direct ? partials : nullptr, nparts, 0};
+    if (!direct)
+        hipLaunchKernelGGL(reduce_parts_kernel<0>, dim3(nchunks, sed_cdiv(K, 256)), dim3(256), 0, stream, partials, nparts, K,
+                           ppc, N, 0, ws);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sed_cdiv(C, 4)), dim3(256), 0, stream, ws, nchunks, dp, C, N, mean, invstd,
                        scale, batch_stats, dgamma, dbeta, coef, y_amax, g_amax, ginv, bound_out);
     SED_LAUNCH_CHECK();
     return 0;
