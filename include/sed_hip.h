@@ -336,17 +336,19 @@ int sed_scale_by_scalar(const float* x, const float* scalar_dev, long n, float* 
 /* ---- heads -----------------------------------------------------------------------------------------------
  * FrameAvg (models.py:306-312) / FrameMax (:221-227): logits [B][T][ldn] = feat x Wfc^T by sed_gemm_nt, then
  * frame = sigmoid(logits + bias), clip = mean_t (mode 0) or max_t (mode 1).
- * AttBlock (models.py:135-143): logits columns [0,ncls) = att, [ncls,2ncls) = cla pre-activations; clamp +-10,
- * exp + 1e-6, normalise over time, sigmoid, weighted sum.  sed_interpolate = models.py:58-69 (x8 repeat). */
+ * AttBlock (models.py:118-149): logits columns [0,ncls) = att, [ncls,2ncls) = cla pre-activations; clamp +-10,
+ * exp(. / temperature) + 1e-6, normalise over time, cla = activation (0: 'linear', 1: 'sigmoid'; models.py:145-149), weighted
+ * sum.  sed_interpolate = models.py:58-69 (x8 repeat). */
 int sed_head_pool_fwd(const float* logits, int B, int T, int ldn, int ncls, const float* bias, int mode, float* frame,
                       float* clip, int* amax, sed_stream_t stream);
 int sed_head_pool_bwd(const float* g_clip, const float* frame, const int* amax, int B, int T, int ldn, int ncls,
                       int mode, float* g_logits, sed_stream_t stream);
 int sed_att_pool_fwd(const float* logits, int B, int T, int ldn, int ncls, const float* b_att, const float* b_cla,
-                     float* clip, float* cla, float* norm_att, float* att_sum, sed_stream_t stream);
+                     float* clip, float* cla, float* norm_att, float* att_sum, int activation, float temperature,
+                     sed_stream_t stream);
 int sed_att_pool_bwd(const float* g_clip, const float* logits, const float* b_att, const float* clip,
                      const float* cla, const float* norm_att, const float* att_sum, int B, int T, int ldn, int ncls,
-                     float* g_logits, sed_stream_t stream);
+                     float* g_logits, int activation, float temperature, sed_stream_t stream);
 int sed_interpolate(const float* x, long BT, int ncls, int ratio, float* out, sed_stream_t stream);
 
 /* ---- nn.GRU gate math (models.py:529-530; PyTorch gate order r,z,n, b_hn inside r*(.)) -------------------------

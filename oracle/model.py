@@ -176,13 +176,18 @@ def gru_bidir(x, st):
     return torch.cat(outs, dim=2)
 
 
-def att_block(x, st):
-    """models.py:135-143.  x (B,512,T) -> clip (B,17), norm_att (B,17,T), cla (B,17,T)."""
+def att_block(x, st, activation="sigmoid", temperature=1.0):
+    """models.py:118-149 (every model of the reference: 'sigmoid', temperature 1).  x (B,n_in,T) -> clip (B,n_out),
+    norm_att (B,n_out,T), cla (B,n_out,T)."""
     tmp = F.conv1d(x, st["att_block.att.weight"], st["att_block.att.bias"])
     tmp = torch.clamp(tmp, -10, 10)
-    att = torch.exp(tmp / 1.0) + 1e-6
+    att = torch.exp(tmp / temperature) + 1e-6
     norm_att = att / torch.sum(att, dim=2)[:, :, None]
-    cla = torch.sigmoid(F.conv1d(x, st["att_block.cla.weight"], st["att_block.cla.bias"]))
+    cla = F.conv1d(x, st["att_block.cla.weight"], st["att_block.cla.bias"])
+    if activation == "sigmoid":
+        cla = torch.sigmoid(cla)
+    elif activation != "linear":
+        raise ValueError(activation)
     return torch.sum(norm_att * cla, dim=2), norm_att, cla
 
 

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(128) void att_pool_fwd_kernel(const float* __restri
                                                            const float* __restrict__ b_att,
                                                            const float* __restrict__ b_cla, float* __restrict__ clip,
                                                            float* __restrict__ cla, float* __restrict__ norm_att,
-                                                           float* __restrict__ att_sum) {
+                                                           float* __restrict__ att_sum, int activation, float inv_temp) {
     extern __shared__ float sh[];          // e [T][ncls], c [T][ncls]
     float* es = sh;
     float* cs = sh + T * ncls;
@@ -124,8 +124,9 @@ __global__ __launch_bounds__(128) void att_pool_fwd_kernel(const float* __restri
         const float* row = logits + ((long)b * T + t) * ldn;
         float a = row[k] + b_att[k];
         a = fminf(fmaxf(a, -10.0f), 10.0f);
-        es[i] = expf(a) + 1e-6f;
-        cs[i] = sigmoidf_(row[ncls + k] + b_cla[k]);
+        es[i] = expf(a * inv_temp) + 1e-6f;              // models.py:138-139: clamp, then exp(. / temperature) + 1e-6
+        const float z = row[ncls + k] + b_cla[k];
+        cs[i] = activation ? sigmoidf_(z) : z;           // nonlinear_transform (models.py:145-149): 'sigmoid' | 'linear'
     }
     __syncthreads();
     if (threadIdx.x < ncls) {
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(128) void att_pool_bwd_kernel(const float* __restri
                                                            const float* __restrict__ b_att, const float* __restrict__ clip,
                                                            const float* __restrict__ cla, const float* __restrict__ norm_att,
                                                            const float* __restrict__ att_sum, int T, int ldn, int ncls,
-                                                           float* __restrict__ g_logits) {
+                                                           float* __restrict__ g_logits, int activation, float inv_temp) {
     const int b = blockIdx.x;
     for (int i = threadIdx.x; i < T * ldn; i += 128) {
         int t = i / ldn, k = i % ldn;
@@ -162,12 +163,12 @@ __global__ __launch_bounds__(128) void att_pool_bwd_kernel(const float* __restri
             bool pass = (a >= -10.0f) && (a <= 10.0f);
             float n = norm_att[o], S = att_sum[b * ncls + k];
             float c = cla[o];
-            g = pass ? g_clip[b * ncls + k] * (c - clip[b * ncls + k]) * (n - 1e-6f / S) : 0.f;
+            g = pass ? g_clip[b * ncls + k] * (c - clip[b * ncls + k]) * (n - 1e-6f / S) * inv_temp : 0.f;
         } else if (k < 2 * ncls) {
             int kk = k - ncls;
             long o = ((long)b * T + t) * ncls + kk;
             float c = cla[o];
-            g = g_clip[b * ncls + kk] * norm_att[o] * c * (1.0f - c);
+            g = g_clip[b * ncls + kk] * norm_att[o] * (activation ? c * (1.0f - c) : 1.0f);
         }
         g_logits[((long)b * T) * ldn + i] = g;
     }
@@ -401,20 +402,23 @@ SED_API int sed_head_pool_bwd(const float* g_clip, const float* frame, const int
 }
 
 SED_API int sed_att_pool_fwd(const float* logits, int B, int T, int ldn, int ncls, const float* b_att, const float* b_cla,
-                             float* clip, float* cla, float* norm_att, float* att_sum, hipStream_t stream) {
-    if (B <= 0 || ncls > NCLS_MAX || 2 * ncls > ldn || (size_t)T * ncls * 8 > 60000) return SED_EINVAL;
+                             float* clip, float* cla, float* norm_att, float* att_sum, int activation, float temperature,
+                             hipStream_t stream) {
+    if (B <= 0 || ncls > NCLS_MAX || 2 * ncls > ldn || (size_t)T * ncls * 8 > 60000 || (activation != 0 && activation != 1) ||
+        !(temperature > 0.f))
+        return SED_EINVAL;
     hipLaunchKernelGGL(att_pool_fwd_kernel, dim3(B), dim3(128), (size_t)T * ncls * 8, stream, logits, T, ldn, ncls, b_att, b_cla,
-                       clip, cla, norm_att, att_sum);
+                       clip, cla, norm_att, att_sum, activation, 1.0f / temperature);
     SED_LAUNCH_CHECK();
     return 0;
 }
 
 SED_API int sed_att_pool_bwd(const float* g_clip, const float* logits, const float* b_att, const float* clip,
                              const float* cla, const float* norm_att, const float* att_sum, int B, int T, int ldn,
-                             int ncls, float* g_logits, hipStream_t stream) {
-    if (B <= 0 || 2 * ncls > ldn) return SED_EINVAL;
+                             int ncls, float* g_logits, int activation, float temperature, hipStream_t stream) {
+    if (B <= 0 || 2 * ncls > ldn || (activation != 0 && activation != 1) || !(temperature > 0.f)) return SED_EINVAL;
     hipLaunchKernelGGL(att_pool_bwd_kernel, dim3(B), dim3(128), 0, stream, g_clip, logits, b_att, clip, cla, norm_att, att_sum,
-                       T, ldn, ncls, g_logits);
+                       T, ldn, ncls, g_logits, activation, 1.0f / temperature);
     SED_LAUNCH_CHECK();
     return 0;
 }

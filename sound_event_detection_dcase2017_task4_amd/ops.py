@@ -1528,12 +1528,16 @@ class FcHeadFn(torch.autograd.Function):
 
 
 class AttHeadFn(torch.autograd.Function):
-    """AttBlock(512, 17, 'sigmoid') (models.py:118-149).  feat (B,T,512) -> clip (B,17), cla (B,T,17),
-    norm_att (B,T,17).  The training loss (clip_bce) feeds `clip`; gradients arriving through `cla` / `norm_att`
-    (strong-label losses, not used by the reference's main.py) are honoured too, off the hot path."""
+    """AttBlock(n_in, n_out, activation, temperature) (models.py:118-149; every model of the reference uses 'sigmoid', 1.0).
+    feat (B,T,n_in) -> clip (B,n_out), cla (B,T,n_out), norm_att (B,T,n_out).  The training loss (clip_bce) feeds `clip`; gradients
+    arriving through `cla` / `norm_att` (strong-label losses, not used by the reference's main.py) are honoured too, off the
+    hot path."""
 
     @staticmethod
-    def forward(ctx, feat, w_att, b_att, w_cla, b_cla):
+    def forward(ctx, feat, w_att, b_att, w_cla, b_cla, activation="sigmoid", temperature=1.0):
+        if activation not in ("linear", "sigmoid") or not temperature > 0:
+            raise Exception("Incorrect argument!")
+        ctx.act, ctx.temp = (1 if activation == "sigmoid" else 0), float(temperature)
         _chk_dev(feat, w_att)
         feat = _f32c(feat)
         B, T, C = feat.shape
@@ -1547,7 +1551,7 @@ class AttHeadFn(torch.autograd.Function):
         asum = torch.empty((B, ncls), dtype=torch.float32, device=dev)
         b_att, b_cla = _f32c(b_att), _f32c(b_cla)
         _call("sed_att_pool_fwd", _ptr(logits), B, T, LDN, ncls, _ptr(b_att), _ptr(b_cla), _ptr(clip), _ptr(cla), _ptr(natt),
-              _ptr(asum), _stream())
+              _ptr(asum), ctx.act, ctx.temp, _stream())
         ctx.save_for_backward(feat, wpt, logits, b_att, clip, cla, natt, asum)
         ctx.ncls, ctx.wshape = ncls, w_att.shape
         ctx.sinks = _sinks(ctx, (w_att, b_att, w_cla, b_cla), 1)
@@ -1562,21 +1566,21 @@ class AttHeadFn(torch.autograd.Function):
         g_clip = _f32c(g_clip) if g_clip is not None else torch.zeros((B, ncls), dtype=torch.float32, device=feat.device)
         gl = torch.empty((B * T, LDN), dtype=torch.float32, device=feat.device)
         _call("sed_att_pool_bwd", _ptr(g_clip), _ptr(logits), _ptr(b_att), _ptr(clip), _ptr(cla), _ptr(natt), _ptr(asum), B, T,
-              LDN, ncls, _ptr(gl), _stream())
+              LDN, ncls, _ptr(gl), ctx.act, ctx.temp, _stream())
         gl3 = gl.view(B, T, LDN)
-        if g_cla is not None:                         # cla = sigmoid(.)
-            gl3[:, :, ncls:2 * ncls] += g_cla * cla * (1.0 - cla)
-        if g_natt is not None:                        # norm_att = a / sum_t a,  a = exp(clamp(z, -10, 10)) + 1e-6
+        if g_cla is not None:                         # cla = sigmoid(.) or the identity
+            gl3[:, :, ncls:2 * ncls] += (g_cla * cla * (1.0 - cla)) if ctx.act else g_cla
+        if g_natt is not None:                        # norm_att = a / sum_t a,  a = exp(clamp(z, -10, 10) / temperature) + 1e-6
             S = asum.view(B, 1, ncls)
             da = (g_natt - (g_natt * natt).sum(dim=1, keepdim=True)) / S
             z = logits.view(B, T, LDN)[:, :, :ncls] + b_att.view(1, 1, ncls)
-            gl3[:, :, :ncls] += da * (natt * S - 1e-6) * ((z >= -10.0) & (z <= 10.0)).to(da.dtype)
+            gl3[:, :, :ncls] += da * (natt * S - 1e-6) * ((z >= -10.0) & (z <= 10.0)).to(da.dtype) / ctx.temp
         g_feat = gemm_nt(gl, wpt).view(B, T, C)
         dwp = gemm_tn(feat.view(B * T, C), gl)
         dbias = col_sums(gl, 2 * ncls)
         sk = ctx.sinks
         return (g_feat, _put(sk[0], dwp[:ncls].reshape(ctx.wshape)), _put(sk[1], dbias[:ncls]),
-                _put(sk[2], dwp[ncls:2 * ncls].reshape(ctx.wshape)), _put(sk[3], dbias[ncls:2 * ncls]))
+                _put(sk[2], dwp[ncls:2 * ncls].reshape(ctx.wshape)), _put(sk[3], dbias[ncls:2 * ncls]), None, None)
 
 
 class MultiHeadFn(torch.autograd.Function):

@@ -176,14 +176,14 @@ class ConvBlock(nn.Module):
 
 
 class AttBlock(nn.Module):
-    """models.py:118-149 (activation 'sigmoid' or 'linear' container; the kernel implements 'sigmoid', the only one
-    used).  Input (B, T, n_in) [time-major]; returns (clip (B,n_out), norm_att (B,n_out,T), cla (B,n_out,T)) like the
-    reference (the last two as transposed views).  `bn_att` exists in the state_dict but is unused, as in the
+    """models.py:118-149: activation 'linear' (the reference's default) or 'sigmoid' (what every model passes), any
+    temperature > 0.  Input (B, T, n_in) [time-major]; returns (clip (B,n_out), norm_att (B,n_out,T), cla (B,n_out,T)) like
+    the reference (the last two as transposed views).  `bn_att` exists in the state_dict but is unused, as in the
     reference."""
 
     def __init__(self, n_in, n_out, activation='linear', temperature=1.):
         super(AttBlock, self).__init__()
-        if activation != 'sigmoid' or temperature != 1.:
+        if activation not in ('linear', 'sigmoid') or not temperature > 0:
             raise Exception('Incorrect argument!')
         self.activation = activation
         self.temperature = temperature
@@ -198,7 +198,8 @@ class AttBlock(nn.Module):
         init_bn(self.bn_att)
 
     def forward(self, x_btc):
-        clip, cla, natt = ops.AttHeadFn.apply(x_btc, self.att.weight, self.att.bias, self.cla.weight, self.cla.bias)
+        clip, cla, natt = ops.AttHeadFn.apply(x_btc, self.att.weight, self.att.bias, self.cla.weight, self.cla.bias,
+                                              self.activation, self.temperature)
         return clip, natt.transpose(1, 2), cla.transpose(1, 2)
 
 

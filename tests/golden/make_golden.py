@@ -334,6 +334,57 @@ def flipfree_fixture(model_type, seed):
     return out
 
 
+ATT_CASES = (("linear", 1.0), ("sigmoid", 2.5), ("linear", 0.5), ("sigmoid", 1.0))
+
+
+def attblock_fixture():
+    """The genuine AttBlock (models.py:118-149) with the constructor arguments NO model of the reference uses -- activation
+    'linear' (its default) and temperatures != 1 -- besides the usual ('sigmoid', 1): forward outputs and every gradient of
+    a loss that reaches all three outputs, evaluated in float64 (stored as float32; large gradients as the deterministic
+    subsample `sample_index` + their L2 norm).  Inputs are scaled so that some attention logits leave the +-10 clamp."""
+    out = {"cases": np.array(["%s,%g" % c for c in ATT_CASES])}
+    rs = np.random.RandomState(77)
+    B, C, T, K = 2, 512, 21, 17
+    x = (rs.randn(B, C, T) * 2.0).astype(np.float32)
+    w = {"att.weight": (rs.randn(K, C, 1) * 0.09).astype(np.float32), "att.bias": (rs.randn(K) * 0.5).astype(np.float32),
+         "cla.weight": (rs.randn(K, C, 1) * 0.05).astype(np.float32), "cla.bias": (rs.randn(K) * 0.3).astype(np.float32)}
+    gc, gn, gl = rs.randn(B, K).astype(np.float32), (rs.randn(B, K, T) * 0.1).astype(np.float32), (rs.randn(B, K, T) * 0.1).astype(np.float32)
+    out.update({"x": x, "g_clip": gc, "g_norm_att": gn, "g_cla": gl})
+    out.update({"w/" + k: v for k, v in w.items()})
+
+    def put(key, g):
+        g = np.asarray(g, dtype=np.float64)
+        out[key] = g.reshape(-1)[sample_index(g.size)].astype(np.float32)
+        out[key + "/l2"] = np.array(np.sqrt((g ** 2).sum()))
+    fr = []
+    for i, (act, temp) in enumerate(ATT_CASES):
+        m = ref_models.AttBlock(C, K, activation=act, temperature=temp).double()
+        with torch.no_grad():
+            for k, v in w.items():
+                dict(m.named_parameters())[k].copy_(torch.from_numpy(v).double())
+        xt = torch.from_numpy(x).double().requires_grad_(True)
+        clip, natt, cla = m(xt)
+        loss = (clip * torch.from_numpy(gc).double()).sum() + (natt * torch.from_numpy(gn).double()).sum() + \
+               (cla * torch.from_numpy(gl).double()).sum()
+        loss.backward()
+        tmp = m.att(xt)
+        fr.append(float(((tmp < -10) | (tmp > 10)).double().mean()))
+        out["%d/clip" % i], out["%d/norm_att" % i], out["%d/cla" % i] = (t.detach().numpy().astype(np.float32) for t in (clip, natt, cla))
+        put("%d/g_x" % i, xt.grad.numpy())
+        for k, p_ in m.named_parameters():
+            if p_.grad is not None:
+                put("%d/g_%s" % (i, k), p_.grad.numpy())
+        # ... and the clip-only gradient the training loss produces (the hot path of the kernels)
+        m.zero_grad(); xt2 = torch.from_numpy(x).double().requires_grad_(True)
+        (m(xt2)[0] * torch.from_numpy(gc).double()).sum().backward()
+        put("%d/gclip_x" % i, xt2.grad.numpy())
+        put("%d/gclip_att.weight" % i, dict(m.named_parameters())["att.weight"].grad.numpy())
+    out["clamped_frac"] = np.array(fr)
+    assert min(fr) > 0.005, fr                         # the clamp branch is exercised
+    print("attblock fixture: clamped fraction of the attention logits", fr)
+    return out
+
+
 def misc_fixture():
     out = {"mixup_lambda64": ofe.mixup_lambdas(64, np.random.RandomState(1234))}
     torch.manual_seed(7)
@@ -358,6 +409,10 @@ if __name__ == "__main__":
             np.savez_compressed(os.path.join(HERE, mt + "__big.npz"), **big_fixture(mt, seed=i + 1))
             print(mt + "__big.npz", os.path.getsize(os.path.join(HERE, mt + "__big.npz")))
         sys.exit(0)
+    if only and only[0] == "--attblock":
+        np.savez_compressed(os.path.join(HERE, "attblock.npz"), **attblock_fixture())
+        print("attblock.npz", os.path.getsize(os.path.join(HERE, "attblock.npz")))
+        sys.exit(0)
     if only and only[0] == "--flipfree":    # only the <model>__flipfree.npz files (whole-model gradients without ReLU flips)
         for i, mt in enumerate(om.MODEL_TYPES):
             if mt in (only[1:] or ("Cnn_9layers_FrameAvg", "Cnn_9layers_Gru_FrameAtt")):
@@ -367,6 +422,7 @@ if __name__ == "__main__":
     if not only:
         np.savez_compressed(os.path.join(HERE, "frontend.npz"), **frontend_fixture())
         np.savez_compressed(os.path.join(HERE, "misc.npz"), **misc_fixture())
+        np.savez_compressed(os.path.join(HERE, "attblock.npz"), **attblock_fixture())
     for i, mt in enumerate(om.MODEL_TYPES):
         if only and mt not in only:
             continue

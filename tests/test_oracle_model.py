@@ -161,3 +161,34 @@ def test_oracle_conv_block_pool_types_vs_reference(golden_dir):
         tag = pt.replace("+", "_")
         assert np.abs(y.detach().numpy() - fx[tag + "/out"]).max() < 1e-5
         assert np.abs(xt.grad.numpy().reshape(-1)[::7] - fx[tag + "/dx/sample7"]).max() <= 1e-4 * np.abs(fx[tag + "/dx/sample7"]).max()
+
+
+def _att_case(fx, i):
+    act, temp = str(fx["cases"][i]).split(",")
+    st = {"att_block.att.weight": torch.from_numpy(fx["w/att.weight"]), "att_block.att.bias": torch.from_numpy(fx["w/att.bias"]),
+          "att_block.cla.weight": torch.from_numpy(fx["w/cla.weight"]), "att_block.cla.bias": torch.from_numpy(fx["w/cla.bias"])}
+    return act, float(temp), st
+
+
+def sample_index(numel, cap=2048):
+    return np.arange(0, numel, max(1, -(-numel // cap)))
+
+
+def test_att_block_generic_arguments_vs_reference(golden_dir):
+    """AttBlock with the constructor arguments no model of the reference passes ('linear' activation -- its default --, temperature
+    != 1) besides ('sigmoid', 1): the oracle against outputs and gradients of the genuine class in float64 (attblock.npz)."""
+    fx = np.load(os.path.join(golden_dir, "attblock.npz"))
+    assert float(fx["clamped_frac"].min()) > 0.005
+    for i in range(len(fx["cases"])):
+        act, temp, st = _att_case(fx, i)
+        st = {k: v.double().requires_grad_(True) for k, v in st.items()}
+        x = torch.from_numpy(fx["x"]).double().requires_grad_(True)
+        clip, natt, cla = om.att_block(x, st, activation=act, temperature=temp)
+        for got, key in ((clip, "clip"), (natt, "norm_att"), (cla, "cla")):
+            np.testing.assert_allclose(got.detach().numpy(), fx["%d/%s" % (i, key)], rtol=2e-6, atol=1e-7, err_msg="%s %s" % (fx["cases"][i], key))
+        loss = (clip * torch.from_numpy(fx["g_clip"]).double()).sum() + (natt * torch.from_numpy(fx["g_norm_att"]).double()).sum() + \
+               (cla * torch.from_numpy(fx["g_cla"]).double()).sum()
+        loss.backward()
+        for got, key in ((x.grad, "g_x"), (st["att_block.att.weight"].grad, "g_att.weight"), (st["att_block.cla.bias"].grad, "g_cla.bias")):
+            g = got.numpy().reshape(-1)
+            np.testing.assert_allclose(g[sample_index(g.size)], fx["%d/%s" % (i, key)], rtol=2e-6, atol=1e-9 + 2e-7 * float(fx["%d/%s/l2" % (i, key)]))
