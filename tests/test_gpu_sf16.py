@@ -582,3 +582,58 @@ def test_gradient_amax_hand_over_never_outlives_its_backward_pass():
     out.backward(torch.randn(out.shape, generator=g).cuda())
     torch.cuda.synchronize()
     assert x.grad is not None and len(ops._GRAD_AMAX) == 0
+
+
+def _random_shapes(n, seed):
+    """Seeded sweep over what the split-f16 kernels accept: every width, ragged heights around the tile sizes (256 / W rows per
+    tile; 64 / W rows per weight-gradient stage), odd batch sizes, every channel count of the model and a few others."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        W = int(rs.choice([8, 16, 32, 64]))
+        tr = 256 // W
+        H = int(rs.choice([1, 2, tr - 1, tr, tr + 1, 2 * tr + 3, 3 * tr - 2, int(rs.randint(1, 5 * tr))]))
+        B = int(rs.randint(1, 6))
+        Cin = int(rs.choice([32, 64, 96, 128, 256, 512]))
+        Cout = int(rs.choice([64, 128, 192, 256, 512]))
+        out.append((B, max(H, 1), W, Cin, Cout, bool(rs.randint(0, 2))))
+    return out
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,inT", _random_shapes(14, 20250930))
+def test_sf16_random_shape_sweep_forward_dgrad_wgrad_vs_float64(B, H, W, Cin, Cout, inT):
+    """Forward (with / without the fused operand transform), dgrad and weight gradient of ONE random shape against float64 --
+    shapes nobody hand-picked (ragged last tiles, one-row images, tile-boundary heights, channel counts between the model's)."""
+    from sound_event_detection_dcase2017_task4_amd import ops
+    g = torch.Generator().manual_seed(B * 1009 + H * 31 + W + Cin + Cout)
+    x = torch.randn((B, H, W, Cin), generator=g) * 1.3
+    w = (torch.rand((Cout, Cin, 3, 3), generator=g) * 2 - 1) * float(np.sqrt(6.0 / (9 * Cin + 9 * Cout)))
+    gy = torch.randn((B, H, W, Cout), generator=g) * 1e-5
+    st = scale = shift = None
+    if inT:
+        scale, shift = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+        st = ops.BnStats(Cin, "cuda")
+        st.scale.copy_(scale); st.shift.copy_(shift)
+    xd, gyd, wd = x.cuda(), gy.cuda(), w.cuda()
+    # forward
+    want = _ref(x, w, scale, shift)
+    y = ops.conv3x3_sf16(xd, ops.pack_sf16(wd), B, H, W, Cin, Cout, in_st=st)
+    rel, mx = _err(y, want)
+    assert rel < 1e-6 and mx < 1e-5, ("forward", rel, mx)
+    # dgrad (the transposed convolution; needs Cin % 64 == 0 as ITS output channel count and Cout % 16 == 0 as its K)
+    if Cin % 64 == 0:
+        xr = torch.zeros((B, Cin, H, W), dtype=torch.float64, requires_grad=True)
+        F.conv2d(xr, w.double(), padding=1).backward(gy.double().permute(0, 3, 1, 2))
+        gx = ops.conv3x3_sf16(gyd, ops.pack_sf16(wd, dgrad=True), B, H, W, Cout, Cin)
+        rel, mx = _err(gx, xr.grad.permute(0, 2, 3, 1).contiguous())
+        assert rel < 1e-6 and mx < 1e-5, ("dgrad", rel, mx)
+    # weight gradient
+    L = ops._lib.lib()
+    if L.sed_wgrad_sf16_supported(H, W, Cin, Cout):
+        a = x.double() if not inT else torch.relu(torch.addcmul(shift, x, scale)).double()
+        wantw = torch.nn.grad.conv2d_weight(a.permute(0, 3, 1, 2), (Cout, Cin, 3, 3), gy.double().permute(0, 3, 1, 2), padding=1)
+        dw = ops._wgrad_sf16(xd, gyd, B, H, W, Cin, Cout, in_st=st)
+        rel, mx = _err(dw, wantw)
+        assert rel < 1e-6 and mx < 1e-5, ("wgrad", rel, mx)
+    torch.cuda.synchronize()
+    ops.check_device_errors(synchronize=True)
