@@ -61,6 +61,12 @@ struct Sf16P {
     // EPI 4 (block 1's dgrad): the previous activations y1 = conv1(x0) are RECOMPUTED from the one-channel input
     const float* x0;           // [B][H][W]
     const float* w1;           // conv1 weights [64][9] (OIHW with I = 1)
+    // SPLITK (small-M launches: fewer workgroups than resident slots): ksplit workgroups share one output tile, each over its
+    // range of K-steps; they leave their raw accumulators in ws [tile][ksplit][4 waves][64 registers][64 lanes] and the LAST one
+    // to arrive (per-tile ticket in `tickets`, self-resetting) adds the others' and runs the epilogue
+    int ksplit;
+    float* ws;
+    int* tickets;
 };
 
 __device__ __forceinline__ int sf_sw(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 3) & 1)) << 4); }
@@ -115,7 +121,7 @@ __device__ __forceinline__ float fma_scalar(float a, float b, float c) {
     return d;
 }
 
-template <int MW, bool INT, int EPI, bool PRE = false>
+template <int MW, bool INT, int EPI, bool PRE = false, bool SPLITK = false>
 __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p) {
     constexpr int NW = 4 / MW, BN = 64 * NW, RB = BN / 32;
     constexpr int AROWS = MW == 2 ? 264 : 408;         // >= (TR+2) * WP over the supported W (W = 8: 34 * 12)
@@ -131,14 +137,19 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
     const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wvu % MW, wn = wvu / MW;
     const int nb = p.N / BN;
-    const int logical = xcd_remap_sf(blockIdx.x, gridDim.x);
+    const int logical_all = xcd_remap_sf(blockIdx.x, gridDim.x);
+    // SPLITK: the ksplit workgroups of a tile are neighbours in the logical order (same XCD, same time)
+    const int ksid = SPLITK ? logical_all % p.ksplit : 0;
+    const int logical = SPLITK ? logical_all / p.ksplit : logical_all;
     const int n0 = (logical % nb) * BN;
     const int t = logical / nb;
     const int b = t / p.ntile, tile = t % p.ntile;
     const int W = p.W, logW = p.logW, TR = p.TR, WP = W == 8 ? 12 : W + 2;
     const bool rowkey = W < 32;
     const int h0 = tile * TR;
-    const int KT = p.K >> 4;
+    const int KTALL = p.K >> 4;
+    const int k_begin = SPLITK ? (int)((long)ksid * KTALL / p.ksplit) : 0;
+    const int KT = SPLITK ? (int)((long)(ksid + 1) * KTALL / p.ksplit) : KTALL;       // K-steps [k_begin, KT)
 
     const float sa = sf_scale_of(amax_read(p.x_amax));
     const float inv = 1.0f / (sa * p.wscale[SED_AMAX_SLOTS]);
@@ -244,8 +255,8 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
         SF_AZERO(0) SF_AZERO(1) SF_AZERO(2) SF_AZERO(3) SF_AZERO(4) SF_AZERO(5)
 #undef SF_AZERO
     }
-    sf_aload(0);
-    sf_bdma(0, 0);
+    sf_aload(k_begin);
+    sf_bdma(k_begin * 3, 0);
     sf_astore();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -279,14 +290,14 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 
-    const int nsteps = KT * 3;
+    const int nsteps = (KT - k_begin) * 3, step0 = k_begin * 3;
     int step = 0;
-    for (int ks = 0; ks < KT; ++ks) {
+    for (int ks = k_begin; ks < KT; ++ks) {
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy, ++step) {
             const int st = step & 1;
             if (step + 1 < nsteps) {
-                if (st) { sf_bdma(step + 1, 0) } else { sf_bdma(step + 1, 1) }
+                if (st) { sf_bdma(step0 + step + 1, 0) } else { sf_bdma(step0 + step + 1, 1) }
             }
             if (dy == 0 && ks + 1 < KT) sf_aload(ks + 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -348,6 +359,58 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
         if (p.err_dev) __hip_atomic_store(p.err_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
+    if (SPLITK) {
+        // ---- the K ranges of this tile meet: everyone leaves its accumulators, the last to take a ticket collects them.  The
+        // shares travel with agent-scope (sc1) stores and loads -- they go to the coherence point, whichever XCDs the workgroups
+        // run on -- and NO fence: an agent-scope release / acquire pair writes back and invalidates a whole L2 (~10 us per
+        // workgroup on this 8-XCD part, csrc/gru.hip; the first build of this path used them and was 10-100 % slower than not splitting)
+        __shared__ int sk_last;
+        const long tile_id = logical;
+        float* const mine = p.ws + ((tile_id * p.ksplit + ksid) * 4 + wvu) * 4096 + lane * 4;      // [16 chunks][64 lanes][4 floats]
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float2 v2 = make_float2(acc[a][c][r], acc[a][c][r + 1]);
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(mine + (((a * 2 + c) * 16 + r) >> 2) * 256 + (r & 3)),
+                                       __builtin_bit_cast(unsigned long long, v2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the stores have reached the coherence point
+        __syncthreads();
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(p.tickets + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sk_last = old == p.ksplit - 1;
+            if (sk_last) __hip_atomic_store(p.tickets + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+        __syncthreads();
+        if (!sk_last) return;
+        // sum in the FIXED order 0 .. ksplit - 1, this workgroup's own share re-read like the others': whoever happens to be last,
+        // the result has the same bits (training runs are reproducible, graph replays equal eager steps)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+        for (int o = 0; o < p.ksplit; ++o) {
+            const float* const theirs = p.ws + ((tile_id * p.ksplit + o) * 4 + wvu) * 4096 + lane * 4;
+            floatx4 q[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(q[j]) : "v"(theirs + j * 256) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(q[j]));
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][c][r] += q[((a * 2 + c) * 16 + r) >> 2][r & 3];
+        }
+        __syncthreads();                   // (the epilogues re-use the staging memory behind a barrier of their own; keep the waves together)
+    }
     if (EPI == 3) {
         // ---- inference epilogue: relu(scale * y + shift) -> average pool -> store (accumulator register r of a 32-pixel block
         // holds pixel i = (r & 3) + 4 * kh + 8 * (r >> 2) of it, channel = lane & 31)
@@ -839,6 +902,7 @@ SED_API int sed_conv3x3_sf16_eval_pool(const float* x, const void* wp, const flo
     p.mm = nullptr; p.err_host = err_host; p.err_dev = err_dev;
     p.pool_amax = out_amax; p.ph = ph; p.pw = pw;
     p.x0 = p.w1 = nullptr; p.out_amax = nullptr;
+    p.ksplit = 1; p.ws = nullptr; p.tickets = nullptr;
     const long nblk = (long)B * p.ntile * (Cout / 64);
     if (nblk > 0x7fffffffL) return SED_EINVAL;
     if (in_scale) hipLaunchKernelGGL((conv_sf16_kernel<4, true, 3>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
@@ -847,11 +911,13 @@ SED_API int sed_conv3x3_sf16_eval_pool(const float* x, const void* wp, const flo
     return 0;
 }
 
-SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale, float* y, int B, int H, int W, int Cin,
-                             int Cout, const float* in_scale, const float* in_shift, int epi, float* partials,
-                             const float* yprev, const float* p_scale, const float* p_shift, const float* p_mean,
-                             const float* p_invstd, const float* x_amax, float* minmax, int* err_host, int* err_dev,
-                             int flags, float* out_amax, sed_stream_t stream) {
+namespace {
+int conv_sf16_launch(const float* x, const void* wp, const float* wscale, float* y, int B, int H, int W, int Cin,
+                     int Cout, const float* in_scale, const float* in_shift, int epi, float* partials,
+                     const float* yprev, const float* p_scale, const float* p_shift, const float* p_mean,
+                     const float* p_invstd, const float* x_amax, float* minmax, int* err_host, int* err_dev,
+                     int flags, float* out_amax, int ksplit, float* ws, int* tickets, sed_stream_t stream) {
+    if (ksplit < 1 || ksplit > (Cin >> 4) || (ksplit > 1 && (!ws || !tickets))) return SED_EINVAL;
     if (!x || !wp || !wscale || !y || !x_amax || B <= 0 || !sed_conv3x3_sf16_supported(H, W, Cin, Cout) || epi < 0 || epi > 2)
         return SED_EINVAL;
     // flags bit 0: x holds split-f16 pairs already (sed_conv1_act_sf16 format, scaled by x_amax): epi 0 / 1, no input transform
@@ -878,10 +944,22 @@ SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale
     p.mm = minmax; p.err_host = err_host; p.err_dev = err_dev;
     p.pool_amax = nullptr; p.ph = p.pw = 1;
     p.x0 = p.w1 = nullptr; p.out_amax = out_amax;
-    const long nblk = (long)B * p.ntile * (Cout / (mw == 2 ? 128 : 64));
+    p.ksplit = ksplit; p.ws = ws; p.tickets = tickets;
+    const long nblk = (long)B * p.ntile * (Cout / (mw == 2 ? 128 : 64)) * ksplit;
     if (nblk > 0x7fffffffL) return SED_EINVAL;
     const dim3 g((unsigned)nblk), blk(256);
     hipStream_t s = (hipStream_t)stream;
+    if (ksplit > 1) {
+        const bool itk = in_scale != nullptr;
+#define SF_LAUNCHK(INTV, EPIV, PREV) hipLaunchKernelGGL((conv_sf16_kernel<4, INTV, EPIV, PREV, true>), g, blk, 0, s, p)
+        if (pre) { if (epi == 0) SF_LAUNCHK(false, 0, true); else if (epi == 1) SF_LAUNCHK(false, 1, true); else SF_LAUNCHK(false, 2, true); }
+        else if (epi == 0) { if (itk) SF_LAUNCHK(true, 0, false); else SF_LAUNCHK(false, 0, false); }
+        else if (epi == 1) { if (itk) SF_LAUNCHK(true, 1, false); else SF_LAUNCHK(false, 1, false); }
+        else SF_LAUNCHK(false, 2, false);
+#undef SF_LAUNCHK
+        SED_LAUNCH_CHECK();
+        return 0;
+    }
 #define SF_LAUNCH(MWV, INTV, EPIV) hipLaunchKernelGGL((conv_sf16_kernel<MWV, INTV, EPIV>), g, blk, 0, s, p)
     const bool it = in_scale != nullptr;
     if (pre) {
@@ -896,6 +974,51 @@ SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale
 #undef SF_LAUNCH
     SED_LAUNCH_CHECK();
     return 0;
+}
+}  // namespace
+
+SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale, float* y, int B, int H, int W, int Cin,
+                             int Cout, const float* in_scale, const float* in_shift, int epi, float* partials,
+                             const float* yprev, const float* p_scale, const float* p_shift, const float* p_mean,
+                             const float* p_invstd, const float* x_amax, float* minmax, int* err_host, int* err_dev,
+                             int flags, float* out_amax, sed_stream_t stream) {
+    return conv_sf16_launch(x, wp, wscale, y, B, H, W, Cin, Cout, in_scale, in_shift, epi, partials, yprev, p_scale, p_shift, p_mean,
+                            p_invstd, x_amax, minmax, err_host, err_dev, flags, out_amax, 1, nullptr, nullptr, stream);
+}
+
+// Small-M form: when a launch has fewer workgroups than the chip has resident slots (4 clips per GPU: the 512-channel layers run
+// 128 workgroups of 96 dependent stages on 256 CUs), `ksplit` workgroups share one output tile, each over 1/ksplit of the K-steps,
+// and the last one to arrive adds the others' accumulators and runs the (unchanged) epilogue.  sed_conv_sf16_ksplit: the split this
+// library would choose (1: do not split); ws: sed_conv_sf16_splitk_floats(...) floats; tickets: sed_conv_sf16_splitk_tickets(...)
+// ints, ZERO before the first use (every launch leaves them zero again).
+SED_API int sed_conv_sf16_ksplit(int B, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || !sed_conv3x3_sf16_supported(H, W, Cin, Cout)) return 1;
+    const int tr = 256 >> sf_log2w(W);
+    const long wgs = (long)B * ((H + tr - 1) / tr) * (Cout / 64);
+    const int kt = Cin >> 4;
+    int s = 1;
+    // Only launches that leave most CUs EMPTY are split (<= 160 workgroups on 256 CUs; measured at 4 clips per GPU: the 250 x 16
+    // layers -- 252 workgroups -- lose 20-40 % when split, the 125 x 8 layers -- 64-128 workgroups -- gain 15-50 %), up to the
+    // 768 resident slots, never below 6 K-steps per share (prologue + epilogue of a workgroup cost about 2)
+    if (wgs > 160) return 1;
+    while (s < 8 && wgs * (s * 2) <= 768 && kt / (s * 2) >= 6) s *= 2;
+    return s;
+}
+SED_API long sed_conv_sf16_splitk_floats(int B, int H, int W, int Cout, int ksplit) {
+    const int tr = 256 >> sf_log2w(W);
+    return (long)B * ((H + tr - 1) / tr) * (Cout / 64) * ksplit * 16384L;
+}
+SED_API long sed_conv_sf16_splitk_tickets(int B, int H, int W, int Cout) {
+    const int tr = 256 >> sf_log2w(W);
+    return (long)B * ((H + tr - 1) / tr) * (Cout / 64);
+}
+SED_API int sed_conv3x3_sf16_splitk(const float* x, const void* wp, const float* wscale, float* y, int B, int H, int W, int Cin,
+                                    int Cout, const float* in_scale, const float* in_shift, int epi, float* partials,
+                                    const float* yprev, const float* p_scale, const float* p_shift, const float* p_mean,
+                                    const float* p_invstd, const float* x_amax, float* minmax, int* err_host, int* err_dev,
+                                    int flags, float* out_amax, int ksplit, float* ws, int* tickets, sed_stream_t stream) {
+    return conv_sf16_launch(x, wp, wscale, y, B, H, W, Cin, Cout, in_scale, in_shift, epi, partials, yprev, p_scale, p_shift, p_mean,
+                            p_invstd, x_amax, minmax, err_host, err_dev, flags, out_amax, ksplit, ws, tickets, stream);
 }
 
 // Block 1's dgrad (round 4): g_y1 = conv_transpose(gy, w2) masked by relu'(bn1(y1)) + the BatchNorm-backward sums of bn1, with
@@ -925,6 +1048,7 @@ SED_API int sed_conv3x3_sf16_dgrad_b1(const float* gy, const void* wp, const flo
     p.mm = nullptr; p.err_host = err_host; p.err_dev = err_dev;
     p.pool_amax = nullptr; p.ph = p.pw = 1;
     p.x0 = x0; p.w1 = w1_oihw; p.out_amax = out_amax;
+    p.ksplit = 1; p.ws = nullptr; p.tickets = nullptr;
     const long nblk = (long)B * p.ntile * (Cout / 64);
     if (nblk > 0x7fffffffL) return SED_EINVAL;
     if (flags & 1) hipLaunchKernelGGL((conv_sf16_kernel<4, false, 4, true>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);

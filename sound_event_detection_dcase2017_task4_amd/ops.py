@@ -999,15 +999,50 @@ def conv3x3_sf16(x, pack, B, H, W, Cin, Cout, in_st=None, epi=0, partials=None, 
     if x_amax is None:
         x_amax = act_amax_full(x, in_st) if in_st is not None else amax_of(x)
     y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+    ks = _conv_ksplit(B, H, W, Cin, Cout)
     with _timed("conv3x3_sf16_mfma(fwd+dgrad)|%d->%d@%dx%d epi%d%s", (Cin, Cout, H, W, epi, "+inT" if in_st is not None else ""),
                 2.0 * 9 * B * H * W * Cin * Cout):
-        _call("sed_conv3x3_sf16", _ptr(x), _ptr(wp), _ptr(wscale), _ptr(y), B, H, W, Cin, Cout,
-              _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, epi,
-              _ptr(partials), _ptr(yprev), _ptr(p_st.scale) if p_st is not None else None,
-              _ptr(p_st.shift) if p_st is not None else None, _ptr(p_st.mean) if p_st is not None else None,
-              _ptr(p_st.invstd) if p_st is not None else None, _ptr(x_amax), _ptr(minmax), _sf16_err_ptr(),
-              _sf16_err_dev_ptr(x.device), 1 if presplit else 0, _ptr(out_amax), _stream())
+        args = (_ptr(x), _ptr(wp), _ptr(wscale), _ptr(y), B, H, W, Cin, Cout,
+                _ptr(in_st.scale) if in_st is not None else None, _ptr(in_st.shift) if in_st is not None else None, epi,
+                _ptr(partials), _ptr(yprev), _ptr(p_st.scale) if p_st is not None else None,
+                _ptr(p_st.shift) if p_st is not None else None, _ptr(p_st.mean) if p_st is not None else None,
+                _ptr(p_st.invstd) if p_st is not None else None, _ptr(x_amax), _ptr(minmax), _sf16_err_ptr(),
+                _sf16_err_dev_ptr(x.device), 1 if presplit else 0, _ptr(out_amax))
+        if ks > 1:
+            # small-M launch (fewer workgroups than resident slots): `ks` workgroups per output tile, each over 1/ks of the K-steps
+            L = _lib.lib()
+            ws = torch.empty((L.sed_conv_sf16_splitk_floats(B, H, W, Cout, ks),), dtype=torch.float32, device=x.device)
+            tickets = _splitk_tickets(x.device, L.sed_conv_sf16_splitk_tickets(B, H, W, Cout))
+            _call("sed_conv3x3_sf16_splitk", *(args + (ks, _ptr(ws), _ptr(tickets), _stream())))
+        else:
+            _call("sed_conv3x3_sf16", *(args + (_stream(),)))
     return y
+
+
+CONV_SPLITK = os.environ.get("SED_CONV_SPLITK", "1") != "0"      # small-M convolutions split their K range over workgroups
+_KSPLIT = {}
+_TICKETS = {}
+
+
+def _conv_ksplit(B, H, W, Cin, Cout):
+    if not CONV_SPLITK:
+        return 1
+    key = (B, H, W, Cin, Cout)
+    v = _KSPLIT.get(key)
+    if v is None:
+        v = _KSPLIT[key] = int(_lib.lib().sed_conv_sf16_ksplit(B, H, W, Cin, Cout))
+    return v
+
+
+def _splitk_tickets(device, n):
+    """Per-device ticket words of the split-K convolutions: zero once; every launch leaves them zero (the last workgroup of a tile
+    resets its ticket), and launches on one stream never overlap, so ONE buffer serves them all."""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    t = _TICKETS.get(key)
+    if t is None or t.numel() < n:
+        t = _TICKETS[key] = torch.zeros((max(int(n), 4096),), dtype=torch.int32, device=torch.device("cuda", key))
+    return t
 
 
 def _conv_algo(H, W, Cin, Cout):

@@ -637,3 +637,72 @@ def test_sf16_random_shape_sweep_forward_dgrad_wgrad_vs_float64(B, H, W, Cin, Co
         assert rel < 1e-6 and mx < 1e-5, ("wgrad", rel, mx)
     torch.cuda.synchronize()
     ops.check_device_errors(synchronize=True)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 125, 8, 512, 512), (2, 125, 8, 256, 512), (1, 250, 16, 256, 256), (1, 37, 32, 256, 128),
+                                            (3, 13, 8, 512, 256)])
+def test_sf16_split_k_small_m_launches(B, H, W, Cin, Cout, monkeypatch):
+    """Small-M launches (the reference's `--batch_size 32` over 8 GPUs leaves 4 clips per GPU: the 512-channel layers are 128
+    workgroups of 96 dependent stages on 256 CUs) split their K range over `ksplit` workgroups per output tile; the last one to
+    arrive adds the others' accumulators and runs the UNCHANGED epilogue.  Checked against float64 and against the un-split launch
+    for every epilogue the training step uses: plain / statistics + range (with and without the fused operand transform), and the
+    dgrad form with ReLU mask + BatchNorm-backward sums; the tickets are back at zero afterwards, and a second launch agrees with
+    the first bit for bit (same partial sums, same order)."""
+    from sound_event_detection_dcase2017_task4_amd import ops
+    L = ops._lib.lib()
+    ks = int(L.sed_conv_sf16_ksplit(B, H, W, Cin, Cout))
+    assert ks > 1, "pick a shape the library splits"
+    g = torch.Generator().manual_seed(B + H + Cin)
+    x = torch.randn((B, H, W, Cin), generator=g)
+    w = (torch.rand((Cout, Cin, 3, 3), generator=g) * 2 - 1) * float(np.sqrt(6.0 / (9 * Cin + 9 * Cout)))
+    scale, shift = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    st = ops.BnStats(Cin, "cuda"); st.scale.copy_(scale); st.shift.copy_(shift)
+    xd, wd = x.cuda(), w.cuda()
+    pack = ops.pack_sf16(wd)
+    P = int(L.sed_conv_sf16_num_parts(B, H, W, Cout))
+
+    def run(split, in_st, epi):
+        monkeypatch.setattr(ops, "CONV_SPLITK", split)
+        parts = torch.zeros((P * 2 * Cout + P,), device="cuda") if epi else None
+        mm = torch.zeros((P, 2, Cout), device="cuda")
+        y = ops.conv3x3_sf16(xd, pack, B, H, W, Cin, Cout, in_st=in_st, epi=epi, partials=parts, minmax=mm)
+        torch.cuda.synchronize()
+        return y, parts, mm
+
+    for in_st, sc, sh in ((None, None, None), (st, scale, shift)):
+        want = _ref(x, w, sc, sh)
+        for epi in (0, 1):
+            y1, p1, m1 = run(True, in_st, epi)
+            y0, p0, m0 = run(False, in_st, epi)
+            rel, mx = _err(y1, want)
+            assert rel < 1e-6 and mx < 1e-5, (in_st is not None, epi, rel, mx)
+            assert (y1 - y0).abs().max().item() <= 2e-6 * want.abs().max().item()
+            assert torch.allclose(m1, m0, rtol=1e-5, atol=2e-6 * float(want.abs().max()))
+            if epi:
+                n = P * Cout
+                assert torch.allclose(p1[:n], p0[:n], rtol=1e-4, atol=1e-3) and torch.equal(p1[2 * n:], p0[2 * n:])     # sums, counts
+                assert torch.allclose(p1[n:2 * n], p0[n:2 * n], rtol=1e-3, atol=1e-3)                                   # M2
+            y2, _, _ = run(True, in_st, epi)
+            assert torch.equal(y1, y2)
+    # dgrad form: transposed convolution of a gradient-sized tensor, masked by relu'(bn(yprev)), with the BatchNorm-backward sums
+    ks_d = int(L.sed_conv_sf16_ksplit(B, H, W, Cout, Cin))
+    if ks_d > 1:
+        gy = (torch.randn((B, H, W, Cout), generator=g) * 1e-5).cuda()
+        yprev = torch.randn((B, H, W, Cin), generator=g).cuda()
+        pst = ops.BnStats(Cin, "cuda"); pst.scale.copy_(scale); pst.shift.copy_(shift); pst.mean.fill_(0.1); pst.invstd.fill_(0.9)
+        packd = ops.pack_sf16(wd, dgrad=True)
+        Pd = int(L.sed_conv_sf16_num_parts(B, H, W, Cin))
+        outs = []
+        for split in (True, False):
+            monkeypatch.setattr(ops, "CONV_SPLITK", split)
+            parts = torch.zeros((Pd * 2 * Cin,), device="cuda")
+            gx = ops.conv3x3_sf16(gy, packd, B, H, W, Cout, Cin, epi=2, partials=parts, yprev=yprev, p_st=pst)
+            torch.cuda.synchronize()
+            outs.append((gx, parts))
+        (g1, q1), (g0, q0) = outs
+        assert torch.equal(g1 == 0, g0 == 0)                                   # the same ReLU mask
+        assert (g1 - g0).abs().max().item() <= 2e-6 * g0.abs().max().item()
+        assert torch.allclose(q1, q0, rtol=1e-4, atol=1e-6 * float(q0.abs().max()))
+    t = ops._TICKETS[torch.cuda.current_device()]
+    assert int(t.abs().sum()) == 0
+    ops.check_device_errors(synchronize=True)
