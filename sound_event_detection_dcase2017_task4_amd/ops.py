@@ -1035,13 +1035,14 @@ def _conv_ksplit(B, H, W, Cin, Cout):
 
 
 def _splitk_tickets(device, n):
-    """Per-device ticket words of the split-K convolutions: zero once; every launch leaves them zero (the last workgroup of a tile
-    resets its ticket), and launches on one stream never overlap, so ONE buffer serves them all."""
+    """Ticket words of the split-K convolutions, one buffer per (device, stream): zero once; every launch leaves them zero (the
+    last workgroup of a tile resets its ticket) and launches on ONE stream never overlap -- two streams must not share tickets."""
     dev = torch.device(device)
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, int(_stream() or 0))
     t = _TICKETS.get(key)
     if t is None or t.numel() < n:
-        t = _TICKETS[key] = torch.zeros((max(int(n), 4096),), dtype=torch.int32, device=torch.device("cuda", key))
+        t = _TICKETS[key] = torch.zeros((max(int(n), 4096),), dtype=torch.int32, device=torch.device("cuda", idx))
     return t
 
 
