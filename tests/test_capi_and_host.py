@@ -425,3 +425,56 @@ def test_bench_refuses_to_quote_stale_pmc_figures(tmp_path, monkeypatch):
     (prof / "pmc_traffic_b32.json").write_text(json.dumps(dict(body, _meta={"sources": other})))
     val, src = bench.pmc_traffic(["conv_sf16_kernel"], "pmc_traffic_b32.json")
     assert val is None and "NOT quoted" in src
+
+
+def test_hdf5_pack_branch_through_a_stand_in_h5py(tmp_path, monkeypatch):
+    """The reference reads its packs with h5py (`h5py.File(path, 'r')`, `hf['waveform'][index]`, `hf.keys()`, context manager:
+    data_generator.py:37-47, features.py:232-260).  h5py is not installed here, so the `.h5` branch of `open_store` could never
+    run; a stand-in module with exactly that access surface (backed by the arrays of a pack) is put in `sys.modules` and the same
+    samplers / dataset / threaded loader must hand out the same batches from `<pack>.h5` as from the `.npy` directory.  (This
+    pins the branch's own logic -- names as bytes, int16 rows, the optional strong_target -- not the HDF5 file format.)"""
+    import sys
+    import types
+    from sound_event_detection_dcase2017_task4_amd.utils import data_generator as dg
+    rs = np.random.RandomState(3)
+    N, L = 21, 320
+    arrays = {"waveform": (rs.randn(N, L) * 2000).astype(np.int16), "target": (rs.rand(N, 17) < 0.2).astype(np.float32),
+              "strong_target": rs.rand(N, 3, 17) < 0.3, "audio_name": np.array([("h%02d.wav" % i).encode() for i in range(N)])}
+    d = tmp_path / "pack"
+    d.mkdir()
+    for k, v in arrays.items():
+        np.save(d / (k + ".npy"), v)
+    opened = []
+
+    class File(object):                                   # the h5py.File surface the reference (and this build) uses
+        def __init__(self, path, mode):
+            assert mode == "r" and path.endswith(".h5")
+            opened.append(path)
+        def __enter__(self):
+            return self
+        def __exit__(self, *a):
+            return False
+        def __getitem__(self, k):
+            return arrays[k]
+        def keys(self):
+            return arrays.keys()
+        def close(self):
+            pass
+    fake = types.ModuleType("h5py")
+    fake.File = File
+    monkeypatch.setitem(sys.modules, "h5py", fake)
+    h5 = str(tmp_path / "training.h5")
+    open(h5, "wb").close()                                # a FILE ending in .h5 selects the h5py branch
+    a = dg.PinnedBatchLoader(h5, dg.TrainSampler(h5, 6), depth=2, threads=2)
+    b = dg.PinnedBatchLoader(str(d), dg.TrainSampler(str(d), 6), depth=2, threads=2)
+    ia, ib = iter(a), iter(b)
+    for _ in range(9):                                    # > 2 epochs: across the sampler's reshuffle
+        x, y = next(ia), next(ib)
+        assert x["audio_name"] == y["audio_name"] and x["waveform"].dtype == torch.int16
+        for k in ("waveform", "target", "strong_target"):
+            assert torch.equal(x[k], y[k]), k
+    ia.close(); ib.close()
+    item = dg.DCASE2017Task4Dataset()[{"hdf5_path": h5, "index_in_hdf5": 4}]
+    assert item["audio_name"] == "h04.wav" and item["waveform"].dtype == np.float32
+    np.testing.assert_allclose(item["waveform"], arrays["waveform"][4] / 32767.0, rtol=1e-6)
+    assert opened
