@@ -31,7 +31,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 from sound_event_detection_dcase2017_task4_amd import ops, parallel
-from sound_event_detection_dcase2017_task4_amd.graph import GraphedTrainStep
+from sound_event_detection_dcase2017_task4_amd.graph import GraphCaptureError, GraphedTrainStep
 from sound_event_detection_dcase2017_task4_amd.optim import FusedAdamAmsgrad
 from sound_event_detection_dcase2017_task4_amd.pytorch import models
 from sound_event_detection_dcase2017_task4_amd.pytorch.losses import get_loss_func
@@ -294,13 +294,20 @@ class Workload(object):
                 out = self.model(wave, None)
             return out["clipwise_output"].sum()
         if self.graphed is not None:
+            lam_h = self.mixup.get_lambda(self.B2) if self.mix else None
             try:
-                return self.graphed(wave, target, self.mixup.get_lambda(self.B2) if self.mix else None)
-            except ops.NonFiniteOperand:
-                raise
-            except Exception as e:             # capture refused (never seen; a side feature must not lose the line): eager from here on
+                return self.graphed(wave, target, lam_h)
+            except GraphCaptureError as e:     # capture refused (on every rank together; nothing of this step has run): eager from here on
                 self.hip_graph_error, self.graphed = repr(e), None
                 torch.cuda.synchronize()
+                if self.mix:                   # the lambdas drawn for this step are used by the eager body below
+                    lam = ops.upload_small(lam_h, self.dev, torch.float32)
+                    out = self.model(wave, lam)
+                    loss = self.loss_func(out, {"target": do_mixup(target, lam)})
+                    self.opt.zero_grad()
+                    loss.backward()
+                    self.opt.step()
+                    return loss
         if self.mix:
             lam = ops.upload_small(self.mixup.get_lambda(self.B2), self.dev, torch.float32)   # pinned staging, async
             out = self.model(wave, lam)

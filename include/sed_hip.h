@@ -230,19 +230,26 @@ int sed_conv3x3_wgrad_wino2(const float* x, const float* gy, float* dw_oihw, flo
  * channel, [sed_conv_sf16_num_parts(...)][2][Cout], the input of sed_act_amax for the NEXT convolution.
  * Needs W in {8,16,32,64}, Cin % 16 == 0, Cout % 64 == 0. */
 int sed_conv3x3_sf16_supported(int H, int W, int Cin, int Cout);
-/* Small-M form of sed_conv3x3_sf16 (same arguments and results up to summation order): `ksplit` workgroups share one output tile,
- * each over 1/ksplit of the K-steps; the last to arrive adds the others' accumulators (ws) and runs the epilogue.  For launches with
- * fewer workgroups than resident slots -- the reference's `--batch_size 32` spread over 8 GPUs (main.py:138) leaves 4 clips per GPU.
- * sed_conv_sf16_ksplit: the split the library recommends (1 = none); ws: sed_conv_sf16_splitk_floats(...) floats; tickets:
- * sed_conv_sf16_splitk_tickets(...) ints, zero before the FIRST use (every launch leaves them zero). */
+/* Split-K forms of sed_conv3x3_sf16 (same arguments and results up to summation order): `ksplit` workgroups share one output tile,
+ * each over 1/ksplit of the K-steps; the last to arrive adds the others' accumulators (ws) in a fixed order and runs the epilogue.
+ * Tiles [0, nfull) of the launch stay un-split (nfull % 8 == 0).  nfull = 0: the small-M form, for launches with fewer workgroups
+ * than resident slots -- the reference's `--batch_size 32` spread over 8 GPUs (main.py:138) leaves 4 clips per GPU.  nfull = a
+ * multiple of the 768 resident slots: the tail form -- only the workgroups of the last, partial round of the chip are split (the
+ * 125 x 8 layers at the metric's own batch, 32 clips: 1024 workgroups = 1.33 rounds).  Measured slower than not splitting on every
+ * production shape (profiles/r06/tail_split_ab.txt), so the library's own rule never selects it: tail_ks = 0 asks for that rule,
+ * tail_ks = 2 .. 8 forces a tail split that many ways (A/B runs, tests).
+ * sed_conv_sf16_split_plan: the split the library recommends (returns ksplit, 1 = none; *nfull); sed_conv_sf16_ksplit: its small-M
+ * part alone; ws: sed_conv_sf16_splitk_floats(...) floats; tickets: sed_conv_sf16_splitk_tickets(...) ints, zero before the FIRST
+ * use (every launch leaves them zero). */
+int sed_conv_sf16_split_plan(int B, int H, int W, int Cin, int Cout, int tail_ks, int* nfull);
 int sed_conv_sf16_ksplit(int B, int H, int W, int Cin, int Cout);
-long sed_conv_sf16_splitk_floats(int B, int H, int W, int Cout, int ksplit);
-long sed_conv_sf16_splitk_tickets(int B, int H, int W, int Cout);
+long sed_conv_sf16_splitk_floats(int B, int H, int W, int Cout, int ksplit, int nfull);
+long sed_conv_sf16_splitk_tickets(int B, int H, int W, int Cout, int nfull);
 int sed_conv3x3_sf16_splitk(const float* x, const void* wp, const float* wscale, float* y, int B, int H, int W, int Cin, int Cout,
                             const float* in_scale, const float* in_shift, int epi, float* partials, const float* yprev,
                             const float* p_scale, const float* p_shift, const float* p_mean, const float* p_invstd,
                             const float* x_amax, float* minmax, int* err_host, int* err_dev, int flags, float* out_amax,
-                            int ksplit, float* ws, int* tickets, sed_stream_t stream);
+                            int ksplit, int nfull, float* ws, int* tickets, sed_stream_t stream);
 long sed_conv_sf16_pack_halfs(int Cin, int Cout);
 long sed_conv_sf16_num_parts(int B, int H, int W, int Cout);
 /* Device-resident amax values are float[sed_amax_slots()] (= 64), NOT one float: producers publish one atomic per block

@@ -61,10 +61,14 @@ struct Sf16P {
     // EPI 4 (block 1's dgrad): the previous activations y1 = conv1(x0) are RECOMPUTED from the one-channel input
     const float* x0;           // [B][H][W]
     const float* w1;           // conv1 weights [64][9] (OIHW with I = 1)
-    // SPLITK (small-M launches: fewer workgroups than resident slots): ksplit workgroups share one output tile, each over its
-    // range of K-steps; they leave their raw accumulators in ws [tile][ksplit][4 waves][64 registers][64 lanes] and the LAST one
-    // to arrive (per-tile ticket in `tickets`, self-resetting) adds the others' and runs the epilogue
+    // SPLITK: ksplit workgroups share one output tile, each over its range of K-steps; they leave their raw accumulators in ws
+    // [split tile][ksplit][4 waves][64 registers][64 lanes] and the LAST one to arrive (per-tile ticket in `tickets`,
+    // self-resetting) adds the others' and runs the epilogue.  Workgroups [0, nfull) of the grid are ordinary UN-split tiles, the
+    // rest are the shares of tiles nfull ..: nfull = 0 is the small-M form (fewer tiles than resident slots: every tile is split),
+    // nfull = a multiple of the 768 resident slots is the TAIL split (the tiles of the last, partial round of the chip are split
+    // so that their shares fill it; the full rounds in front of them run exactly as in the un-split kernel)
     int ksplit;
+    int nfull;
     float* ws;
     int* tickets;
 };
@@ -137,10 +141,17 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
     const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wvu % MW, wn = wvu / MW;
     const int nb = p.N / BN;
-    const int logical_all = xcd_remap_sf(blockIdx.x, gridDim.x);
-    // SPLITK: the ksplit workgroups of a tile are neighbours in the logical order (same XCD, same time)
-    const int ksid = SPLITK ? logical_all % p.ksplit : 0;
-    const int logical = SPLITK ? logical_all / p.ksplit : logical_all;
+    // SPLITK: workgroups [0, nfull) are un-split tiles (dispatched first: the full rounds), the rest are shares; the ksplit shares
+    // of a tile are neighbours in the logical order (same XCD, same time)
+    int ksid = 0, logical, ks_here = 1;
+    if (SPLITK && (int)blockIdx.x >= p.nfull) {
+        const int tl = xcd_remap_sf((int)blockIdx.x - p.nfull, (int)gridDim.x - p.nfull);
+        ks_here = p.ksplit;
+        ksid = tl % ks_here;
+        logical = p.nfull + tl / ks_here;
+    } else {
+        logical = xcd_remap_sf(blockIdx.x, SPLITK ? p.nfull : (int)gridDim.x);
+    }
     const int n0 = (logical % nb) * BN;
     const int t = logical / nb;
     const int b = t / p.ntile, tile = t % p.ntile;
@@ -148,8 +159,8 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
     const bool rowkey = W < 32;
     const int h0 = tile * TR;
     const int KTALL = p.K >> 4;
-    const int k_begin = SPLITK ? (int)((long)ksid * KTALL / p.ksplit) : 0;
-    const int KT = SPLITK ? (int)((long)(ksid + 1) * KTALL / p.ksplit) : KTALL;       // K-steps [k_begin, KT)
+    const int k_begin = SPLITK ? (int)((long)ksid * KTALL / ks_here) : 0;
+    const int KT = SPLITK ? (int)((long)(ksid + 1) * KTALL / ks_here) : KTALL;       // K-steps [k_begin, KT)
 
     const float sa = sf_scale_of(amax_read(p.x_amax));
     const float inv = 1.0f / (sa * p.wscale[SED_AMAX_SLOTS]);
@@ -359,13 +370,20 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
         if (p.err_dev) __hip_atomic_store(p.err_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
-    if (SPLITK) {
+    if (SPLITK && ks_here > 1) {
         // ---- the K ranges of this tile meet: everyone leaves its accumulators, the last to take a ticket collects them.  The
         // shares travel with agent-scope (sc1) stores and loads -- they go to the coherence point, whichever XCDs the workgroups
         // run on -- and NO fence: an agent-scope release / acquire pair writes back and invalidates a whole L2 (~10 us per
         // workgroup on this 8-XCD part, csrc/gru.hip; the first build of this path used them and was 10-100 % slower than not splitting)
+        // (What this rests on, stated once: a relaxed agent-scope store is written THROUGH to the device coherence point and
+        // `s_waitcnt vmcnt(0)` returns when that write has been acknowledged; the ticket is an agent-scope atomic executed at the
+        // same point; the shares are read back with sc1 loads, which bypass the reader's own non-coherent cache levels.  The HIP
+        // memory model promises this ordering only through fences; gfx950 delivers it for this pattern, and the stress test
+        // tests/test_gpu_sf16.py::test_sf16_split_k_exchange_across_xcds holds it to bit equality over thousands of groups that
+        // straddle XCDs.  The tickets are per stream and self-resetting; ops.clear_nonfinite_flags() / recover() zero them, so an
+        // aborted launch cannot leave a later one without its epilogue.)
         __shared__ int sk_last;
-        const long tile_id = logical;
+        const long tile_id = logical - p.nfull;
         float* const mine = p.ws + ((tile_id * p.ksplit + ksid) * 4 + wvu) * 4096 + lane * 4;      // [16 chunks][64 lanes][4 floats]
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -902,7 +920,7 @@ SED_API int sed_conv3x3_sf16_eval_pool(const float* x, const void* wp, const flo
     p.mm = nullptr; p.err_host = err_host; p.err_dev = err_dev;
     p.pool_amax = out_amax; p.ph = ph; p.pw = pw;
     p.x0 = p.w1 = nullptr; p.out_amax = nullptr;
-    p.ksplit = 1; p.ws = nullptr; p.tickets = nullptr;
+    p.ksplit = 1; p.nfull = 0; p.ws = nullptr; p.tickets = nullptr;
     const long nblk = (long)B * p.ntile * (Cout / 64);
     if (nblk > 0x7fffffffL) return SED_EINVAL;
     if (in_scale) hipLaunchKernelGGL((conv_sf16_kernel<4, true, 3>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
@@ -916,8 +934,8 @@ int conv_sf16_launch(const float* x, const void* wp, const float* wscale, float*
                      int Cout, const float* in_scale, const float* in_shift, int epi, float* partials,
                      const float* yprev, const float* p_scale, const float* p_shift, const float* p_mean,
                      const float* p_invstd, const float* x_amax, float* minmax, int* err_host, int* err_dev,
-                     int flags, float* out_amax, int ksplit, float* ws, int* tickets, sed_stream_t stream) {
-    if (ksplit < 1 || ksplit > (Cin >> 4) || (ksplit > 1 && (!ws || !tickets))) return SED_EINVAL;
+                     int flags, float* out_amax, int ksplit, int nfull, float* ws, int* tickets, sed_stream_t stream) {
+    if (ksplit < 1 || ksplit > (Cin >> 4) || (ksplit > 1 && (!ws || !tickets)) || nfull < 0 || (nfull & 7)) return SED_EINVAL;
     if (!x || !wp || !wscale || !y || !x_amax || B <= 0 || !sed_conv3x3_sf16_supported(H, W, Cin, Cout) || epi < 0 || epi > 2)
         return SED_EINVAL;
     // flags bit 0: x holds split-f16 pairs already (sed_conv1_act_sf16 format, scaled by x_amax): epi 0 / 1, no input transform
@@ -944,8 +962,10 @@ int conv_sf16_launch(const float* x, const void* wp, const float* wscale, float*
     p.mm = minmax; p.err_host = err_host; p.err_dev = err_dev;
     p.pool_amax = nullptr; p.ph = p.pw = 1;
     p.x0 = p.w1 = nullptr; p.out_amax = out_amax;
-    p.ksplit = ksplit; p.ws = ws; p.tickets = tickets;
-    const long nblk = (long)B * p.ntile * (Cout / (mw == 2 ? 128 : 64)) * ksplit;
+    p.ksplit = ksplit; p.nfull = ksplit > 1 ? nfull : 0; p.ws = ws; p.tickets = tickets;
+    const long ntiles = (long)B * p.ntile * (Cout / (mw == 2 ? 128 : 64));
+    if (ksplit > 1 && nfull >= ntiles) return SED_EINVAL;            // nothing left to split
+    const long nblk = ksplit > 1 ? nfull + (ntiles - nfull) * ksplit : ntiles;
     if (nblk > 0x7fffffffL) return SED_EINVAL;
     const dim3 g((unsigned)nblk), blk(256);
     hipStream_t s = (hipStream_t)stream;
@@ -983,42 +1003,74 @@ SED_API int sed_conv3x3_sf16(const float* x, const void* wp, const float* wscale
                              const float* p_invstd, const float* x_amax, float* minmax, int* err_host, int* err_dev,
                              int flags, float* out_amax, sed_stream_t stream) {
     return conv_sf16_launch(x, wp, wscale, y, B, H, W, Cin, Cout, in_scale, in_shift, epi, partials, yprev, p_scale, p_shift, p_mean,
-                            p_invstd, x_amax, minmax, err_host, err_dev, flags, out_amax, 1, nullptr, nullptr, stream);
+                            p_invstd, x_amax, minmax, err_host, err_dev, flags, out_amax, 1, 0, nullptr, nullptr, stream);
 }
 
-// Small-M form: when a launch has fewer workgroups than the chip has resident slots (4 clips per GPU: the 512-channel layers run
-// 128 workgroups of 96 dependent stages on 256 CUs), `ksplit` workgroups share one output tile, each over 1/ksplit of the K-steps,
-// and the last one to arrive adds the others' accumulators and runs the (unchanged) epilogue.  sed_conv_sf16_ksplit: the split this
-// library would choose (1: do not split); ws: sed_conv_sf16_splitk_floats(...) floats; tickets: sed_conv_sf16_splitk_tickets(...)
-// ints, ZERO before the first use (every launch leaves them zero again).
-SED_API int sed_conv_sf16_ksplit(int B, int H, int W, int Cin, int Cout) {
+// Split-K forms.  `ksplit` workgroups share one output tile, each over 1/ksplit of the K-steps, and the last one to arrive adds the
+// others' accumulators (fixed order: the same bits whoever is last) and runs the (unchanged) epilogue.  Tiles [0, nfull) of the
+// launch stay un-split.
+//   small-M (round 5; nfull = 0): a launch with fewer workgroups than the chip has resident slots (4 clips per GPU: the
+//     512-channel layers are 128 workgroups of 96 dependent stages on 256 CUs) splits EVERY tile;
+//   tail (round 6; nfull = a multiple of the 768 resident slots): at the metric's batch (bs = 32) the 125 x 8 layers are 1024
+//     workgroups = 1.33 rounds of the chip; the 256 workgroups of the last round, split three ways, are 768 workgroups of a third
+//     of the work each -- a full round again.  Built, parity-green, measured, and NOT selected by the library (see below).
+// sed_conv_sf16_split_plan: the split this library would choose -- returns ksplit (1: do not split) and *nfull; ws:
+// sed_conv_sf16_splitk_floats(...) floats; tickets: sed_conv_sf16_splitk_tickets(...) ints, ZERO before the first use (every launch
+// leaves them zero again).
+namespace {
+constexpr int SF_SLOTS = 768;        // resident workgroups of conv_sf16_kernel<4, ...>: 256 CUs x 3
+}  // namespace
+// tail_ks: 0 = the library's rule for tails, 2 .. 8 = split a partial last round that many ways wherever one exists (A/B runs, tests).
+// THE LIBRARY'S RULE IS "NEVER" (round 6, profiles/r06/tail_split_ab.txt): at the metric's batch every production shape was
+// timed un-split and with its tail split 2 / 3 / 4 ways -- the split form is 0-4 % SLOWER on the 125 x 8 layers it was built for
+// (512 -> 512: 0.349 ms un-split, 0.350 / 0.366 / 0.356 split) and 3-30 % slower elsewhere; whole step 8.16 -> 8.24 ms.  The
+// dispatcher already fills a partial round well: a workgroup alone on a CU gets close to the MFMA share three get together, so
+// the tail of 256 workgroups costs ~0.4 of a round, not 1, and the exchange (64 KB per share through the coherence point + the
+// re-read by the last arriver, ~15 us) is more than what is left to win.
+SED_API int sed_conv_sf16_split_plan(int B, int H, int W, int Cin, int Cout, int tail_ks, int* nfull) {
+    if (nfull) *nfull = 0;
     if (B <= 0 || !sed_conv3x3_sf16_supported(H, W, Cin, Cout)) return 1;
     const int tr = 256 >> sf_log2w(W);
     const long wgs = (long)B * ((H + tr - 1) / tr) * (Cout / 64);
     const int kt = Cin >> 4;
-    int s = 1;
-    // Only launches that leave most CUs EMPTY are split (<= 160 workgroups on 256 CUs; measured at 4 clips per GPU: the 250 x 16
-    // layers -- 252 workgroups -- lose 20-40 % when split, the 125 x 8 layers -- 64-128 workgroups -- gain 15-50 %), up to the
-    // 768 resident slots, never below 6 K-steps per share (prologue + epilogue of a workgroup cost about 2)
-    if (wgs > 160) return 1;
-    while (s < 8 && wgs * (s * 2) <= 768 && kt / (s * 2) >= 6) s *= 2;
+    if (wgs <= 160) {
+        // small-M: only launches that leave most CUs EMPTY are split (<= 160 workgroups on 256 CUs; measured at 4 clips per GPU:
+        // the 250 x 16 layers -- 252 workgroups -- lose 20-40 % when split, the 125 x 8 layers -- 64-128 workgroups -- gain
+        // 15-50 %), up to the 768 resident slots, never below 6 K-steps per share (prologue + epilogue of a workgroup cost about 2)
+        int s = 1;
+        while (s < 8 && wgs * (s * 2) <= SF_SLOTS && kt / (s * 2) >= 6) s *= 2;
+        return s;
+    }
+    if (tail_ks < 2 || tail_ks > 8 || wgs <= SF_SLOTS) return 1;
+    const long full = (wgs / SF_SLOTS) * SF_SLOTS;
+    if (full == wgs) return 1;
+    int s = tail_ks;
+    while (s > 1 && kt / s < 2) --s;             // at least two K-steps per share
+    if (s <= 1) return 1;
+    if (nfull) *nfull = (int)full;
     return s;
 }
-SED_API long sed_conv_sf16_splitk_floats(int B, int H, int W, int Cout, int ksplit) {
-    const int tr = 256 >> sf_log2w(W);
-    return (long)B * ((H + tr - 1) / tr) * (Cout / 64) * ksplit * 16384L;
+// the round-5 name: the small-M recommendation only (1 wherever the launch has more than 160 workgroups)
+SED_API int sed_conv_sf16_ksplit(int B, int H, int W, int Cin, int Cout) {
+    return sed_conv_sf16_split_plan(B, H, W, Cin, Cout, 0, nullptr);
 }
-SED_API long sed_conv_sf16_splitk_tickets(int B, int H, int W, int Cout) {
+SED_API long sed_conv_sf16_splitk_floats(int B, int H, int W, int Cout, int ksplit, int nfull) {
     const int tr = 256 >> sf_log2w(W);
-    return (long)B * ((H + tr - 1) / tr) * (Cout / 64);
+    const long tiles = (long)B * ((H + tr - 1) / tr) * (Cout / 64) - nfull;
+    return tiles > 0 ? tiles * ksplit * 16384L : 0;
+}
+SED_API long sed_conv_sf16_splitk_tickets(int B, int H, int W, int Cout, int nfull) {
+    const int tr = 256 >> sf_log2w(W);
+    const long tiles = (long)B * ((H + tr - 1) / tr) * (Cout / 64) - nfull;
+    return tiles > 0 ? tiles : 0;
 }
 SED_API int sed_conv3x3_sf16_splitk(const float* x, const void* wp, const float* wscale, float* y, int B, int H, int W, int Cin,
                                     int Cout, const float* in_scale, const float* in_shift, int epi, float* partials,
                                     const float* yprev, const float* p_scale, const float* p_shift, const float* p_mean,
                                     const float* p_invstd, const float* x_amax, float* minmax, int* err_host, int* err_dev,
-                                    int flags, float* out_amax, int ksplit, float* ws, int* tickets, sed_stream_t stream) {
+                                    int flags, float* out_amax, int ksplit, int nfull, float* ws, int* tickets, sed_stream_t stream) {
     return conv_sf16_launch(x, wp, wscale, y, B, H, W, Cin, Cout, in_scale, in_shift, epi, partials, yprev, p_scale, p_shift, p_mean,
-                            p_invstd, x_amax, minmax, err_host, err_dev, flags, out_amax, ksplit, ws, tickets, stream);
+                            p_invstd, x_amax, minmax, err_host, err_dev, flags, out_amax, ksplit, nfull, ws, tickets, stream);
 }
 
 // Block 1's dgrad (round 4): g_y1 = conv_transpose(gy, w2) masked by relu'(bn1(y1)) + the BatchNorm-backward sums of bn1, with
@@ -1048,7 +1100,7 @@ SED_API int sed_conv3x3_sf16_dgrad_b1(const float* gy, const void* wp, const flo
     p.mm = nullptr; p.err_host = err_host; p.err_dev = err_dev;
     p.pool_amax = nullptr; p.ph = p.pw = 1;
     p.x0 = x0; p.w1 = w1_oihw; p.out_amax = out_amax;
-    p.ksplit = 1; p.ws = nullptr; p.tickets = nullptr;
+    p.ksplit = 1; p.nfull = 0; p.ws = nullptr; p.tickets = nullptr;
     const long nblk = (long)B * p.ntile * (Cout / 64);
     if (nblk > 0x7fffffffL) return SED_EINVAL;
     if (flags & 1) hipLaunchKernelGGL((conv_sf16_kernel<4, false, 4, true>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);

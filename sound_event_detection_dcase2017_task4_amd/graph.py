@@ -21,10 +21,18 @@ training flag or of ops.USE_SF16 drops the graph and starts over.
 """
 import torch
 
-from . import ops
+from . import ops, parallel
 from .pytorch.pytorch_utils import do_mixup
 
 HOP_SIZE, MEL_BINS = 320, 64        # utils/config.py constants the kernels are specialised for (pytorch/models.py checks them)
+
+
+class GraphCaptureError(RuntimeError):
+    """The HIP-graph CAPTURE of the step was refused -- on this rank or on another one of the job.  Nothing of the step the
+    caller is at has run (a capture only records), so the caller may run that batch eagerly instead.  Every other exception
+    out of GraphedTrainStep.__call__ (eager warm-up steps, the replay, optimizer.step() with its all-reduces and polls) comes
+    from a step that HAS been partly or fully applied and must propagate: re-running that batch would update Adam and the
+    BatchNorm statistics twice."""
 
 
 class GraphedTrainStep(object):
@@ -77,7 +85,7 @@ class GraphedTrainStep(object):
 
     def _capture(self):
         if not self.model.training:
-            raise RuntimeError("GraphedTrainStep: the model is in eval mode")
+            raise GraphCaptureError("GraphedTrainStep: the model is in eval mode")
         buckets = self.opt.buckets
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -86,11 +94,17 @@ class GraphedTrainStep(object):
             with torch.cuda.graph(g):
                 ops.reset_amax_pool()           # the zero fill of the amax rows used below becomes part of the graph
                 loss = self._body()
+        except GraphCaptureError:
+            raise
+        except Exception as err:                # whatever refused the recording: nothing of this step has run
+            ops.drop_pending_wgrads()
+            raise GraphCaptureError("HIP graph capture of the training step failed: %r" % (err,)) from err
         finally:
             buckets.deferred = prev
             ops.reset_amax_pool()               # ... and eager code never gets rows of the graph's pool
         if ops.pending_sink_indices():
-            raise RuntimeError("GraphedTrainStep: side-stream weight gradients were left un-joined by the captured backward pass")
+            ops.drop_pending_wgrads()
+            raise GraphCaptureError("GraphedTrainStep: side-stream weight gradients were left un-joined by the captured backward pass")
         self.graph, self.loss = g, loss
         # which gradients the captured backward pass writes through the sinks: a replay runs no Python, so the buckets'
         # `written` set must be restored by hand before every optimiser step -- otherwise FusedAdamAmsgrad._gather() would
@@ -99,6 +113,27 @@ class GraphedTrainStep(object):
         self._written = set(buckets.written)
         # ... and likewise the BatchNorm entries of the captured forward pass (ops.restore_bn_if_refused() after every replay)
         self._bn_last = ops._BN_LAST
+
+    def _capture_together(self):
+        """Capture, and agree on the outcome with the other ranks: a rank that fell back to the eager loop alone would fire its
+        gradient buckets from inside backward while its peers (still graphed) issue theirs behind the graph -- the collective
+        sequences would diverge.  One MAX all-reduce of a 'refused' bit (capture time only, never per step): if any rank's
+        capture was refused, EVERY rank drops its graph and raises GraphCaptureError from this very call."""
+        mine = None
+        try:
+            self._capture()
+        except GraphCaptureError as err:
+            mine = err
+        if parallel.collectives_on():
+            dev = self.wave.device if torch.distributed.get_backend() == "nccl" else torch.device("cpu")
+            bit = torch.tensor([1.0 if mine is not None else 0.0], dtype=torch.float32, device=dev)
+            torch.distributed.all_reduce(bit, op=torch.distributed.ReduceOp.MAX)
+            if mine is None and float(bit.item()) > 0:
+                mine = GraphCaptureError("the HIP graph capture was refused on another rank: every rank falls back together")
+        if mine is not None:
+            self.reset()
+            self.calls -= 1                     # the caller runs this batch eagerly: not one of this object's steps
+            raise mine
 
     def __call__(self, wave, target, lam=None, stripes=None):
         if self.mixup and lam is None:
@@ -117,7 +152,7 @@ class GraphedTrainStep(object):
             loss = self._body()
         else:
             if self.graph is None:
-                self._capture()                 # records only: the replay below is this call's step
+                self._capture_together()        # records only: the replay below is this call's step
             self.opt.buckets.new_gradients()
             self.graph.replay()
             self.replays += 1

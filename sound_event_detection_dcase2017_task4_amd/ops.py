@@ -307,6 +307,8 @@ def clear_nonfinite_flags():
     """Reset the found-non-finite words (host-mapped + device) after they have been reported."""
     for t in _ERR_DEV.values():
         t.zero_()
+    for t in _TICKETS.values():        # split-K tickets are self-resetting -- unless a launch was aborted half-way: after an error
+        t.zero_()                      # report they are zero again, so no later launch can be left without its last arriver
     torch.cuda.synchronize()
     if _ERR_FLAG is not None:
         _ERR_FLAG[1] = 0
@@ -604,13 +606,25 @@ def bn_finalize(partials, nparts, rows_per_part, N, bn_w, bn_b, running_mean, ru
         # begin_bn_commit / commit_bn) -- or right here for a BatchNorm used on its own -- unless the pass met NaN / inf
         if _BN_COMMIT is not None:
             _BN_COMMIT.append((cand, running_mean, running_var, C))
-        else:
+        else:                                   # a BatchNorm used on its own: installed right away, tracked like the others
             _commit_bn_entries([(cand, running_mean, running_var, C)])
+            _track_bn([(cand, running_mean, running_var, C)])
     return st
 
 
 _BN_COMMIT = None        # [(cand, running_mean, running_var, C)] while a forward pass collects its BatchNorm updates
-_BN_LAST = None          # the entries the newest forward pass installed; their `cand` now hold the statistics from before it
+# Entry groups installed since the last optimiser step, oldest first (one group per forward pass / stand-alone BatchNorm); their
+# `cand` now hold the statistics they replaced.  SEVERAL groups exist with gradient accumulation (direct_grads=False) or any second
+# train-mode forward before optimizer.step(): a refused step takes ALL of them back, newest first, so that the buffers end up as
+# they were before the first pass of the cycle.  Train-mode forward passes that are never followed by an optimiser step (statistics
+# recalibration loops) would let the list grow: only the newest _BN_TRACK_MAX groups are kept.
+_BN_LAST = None
+_BN_TRACK_MAX = 64
+
+
+def _track_bn(entries):
+    global _BN_LAST
+    _BN_LAST = ((_BN_LAST or []) + [entries])[-_BN_TRACK_MAX:]
 
 
 def begin_bn_commit():
@@ -627,7 +641,7 @@ def commit_bn(drop=False):
     if entries and not drop:
         for i in range(0, len(entries), 16):
             _commit_bn_entries(entries[i:i + 16])
-        _BN_LAST = entries
+        _track_bn(entries)
 
 
 def restore_bn_if_refused():
@@ -636,10 +650,11 @@ def restore_bn_if_refused():
     running statistics the forward pass installed are taken back on the device -- the found-non-finite word decides, no
     synchronisation.  A refused step leaves the BatchNorm buffers as intact as parameters and moments, on every rank."""
     global _BN_LAST
-    entries, _BN_LAST = _BN_LAST, None
-    if entries and USE_SF16:
-        for i in range(0, len(entries), 16):
-            _commit_bn_entries(entries[i:i + 16], restore=True)
+    groups, _BN_LAST = _BN_LAST, None
+    if groups and USE_SF16:
+        for entries in reversed(groups):         # newest pass first: the oldest `cand` of a buffer is what it ends up with
+            for i in range(0, len(entries), 16):
+                _commit_bn_entries(entries[i:i + 16], restore=True)
 
 
 def _commit_bn_entries(entries, restore=False):
@@ -999,7 +1014,7 @@ def conv3x3_sf16(x, pack, B, H, W, Cin, Cout, in_st=None, epi=0, partials=None, 
     if x_amax is None:
         x_amax = act_amax_full(x, in_st) if in_st is not None else amax_of(x)
     y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
-    ks = _conv_ksplit(B, H, W, Cin, Cout)
+    ks, nfull = _conv_split_plan(B, H, W, Cin, Cout)
     with _timed("conv3x3_sf16_mfma(fwd+dgrad)|%d->%d@%dx%d epi%d%s", (Cin, Cout, H, W, epi, "+inT" if in_st is not None else ""),
                 2.0 * 9 * B * H * W * Cin * Cout):
         args = (_ptr(x), _ptr(wp), _ptr(wscale), _ptr(y), B, H, W, Cin, Cout,
@@ -1009,28 +1024,36 @@ def conv3x3_sf16(x, pack, B, H, W, Cin, Cout, in_st=None, epi=0, partials=None, 
                 _ptr(p_st.invstd) if p_st is not None else None, _ptr(x_amax), _ptr(minmax), _sf16_err_ptr(),
                 _sf16_err_dev_ptr(x.device), 1 if presplit else 0, _ptr(out_amax))
         if ks > 1:
-            # small-M launch (fewer workgroups than resident slots): `ks` workgroups per output tile, each over 1/ks of the K-steps
+            # `ks` workgroups per output tile, each over 1/ks of the K-steps: every tile of a small-M launch (fewer workgroups than
+            # resident slots; nfull = 0), or only the tiles of the last, partial round of the chip (nfull = the full rounds' tiles)
             L = _lib.lib()
-            ws = torch.empty((L.sed_conv_sf16_splitk_floats(B, H, W, Cout, ks),), dtype=torch.float32, device=x.device)
-            tickets = _splitk_tickets(x.device, L.sed_conv_sf16_splitk_tickets(B, H, W, Cout))
-            _call("sed_conv3x3_sf16_splitk", *(args + (ks, _ptr(ws), _ptr(tickets), _stream())))
+            ws = torch.empty((L.sed_conv_sf16_splitk_floats(B, H, W, Cout, ks, nfull),), dtype=torch.float32, device=x.device)
+            tickets = _splitk_tickets(x.device, L.sed_conv_sf16_splitk_tickets(B, H, W, Cout, nfull))
+            _call("sed_conv3x3_sf16_splitk", *(args + (ks, nfull, _ptr(ws), _ptr(tickets), _stream())))
         else:
             _call("sed_conv3x3_sf16", *(args + (_stream(),)))
     return y
 
 
-CONV_SPLITK = os.environ.get("SED_CONV_SPLITK", "1") != "0"      # small-M convolutions split their K range over workgroups
+CONV_SPLITK = os.environ.get("SED_CONV_SPLITK", "1") != "0"      # convolutions may split the K range of (some of) their tiles over workgroups
+# tail split of launches with a partial last round: 0 = the library's rule (never: measured slower, profiles/r06/tail_split_ab.txt),
+# 2 .. 8 = force that many shares per tail tile (A/B runs: SED_CONV_TAIL; tests set it directly)
+CONV_TAIL = int(os.environ.get("SED_CONV_TAIL", "0") or 0)
 _KSPLIT = {}
 _TICKETS = {}
 
 
-def _conv_ksplit(B, H, W, Cin, Cout):
+def _conv_split_plan(B, H, W, Cin, Cout):
+    """(ksplit, nfull) of a split-f16 convolution launch: (1, 0) = un-split; nfull = 0 = every tile split (small-M launches);
+    nfull > 0 = only the tiles behind the first nfull -- the last, partial round of the chip -- are split (csrc/conv_sf16.hip)."""
     if not CONV_SPLITK:
-        return 1
-    key = (B, H, W, Cin, Cout)
+        return 1, 0
+    key = (B, H, W, Cin, Cout, CONV_TAIL)
     v = _KSPLIT.get(key)
     if v is None:
-        v = _KSPLIT[key] = int(_lib.lib().sed_conv_sf16_ksplit(B, H, W, Cin, Cout))
+        nfull = ctypes.c_int(0)
+        ks = int(_lib.lib().sed_conv_sf16_split_plan(B, H, W, Cin, Cout, CONV_TAIL, ctypes.byref(nfull)))
+        v = _KSPLIT[key] = (ks, int(nfull.value) if ks > 1 else 0)
     return v
 
 

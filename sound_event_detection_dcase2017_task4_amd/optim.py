@@ -62,6 +62,56 @@ def bucket_cuts(names, offsets, numels, min_bytes=1 << 19):
     return sorted(cuts)
 
 
+def torch_adam_state_to_flat(sd, numels, trainable):
+    """A `torch.optim.Adam(model.parameters(), amsgrad=True).state_dict()` -- the 'optimizer' entry of a checkpoint the REFERENCE
+    writes (main.py:144-145, :222-230) -- as flat moment vectors over the TRAINABLE parameters in `model.parameters()` order.
+
+    sd: {'state': {index: {'step', 'exp_avg', 'exp_avg_sq', 'max_exp_avg_sq'}}, 'param_groups': [{'params': [indices], 'lr',
+    'betas', 'eps', 'amsgrad', ...}]}; numels / trainable: element count / requires_grad of EVERY parameter of the model, in
+    `model.parameters()` order (the reference hands Adam the frozen STFT / mel tensors too: they occupy indices, never state).
+    Returns (step, exp_avg, exp_avg_sq, max_exp_avg_sq, hyper) with zero moments for parameters that never received a gradient
+    (torch keeps no state for them: the unused `att_block.bn_att.*`).  Raises ValueError with the reason when the state does not
+    fit this model or is not Adam-amsgrad."""
+    import torch
+    groups = sd.get("param_groups")
+    state = sd.get("state")
+    if not isinstance(groups, (list, tuple)) or not isinstance(state, dict) or len(groups) != 1:
+        raise ValueError("not a torch.optim.Adam state_dict with ONE parameter group (keys: %s)" % sorted(sd.keys()))
+    grp = groups[0]
+    if not grp.get("amsgrad", False):
+        raise ValueError("the checkpoint's optimiser is Adam WITHOUT amsgrad: no max_exp_avg_sq to resume from "
+                         "(the reference trains with amsgrad=True, main.py:144-145)")
+    if float(grp.get("weight_decay", 0.0)) != 0.0:
+        raise ValueError("the checkpoint's optimiser uses weight_decay=%g; FusedAdamAmsgrad implements weight_decay=0 only" % grp["weight_decay"])
+    idx = list(grp["params"])
+    if len(idx) != len(numels):
+        raise ValueError("the checkpoint's optimiser holds %d parameters, this model has %d (model.parameters() order, frozen "
+                         "front-end tensors included)" % (len(idx), len(numels)))
+    total = sum(k for k, t in zip(numels, trainable) if t)
+    out = [torch.zeros((total,), dtype=torch.float32) for _ in range(3)]
+    steps = set()
+    off = 0
+    for pos, (i, k, t) in enumerate(zip(idx, numels, trainable)):
+        st = state.get(i)
+        if st is not None and not t:
+            raise ValueError("the checkpoint holds Adam moments for parameter %d, which is frozen in this model" % pos)
+        if t:
+            if st is not None:
+                for dst, key in zip(out, ("exp_avg", "exp_avg_sq", "max_exp_avg_sq")):
+                    if key not in st:
+                        raise ValueError("parameter %d of the checkpoint's optimiser has no '%s'" % (pos, key))
+                    v = torch.as_tensor(st[key]).detach().to("cpu", torch.float32).reshape(-1)
+                    if v.numel() != k:
+                        raise ValueError("parameter %d: the checkpoint's %s has %d elements, the model's parameter %d" % (pos, key, v.numel(), k))
+                    dst[off:off + k].copy_(v)
+                steps.add(int(round(float(torch.as_tensor(st["step"]).item()))))
+            off += k
+    if len(steps) > 1:
+        raise ValueError("the checkpoint's parameters are at different Adam steps %s: one flat step counter cannot resume them" % sorted(steps))
+    hyper = {"lr": float(grp["lr"]), "betas": tuple(float(b) for b in grp["betas"]), "eps": float(grp["eps"])}
+    return (steps.pop() if steps else 0), out[0], out[1], out[2], hyper
+
+
 class FusedAdamAmsgrad(object):
     """poll_lag: how the host learns that the Adam kernel refused a step (found-non-finite guard of the split-f16 path).
     None (default for one process): opportunistically -- ops.check_device_errors() raises at whatever call first sees the
@@ -80,6 +130,10 @@ class FusedAdamAmsgrad(object):
             raise ValueError("no trainable parameters")
         names = [n for n, _ in named]
         params = [p for _, p in named]
+        # every parameter in model.parameters() order, frozen ones included: how torch.optim.Adam numbers them (checkpoint interchange)
+        every = list(model.parameters()) if hasattr(model, "parameters") else list(params)
+        self._all_numels = [p.numel() for p in every]
+        self._all_trainable = [bool(p.requires_grad) for p in every]
         dev = params[0].device
         if dev.type != "cuda":
             raise RuntimeError("FusedAdamAmsgrad: move the model to the GPU first (HIP kernel, no CPU path)")
@@ -234,8 +288,42 @@ class FusedAdamAmsgrad(object):
         return {"step": self.step_count, "lr": self.lr, "betas": self.betas, "eps": self.eps,
                 "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "max_exp_avg_sq": self.max_exp_avg_sq}
 
+    def torch_state_dict(self):
+        """The same state in `torch.optim.Adam(model.parameters(), amsgrad=True).state_dict()` layout -- what the reference writes
+        into its checkpoints (main.py:222-230) -- for tools that expect it: per-parameter views of the flat moments, indices in
+        model.parameters() order (frozen tensors occupy an index and carry no state)."""
+        state, ours = {}, 0
+        for i, (k, t) in enumerate(zip(self._all_numels, self._all_trainable)):
+            if not t:
+                continue
+            off, shape = self.offsets[ours], self.params[ours].shape
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": self.exp_avg[off:off + k].view(shape).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[off:off + k].view(shape).clone(),
+                        "max_exp_avg_sq": self.max_exp_avg_sq[off:off + k].view(shape).clone()}
+            ours += 1
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0.0, "amsgrad": True, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": False,
+                 "params": list(range(len(self._all_numels)))}
+        return {"state": state, "param_groups": [group]}
+
     def load_state_dict(self, sd):
-        self.step_count = int(sd["step"])
-        for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
-            getattr(self, k).copy_(sd[k])
+        """Accepts this class's own state_dict() AND a stock `torch.optim.Adam(amsgrad=True)` one (the 'optimizer' entry of a
+        checkpoint written by the reference, main.py:222-230: {'state', 'param_groups'}); anything else is refused with the reason
+        (ValueError) -- never half-loaded."""
+        if "exp_avg" in sd and "step" in sd:
+            step = int(sd["step"])
+            moments = [torch.as_tensor(sd[k]) for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq")]
+            for k, m in zip(("exp_avg", "exp_avg_sq", "max_exp_avg_sq"), moments):
+                if m.numel() != self.flat.numel():
+                    raise ValueError("optimiser state '%s' has %d elements, this model's flat buffer %d" % (k, m.numel(), self.flat.numel()))
+        elif "state" in sd and "param_groups" in sd:
+            step, m1, m2, m3, hyper = torch_adam_state_to_flat(sd, self._all_numels, self._all_trainable)
+            moments = [m1, m2, m3]
+        else:
+            raise ValueError("unknown optimiser state layout (keys: %s): expected FusedAdamAmsgrad.state_dict() or a "
+                             "torch.optim.Adam(amsgrad=True).state_dict()" % sorted(sd.keys()))
+        self.step_count = step
+        for k, m in zip(("exp_avg", "exp_avg_sq", "max_exp_avg_sq"), moments):
+            getattr(self, k).copy_(m.reshape(-1))
         ops.invalidate_weight_caches()

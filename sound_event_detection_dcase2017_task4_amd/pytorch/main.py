@@ -31,7 +31,7 @@ import torch
 import torch.utils.data
 
 from .. import ops, parallel
-from ..graph import GraphedTrainStep
+from ..graph import GraphCaptureError, GraphedTrainStep
 from ..optim import FusedAdamAmsgrad
 from ..utils.config import (sample_rate, classes_num, mel_bins, fmin, fmax, window_size, hop_size)
 from ..utils.augmentation import draw_specaug_stripes
@@ -121,11 +121,16 @@ def train(args):
     # then replayed as ONE HIP graph unless --hip_graph off; larger batches keep the eager loop (no gain there)
     per_rank_clips = global_batch // world
     mode = getattr(args, 'hip_graph', 'auto')
-    mode = {True: 'on', False: 'auto', None: 'auto'}.get(mode, mode)
+    mode = {True: 'on', False: 'off', None: 'auto'}.get(mode, mode)       # programmatic callers: False has always meant off
     use_graph = mode == 'on' or (mode == 'auto' and per_rank_clips <= HIP_GRAPH_AUTO_MAX_CLIPS)
     graphed = GraphedTrainStep(model, optimizer, loss_func, mixup=mix) if use_graph else None
     if rank == 0:
         logging.info('HIP graph replay of forward + loss + backward: {} ({} clips per GPU)'.format('on' if use_graph else 'off', per_rank_clips))
+        if use_graph and world > 1:
+            logging.info('  (graph replay with %d ranks: the gradient buckets are all-reduced BEHIND the graph, not beside the '
+                         'backward pass -- at <= %d clips per GPU the step is launch-bound and the exposed exchange is smaller '
+                         'than the launch gaps it removes; --hip_graph off restores the overlapped exchange)',
+                         world, HIP_GRAPH_AUTO_MAX_CLIPS)
     train_bgn_time = time.time()
 
     # evaluation sets of the every-1000-iterations branch (main.py:78-89, :150-176): used when present
@@ -161,9 +166,11 @@ def train(args):
         if graph_box[0] is not None:                 # same body, captured once per input shape and replayed
             try:
                 return graph_box[0](wave, target, lam, stripes)
-            except ops.NonFiniteOperand:
-                raise
-            except Exception as err:                 # the capture was refused (nothing of this step has run yet)
+            except GraphCaptureError as err:
+                # ONLY the refused capture lands here: nothing of this step has run yet, and with several ranks every rank is
+                # here together (graph.GraphedTrainStep._capture_together).  Anything else -- an eager warm-up step, a replay,
+                # optimizer.step() with its all-reduces and polls -- comes from a step that has been (partly) applied and
+                # propagates: re-running it would update Adam and the BatchNorm statistics twice.
                 if mode == 'on':
                     raise                            # asked for explicitly: fail loudly
                 logging.warning('--hip_graph auto: the HIP graph capture failed (%r); continuing with the eager loop', err)

@@ -118,6 +118,18 @@ class TrainSampler(object):
         self.random_state.shuffle(self.audio_indexes)
         self.pointer = 0
 
+    def skip(self, n_batches):
+        """Advance the stream by n_batches without building them (resume: the stream continues where the checkpointed run was;
+        same pointer walk and reshuffles as __iter__)."""
+        todo = int(n_batches) * self.batch_size
+        while todo > 0:
+            step = min(todo, self.audios_num - self.pointer)
+            self.pointer += step
+            todo -= step
+            if self.pointer >= self.audios_num:
+                self.pointer = 0
+                self.random_state.shuffle(self.audio_indexes)
+
     def __iter__(self):
         while True:
             batch_meta = []

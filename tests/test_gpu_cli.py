@@ -198,9 +198,13 @@ def test_train_cli_auto_graph_falls_back_to_the_eager_loop_when_capture_fails(tm
     cli.main(args(ws, "--hip_graph", "off"))
     want = losses()
 
-    def refuse(self):
-        raise RuntimeError("capture refused (test)")
-    monkeypatch.setattr(graph.GraphedTrainStep, "_capture", refuse)
+    real_body = graph.GraphedTrainStep._body
+
+    def refuse(self):                                 # fails INSIDE the capture region only (the eager warm-up steps run)
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("capture refused (test)")
+        return real_body(self)
+    monkeypatch.setattr(graph.GraphedTrainStep, "_body", refuse)
     ws = str(tmp_path / "auto"); os.makedirs(ws)
     torch.manual_seed(99)
     with caplog.at_level(logging.WARNING):
@@ -210,5 +214,32 @@ def test_train_cli_auto_graph_falls_back_to_the_eager_loop_when_capture_fails(tm
     np.testing.assert_allclose(got, want, rtol=5e-6, atol=0)
     assert any("HIP graph capture failed" in r.getMessage() for r in caplog.records)
     ws = str(tmp_path / "on"); os.makedirs(ws)
-    with pytest.raises(RuntimeError, match="capture refused"):
+    with pytest.raises(graph.GraphCaptureError, match="capture refused"):
         cli.main(args(ws, "--hip_graph", "on"))
+
+
+def test_train_cli_auto_graph_does_not_swallow_errors_of_applied_steps(tmp_path, monkeypatch, caplog):
+    """Only a refused CAPTURE may cost the graph (graph.GraphCaptureError: nothing of the step has run).  An exception out of a
+    step that has been applied -- here optimizer.step() behind the first graph replay -- must propagate: re-running that batch
+    eagerly would update Adam and the BatchNorm statistics twice and log the real error as a capture warning (round-5 advisor)."""
+    import logging
+    from sound_event_detection_dcase2017_task4_amd import optim
+    from sound_event_detection_dcase2017_task4_amd.pytorch import main as cli
+    real_step = optim.FusedAdamAmsgrad.step
+    calls = {"n": 0}
+
+    def step(self):
+        calls["n"] += 1
+        if calls["n"] == 4:                           # three eager warm-up steps, then the first replay's optimiser step
+            raise RuntimeError("boom behind the replay (test)")
+        return real_step(self)
+    monkeypatch.setattr(optim.FusedAdamAmsgrad, "step", step)
+    ws = str(tmp_path)
+    with caplog.at_level(logging.WARNING):
+        with pytest.raises(RuntimeError, match="boom behind the replay"):
+            cli.main(["train", "--dataset_dir", ws, "--workspace", ws, "--holdout_fold", "1", "--model_type", "Cnn_9layers_FrameAvg",
+                      "--loss_type", "clip_bce", "--augmentation", "mixup", "--batch_size", "4", "--cuda", "--synthetic", "12",
+                      "--learning_rate", "1e-3", "--resume_iteration", "0", "--stop_iteration", "5", "--print_every", "1"])
+    assert calls["n"] == 4                            # the batch was NOT run again
+    assert not any("HIP graph capture failed" in r.getMessage() for r in caplog.records)
+    torch.cuda.synchronize()

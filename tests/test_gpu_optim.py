@@ -451,3 +451,35 @@ def test_step_refused_after_its_forward_pass_takes_the_batchnorm_statistics_back
     step()                                                   # the run goes on, and now the statistics DO move
     ops.check_device_errors(synchronize=True)
     assert opt.step_count == 4 and not torch.equal(m.bn0.running_mean, bufs["bn0.running_mean"])
+
+
+def test_refused_step_takes_back_every_forward_pass_since_the_last_step():
+    """Gradient accumulation (direct_grads=False) or any second train-mode forward before optimizer.step(): every one of those
+    passes installed running statistics, and a refused step must take ALL of them back (newest first), not only the newest
+    pass's -- the buffers end up exactly as they were before the first pass of the cycle (round-5 advisor, ops._BN_LAST)."""
+    from sound_event_detection_dcase2017_task4_amd import ops
+    from sound_event_detection_dcase2017_task4_amd.optim import FusedAdamAmsgrad
+    from sound_event_detection_dcase2017_task4_amd.pytorch.losses import clip_bce
+    m = _build("Cnn_9layers_FrameAvg")
+    opt = FusedAdamAmsgrad(m, lr=1e-3, direct_grads=False)
+    x, y, lam, stripes = _batch(rows=4)
+    x2 = x * 0.5
+    ops.check_device_errors(synchronize=True)
+    loss = clip_bce(m(x, None, specaug_stripes=stripes), {"target": y})
+    opt.zero_grad(); loss.backward(); opt.step()                 # one clean step
+    ops.check_device_errors(synchronize=True)
+    before = opt.flat.clone()
+    bufs = {k: v.clone() for k, v in m.named_buffers() if not k.endswith("num_batches_tracked")}
+    opt.zero_grad()
+    clip_bce(m(x, None, specaug_stripes=stripes), {"target": y}).backward()          # pass 1 of the cycle: clean
+    mid = m.bn0.running_mean.clone()
+    assert not torch.equal(mid, bufs["bn0.running_mean"])
+    (clip_bce(m(x2, None, specaug_stripes=stripes), {"target": y}) * float("nan")).backward()    # pass 2: NaN gradient
+    assert not torch.equal(m.bn0.running_mean, mid)
+    with pytest.raises(ops.NonFiniteOperand):
+        opt.step()
+        ops.check_device_errors(synchronize=True)
+    assert torch.equal(opt.flat, before)
+    for k, v in m.named_buffers():
+        if not k.endswith("num_batches_tracked"):
+            assert torch.equal(v, bufs[k]), k                    # BOTH passes taken back, bit for bit

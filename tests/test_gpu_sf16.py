@@ -705,3 +705,109 @@ def test_sf16_split_k_small_m_launches(B, H, W, Cin, Cout, monkeypatch):
         assert torch.allclose(q1, q0, rtol=1e-4, atol=1e-6 * float(q0.abs().max()))
     assert ops._TICKETS and all(int(t.abs().sum()) == 0 for t in ops._TICKETS.values())
     ops.check_device_errors(synchronize=True)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(100, 8, 8, 256, 512), (26, 125, 8, 512, 512), (13, 250, 16, 256, 256)])
+def test_sf16_tail_split_fills_the_last_round(B, H, W, Cin, Cout, monkeypatch):
+    """Round 6: a launch of more than one round of the chip's 768 resident workgroups (the 125 x 8 layers at the metric's batch: 1024
+    workgroups = 1.33 rounds) can split the K range of the tiles of its last round only, so that their shares fill it; the full
+    rounds in front run exactly as un-split.  The library's own rule never selects this form (measured slower:
+    profiles/r06/tail_split_ab.txt) -- it stays reachable for A/B runs (SED_CONV_TAIL) and must stay correct: against float64,
+    against the un-split launch (the un-split tiles bit for bit, the split ones to a rounding), every training epilogue, tickets
+    back at zero, bit-reproducible."""
+    import ctypes
+    from sound_event_detection_dcase2017_task4_amd import ops
+    L = ops._lib.lib()
+    nfull = ctypes.c_int(0)
+    assert int(L.sed_conv_sf16_split_plan(B, H, W, Cin, Cout, 0, ctypes.byref(nfull))) == 1        # the library's rule: un-split
+    monkeypatch.setattr(ops, "CONV_TAIL", 3)
+    ks = int(L.sed_conv_sf16_split_plan(B, H, W, Cin, Cout, 3, ctypes.byref(nfull)))
+    tr = 256 // W
+    tiles = B * ((H + tr - 1) // tr) * (Cout // 64)
+    assert ks > 1 and nfull.value > 0 and nfull.value % 768 == 0 and nfull.value < tiles, (ks, nfull.value, tiles)
+    g = torch.Generator().manual_seed(B + H + Cin)
+    x = torch.randn((B, H, W, Cin), generator=g)
+    w = (torch.rand((Cout, Cin, 3, 3), generator=g) * 2 - 1) * float(np.sqrt(6.0 / (9 * Cin + 9 * Cout)))
+    scale, shift = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    st = ops.BnStats(Cin, "cuda"); st.scale.copy_(scale); st.shift.copy_(shift)
+    xd, wd = x.cuda(), w.cuda()
+    pack = ops.pack_sf16(wd)
+    P = int(L.sed_conv_sf16_num_parts(B, H, W, Cout))
+
+    def run(split, in_st, epi):
+        monkeypatch.setattr(ops, "CONV_SPLITK", split)
+        parts = torch.zeros((P * 2 * Cout + P,), device="cuda") if epi else None
+        mm = torch.zeros((P, 2, Cout), device="cuda")
+        y = ops.conv3x3_sf16(xd, pack, B, H, W, Cin, Cout, in_st=in_st, epi=epi, partials=parts, minmax=mm)
+        torch.cuda.synchronize()
+        return y, parts, mm
+
+    for in_st, sc, sh in ((None, None, None), (st, scale, shift)):
+        want = _ref(x, w, sc, sh)
+        for epi in (0, 1):
+            y1, p1, m1 = run(True, in_st, epi)
+            y0, p0, m0 = run(False, in_st, epi)
+            rel, mx = _err(y1, want)
+            assert rel < 1e-6 and mx < 1e-5, (in_st is not None, epi, rel, mx)
+            same = (y1 == y0).reshape(B, -1).all(dim=1)
+            assert int(same.sum()) >= nfull.value // ((H + tr - 1) // tr * (Cout // 64))       # the images of the full rounds: identical bits
+            assert not bool(same.all())                                                         # ... and the tail WAS summed differently
+            assert (y1 - y0).abs().max().item() <= 2e-6 * want.abs().max().item()
+            assert torch.allclose(m1, m0, rtol=1e-5, atol=2e-6 * float(want.abs().max()))
+            if epi:
+                n = P * Cout
+                assert torch.allclose(p1[:n], p0[:n], rtol=1e-4, atol=1e-3) and torch.equal(p1[2 * n:], p0[2 * n:])
+                assert torch.allclose(p1[n:2 * n], p0[n:2 * n], rtol=1e-3, atol=1e-3)
+            y2, _, _ = run(True, in_st, epi)
+            assert torch.equal(y1, y2)
+    if Cin == Cout:        # dgrad form (conv2's backward: same channel count both ways)
+        gy = (torch.randn((B, H, W, Cout), generator=g) * 1e-5).cuda()
+        yprev = torch.randn((B, H, W, Cin), generator=g).cuda()
+        pst = ops.BnStats(Cin, "cuda"); pst.scale.copy_(scale); pst.shift.copy_(shift); pst.mean.fill_(0.1); pst.invstd.fill_(0.9)
+        packd = ops.pack_sf16(wd, dgrad=True)
+        outs = []
+        for split in (True, False, True):
+            monkeypatch.setattr(ops, "CONV_SPLITK", split)
+            parts = torch.zeros((P * 2 * Cin,), device="cuda")
+            gx = ops.conv3x3_sf16(gy, packd, B, H, W, Cout, Cin, epi=2, partials=parts, yprev=yprev, p_st=pst)
+            torch.cuda.synchronize()
+            outs.append((gx, parts))
+        (g1, q1), (g0, q0), (g2, q2) = outs
+        assert torch.equal(g1 == 0, g0 == 0) and torch.equal(g1, g2) and torch.equal(q1, q2)
+        assert (g1 - g0).abs().max().item() <= 2e-6 * g0.abs().max().item()
+        assert torch.allclose(q1, q0, rtol=1e-4, atol=1e-6 * float(q0.abs().max()))
+    assert ops._TICKETS and all(int(t.abs().sum()) == 0 for t in ops._TICKETS.values())
+    ops.check_device_errors(synchronize=True)
+
+
+def test_sf16_split_k_exchange_across_xcds():
+    """The split-K exchange carries no release / acquire fence (an agent-scope fence pair costs ~10 us per workgroup on this 8-XCD
+    part): shares travel with relaxed agent-scope stores behind `s_waitcnt vmcnt(0)`, a relaxed ticket, and sc1 loads
+    (csrc/conv_sf16.hip).  That rests on write-through-and-acknowledge behaviour the memory model does not spell out, so it is held
+    to evidence: 100 tiles x 4 shares = 400 workgroups, 50 per XCD -- 50 % 4 != 0, so a share group straddles EVERY XCD boundary --
+    launched 300 times with two alternating inputs (a stale or half-written share of the previous launch would carry the OTHER
+    input's sums).  Every launch must reproduce the first result of its input bit for bit, and the tickets end at zero."""
+    from sound_event_detection_dcase2017_task4_amd import ops
+    L = ops._lib.lib()
+    B, H, W, Cin, Cout = 25, 8, 8, 512, 256
+    ks = int(L.sed_conv_sf16_ksplit(B, H, W, Cin, Cout))
+    assert ks == 4 and (B * (Cout // 64) * ks // 8) % ks != 0
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn((B, H, W, Cin), generator=g).cuda() for _ in range(2)]
+    w = ((torch.rand((Cout, Cin, 3, 3), generator=g) * 2 - 1) * 0.02).cuda()
+    pack = ops.pack_sf16(w)
+    ams = [ops.amax_of(x) for x in xs]
+    first = [ops.conv3x3_sf16(x, pack, B, H, W, Cin, Cout, x_amax=a).clone() for x, a in zip(xs, ams)]
+    torch.cuda.synchronize()
+    assert not torch.equal(first[0], first[1])
+    want = _ref(xs[0].cpu(), w.cpu())
+    rel, mx = _err(first[0], want)
+    assert rel < 1e-6 and mx < 1e-5
+    bad = torch.zeros((), dtype=torch.int64, device="cuda")
+    for it in range(300):
+        y = ops.conv3x3_sf16(xs[it & 1], pack, B, H, W, Cin, Cout, x_amax=ams[it & 1])
+        bad += (y != first[it & 1]).sum()
+    torch.cuda.synchronize()
+    assert int(bad) == 0
+    assert all(int(t.abs().sum()) == 0 for t in ops._TICKETS.values())
+    ops.check_device_errors(synchronize=True)
