@@ -37,7 +37,8 @@ from ..utils.config import (sample_rate, classes_num, mel_bins, fmin, fmax, wind
 from ..utils.augmentation import draw_specaug_stripes
 from ..utils.data_generator import (DCASE2017Task4Dataset, PinnedBatchLoader, ShardedBatchSampler, TrainSampler, TestSampler,
                                     collate_fn)
-from ..utils.utilities import create_folder, get_filename, create_logging, Mixup, StatisticsContainer
+from ..utils.utilities import (create_folder, get_filename, create_logging, Mixup, StatisticsContainer, random_state_to_plain,
+                               random_state_from_plain)
 from .evaluate import Evaluator
 from . import models as _models
 from .losses import get_loss_func
@@ -90,16 +91,28 @@ def train(args):
 
     model = _build_model(args.model_type)
     iteration = 0
+    ck = None
     if args.resume_iteration:
-        ck = torch.load(os.path.join(checkpoints_dir, '{}_iterations.pth'.format(args.resume_iteration)), map_location='cpu')
+        # reference main.py:125-134 (which loads the model only and then fails on an undefined name): here the run CONTINUES --
+        # model, optimiser moments and step, BatchNorm statistics, and the sampler / mixup / SpecAugment streams all pick up where
+        # the checkpointed run was, so N iterations + resume + M iterations equal N + M iterations bit for bit (tests/test_gpu_cli.py)
+        ck_path = os.path.join(checkpoints_dir, '{}_iterations.pth'.format(args.resume_iteration))
+        if rank == 0:
+            logging.info('Load resume model from {}'.format(ck_path))
+        ck = torch.load(ck_path, map_location='cpu')
         model.load_state_dict(ck['model'])
         iteration = ck['iteration']
     model.to(device)
     # poll_lag: the found-non-finite guard is polled deterministically, POLL_LAG steps behind the newest one, so that every rank
     # learns about a refused step inside the same optimizer.step() call (optim.FusedAdamAmsgrad)
     optimizer = FusedAdamAmsgrad(model, lr=args.learning_rate, betas=(0.9, 0.999), eps=1e-08, world_size=world, poll_lag=POLL_LAG)
-    if args.resume_iteration and 'exp_avg' in ck.get('optimizer', {}):
+    if ck is not None and ck.get('optimizer'):
+        # this build's flat moments, or the reference's torch.optim.Adam(amsgrad=True) state (main.py:222-230); anything else is
+        # refused with the reason (optim.FusedAdamAmsgrad.load_state_dict) -- a resume never silently restarts the moments
         optimizer.load_state_dict(ck['optimizer'])
+    streams = (ck or {}).get('streams') or {}
+    if streams.get('torch_rng') is not None:
+        torch.set_rng_state(streams['torch_rng'])          # SpecAugment draws continue (rank 0's state is broadcast below)
     parallel.broadcast_flat(optimizer.flat)
     parallel.broadcast_buffers(model)
     parallel.broadcast_rng_state()
@@ -117,6 +130,15 @@ def train(args):
     # hold: a batch stays valid while POLL_LAG + 1 later ones are requested -- the batches of refused steps are re-run
     train_loader = PinnedBatchLoader(train_path, train_sampler, device=device, hold=POLL_LAG + 1)
     mixup_augmenter = Mixup(mixup_alpha=1., random_seed=1234) if mix else None
+    if iteration:
+        # the streams continue: the sampler has handed out `iteration` global batches, the mixup generator `iteration` lambda
+        # vectors (its exact state is in the checkpoints this build writes; for a reference-written checkpoint it is replayed)
+        train_sampler.sampler.skip(iteration)
+        if mix and streams.get('mixup_rng') is not None:
+            random_state_from_plain(mixup_augmenter.random_state, streams['mixup_rng'])
+        elif mix:
+            for _ in range(iteration):
+                mixup_augmenter.get_lambda(batch_size=rows_global)
     # small per-GPU batches are launch-bound (--batch_size 32 over 8 GPUs = 4 clips each: ~140 kernels of 5-100 us): the step is
     # then replayed as ONE HIP graph unless --hip_graph off; larger batches keep the eager loop (no gain there)
     per_rank_clips = global_batch // world
@@ -208,7 +230,7 @@ def train(args):
 
     for batch_data_dict in train_loader:
         evaluate_now = iteration % 1000 == 0 and iteration > (args.resume_iteration or 0)
-        checkpoint_now = iteration % 10000 == 0
+        checkpoint_now = iteration % (getattr(args, 'checkpoint_every', None) or 10000) == 0
         if evaluate_now or checkpoint_now:
             try:                                         # ALL ranks: nothing half-reported may reach an evaluation / checkpoint
                 optimizer.poll(0)
@@ -233,7 +255,12 @@ def train(args):
         if evaluate_now:
             parallel.barrier()           # the other ranks wait here (not inside an all-reduce) while rank 0 evaluates
         if checkpoint_now and rank == 0:
-            checkpoint = {'iteration': iteration, 'model': model.state_dict(), 'optimizer': optimizer.state_dict()}
+            # the reference's three keys (main.py:222-230) + 'streams' (additive; the reference reads 'model' and 'iteration'
+            # only): what the NEXT iteration would draw from -- global torch generator (SpecAugment), mixup generator; the sampler
+            # position is `iteration` batches into its seed-1234 stream
+            checkpoint = {'iteration': iteration, 'model': model.state_dict(), 'optimizer': optimizer.state_dict(),
+                          'streams': {'torch_rng': torch.get_rng_state(),
+                                      'mixup_rng': random_state_to_plain(mixup_augmenter.random_state) if mix else None}}
             checkpoint_path = os.path.join(checkpoints_dir, '{}_iterations.pth'.format(iteration))
             torch.save(checkpoint, checkpoint_path)
             logging.info('Model saved to {}'.format(checkpoint_path))
@@ -308,6 +335,8 @@ def build_parser():
                    help='(extension) replay forward + loss + backward as ONE HIP graph per step (graph.GraphedTrainStep): '
                         'frees the host from enqueueing ~140 kernels per step.  auto (default): on when a rank trains on '
                         '<= 8 clips per step (the launch-bound regime, e.g. --batch_size 32 over 8 GPUs), off otherwise')
+    p.add_argument('--checkpoint_every', type=int, default=10000,
+                   help='(extension, tests) checkpoint cadence in iterations; 10000 = reference (main.py:221)')
     p.add_argument('--per_gpu_batch', action='store_true', default=False,
                    help='(extension) --batch_size is per GPU (global batch = ranks x batch_size) instead of the global batch')
     q = subparsers.add_parser('inference_prob')

@@ -74,6 +74,20 @@ class Mixup(object):
         return np.stack([lam, 1.0 - lam], axis=1).reshape(-1)[:2 * pairs].astype(np.float64)
 
 
+def random_state_to_plain(rs):
+    """numpy RandomState -> a dict of a torch tensor and Python scalars (what a checkpoint may hold and still load under
+    torch.load(weights_only=True))."""
+    import torch
+    name, keys, pos, has_gauss, cached = rs.get_state()
+    return {'name': str(name), 'keys': torch.from_numpy(np.asarray(keys, dtype=np.int64).copy()), 'pos': int(pos),
+            'has_gauss': int(has_gauss), 'cached_gaussian': float(cached)}
+
+
+def random_state_from_plain(rs, d):
+    rs.set_state((d['name'], np.asarray(d['keys'], dtype=np.uint32), int(d['pos']), int(d['has_gauss']), float(d['cached_gaussian'])))
+    return rs
+
+
 class StatisticsContainer(object):
     """Evaluation statistics of a run, appended every 1000 iterations and pickled (utilities.py:188-217): a dict
     {'train': [...], 'test': [...], 'evaluate': [...]} of per-iteration dicts, written to `statistics_path` and to a

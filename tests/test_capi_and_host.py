@@ -478,3 +478,61 @@ def test_hdf5_pack_branch_through_a_stand_in_h5py(tmp_path, monkeypatch):
     assert item["audio_name"] == "h04.wav" and item["waveform"].dtype == np.float32
     np.testing.assert_allclose(item["waveform"], arrays["waveform"][4] / 32767.0, rtol=1e-6)
     assert opened
+
+
+def test_reference_optimizer_state_and_streams_resume_on_the_host(tmp_path):
+    """Host side of resume / checkpoint interchange (reference main.py:125-134, :144-145, :221-231), no GPU needed:
+    (a) optim.torch_adam_state_to_flat turns a stock torch.optim.Adam(amsgrad=True).state_dict() over model.parameters() -- frozen
+        tensors occupy indices, never-used parameters carry no state -- into flat moments over the trainable parameters, and
+        refuses anything else with the reason;
+    (b) TrainSampler.skip(n) leaves the seed-1234 stream exactly where n iterated batches leave it (wrap-around reshuffles included);
+    (c) the mixup generator's state survives a checkpoint as plain tensors / scalars (torch.load with weights_only=True)."""
+    import io
+    import torch
+    from sound_event_detection_dcase2017_task4_amd.optim import torch_adam_state_to_flat
+    from sound_event_detection_dcase2017_task4_amd.utils.data_generator import TrainSampler
+    from sound_event_detection_dcase2017_task4_amd.utils.utilities import Mixup, random_state_from_plain, random_state_to_plain
+    torch.manual_seed(0)
+    params = [torch.randn(5, 3), torch.randn(4, requires_grad=True), torch.randn(2, 3, requires_grad=True), torch.randn(7, requires_grad=True)]
+    opt = torch.optim.Adam(params, lr=2e-3, betas=(0.8, 0.95), eps=1e-7, weight_decay=0., amsgrad=True)
+    for _ in range(3):
+        params[1].grad = torch.randn(4); params[2].grad = torch.randn(2, 3); params[3].grad = None       # params[3]: never used
+        opt.step()
+    numels, trainable = [p.numel() for p in params], [p.requires_grad for p in params]
+    step, m, v, vmax, hyper = torch_adam_state_to_flat(opt.state_dict(), numels, trainable)
+    assert step == 3 and hyper == {"lr": 2e-3, "betas": (0.8, 0.95), "eps": 1e-7} and m.numel() == 4 + 6 + 7
+    st = opt.state_dict()["state"]
+    assert torch.equal(m[:4], st[1]["exp_avg"]) and torch.equal(v[4:10], st[2]["exp_avg_sq"].reshape(-1))
+    assert torch.equal(vmax[:4], st[1]["max_exp_avg_sq"]) and float(m[10:].abs().sum()) == 0 and float(vmax[10:].abs().sum()) == 0
+    with pytest.raises(ValueError, match="WITHOUT amsgrad"):
+        torch_adam_state_to_flat(torch.optim.Adam(params, lr=1e-3).state_dict(), numels, trainable)
+    with pytest.raises(ValueError, match="holds 4 parameters, this model has 3"):
+        torch_adam_state_to_flat(opt.state_dict(), numels[:3], trainable[:3])
+    with pytest.raises(ValueError, match="weight_decay"):
+        torch_adam_state_to_flat(torch.optim.Adam(params, lr=1e-3, amsgrad=True, weight_decay=0.1).state_dict(), numels, trainable)
+    with pytest.raises(ValueError, match="has 4 elements, the model's parameter 9"):
+        torch_adam_state_to_flat(opt.state_dict(), [15, 9, 6, 7], trainable)
+    with pytest.raises(ValueError, match="frozen in this model"):
+        torch_adam_state_to_flat(opt.state_dict(), numels, [False, False, True, True])
+    with pytest.raises(ValueError, match="ONE parameter group"):
+        torch_adam_state_to_flat({"state": {}, "param_groups": []}, numels, trainable)
+    # (b) sampler: 23 clips, batches of 8 -> wraps (and reshuffles) every third batch
+    for n in (0, 1, 2, 3, 7, 40):
+        a, b = TrainSampler("synthetic:23:1000", 8), TrainSampler("synthetic:23:1000", 8)
+        it = iter(a)
+        for _ in range(n):
+            next(it)
+        b.skip(n)
+        ib = iter(b)
+        for _ in range(4):
+            assert [x["index_in_hdf5"] for x in next(it)] == [x["index_in_hdf5"] for x in next(ib)], n
+    # (c) mixup stream through a checkpoint file
+    mix = Mixup(1.)
+    for _ in range(5):
+        mix.get_lambda(64)
+    path = str(tmp_path / "ck.pth")
+    torch.save({"streams": {"mixup_rng": random_state_to_plain(mix.random_state), "torch_rng": torch.get_rng_state()}}, path)
+    ck = torch.load(path, map_location="cpu")                     # default weights_only=True must accept it
+    mix2 = Mixup(1., random_seed=99)
+    random_state_from_plain(mix2.random_state, ck["streams"]["mixup_rng"])
+    assert np.array_equal(mix.get_lambda(64), mix2.get_lambda(64))

@@ -19,7 +19,8 @@ def test_train_then_inference_cli(tmp_path):
     ck_dir = os.path.join(ws, "checkpoints", "main", "holdout_fold=1", "model_type=Cnn_9layers_FrameAtt",
                           "loss_type=clip_bce", "augmentation=mixup", "batch_size=4")
     ck = torch.load(os.path.join(ck_dir, "0_iterations.pth"), map_location="cpu")
-    assert set(ck.keys()) == {"iteration", "model", "optimizer"} and ck["iteration"] == 0
+    # the reference's three keys (main.py:222-230) + 'streams' (additive: what a resumed run continues its random streams from)
+    assert set(ck.keys()) == {"iteration", "model", "optimizer", "streams"} and ck["iteration"] == 0
     assert "att_block.bn_att.weight" in ck["model"] and ck["model"]["conv_block1.conv1.weight"].shape == (64, 1, 3, 3)
     cli.main(["inference_prob"] + common + ["--iteration", "0"])
     pred = pickle.load(open(os.path.join(ws, "predictions", "main", "holdout_fold=1", "model_type=Cnn_9layers_FrameAtt",
@@ -243,3 +244,56 @@ def test_train_cli_auto_graph_does_not_swallow_errors_of_applied_steps(tmp_path,
     assert calls["n"] == 4                            # the batch was NOT run again
     assert not any("HIP graph capture failed" in r.getMessage() for r in caplog.records)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("mt", ["Cnn_9layers_FrameAvg", "Cnn_9layers_Gru_FrameAtt"])
+def test_train_cli_resume_continues_the_run_bit_for_bit(tmp_path, capsys, monkeypatch, mt):
+    """reference pytorch/main.py:125-134 (resume; broken there: undefined name, optimiser and streams restart) and :221-231
+    (checkpoint).  Here six iterations straight == three iterations + checkpoint + `--resume_iteration 3` + three more, bit for bit:
+    parameters, Adam first / second moments, the amsgrad maximum, the step counter, every BatchNorm buffer, and the three streams
+    (seed-1234 sampler, seed-1234 mixup lambdas, SpecAugment draws of the global torch generator) -- the losses printed for
+    iterations 3..5 are the straight run's.  The checkpoint still loads under torch.load's default weights_only=True."""
+    from sound_event_detection_dcase2017_task4_amd import optim
+    from sound_event_detection_dcase2017_task4_amd.pytorch import main as cli
+    kept = []
+
+    class Recording(optim.FusedAdamAmsgrad):
+        def __init__(self, model, *a, **k):
+            super().__init__(model, *a, **k)
+            kept.append((self, model))
+    monkeypatch.setattr(cli, "FusedAdamAmsgrad", Recording)
+    ws = str(tmp_path)
+    common = ["train", "--dataset_dir", ws, "--workspace", ws, "--holdout_fold", "1", "--model_type", mt, "--loss_type", "clip_bce",
+              "--augmentation", "mixup", "--batch_size", "4", "--cuda", "--synthetic", "14", "--learning_rate", "1e-3",
+              "--print_every", "1", "--hip_graph", "off", "--checkpoint_every", "3"]
+
+    def losses():
+        out = capsys.readouterr().out
+        return {int(l.split()[0]): float(l.split()[1]) for l in out.splitlines() if len(l.split()) == 2 and l.split()[0].isdigit()}
+
+    def snapshot():
+        opt, model = kept[-1]
+        torch.cuda.synchronize()
+        st = {"flat": opt.flat.clone(), "m": opt.exp_avg.clone(), "v": opt.exp_avg_sq.clone(), "vmax": opt.max_exp_avg_sq.clone(),
+              "step": opt.step_count}
+        st.update({"buf:" + k: v.clone() for k, v in model.named_buffers()})
+        return st
+
+    torch.manual_seed(2024)
+    cli.main(common + ["--resume_iteration", "0", "--stop_iteration", "5"])          # iterations 0..5; checkpoints at 0 and 3
+    straight, l_straight = snapshot(), losses()
+    assert sorted(l_straight) == [0, 1, 2, 3, 4, 5]
+    ck_dir = os.path.join(ws, "checkpoints", "main", "holdout_fold=1", "model_type=" + mt, "loss_type=clip_bce", "augmentation=mixup",
+                          "batch_size=4")
+    ck = torch.load(os.path.join(ck_dir, "3_iterations.pth"), map_location="cpu")        # default weights_only=True
+    assert set(ck.keys()) == {"iteration", "model", "optimizer", "streams"} and ck["iteration"] == 3 and ck["optimizer"]["step"] == 3
+    torch.manual_seed(1)                                   # a different generator state: the stream must come from the checkpoint
+    cli.main(common + ["--resume_iteration", "3", "--stop_iteration", "5"])          # iterations 3..5
+    resumed, l_resumed = snapshot(), losses()
+    assert sorted(l_resumed) == [3, 4, 5]
+    assert [l_resumed[i] for i in (3, 4, 5)] == [l_straight[i] for i in (3, 4, 5)]
+    assert resumed["step"] == straight["step"] == 6
+    for k in straight:
+        if k != "step":
+            assert torch.equal(straight[k], resumed[k]), k
+    assert len(kept) == 2 and kept[0][0] is not kept[1][0]

@@ -483,3 +483,83 @@ def test_refused_step_takes_back_every_forward_pass_since_the_last_step():
     for k, v in m.named_buffers():
         if not k.endswith("num_batches_tracked"):
             assert torch.equal(v, bufs[k]), k                    # BOTH passes taken back, bit for bit
+
+
+def test_optimizer_state_interchanges_with_torch_adam_amsgrad():
+    """Checkpoint interchange (reference main.py:144-145, :222-230: the 'optimizer' entry is torch.optim.Adam(amsgrad=True)'s
+    state_dict over ALL model.parameters(), the frozen front-end tensors included).  Two steps of stock torch Adam and of
+    FusedAdamAmsgrad on the same gradients agree; the stock state_dict then loads into a fresh FusedAdamAmsgrad (moments, amsgrad
+    maximum, step), this class's torch_state_dict() loads into stock Adam, and a third step agrees everywhere.  Parameters that
+    never receive a gradient (`att_block.bn_att.*`) carry no torch state and load as zero moments.  A state that is not
+    Adam-amsgrad for this model is refused with the reason."""
+    from sound_event_detection_dcase2017_task4_amd.optim import FusedAdamAmsgrad
+    mt = "Cnn_9layers_FrameAtt"
+    m = _build(mt)
+    every = list(m.parameters())
+    names = [n for n, _ in m.named_parameters()]
+    ref = [p.detach().clone().requires_grad_(p.requires_grad) for p in every]
+    topt = torch.optim.Adam(ref, lr=1e-3, betas=(0.9, 0.999), eps=1e-08, weight_decay=0., amsgrad=True)
+    opt = FusedAdamAmsgrad(m, lr=1e-3, direct_grads=False)
+    unused = [i for i, n in enumerate(names) if ".bn_att." in n]
+    assert unused and not every[0].requires_grad
+    g = torch.Generator(device="cuda").manual_seed(3)
+
+    def fused_step(o, model_params, grads):
+        o.zero_grad()
+        for p, gr in zip(model_params, grads):
+            if gr is not None:
+                p.grad.copy_(gr)
+        o.step()
+
+    def torch_step(o, params, grads):
+        for p, gr in zip(params, grads):
+            p.grad = gr.clone() if gr is not None else None
+        o.step()
+
+    def grads():
+        return [torch.randn(p.shape, device="cuda", generator=g) * 1e-2 if (p.requires_grad and i not in unused) else None
+                for i, p in enumerate(every)]
+
+    for _ in range(2):
+        gr = grads()
+        torch_step(topt, ref, gr)
+        fused_step(opt, every, gr)
+    torch.cuda.synchronize()
+    for p, q, n in zip(every, ref, names):
+        assert torch.allclose(p, q, rtol=0, atol=2e-7), n
+    sd = topt.state_dict()
+    assert sorted(sd["state"].keys()) == [i for i, p in enumerate(every) if p.requires_grad and i not in unused]
+    # torch state -> a fresh fused optimiser
+    m2 = _build(mt)
+    with torch.no_grad():
+        for p, q in zip(m2.parameters(), ref):
+            p.copy_(q)
+    opt2 = FusedAdamAmsgrad(m2, lr=1e-3, direct_grads=False)
+    opt2.load_state_dict(sd)
+    assert opt2.step_count == 2
+    for a, b in ((opt2.exp_avg, opt.exp_avg), (opt2.exp_avg_sq, opt.exp_avg_sq), (opt2.max_exp_avg_sq, opt.max_exp_avg_sq)):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-12)
+    # fused state -> stock Adam
+    ref3 = [q.detach().clone().requires_grad_(q.requires_grad) for q in ref]
+    topt3 = torch.optim.Adam(ref3, lr=1e-3, betas=(0.9, 0.999), eps=1e-08, weight_decay=0., amsgrad=True)
+    topt3.load_state_dict(opt.torch_state_dict())
+    gr = grads()
+    torch_step(topt, ref, gr)
+    torch_step(topt3, ref3, gr)
+    fused_step(opt, every, gr)
+    fused_step(opt2, list(m2.parameters()), gr)
+    torch.cuda.synchronize()
+    for p, p2, q, q3, n in zip(every, m2.parameters(), ref, ref3, names):
+        assert torch.allclose(p, q, rtol=0, atol=3e-7) and torch.allclose(p2, q, rtol=0, atol=3e-7) and torch.allclose(q3, q, rtol=0, atol=3e-7), n
+    for i in unused:                                                   # never moved, anywhere
+        assert torch.equal(every[i], ref[i])
+    # refusals carry the reason
+    plain = torch.optim.Adam([q for q in ref], lr=1e-3)
+    with pytest.raises(ValueError, match="WITHOUT amsgrad"):
+        opt2.load_state_dict(plain.state_dict())
+    short = torch.optim.Adam(ref[:-1], lr=1e-3, amsgrad=True)
+    with pytest.raises(ValueError, match="holds %d parameters" % (len(ref) - 1)):
+        opt2.load_state_dict(short.state_dict())
+    with pytest.raises(ValueError, match="unknown optimiser state layout"):
+        opt2.load_state_dict({"momentum_buffer": 1})
+    assert opt2.step_count == 3                                        # a refused load changed nothing
