@@ -10,11 +10,12 @@ waveforms already resident in HBM.  Workload = the configuration BASELINE.json's
 batch_size 32 (post-mixup clips per GPU = 64 waveforms per step, mixup + SpecAugment on: the reference README's training
 command); weak scaling (batch per GPU fixed).  `--gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment)
 re-executes itself as N ranks under torch.distributed.run and refuses to run if the node has fewer than N GPUs.  Prints ONE
-JSON line on rank 0 carrying `roofline` (the dominant kernel family, HIP-event timed INSIDE the timed region), `kernels`
-(every MFMA family, from a second pass with the weight gradients on the main stream so that no duration includes waiting
-beside another kernel), `cpu_baseline` (the CPU oracle timed on this host's cores, config 0) and, at N=1, `extra_configs`:
-BASELINE.json configs[1] (B=256, with its own roofline / front-end / traffic objects) first, then the other configurations, a
-few steps each in the same process.
+JSON line on rank 0: `value` / `ms_per_step` from a timed region with NO instrumentation inside it; `roofline` (the dominant kernel
+family, HIP-event timed live over the same K steps run again straight behind it: `roofline_pass`), `kernels` (every MFMA family,
+from a third pass with the weight gradients on the main stream so that no duration includes waiting beside another kernel),
+`cpu_baseline` (the CPU oracle timed on this host's cores, config 0) and, at N=1, `extra_configs`: BASELINE.json configs[1]
+(B=256, with its own roofline / front-end / traffic objects) first, then the other configurations, a few steps each in the same
+process, and last the two input-path rows of SURVEY.md 8(d) (H2D-inclusive; the train CLI's loader in the loop).
 """
 import argparse
 import gc
@@ -247,9 +248,11 @@ def kernel_report(timing, steps, B2, default_workload, by_shape=False, frames=10
 class Workload(object):
     """One configuration of the hot path on this rank: model + optimiser + a resident pool of synthetic batches."""
 
-    def __init__(self, model_type, B, mix, rank, world, dev, seconds=10, inference=False, int16=False, h2d=False, hip_graph=False):
+    def __init__(self, model_type, B, mix, rank, world, dev, seconds=10, inference=False, int16=False, h2d=False, hip_graph=False,
+                 loader_clips=0):
         self.mt, self.B, self.mix, self.inference, self.h2d = model_type, B, mix, inference, h2d
         self.graphed, self.hip_graph_error = None, None
+        self.loader = self.loader_iter = None
         self.rank, self.world, self.dev = rank, world, dev
         self.B2 = 2 * B if (mix and not inference) else B
         L = 32000 * seconds
@@ -261,7 +264,15 @@ class Workload(object):
         parallel.broadcast_buffers(self.model)
         self.loss_func = get_loss_func("clip_bce")
         self.mixup = Mixup(mixup_alpha=1., random_seed=1234 + rank)
-        self.pool = [synth_batch(self.B2, L, 1000 * rank + i, dev) for i in range(2)]
+        self.pool = [synth_batch(self.B2, L, 1000 * rank + i, dev) for i in range(2)] if not loader_clips else []
+        if loader_clips:
+            # the train CLI's input pipeline in the loop (pytorch/main.py: seed-1234 TrainSampler -> PinnedBatchLoader: threads fill
+            # page-locked int16 buffers from the packed store, uploads run one batch ahead on a copy stream) on an in-memory
+            # synthetic store -- what reference main.py:160-170, :238-239 do with DataLoader workers + move_data_to_device
+            from sound_event_detection_dcase2017_task4_amd.utils.data_generator import PinnedBatchLoader, TrainSampler
+            path = "synthetic:%d:%d" % (loader_clips, L)
+            self.loader = PinnedBatchLoader(path, TrainSampler(path, self.B2, random_seed=1234 + rank), device=dev)
+            self.loader_iter = iter(self.loader)
         if int16 or h2d:
             self.pool = [((w * 32767.0).round().to(torch.int16), t) for (w, t) in self.pool]
         if h2d:                       # double-buffered upload on a copy stream, one batch ahead of the compute
@@ -284,7 +295,11 @@ class Workload(object):
             self.dev_ready[i % 2].record(self.copy_stream)
 
     def step(self, i):
-        wave, target = self.pool[i % len(self.pool)]
+        if self.loader_iter is not None:
+            batch = next(self.loader_iter)
+            wave, target = batch["waveform"], batch["target"]
+        else:
+            wave, target = self.pool[i % len(self.pool)]
         if self.h2d:
             torch.cuda.current_stream().wait_event(self.dev_ready[i % 2])
             wave = self.dbuf[i % 2]
@@ -383,10 +398,18 @@ class Workload(object):
         kern, roof, fe = kernel_report(tm, steps, self.B2, default_workload, by_shape=by_shape, frames=frames, pmc_file=pmc_file)
         return kern, roof, fe, dt / steps * 1e3
 
+    def close(self):
+        if self.loader_iter is not None:
+            self.loader_iter.close()
+            self.loader_iter = None
+
     def describe(self, seconds=10, int16=False):
-        return "%s, batch_size=%d per GPU%s, %d s @ 32 kHz %s waveforms resident in HBM, %s" % (
+        where = ("waveforms resident in HBM" if not (self.h2d or self.loader) else
+                 "waveforms uploaded from pinned host memory one batch ahead on a copy stream (PCIe inside the step)" if self.h2d else
+                 "waveforms through the train CLI's input pipeline (sampler -> PinnedBatchLoader threads -> pinned int16 -> H2D copy stream)")
+        return "%s, batch_size=%d per GPU%s, %d s @ 32 kHz %s %s, %s" % (
             self.mt, self.B, (" (post-mixup clips), mixup (%d waveforms/step/GPU)" % self.B2) if (self.mix and not self.inference)
-            else ", no mixup", seconds, "int16" if int16 else "fp32",
+            else ", no mixup", seconds, "int16" if (int16 or self.h2d or self.loader) else "fp32", where,
             "eval-mode forward only" if self.inference else "SpecAugment on, clip_bce, Adam-amsgrad")
 
 
@@ -404,15 +427,26 @@ DOMINANT = ("conv3x3_sf16_mfma(fwd+dgrad)", "conv3x3_wino2d_mfma(fwd+dgrad)",
 
 
 def measure(w, steps, warmup, default_workload, pmc_file, by_shape=False, frames=1001, events_in_region=True):
-    """The full set of numbers of one training workload: (row dict).  `value` comes from the timed region on the default
-    schedule, WITH HIP-event pairs around the forward / dgrad convolutions and the log-mel kernel (the `roofline` /
-    `roofline_frontend` objects are measured live over that very region; those kernels never run beside another one, so the
-    side-stream weight gradients do not distort them); `kernels` from a second, one-stream pass."""
-    dt, loss, tm = w.run(steps, warmup, timing=events_in_region, timing_only=DOMINANT)
-    _, roof, fe = kernel_report(tm, steps, w.B2, default_workload, frames=frames, pmc_file=pmc_file)
+    """The full set of numbers of one training workload: (row dict).  `value` / `ms_per_step` come from a timed region on the
+    default schedule with NO instrumentation inside it (round 5's headline carried 15 HIP-event pairs per step: +0.15 ms).  The
+    `roofline` / `roofline_frontend` objects are measured live over the SAME K steps run again straight behind it, with HIP-event
+    pairs around the forward / dgrad convolutions and the log-mel kernel on the stream they are launched on (those kernels never run
+    beside another one, so the side-stream weight gradients do not distort them; its own ms is reported beside the headline's);
+    `kernels` from a third, one-stream pass."""
+    dt, loss, _ = w.run(steps, warmup)
     row = {"value": round(w.B * w.world * steps / dt, 2), "unit": "clips/s", "steps": steps, "warmup": warmup,
-           "ms_per_step": round(dt / steps * 1e3, 3), "loss": round(loss, 5), "roofline": roof, "roofline_frontend": fe}
+           "ms_per_step": round(dt / steps * 1e3, 3), "loss": round(loss, 5), "roofline": None, "roofline_frontend": None}
     row.update(w.graph_info())
+    row["ms_per_step_without_kernel_events"] = row["ms_per_step"]          # (the name round 5 reported this figure under)
+    row["value_without_kernel_events"] = row["value"]
+    if events_in_region:
+        dte, _, tm = w.run(steps, 1, timing=True, timing_only=DOMINANT)
+        _, roof, fe = kernel_report(tm, steps, w.B2, default_workload, frames=frames, pmc_file=pmc_file)
+        row["roofline"], row["roofline_frontend"] = roof, fe
+        row["roofline_pass"] = {"ms_per_step": round(dte / steps * 1e3, 3), "steps": steps,
+                                "note": "the headline's K steps run again on the same schedule with HIP-event pairs around the "
+                                        "forward / dgrad convolutions and the log-mel kernel (an event pair costs the stream ~6 us): "
+                                        "`roofline` / `roofline_frontend` are measured over THIS region, `value` over the event-free one"}
     if w.world == 1:
         ksteps = max(2, min(steps, 10))
         kern, roof2, _, ms2 = w.kernel_table(ksteps, default_workload, pmc_file, by_shape=by_shape, frames=frames)
@@ -421,11 +455,34 @@ def measure(w, steps, warmup, default_workload, pmc_file, by_shape=False, frames
                                "note": "every MFMA family HIP-event-timed with the weight gradients on the MAIN stream (no "
                                        "kernel runs beside another: clean durations); an event pair costs the stream ~6 us"}
         row["mfma_kernels_share_of_step"] = round(sum(v["ms_total"] for v in kern.values()) / (ms2 * ksteps), 4)
-        dt3, _, _ = w.run(steps, 1)
-        row["ms_per_step_without_kernel_events"] = round(dt3 / steps * 1e3, 3)
-        row["value_without_kernel_events"] = round(w.B * steps / dt3, 2)
         row["host_enqueue_ms_per_step"] = w.host_enqueue_ms()
     return row, dt
+
+
+def input_path_rows(rank, world, dev, B=32, steps=20, warmup=3):
+    """the H2D-inclusive figures beside the headline (never `value`).  Same workload as the headline (FrameAvg,
+    bs=32, mixup), a few steps each: (i) int16 waveforms uploaded from page-locked host memory one batch ahead on a copy stream
+    (what the train CLI's loader amounts to, reference main.py:238-239 move_data_to_device); (ii) the train CLI's whole input
+    pipeline in the loop (seed-1234 sampler -> PinnedBatchLoader threads -> pinned int16 -> copy stream; reference main.py:160-170)."""
+    out = []
+    for tag, kw in (("H2D-inclusive: Cnn_9layers_FrameAvg B=32 mixup, int16 pinned host -> device every step", {"h2d": True}),
+                    ("loader in the loop: Cnn_9layers_FrameAvg B=32 mixup through utils/data_generator.PinnedBatchLoader", {"loader_clips": 192})):
+        w = None
+        try:
+            w = Workload("Cnn_9layers_FrameAvg", B, True, rank, world, dev, **kw)
+            dt, loss, _ = w.run(steps, warmup)
+            out.append({"config": tag, "workload": w.describe(), "value": round(B * steps / dt, 2), "unit": "clips/s", "steps": steps,
+                        "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3), "metric": "training clips/sec, input path inside the step",
+                        "waveform_bytes_per_step_over_pcie": int(w.B2 * 320000 * 2), "loss": round(loss, 5)})
+        except Exception as e:                 # a side number must never lose the headline line
+            out.append({"config": tag, "value": None, "error": repr(e)})
+        finally:
+            if w is not None:
+                w.close()
+            del w
+            gc.collect()
+            torch.cuda.empty_cache()
+    return out
 
 
 def extra_configs(rank, world, dev, steps=5, warmup=2, hip_graph="off"):
@@ -475,6 +532,7 @@ def extra_configs(rank, world, dev, steps=5, warmup=2, hip_graph="off"):
             out.append({"config": tag, "value": None, "error": repr(e)})
         gc.collect()
         torch.cuda.empty_cache()
+    out.extend(input_path_rows(rank, world, dev))
     return out
 
 

@@ -105,19 +105,41 @@ def recipe_state(model_type, seed=0):
 def flipfree_state(model_type, seed=0, beta=24.0):
     """recipe_state with every ConvBlock BatchNorm bias at +beta (gamma keeps its ~1): the normalised pre-activations
     (min xhat = -17 on the fixtures' data: the zero padding makes border pixels outliers in proportion to beta) never reach zero, so no ReLU mask (models.py:102-103) can differ between two evaluations of the same
-    step -- what is left of a gradient difference is arithmetic alone.  The trunk's features then sit around +beta, so the
-    first weights behind them are scaled down to keep the head out of saturation (fc / AttBlock: x 0.16/beta, GRU and
-    MultiHead input projections: x 0.4/beta).  Used by the flip-free whole-model gradient fixtures (tests/golden/make_golden.py --flipfree)."""
+    step -- what is left of a gradient difference is arithmetic alone.  The trunk's features then sit around +beta, which must
+    not saturate the head:
+      * FrameAvg / FrameMax / FrameAtt (fc, AttBlock read the features directly): the rows of the head matrices are CENTRED
+        (zero sum over the 512 channels).  A training-mode BatchNorm pins the batch mean of every channel to exactly beta, so
+        a zero-sum row cancels the offset whatever its scale, and the logits keep the recipe's O(1) spread ACROSS FRAMES:
+        sigma' varies from frame to frame and the loss gradient that enters the trunk is not frame-constant.  (Round 5 scaled
+        these matrices by 0.16 / beta instead: logits within 3e-3 of each other, a frame-constant gradient -- which every
+        BatchNorm backward annihilates -- and trunk gradients that were cancellation residue, 1e-9 .. 1e-11 of the head's.)
+      * GRU / MultiHead input projections: x 0.4 / beta (bounded by tanh / the softmax behind them; unchanged).
+    Used by the flip-free whole-model gradient fixtures (tests/golden/make_golden.py --flipfree) together with flipfree_waves."""
     st = recipe_state(model_type, seed)
+    direct_head = "Gru" not in model_type and "Transformer" not in model_type
     for key in list(st.keys()):
         if key.startswith("conv_block") and ".bn" in key and key.endswith(".bias"):
             st[key] = torch.full_like(st[key], float(beta))
-        elif key == "fc.weight" or (key in ("att_block.att.weight", "att_block.cla.weight") and "Gru" not in model_type
-                                    and "Transformer" not in model_type):
-            st[key] = st[key] * (0.16 / beta)
+        elif direct_head and key in ("fc.weight", "att_block.att.weight", "att_block.cla.weight"):
+            st[key] = st[key] - st[key].mean(dim=1, keepdim=True)
         elif key.startswith("gru.weight_ih") or key in ("multihead.w_qs.weight", "multihead.w_ks.weight", "multihead.w_vs.weight"):
             st[key] = st[key] * (0.4 / beta)
     return st
+
+
+def flipfree_waves(seed, n, length):
+    """Input of the flip-free fixtures: noise whose level, slow amplitude envelope and an added tone differ from clip to clip and
+    vary WITHIN a clip, so that neither the clips of a batch nor the frames of a clip are statistically alike (stationary noise
+    clips have near-identical time-averaged features -- with BatchNorm pinning the batch mean, a clip-level loss then hardly
+    depends on the trunk at all).  float32 (n, length), deterministic in `seed`."""
+    rs = np.random.RandomState(seed)
+    x = rs.randn(n, length) * 0.1
+    t = np.arange(length) / 32000.0
+    for i in range(n):
+        env = 0.35 + 0.65 * (0.5 + 0.5 * np.sin(2 * np.pi * (0.4 + 0.3 * i) * t + rs.rand() * 6.28)) ** 2
+        tone = 0.05 * (i % 3) * np.sin(2 * np.pi * (300.0 * (1 + i)) * t)
+        x[i] = x[i] * env * (0.5 + 0.25 * i) + tone * env
+    return x.astype(np.float32)
 
 
 # --------------------------------------------------------------------------------------------

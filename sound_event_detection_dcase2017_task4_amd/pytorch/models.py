@@ -212,7 +212,9 @@ class MultiHead(nn.Module):
     def __init__(self, n_head, d_model, d_k, d_v, dropout=0.1):
         super(MultiHead, self).__init__()
         if (n_head, d_model, d_k, d_v) != (8, 512, 64, 64):
-            raise Exception('Incorrect argument!')   # the attention kernel is specialised for the reference's sizes
+            # the attention kernels are specialised for the one configuration the reference's models construct (models.py:698, :793)
+            raise ValueError('Incorrect argument! MultiHead(n_head, d_model, d_k, d_v) supports (8, 512, 64, 64) only -- the sizes '
+                             'of Cnn_9layers_Transformer_* -- got (%r, %r, %r, %r)' % (n_head, d_model, d_k, d_v))
         self.n_head, self.d_k, self.d_v = n_head, d_k, d_v
         self.w_qs = nn.Linear(d_model, n_head * d_k)
         self.w_ks = nn.Linear(d_model, n_head * d_k)
@@ -253,7 +255,14 @@ class _Cnn9Base(nn.Module):
     def __init__(self, sample_rate, window_size, hop_size, mel_bins, fmin, fmax, classes_num):
         super(_Cnn9Base, self).__init__()
         if (window_size, hop_size, mel_bins) != (1024, 320, 64):
-            raise Exception('Incorrect argument!')   # the kernels are specialised for the config.py constants
+            # The supported set, precisely: window_size = 1024 (the log-mel kernel is a radix-32 x 32 FFT of two real frames),
+            # hop_size = 320, mel_bins = 64 (the reference itself hard-codes BatchNorm2d(64) on the mel axis, models.py:264, so no
+            # other value constructs a working model there either); sample_rate, fmin, fmax and classes_num are free (they only
+            # shape the mel filter bank and the head).  A ValueError is an Exception: `except Exception` callers of the
+            # reference's bare Exception('Incorrect argument!') (models.py:113) keep working.
+            raise ValueError('Incorrect argument! This build supports window_size=1024, hop_size=320, mel_bins=64 '
+                             '(utils/config.py) with any sample_rate / fmin / fmax / classes_num; got window_size=%r, hop_size=%r, '
+                             'mel_bins=%r' % (window_size, hop_size, mel_bins))
         self.classes_num = classes_num
         self.spectrogram_extractor = Spectrogram(n_fft=window_size, hop_length=hop_size)
         self.logmel_extractor = LogmelFilterBank(sr=sample_rate, n_fft=window_size, n_mels=mel_bins, fmin=fmin,

@@ -285,14 +285,15 @@ FF_ROWS, FF_L = 8, 64000              # the flip-free fixture: 8 waveforms -> 4 
 
 def flipfree_fixture(model_type, seed):
     """One training step of the genuine reference in FLOAT64 (and in float32, to record the reference's own error) from
-    `oracle.model.flipfree_state`: every ConvBlock BatchNorm bias = +24, so no ReLU mask can flip between evaluations and a
-    gradient difference is arithmetic alone -- the SURVEY 8(d) gate (relative error <= 1e-3) then holds for EVERY trainable
-    tensor without an allow-list.  The generator asserts the premise: the smallest ConvBlock pre-activation of the step is
+    `oracle.model.flipfree_state` on `oracle.model.flipfree_waves`: every ConvBlock BatchNorm bias = +24, so no ReLU mask can flip
+    between evaluations and a gradient difference is arithmetic alone; centred head rows and non-stationary clips keep the loss
+    gradient from being frame-constant (round 5's FrameAvg fixture was degenerate that way) -- the SURVEY 8(d) gate (relative
+    error <= 1e-3) then holds, ten times over, for EVERY trainable tensor without an allow-list.  The generator asserts the premise: the smallest ConvBlock pre-activation of the step is
     far above zero.  Every gradient is stored as a deterministic subsample plus its norms."""
     out = {}
     T = FF_L // 320 + 1
     loss_func = ref_losses.get_loss_func('clip_bce')
-    xw64 = torch.from_numpy(waves(2700 + seed, FF_ROWS, FF_L))
+    xw64 = torch.from_numpy(om.flipfree_waves(2700 + seed, FF_ROWS, FF_L))
     tg64 = torch.from_numpy(targets(2800 + seed, FF_ROWS))
     lam = ofe.mixup_lambdas(FF_ROWS, np.random.RandomState(1234)).astype(np.float32)
     torch.manual_seed(2900 + seed)
@@ -415,7 +416,7 @@ if __name__ == "__main__":
         sys.exit(0)
     if only and only[0] == "--flipfree":    # only the <model>__flipfree.npz files (whole-model gradients without ReLU flips)
         for i, mt in enumerate(om.MODEL_TYPES):
-            if mt in (only[1:] or ("Cnn_9layers_FrameAvg", "Cnn_9layers_Gru_FrameAtt")):
+            if mt in (only[1:] or ("Cnn_9layers_FrameAvg", "Cnn_9layers_FrameAtt", "Cnn_9layers_Gru_FrameAtt")):
                 np.savez_compressed(os.path.join(HERE, mt + "__flipfree.npz"), **flipfree_fixture(mt, seed=i + 1))
                 print(mt + "__flipfree.npz", os.path.getsize(os.path.join(HERE, mt + "__flipfree.npz")))
         sys.exit(0)

@@ -518,22 +518,24 @@ def test_low_noise_training_fixture_vs_float64_reference(mt, golden_dir, conv_pa
 FF_ROWS, FF_L = 8, 64000
 
 
-@pytest.mark.parametrize("mt", ["Cnn_9layers_FrameAvg", "Cnn_9layers_Gru_FrameAtt"])
+FLIPFREE_GATE = 1e-4
+
+
+@pytest.mark.parametrize("mt", ["Cnn_9layers_FrameAvg", "Cnn_9layers_FrameAtt", "Cnn_9layers_Gru_FrameAtt"])
 def test_flip_free_whole_model_gradients_vs_float64_reference(mt, golden_dir, conv_path):
     """The SURVEY 8(d) gradient gate (relative error <= 1e-3) on a WHOLE-MODEL training step in which no ReLU mask can flip:
     `oracle.model.flipfree_state` puts every ConvBlock BatchNorm bias at +24 (the generator asserts that the smallest
     pre-activation of the step is > 6), so what separates this path from the genuine reference evaluated in float64
     (tests/golden/<model>__flipfree.npz, make_golden.py --flipfree) is arithmetic alone -- the measurement behind the "the
-    other fixtures' gate is loose because of flips" argument.  Every trainable tensor is checked, no allow-list:
-      * Gru_FrameAtt: relative L2 <= 1e-4 on EVERY tensor -- ten times below the 8(d) figure; measured <= 1.9e-5 on both
-        convolution paths (profiles/r05/flipfree_gradients.txt), where the reference's own float32 run reads up to 3.5e-4;
-      * FrameAvg: with the ReLUs linear the trunk is an affine map followed by a mean over frames, the clip-level loss
-        gradient is CONSTANT over the frames of a clip, and a BatchNorm backward (g - mean(g) - xhat * mean(g * xhat))
-        annihilates a constant: the trunk gradients are 1e-9 .. 1e-11 of the head's (pure cancellation residue) and the
-        reference's own float32 run is 2e-3 .. 3e-2 from float64 on them (`ff_ref32err/*`; this build: 1e-4 .. 8e-3).
-        There the gate is 8x the reference's own float32 error (or 1e-3 where that is larger), and 1e-3 flat on every
-        tensor the reference itself gets to 1e-4 (bn0, block 1's first layer, the head).
-    Tensors whose true gradient is structurally zero (attention shift invariance) are checked absolutely."""
+    other fixtures' gate is loose because of flips" argument.  EVERY trainable tensor of the headline model (FrameAvg), of
+    FrameAtt and of Gru_FrameAtt is held to relative L2 <= 1e-4 -- ten times below the 8(d) figure -- with no allow-list, on both
+    convolution paths; the reference's own float32 run reads up to 1.7e-4 on the same fixtures (`ff_ref32err/*`).
+    Round 6: the fixtures are no longer degenerate for the models whose head reads the features directly -- centred head rows
+    (the BatchNorm-pinned +24 offset cancels, the logits keep an O(1) spread across frames) and non-stationary clips
+    (`oracle.model.flipfree_waves`); round 5's FrameAvg fixture had a frame-constant loss gradient, which every BatchNorm
+    backward annihilates: its trunk gradients were cancellation residue (1e-9 .. 1e-11 of the head's) and its gate 8x the
+    reference's own float32 error.  The one tensor whose true gradient is structurally zero (`att_block.att.bias`: softmax
+    shift invariance) is checked absolutely."""
     from sound_event_detection_dcase2017_task4_amd.pytorch import models
     from sound_event_detection_dcase2017_task4_amd.pytorch.losses import get_loss_func
     from sound_event_detection_dcase2017_task4_amd.pytorch.pytorch_utils import do_mixup
@@ -545,7 +547,7 @@ def test_flip_free_whole_model_gradients_vs_float64_reference(mt, golden_dir, co
     m.load_state_dict(om.flipfree_state(mt, seed))
     m = m.to("cuda").train()
     opt = FusedAdamAmsgrad(m, lr=1e-3)
-    xw = torch.from_numpy(waves(2700 + seed, FF_ROWS, FF_L)).cuda()
+    xw = torch.from_numpy(om.flipfree_waves(2700 + seed, FF_ROWS, FF_L)).cuda()
     tg = torch.from_numpy(targets(2800 + seed, FF_ROWS)).cuda()
     lam = torch.from_numpy(fx["ff_lambda"]).cuda()
     o = m(xw, lam, specaug_stripes=fx["ff_stripes"])
@@ -555,6 +557,7 @@ def test_flip_free_whole_model_gradients_vs_float64_reference(mt, golden_dir, co
     opt.zero_grad()
     loss.backward()
     report, bad = {}, {}
+    norms = {}
     for k, p in m.named_parameters():
         if ("ff_g64/" + k) not in fx.files:
             continue
@@ -562,21 +565,21 @@ def test_flip_free_whole_model_gradients_vs_float64_reference(mt, golden_dir, co
         l2, _, _, mx = fx["ff_g64n/" + k]
         g = p.grad.detach().double().reshape(-1).cpu().numpy()
         ref = float(fx["ff_ref32err/" + k])
-        if ref > 1.0:                                            # structurally zero in exact arithmetic (the reference's fp32 run
-            assert np.abs(g).max() < 1e-6, (k, np.abs(g).max())  # is pure noise there): absolute check
+        if k == "att_block.att.bias":                            # structurally zero in exact arithmetic (the reference's fp32 run
+            assert np.abs(g).max() < 1e-6, (k, np.abs(g).max())  # is noise there): absolute check
             continue
         got = g[sample_index(g.size)]
         err = float(np.sqrt(((got - want) ** 2).sum() / max((want ** 2).sum(), 1e-300)))
-        if mt == "Cnn_9layers_FrameAvg":
-            gate = 1e-3 if ref <= 1e-4 else max(1e-3, 8.0 * ref)
-        else:
-            gate = 1e-4
-        report[k] = (err, ref, gate)
-        if err > gate:
-            bad[k] = (err, ref, gate)
+        report[k] = (err, ref, FLIPFREE_GATE)
+        norms[k] = float(l2)
+        if err > FLIPFREE_GATE:
+            bad[k] = (err, ref, FLIPFREE_GATE)
+    # the fixture is NOT degenerate: every trunk tensor carries a gradient far above cancellation residue (the reference's own
+    # float32 run resolves it to better than 2e-4), none is noise-level relative to the head's
+    assert max(v[1] for v in report.values()) < 3e-4, max(report.items(), key=lambda kv: kv[1][1])
     print("flip-free gradient relative L2 vs float64 (ours, reference-fp32, gate), worst five:",
           sorted(report.items(), key=lambda kv: -kv[1][0] / kv[1][2])[:5])
-    print("FLIPFREE_REPORT", mt, conv_path, {k: ("%.2e" % v[0], "%.2e" % v[1]) for k, v in report.items()})
+    print("FLIPFREE_REPORT", mt, conv_path, {k: ("%.2e" % v[0], "%.2e" % v[1], "%.1e" % norms[k]) for k, v in report.items()})
     assert len(report) >= 26 and not bad, bad
 
 

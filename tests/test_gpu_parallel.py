@@ -324,3 +324,100 @@ def test_train_cli_two_ranks_survive_a_non_finite_batch_together(tmp_path, graph
         assert len(warns) == 2 and warns[0].startswith("iteration 3:") and "ops.USE_SF16 = False" in warns[1], (k, warns)
     losses = [float(l.split()[1]) for l in r.stdout.splitlines() if len(l.split()) == 2 and l.split()[0].isdigit()]
     assert len(losses) == 6 and all(np.isfinite(losses)), r.stdout[-1500:]
+
+
+def _torchrun(nproc, script_and_args, env, timeout=1500):
+    from sound_event_detection_dcase2017_task4_amd import parallel
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+                           "--master-addr", "127.0.0.1", "--master-port", str(parallel.free_port())] + script_and_args,
+                          capture_output=True, text=True, env=env, timeout=timeout)
+
+
+def test_bench_eight_ranks_code_path_on_one_gpu():
+    """Rehearsal of the driver's FIRST 8-GPU run (`python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8`),
+    with the eight ranks sharing GPU 0 over gloo (SED_SHARE_GPU=1, test-only).  Everything but the bytes on xGMI is real: eight
+    processes, the parameter / buffer broadcasts, the bucketed all-reduces fired from inside backward in the order head -> block 1,
+    barrier + synchronize around the timed region, MAX over ranks, the weak headline row (32 clips per GPU, global batch 256), the
+    strong row (the reference's `--batch_size 32` scattered by DataParallel, main.py:138 = 4 clips per GPU, one HIP graph per step,
+    buckets behind the graph), the proof-by-all-reduce that eight ranks took part, an orderly shutdown without the watchdog
+    firing, ONE JSON line -- and all of it well inside the driver's patience."""
+    import re
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SED_SHARE_GPU"] = "1"
+    env["OMP_NUM_THREADS"] = "2"
+    t0 = time.time()
+    r = _torchrun(8, [os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "4"], env)
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert wall < 600, wall                                   # eight ranks time-slicing ONE GPU; on eight GPUs it is a fraction
+    # weak row = the headline
+    assert line["n_gpus"] == 8 and line["steps"] == 3 and line["warmup"] == 4 and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 256 and line["config"]["waveforms_per_step"] == 512
+    assert abs(line["value"] - 256 * 3 / (line["ms_per_step"] * 3e-3)) < 0.02 * line["value"]
+    assert line["cpu_baseline"] is None and "extra_configs" not in line
+    d = line["dist"]
+    assert d["backend"] == "gloo" and d["world_size"] == 8 and d["n_ranks_seen"] == 8
+    assert d["allreduce_overlap"] is True and d["allreduce_exposed_steps_averaged"] == 3 and "shutdown_error" not in d
+    assert sum(d["bucket_bytes"]) == d["flat_gradient_bytes"] and len(d["bucket_bytes"]) >= 3
+    m = re.search(r"issued from inside backward in the order \[([0-9, ]+)\]", line["config"]["grad_allreduce"])
+    order = [int(x) for x in m.group(1).split(",")]
+    assert order == list(range(len(d["bucket_bytes"]) - 1, -1, -1)), order          # head / block 4 first, block 1 + bn0 last
+    # strong row: 32 clips GLOBAL = 4 per rank, replayed as one HIP graph per step
+    st = line["strong"]
+    assert "error" not in st, st
+    assert st["scaling"] == "strong" and st["global_batch"] == 32 and st["per_gpu_batch"] == 4 and st["value"] > 0
+    assert abs(st["value"] - 32 * 3 / (st["ms_per_step"] * 3e-3)) < 0.02 * st["value"]
+    assert st["hip_graph"] is True and st["hip_graph_replays"] >= 3
+    sd = st["dist"]
+    assert sd["n_ranks_seen"] == 8 and sd["allreduce_overlap"] is False and sd["allreduce_exposed_steps_averaged"] == 3
+    assert sum(sd["bucket_bytes"]) == sd["flat_gradient_bytes"]
+    assert "watchdog" not in r.stdout and "watchdog" not in r.stderr
+
+
+def test_train_cli_eight_ranks_global_batch_32(tmp_path):
+    """The reference's training command (`--batch_size 32`, README) on eight ranks (sharing GPU 0 over gloo): 32 is the GLOBAL batch
+    (main.py:138, :160-166: DataParallel scatters it), every rank trains on its 4 clips = 8 waveforms of every step -- the regime
+    where `--hip_graph auto` replays the step as one graph -- the gradient buckets are exchanged among all eight, rank 0 writes
+    the checkpoint, and every rank ends with the same, finite parameters."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SED_SHARE_GPU"] = "1"
+    env["OMP_NUM_THREADS"] = "2"
+    env["PYTHONPATH"] = REPO + os.pathsep + env.get("PYTHONPATH", "")
+    ws = str(tmp_path)
+    probe = os.path.join(ws, "probe.py")
+    with open(probe, "w") as f:
+        f.write("import os, sys, torch\n"
+                "from sound_event_detection_dcase2017_task4_amd.pytorch import main as cli\n"
+                "from sound_event_detection_dcase2017_task4_amd import graph, optim\n"
+                "keep, steppers = [], []\n"
+                "orig = optim.FusedAdamAmsgrad.__init__\n"
+                "def init(self, *a, **k):\n"
+                "    orig(self, *a, **k); keep.append(self)\n"
+                "optim.FusedAdamAmsgrad.__init__ = init\n"
+                "cli.FusedAdamAmsgrad = optim.FusedAdamAmsgrad\n"
+                "ginit = graph.GraphedTrainStep.__init__\n"
+                "def gi(self, *a, **k):\n"
+                "    ginit(self, *a, **k); steppers.append(self)\n"
+                "graph.GraphedTrainStep.__init__ = gi\n"
+                "cli.main(sys.argv[1:])\n"
+                "ws = sys.argv[sys.argv.index('--workspace') + 1]\n"
+                "torch.save({'flat': keep[0].flat.cpu(), 'steps': keep[0].step_count, 'world': keep[0].world_size,\n"
+                "            'replays': steppers[0].replays if steppers else -1}, os.path.join(ws, 'state_rank%s.pt' % os.environ['RANK']))\n")
+    args = ["train", "--dataset_dir", ws, "--workspace", ws, "--holdout_fold", "1", "--model_type", "Cnn_9layers_FrameAvg",
+            "--loss_type", "clip_bce", "--augmentation", "mixup", "--learning_rate", "1e-3", "--batch_size", "32",
+            "--resume_iteration", "0", "--stop_iteration", "5", "--cuda", "--synthetic", "96", "--print_every", "1"]
+    r = _torchrun(8, [probe] + args, env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    losses = [float(l.split()[1]) for l in r.stdout.splitlines() if len(l.split()) == 2 and l.split()[0].isdigit()]
+    assert len(losses) == 6 and all(np.isfinite(losses)), r.stdout[-1500:]
+    states = [torch.load(os.path.join(ws, "state_rank%d.pt" % k)) for k in range(8)]
+    for st in states:
+        assert st["world"] == 8 and st["steps"] == 6 and st["replays"] >= 2          # 3 eager steps, then graph replays
+        assert torch.equal(st["flat"], states[0]["flat"]) and torch.isfinite(st["flat"]).all()
+    ck = os.path.join(ws, "checkpoints", "main", "holdout_fold=1", "model_type=Cnn_9layers_FrameAvg", "loss_type=clip_bce",
+                      "augmentation=mixup", "batch_size=32", "0_iterations.pth")
+    assert os.path.exists(ck)
