@@ -444,7 +444,8 @@ int sed_drop_relu_bwd(const float* g_y, const float* y, const unsigned char* kee
  * sed_clip_bce: losses.py:5-12 (F.binary_cross_entropy, mean, log clamped at -100) + d loss / d p.
  * sed_mixup_rows: pytorch_utils.py:80-93 on a [B2][D] matrix (the targets, main.py:246).
  * sed_adam_amsgrad: optim.Adam(betas=(0.9,0.999), eps=1e-8, weight_decay=0, amsgrad=True) (main.py:144-145,:258)
- *   over flat buffers; grad_scale is applied to the gradient first (1/world_size after the RCCL all-reduce).
+ *   over flat buffers; grad_scale is applied to the gradient first (1/world_size after the RCCL all-reduce).  lr / betas / eps
+ *   are doubles like torch's Python scalars: lr / (1 - beta1^t), 1 - beta1, 1 - beta2 are formed in double and rounded once.
  *   skip_flag (nullable, device int[2]) = found-non-finite guard: the gradient is first scanned for NaN / inf (which
  *   raises skip_flag[0] and the nullable host-mapped err_host); when skip_flag[0] != 0 -- from that scan or because a
  *   split-f16 kernel of this step met a non-finite operand (their err_dev word) -- parameters and moments are left
@@ -455,8 +456,8 @@ int sed_drop_relu_bwd(const float* g_y, const float* y, const unsigned char* kee
  *   aligned when the guard is used. */
 int sed_clip_bce(const float* p, const float* y, long n, float* loss, float* grad, sed_stream_t stream);
 int sed_mixup_rows(const float* x, const float* lam, long B2, long D, float* out, sed_stream_t stream);
-int sed_adam_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, long n, int step, float lr,
-                     float beta1, float beta2, float eps, float grad_scale, int* skip_flag, int* skipped, int* err_host,
+int sed_adam_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, long n, int step, double lr,
+                     double beta1, double beta2, double eps, float grad_scale, int* skip_flag, int* skipped, int* err_host,
                      int* status_host, const float* rank_flag, sed_stream_t stream);
 /* Rank-consistent found-non-finite guard of a data-parallel job (replaces nothing in the reference: main.py:245-258 has no
  * guard).  sed_guard_publish writes NaN (err_dev[0] != 0) or 0 into flag_out[0]; the caller keeps that word adjacent to

@@ -91,7 +91,7 @@ def test_hooks():
 
 def verify_flags(h):
     """Refuse a library that was not compiled with the default flags of build.py (sed_version() carries the hash of the flags
-    of every object): a timing-experiment build (-DSF_ABL_..., tools/experiment_*.patch) computes wrong results by design
+    of every object): a timing-experiment build (-DSF_ABL_..., tools/experiments/*.patch) computes wrong results by design
     and must never be picked up by accident.  SED_ALLOW_EXPERIMENT=1 lets the experiment tooling load it."""
     from . import build
     fn = h.sed_version

@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "libsed_hip.so")
 SOURCES = ["logmel.hip", "bn.hip", "conv.hip", "conv_wino2.hip", "conv_sf16.hip", "gemm_sf16.hip", "heads.hip", "attention.hip", "gru.hip"]
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-I", INCLUDE]
-# SED_HIPCC_FLAGS: extra flags for kernel experiments (tools/ablate.sh, tools/experiment_*.patch).  A library built with them
+# SED_HIPCC_FLAGS: extra flags for kernel experiments (tools/ablate.sh, tools/experiments/*.patch).  A library built with them
 # carries a different flags hash in sed_version(), and _lib.lib() refuses it unless SED_ALLOW_EXPERIMENT=1.
 FLAGS = BASE_FLAGS + os.environ.get("SED_HIPCC_FLAGS", "").split()
 

@@ -24,7 +24,7 @@
 SED_OBJECT_FLAGS(conv_wino2)
 
 // Round-2 measurements with timing switches that have since been removed from this file (no output stores / no yprev loads /
-// no eta exchange / no statistics / one K-step only; tools/experiment_kernel_ablations.patch) (64->64 @ 1001x64, B = 128): prologue + ONE K-step + epilogue
+// no eta exchange / no statistics / one K-step only; tools/experiments/experiment_kernel_ablations.patch) (64->64 @ 1001x64, B = 128): prologue + ONE K-step + epilogue
 // = 0.94 ms of the 2.69 ms the 8-step kernel takes, i.e. the per-workgroup fixed cost equals 2.8 K-steps and is NOT hidden
 // by the co-resident workgroup; of it the output stores are 0.17 ms, the eta exchange 0.03 ms, the statistics 0, the
 // previous-activation loads of the dgrad epilogue 0.33 ms.  Delaying half of the first generation of workgroups by 7-14 us

@@ -254,8 +254,8 @@ __global__ __launch_bounds__(256) void grad_finite_check_kernel(const float* __r
 
 __global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                            float* __restrict__ m, float* __restrict__ v,
-                                                           float* __restrict__ vmax, long n, float lr, float beta1,
-                                                           float beta2, float eps, float bc1, float bc2_sqrt,
+                                                           float* __restrict__ vmax, long n, float step_size, float omb1,
+                                                           float beta2, float omb2, float eps, float bc2_sqrt,
                                                            float grad_scale, int* __restrict__ skip_flag,
                                                            int* __restrict__ skipped, int* __restrict__ status_host) {
     // found-non-finite skip: a kernel of this step met a NaN / inf operand (skip_flag[0] != 0): leave parameters and
@@ -270,11 +270,12 @@ __global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p
     if (status_host && skip_flag && blockIdx.x == 0 && threadIdx.x == 0)      // cumulative refused steps as of THIS step
         __hip_atomic_store(status_host, __hip_atomic_load(skipped ? skipped : skip_flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const float step_size = lr / bc1;
+    // step_size = lr / (1 - beta1^t), omb1 = 1 - beta1, omb2 = 1 - beta2: formed in DOUBLE on the host and rounded once, as torch
+    // does with its Python scalars (1.0f - 0.999f is 1.0000467e-3, not 1e-3: the second moments of rounds 1-5 ran 4.7e-5 high)
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         float gi = g[i] * grad_scale;
-        float mi = fmaf(1.0f - beta1, gi - m[i], m[i]);                 // exp_avg.lerp_(grad, 1-beta1)
-        float vi = fmaf(1.0f - beta2, gi * gi, v[i] * beta2);           // mul_(beta2).addcmul_(g, g, 1-beta2)
+        float mi = fmaf(omb1, gi - m[i], m[i]);                         // exp_avg.lerp_(grad, 1-beta1)
+        float vi = fmaf(omb2, gi * gi, v[i] * beta2);                   // mul_(beta2).addcmul_(g, g, 1-beta2)
         float vm = fmaxf(vmax[i], vi);
         float denom = sqrtf(vm) / bc2_sqrt + eps;
         p[i] = p[i] - step_size * (mi / denom);
@@ -468,8 +469,8 @@ SED_API int sed_guard_publish(const int* err_dev, float* flag_out, hipStream_t s
 }
 
 // One Adam-amsgrad step (step >= 1) over flat buffers; grad_scale multiplies the gradient first (1/world_size).
-SED_API int sed_adam_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, long n, int step, float lr,
-                             float beta1, float beta2, float eps, float grad_scale, int* skip_flag, int* skipped,
+SED_API int sed_adam_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, long n, int step, double lr,
+                             double beta1, double beta2, double eps, float grad_scale, int* skip_flag, int* skipped,
                              int* err_host, int* status_host, const float* rank_flag, hipStream_t stream) {
     if (n <= 0 || step < 1) return SED_EINVAL;
     if ((reinterpret_cast<uintptr_t>(g) & 15) != 0 && skip_flag) return SED_EINVAL;
@@ -478,10 +479,11 @@ SED_API int sed_adam_amsgrad(float* p, const float* g, float* m, float* v, float
         hipLaunchKernelGGL(grad_finite_check_kernel, dim3((unsigned)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb))), dim3(256), 0, stream, g,
                            n, skip_flag, err_host, rank_flag);
     }
-    double bc1 = 1.0 - pow((double)beta1, (double)step);
-    double bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(adam_amsgrad_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, m, v, vmax, n, lr, beta1, beta2, eps,
-                       (float)bc1, (float)sqrt(bc2), grad_scale, skip_flag, skipped, status_host);
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(adam_amsgrad_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, m, v, vmax, n, (float)(lr / bc1),
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)sqrt(bc2), grad_scale, skip_flag,
+                       skipped, status_host);
     SED_LAUNCH_CHECK();
     return 0;
 }

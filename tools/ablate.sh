@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU-box helper: rebuild one source with extra -D flags and time it (kernel experiments / ablations).
 # BENCH=tools/elem_bench.py selects another micro-benchmark.
-# The timing switches are NOT in the shipped kernels any more: apply tools/experiment_kernel_ablations.patch (or one of the
+# The timing switches are NOT in the shipped kernels any more: apply tools/experiments/experiment_kernel_ablations.patch (or one of the
 # experiment_*_patch.py) first; the library built here carries a non-default flags hash and loads only with SED_ALLOW_EXPERIMENT=1.
 # usage: tools/ablate.sh <source.hip> "<conv_bench args>" <variant...>   variant = base | <N> (-DSED_ABL=N) | D<macro> (-D<macro>)
 SRC=$1; ARGS=$2; shift 2
