@@ -69,6 +69,10 @@ int sed_bn_finalize(const float* partials, int nparts, int rows_per_part, long N
                     int* guard_dev, int* guard_host, float* cand,
                     const float* y_amax /* nullable */, float* act_bound_out /* nullable [64]: what sed_act_bound computes, from
                                                                                 the same launch */,
+                    const float* minmax /* nullable [nparts][2][C]: per-part (max, min) of y, same parts as `partials` */,
+                    float* act_amax_out /* nullable [64]: what sed_act_amax(minmax, nparts, C, scale_out, shift_out) computes -- the
+                                           operand amax of the NEXT convolution -- from the same launch up to 512 parts, by a
+                                           follow-up launch beyond */,
                     sed_stream_t stream);
 int sed_bn_commit(int n, float* const* cand, float* const* running_mean, float* const* running_var, const int* C,
                   const int* guard_dev, sed_stream_t stream);
@@ -83,7 +87,10 @@ int sed_bn_eval_affine(int C, const float* gamma, const float* beta, const float
 int sed_bn_bwd_finalize(const float* partials, int nparts, long N, int C, const float* mean, const float* invstd,
                         const float* scale, int batch_stats, float* dgamma, float* dbeta, float* coef, double* ws,
                         const float* y_amax, const float* g_amax, float ginv,
-                        float* bound_out /* nullable [64]: sed_grad_bound(minmax = NULL, ..., y_amax) from the same launch */,
+                        float* bound_out /* nullable [64]: what sed_grad_bound computes, from the same launch: with y_amax (and
+                                            minmax = NULL) the bound over |y| <= amax; with minmax (and y_amax = NULL) over each
+                                            channel's own range -- up to 512 parts inside this launch, by a follow-up launch beyond */,
+                        const float* minmax /* nullable [nparts][2][C]: per-part (max, min) of y, same parts as `partials` */,
                         sed_stream_t stream);
 /* g_y = a*dy + b*y + c in place on dy [nrows][C].  amax_out (nullable, device): receives max |g_y| (the split-f16
  * convolution that consumes the tensor takes its scale from it; zeroed and accumulated in stream order). */

@@ -121,6 +121,15 @@ __device__ __forceinline__ void direct_sums(const BnDirectP& dp, int C, long N, 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
 }
+// per-channel (max, min) of a tensor over its per-part ranges mm [nparts][2][C]: one wave per channel, xor-shuffle tree
+__device__ __forceinline__ void range_over_parts(const float* __restrict__ mm, int nparts, int C, int c, int sub, float& mx, float& mn) {
+    for (int p = sub; p < nparts; p += 64) {
+        mx = fmaxf(mx, mm[((long)p * 2 + 0) * C + c]);
+        mn = fminf(mn, mm[((long)p * 2 + 1) * C + c]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); mn = fminf(mn, __shfl_xor(mn, o, 64)); }
+}
 // A/B on one box (round 5; 60 steps, twice): two launches 2.12 / 8.068 ms per step (4 clips per GPU under the HIP graph / the
 // metric's bs=32), direct up to 512 parts 2.075 / 8.05, up to 2048 parts 2.09 / 8.07, up to 8192 parts 2.085 / 8.19 -- one wave per
 // channel walking more than ~8 trips of strided loads is slower than the chunked pass it replaces
@@ -132,13 +141,18 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, int nchunks, B
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                    float* __restrict__ scale_out, float* __restrict__ shift_out,
                                    int* __restrict__ guard_dev, int* __restrict__ guard_host, float* __restrict__ cand,
-                                   const float* __restrict__ y_amax, float* __restrict__ act_bound_out) {
+                                   const float* __restrict__ y_amax, float* __restrict__ act_bound_out,
+                                   const float* __restrict__ mm, int mm_parts, float* __restrict__ act_amax_out) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), sub = threadIdx.x & 63;    // 256 threads = 4 channels x one wave
     if (c >= C) return;
     double s1, s2;
     if (dp.parts) direct_sums<1>(dp, C, N, c, sub, s1, s2);
     else chunk_sums16(ws, nchunks, C, c, sub, s1, s2);
     const float A = act_bound_out ? amax_read(y_amax) : 0.f;       // (every lane of the wave takes part in the read)
+    // by-product (round 6; was the separate act_amax launch): the range of this channel of y over the parts (the conv epilogue's
+    // per-part (max, min)), pushed through the affine + ReLU below -- the operand amax of the NEXT convolution
+    float ymx = -__builtin_inff(), ymn = __builtin_inff();
+    if (act_amax_out) range_over_parts(mm, mm_parts, C, c, sub, ymx, ymn);
     if (sub != 0) return;
     double mean = s1 / (double)N;
     double var = s2 / (double)N - mean * mean;
@@ -149,6 +163,9 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, int nchunks, B
     mean_out[c] = meanf; invstd_out[c] = invf;
     const float shf = fmaf(-meanf, sc, beta[c]);
     scale_out[c] = sc; shift_out[c] = shf;
+    if (act_amax_out && ymx >= ymn)          // exact: the affine + ReLU is monotone in y, the extreme sits at a range end
+        atomicMax(reinterpret_cast<unsigned*>(act_amax_out) + (c & (SED_AMAX_SLOTS - 1)),
+                  __float_as_uint(fmaxf(bn_relu(ymx, sc, shf), bn_relu(ymn, sc, shf))));
     // by-product for the split-f16 path (was the separate act_bound kernel): this channel's bound of the pooled activation
     // relu(scale*y + shift) given |y| <= A, merged over the channels by one atomic per channel on the pre-zeroed slots
     if (act_bound_out)
@@ -191,13 +208,17 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int nchunk
                                        const float* __restrict__ scale, int batch_stats,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ coef /*[3][C]*/, const float* __restrict__ y_amax,
-                                       const float* __restrict__ g_amax, float ginv, float* __restrict__ bound_out) {
+                                       const float* __restrict__ g_amax, float ginv, float* __restrict__ bound_out,
+                                       const float* __restrict__ mm, int mm_parts) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), sub = threadIdx.x & 63;
     if (c >= C) return;
     double s1, s2;
     if (dp.parts) direct_sums<0>(dp, C, N, c, sub, s1, s2);
     else chunk_sums16(ws, nchunks, C, c, sub, s1, s2);
-    const float A = bound_out ? amax_read(y_amax) : 0.f, G = bound_out ? amax_read(g_amax) * ginv : 0.f;
+    const float A = (bound_out && !mm) ? amax_read(y_amax) : 0.f, G = bound_out ? amax_read(g_amax) * ginv : 0.f;
+    // mm given (round 6; was the separate grad_bound launch): |y| ranges over this channel's own (min, max) instead of +-A
+    float ymx = A, ymn = -A;
+    if (bound_out && mm) { ymx = -__builtin_inff(); ymn = __builtin_inff(); range_over_parts(mm, mm_parts, C, c, sub, ymx, ymn); }
     if (sub != 0) return;
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
@@ -211,9 +232,9 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int nchunk
         const float af = (float)a, bf = (float)b, cf = (float)cc;
         coef[c] = af; coef[C + c] = bf; coef[2 * C + c] = cf;
         // by-product (was grad_bound_kernel with the y_amax range): bound of |a*dy + b*y + c| for |dy| <= G, |y| <= A
-        if (bound_out)
+        if (bound_out && ymx >= ymn)
             atomicMax(reinterpret_cast<unsigned*>(bound_out) + (c & (SED_AMAX_SLOTS - 1)),
-                      __float_as_uint((fabsf(af) * G + fmaxf(fabsf(fmaf(bf, A, cf)), fabsf(fmaf(bf, -A, cf)))) * 1.0001f));
+                      __float_as_uint((fabsf(af) * G + fmaxf(fabsf(fmaf(bf, ymx, cf)), fabsf(fmaf(bf, ymn, cf)))) * 1.0001f));
     }
 }
 
@@ -688,10 +709,14 @@ SED_API int sed_bn_finalize(const float* partials, int nparts, int rows_per_part
                             const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                             float* mean_out, float* invstd_out, float* scale_out, float* shift_out, double* ws,
                             int* guard_dev, int* guard_host, float* cand, const float* y_amax, float* act_bound_out,
-                            hipStream_t stream) {
-    if (nparts <= 0 || C <= 0 || N <= 0 || (act_bound_out && !y_amax)) return SED_EINVAL;
+                            const float* minmax, float* act_amax_out, hipStream_t stream) {
+    if (nparts <= 0 || C <= 0 || N <= 0 || (act_bound_out && !y_amax) || (act_amax_out && !minmax)) return SED_EINVAL;
     if (act_bound_out) {
         hipError_t e = sed_amax_clear(act_bound_out, stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (act_amax_out) {
+        hipError_t e = sed_amax_clear(act_amax_out, stream);
         if (e != hipSuccess) return (int)e;
     }
     int ppc = reduce_chunks(nparts), nchunks = sed_cdiv(nparts, ppc), K = 2 * C;
@@ -700,9 +725,18 @@ SED_API int sed_bn_finalize(const float* partials, int nparts, int rows_per_part
     if (!direct)
         hipLaunchKernelGGL(reduce_parts_kernel<1>, dim3(nchunks, sed_cdiv(K, 256)), dim3(256), 0, stream, partials, nparts, K,
                            ppc, N, rows_per_part, ws);
+    // the operand amax of the next convolution rides on the finalize launch while one wave per channel walks the parts in a few
+    // trips (the same limit as the direct sums); beyond it the chunked act_amax launch follows as before
+    const bool fold = act_amax_out && direct;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(sed_cdiv(C, 4)), dim3(256), 0, stream, ws, nchunks, dp, C, N, gamma, beta, eps,
                        momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out, guard_dev, guard_host, cand,
-                       y_amax, act_bound_out);
+                       y_amax, act_bound_out, fold ? minmax : nullptr, nparts, fold ? act_amax_out : nullptr);
+    if (act_amax_out && !fold) {
+        int ppb = sed_cdiv(nparts, 1024);
+        if (ppb < 8) ppb = 8;
+        hipLaunchKernelGGL(act_amax_kernel, dim3(sed_cdiv(nparts, ppb)), dim3(256), 0, stream, minmax, nparts, C,
+                           (const float*)scale_out, (const float*)shift_out, ppb, act_amax_out);
+    }
     SED_LAUNCH_CHECK();
     return 0;
 }
@@ -775,11 +809,46 @@ SED_API int sed_bn_eval_affine(int C, const float* gamma, const float* beta, con
 }
 
 // partials [nparts][2][C] = (sum dy, sum dy*xhat).  coef may be null (bn0: only dgamma/dbeta wanted).
+// (defined here, ahead of its two users: sed_bn_bwd_finalize's chunked follow-up launch and sed_grad_bound)
+namespace {
+__global__ __launch_bounds__(256) void grad_bound_kernel(const float* __restrict__ mm, int nparts, int C,
+                                                         const float* __restrict__ coef, const float* __restrict__ g_amax,
+                                                         float ginv, int parts_per_block, float* __restrict__ bound_out,
+                                                         const float* __restrict__ y_amax) {
+    __shared__ float red[256];
+    const int p0 = blockIdx.x * parts_per_block, p1 = min(nparts, p0 + parts_per_block);
+    const float G = amax_read(g_amax) * ginv;
+    const float A = y_amax ? amax_read(y_amax) : 0.f;        // mm null: |y| <= A for every channel (the looser, cheaper range)
+    float best = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float mx = mm ? -__builtin_inff() : A, mn = mm ? __builtin_inff() : -A;
+        for (int q = p0; mm && q < p1; ++q) {
+            mx = fmaxf(mx, mm[((long)q * 2 + 0) * C + c]);
+            mn = fminf(mn, mm[((long)q * 2 + 1) * C + c]);
+        }
+        if (mx >= mn) {
+            const float a = coef[c], b = coef[C + c], cc = coef[2 * C + c];
+            // 1.0001: the kernels evaluate a*dy + (b*y + c) with two roundings; the bound must never fall below the value
+            best = fmaxf(best, (fabsf(a) * G + fmaxf(fabsf(fmaf(b, mx, cc)), fabsf(fmaf(b, mn, cc)))) * 1.0001f);
+        }
+    }
+    red[threadIdx.x] = best;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        atomicMax(reinterpret_cast<unsigned*>(bound_out) + (blockIdx.x & (SED_AMAX_SLOTS - 1)), __float_as_uint(red[0]));
+}
+}  // namespace
+
 SED_API int sed_bn_bwd_finalize(const float* partials, int nparts, long N, int C, const float* mean,
                                 const float* invstd, const float* scale, int batch_stats, float* dgamma, float* dbeta,
                                 float* coef, double* ws, const float* y_amax, const float* g_amax, float ginv, float* bound_out,
-                                hipStream_t stream) {
-    if (nparts <= 0 || C <= 0 || N <= 0 || (bound_out && (!coef || !y_amax || !g_amax))) return SED_EINVAL;
+                                const float* minmax, hipStream_t stream) {
+    if (nparts <= 0 || C <= 0 || N <= 0 || (bound_out && (!coef || !g_amax || ((y_amax == nullptr) == (minmax == nullptr)))))
+        return SED_EINVAL;
     if (bound_out) {
         hipError_t e = sed_amax_clear(bound_out, stream);
         if (e != hipSuccess) return (int)e;
@@ -790,8 +859,19 @@ SED_API int sed_bn_bwd_finalize(const float* partials, int nparts, long N, int C
     if (!direct)
         hipLaunchKernelGGL(reduce_parts_kernel<0>, dim3(nchunks, sed_cdiv(K, 256)), dim3(256), 0, stream, partials, nparts, K,
                            ppc, N, 0, ws);
+    // minmax [nparts][2][C] (the per-part range of y the forward convolution left; same parts as `partials`): the bound uses each
+    // channel's own range -- inside this launch while one wave per channel walks the parts in a few trips, else by the chunked
+    // grad_bound launch behind it, as before round 6
+    const bool late = bound_out && minmax && !direct;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sed_cdiv(C, 4)), dim3(256), 0, stream, ws, nchunks, dp, C, N, mean, invstd,
-                       scale, batch_stats, dgamma, dbeta, coef, y_amax, g_amax, ginv, bound_out);
+                       scale, batch_stats, dgamma, dbeta, coef, y_amax, g_amax, ginv, late ? nullptr : bound_out,
+                       late ? nullptr : minmax, nparts);
+    if (late) {
+        int ppb = sed_cdiv(nparts, 1024);
+        if (ppb < 8) ppb = 8;
+        hipLaunchKernelGGL(grad_bound_kernel, dim3(sed_cdiv(nparts, ppb)), dim3(256), 0, stream, minmax, nparts, C, (const float*)coef,
+                           g_amax, ginv, ppb, bound_out, (const float*)nullptr);
+    }
     SED_LAUNCH_CHECK();
     return 0;
 }
@@ -1084,38 +1164,6 @@ SED_API int sed_bn_bwd_apply(float* dy_inout, const float* y, long nrows, int C,
 // pass: sed_grad_bound gives an upper bound of max |a*dy + b*y + c| from what is known per channel -- the coefficients, the
 // range of y (the conv epilogue's minmax partials) and the amax of the incoming gradient: |a|*G*ginv + max(|b*ymax + c|,
 // |b*ymin + c|).  A bound that is a few times too large costs nothing: hi and lo are floating-point numbers.
-namespace {
-__global__ __launch_bounds__(256) void grad_bound_kernel(const float* __restrict__ mm, int nparts, int C,
-                                                         const float* __restrict__ coef, const float* __restrict__ g_amax,
-                                                         float ginv, int parts_per_block, float* __restrict__ bound_out,
-                                                         const float* __restrict__ y_amax) {
-    __shared__ float red[256];
-    const int p0 = blockIdx.x * parts_per_block, p1 = min(nparts, p0 + parts_per_block);
-    const float G = amax_read(g_amax) * ginv;
-    const float A = y_amax ? amax_read(y_amax) : 0.f;        // mm null: |y| <= A for every channel (the looser, cheaper range)
-    float best = 0.f;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float mx = mm ? -__builtin_inff() : A, mn = mm ? __builtin_inff() : -A;
-        for (int q = p0; mm && q < p1; ++q) {
-            mx = fmaxf(mx, mm[((long)q * 2 + 0) * C + c]);
-            mn = fminf(mn, mm[((long)q * 2 + 1) * C + c]);
-        }
-        if (mx >= mn) {
-            const float a = coef[c], b = coef[C + c], cc = coef[2 * C + c];
-            // 1.0001: the kernels evaluate a*dy + (b*y + c) with two roundings; the bound must never fall below the value
-            best = fmaxf(best, (fabsf(a) * G + fmaxf(fabsf(fmaf(b, mx, cc)), fabsf(fmaf(b, mn, cc)))) * 1.0001f);
-        }
-    }
-    red[threadIdx.x] = best;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0)
-        atomicMax(reinterpret_cast<unsigned*>(bound_out) + (blockIdx.x & (SED_AMAX_SLOTS - 1)), __float_as_uint(red[0]));
-}
-}  // namespace
 
 SED_API int sed_grad_bound(const float* minmax, int nparts, int C, const float* coef, const float* g_amax, float ginv,
                            float* bound_out, const float* y_amax, hipStream_t stream) {

@@ -1400,37 +1400,84 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
         }
 }
 
-// sum the slices in fp64, unscale, scatter to OIHW
-// 64 elements x 4 part groups per block: group g sums parts g, g+4, ... (four independent loads in flight per thread),
-// the groups meet in LDS -- a fixed order, so the result is deterministic.  (One thread per element walking all parts in a
-// dependent chain took 315 us for the 1000 partials of the 64 -> 64 layer at batch 32.)
-__global__ __launch_bounds__(256) void wgrad_sf16_reduce_kernel(const float* __restrict__ partial, int nparts, int N, int K,
-                                                                const float* __restrict__ g_amax,
-                                                                const float* __restrict__ x_amax,
-                                                                float* __restrict__ dw) {
-    __shared__ double red[256];
+// sum the slices in fp64, unscale, scatter to OIHW.  Two cuts of the same sum (fixed orders: deterministic), chosen by the slice
+// count -- the partials are always ~38 MB (512 workgroups x 74 KB), what changes is their shape:
+//   MANY slices x few elements (the <= 128-channel layers: 32 .. 256 slices of 37 K .. 295 K elements): 64 elements x G part
+//     groups per block, group g sums parts g, g + G, ... with four independent loads in flight, the groups meet in LDS.  G = 16
+//     (1024 threads) since round 6: with G = 4 a thread walked 64 parts in 16 dependent rounds of four loads -- latency, not
+//     bandwidth (14.5 us per launch for 38 MB = 2.7 TB/s, whatever the layer).  (One thread per element walking all parts in a
+//     dependent chain took 315 us for the 1000 partials of the 64 -> 64 layer at batch 32.)
+//   FEW slices x many elements (>= 256 input channels: 4 .. 16 slices of 0.6 .. 2.4 M elements): a block owns one output channel
+//     x 64 input channels x all 9 taps, every thread sums the parts of two or three taps (all loads independent), the 576 sums
+//     meet in LDS and leave as ONE contiguous 2304-byte run of the OIHW tensor -- the element-per-thread form wrote 4 bytes every
+//     36 bytes: 2.4 M write transactions for the 512 -> 512 layer.
+template <int G>
+__global__ __launch_bounds__(64 * G) void wgrad_sf16_reduce_kernel(const float* __restrict__ partial, int nparts, int N, int K,
+                                                                   const float* __restrict__ g_amax,
+                                                                   const float* __restrict__ x_amax,
+                                                                   float* __restrict__ dw) {
+    __shared__ double red[64 * G];
     const long nk = (long)9 * N * K;                       // a multiple of 64
     const long e = (long)blockIdx.x * 64 + (threadIdx.x & 63);
     const int grp = threadIdx.x >> 6;
     const double inv = 1.0 / ((double)sf_scale_of(amax_read(g_amax)) * (double)sf_scale_of(amax_read(x_amax)));
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int q = grp;
-    for (; q + 12 < nparts; q += 16) {
-        s0 += (double)partial[(long)q * nk + e];
-        s1 += (double)partial[(long)(q + 4) * nk + e];
-        s2 += (double)partial[(long)(q + 8) * nk + e];
-        s3 += (double)partial[(long)(q + 12) * nk + e];
+    // eight independent loads per trip (all requested before the first add: one memory round trip per eight parts), four fp64 chains
+    for (; q + 7 * G < nparts; q += 8 * G) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = partial[(long)(q + j * G) * nk + e];
+        s0 += (double)v[0]; s1 += (double)v[1]; s2 += (double)v[2]; s3 += (double)v[3];
+        s0 += (double)v[4]; s1 += (double)v[5]; s2 += (double)v[6]; s3 += (double)v[7];
     }
-    for (; q < nparts; q += 4) s0 += (double)partial[(long)q * nk + e];
+    for (; q + 3 * G < nparts; q += 4 * G) {
+        s0 += (double)partial[(long)q * nk + e];
+        s1 += (double)partial[(long)(q + G) * nk + e];
+        s2 += (double)partial[(long)(q + 2 * G) * nk + e];
+        s3 += (double)partial[(long)(q + 3 * G) * nk + e];
+    }
+    for (; q < nparts; q += G) s0 += (double)partial[(long)q * nk + e];
     red[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (grp == 0) {
-        const double s = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+        double s = 0.0;
+#pragma unroll
+        for (int g = 0; g < G; g += 4)
+            s += (red[threadIdx.x + 64 * g] + red[threadIdx.x + 64 * (g + 1)]) + (red[threadIdx.x + 64 * (g + 2)] + red[threadIdx.x + 64 * (g + 3)]);
         const int ci = (int)(e % K);
         const long t = e / K;
         const int co = (int)(t % N), tap = (int)(t / N);
         dw[((long)co * K + ci) * 9 + tap] = (float)(s * inv);
     }
+}
+
+__global__ __launch_bounds__(256) void wgrad_sf16_reduce_rows_kernel(const float* __restrict__ partial, int nparts, int N, int K,
+                                                                     const float* __restrict__ g_amax,
+                                                                     const float* __restrict__ x_amax,
+                                                                     float* __restrict__ dw) {
+    __shared__ float outs[64 * 9];
+    const int kb = K >> 6;                                  // 64-channel chunks of the input channels (K % 64 == 0 here)
+    const int co = blockIdx.x / kb, ci0 = (blockIdx.x % kb) << 6;
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long nk = (long)9 * N * K;
+    const double inv = 1.0 / ((double)sf_scale_of(amax_read(g_amax)) * (double)sf_scale_of(amax_read(x_amax)));
+    for (int tap = g; tap < 9; tap += 4) {                  // group 0: taps 0, 4, 8; groups 1 .. 3: two taps each
+        const float* src = partial + ((long)tap * N + co) * K + ci0 + lane;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int q = 0;
+        for (; q + 3 < nparts; q += 4) {
+            s0 += (double)src[(long)q * nk];
+            s1 += (double)src[(long)(q + 1) * nk];
+            s2 += (double)src[(long)(q + 2) * nk];
+            s3 += (double)src[(long)(q + 3) * nk];
+        }
+        for (; q < nparts; ++q) s0 += (double)src[(long)q * nk];
+        outs[lane * 9 + tap] = (float)(((s0 + s1) + (s2 + s3)) * inv);
+    }
+    __syncthreads();
+    float* dst = dw + ((long)co * K + ci0) * 9;             // 64 input channels x 9 taps of this output channel: contiguous in OIHW
+    for (int i = threadIdx.x; i < 576; i += 256) dst[i] = outs[i];
 }
 
 static void wsf_slicing(int B, int H, int W, int Cin, int Cout, int* spi, int* ips, int* spimg, long* nslices) {
@@ -1509,8 +1556,15 @@ SED_API int sed_conv3x3_wgrad_sf16(const float* x, const float* gy, float* dw_oi
 #undef WSF_LAUNCH
     SED_LAUNCH_CHECK();
     const long nk = 9L * Cin * Cout;
-    hipLaunchKernelGGL(wgrad_sf16_reduce_kernel, dim3((unsigned)(nk / 64)), dim3(256), 0, s, partial, (int)ns, Cout,
-                       Cin, gy_amax, x_amax, dw_oihw);
+    if (ns <= 16 && Cin % 64 == 0)
+        hipLaunchKernelGGL(wgrad_sf16_reduce_rows_kernel, dim3((unsigned)((long)Cout * (Cin / 64))), dim3(256), 0, s, partial, (int)ns,
+                           Cout, Cin, gy_amax, x_amax, dw_oihw);
+    else if (ns >= 32)
+        hipLaunchKernelGGL(wgrad_sf16_reduce_kernel<16>, dim3((unsigned)(nk / 64)), dim3(1024), 0, s, partial, (int)ns, Cout, Cin,
+                           gy_amax, x_amax, dw_oihw);
+    else
+        hipLaunchKernelGGL(wgrad_sf16_reduce_kernel<4>, dim3((unsigned)(nk / 64)), dim3(256), 0, s, partial, (int)ns, Cout, Cin,
+                           gy_amax, x_amax, dw_oihw);
     SED_LAUNCH_CHECK();
     return 0;
 }

@@ -588,8 +588,10 @@ def _ws(C, device):
     return torch.empty((2048 * C,), dtype=torch.float64, device=device)
 
 
-def bn_finalize(partials, nparts, rows_per_part, N, bn_w, bn_b, running_mean, running_var, y_amax=None, act_bound_out=None):
-    """Batch statistics -> folded affine + running-statistics update.  While the found-non-finite guard is on (USE_SF16)
+def bn_finalize(partials, nparts, rows_per_part, N, bn_w, bn_b, running_mean, running_var, y_amax=None, act_bound_out=None,
+                minmax=None, act_amax_out=None):
+    """Batch statistics -> folded affine + running-statistics update.  minmax / act_amax_out: the same launch also leaves the
+    amax of relu(scale*y + shift) from the per-part range of y (what act_amax() computes; a follow-up launch beyond 512 parts).  While the found-non-finite guard is on (USE_SF16)
     NaN / inf batch statistics raise the error words (the Adam kernel then refuses the step) and are NOT blended into
     running_mean / running_var: a refused step leaves the BatchNorm buffers intact like the parameters.  With
     USE_SF16 = False the update is torch's (NaN flows into the buffers, as in the reference)."""
@@ -600,7 +602,8 @@ def bn_finalize(partials, nparts, rows_per_part, N, bn_w, bn_b, running_mean, ru
     _call("sed_bn_finalize", _ptr(partials), nparts, rows_per_part, N, C, _ptr(bn_w), _ptr(bn_b), BN_EPS, BN_MOMENTUM,
           _ptr(running_mean), _ptr(running_var), _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale), _ptr(st.shift),
           _ptr(_ws(C, bn_w.device)), _sf16_err_dev_ptr(bn_w.device) if guard else None, _sf16_err_ptr() if guard else None,
-          _ptr(cand), _ptr(y_amax) if act_bound_out is not None else None, _ptr(act_bound_out), _stream())
+          _ptr(cand), _ptr(y_amax) if act_bound_out is not None else None, _ptr(act_bound_out),
+          _ptr(minmax) if act_amax_out is not None else None, _ptr(act_amax_out), _stream())
     if cand is not None:
         # the proposed running statistics are installed by ONE launch at the end of the forward pass (models' trunk:
         # begin_bn_commit / commit_bn) -- or right here for a BatchNorm used on its own -- unless the pass met NaN / inf
@@ -672,9 +675,10 @@ def bn_eval_affine(bn_w, bn_b, running_mean, running_var):
     return st
 
 
-def bn_bwd_finalize(partials, nparts, N, st, want_coef=True, batch_stats=True, sinks=(None, None), bound=None):
+def bn_bwd_finalize(partials, nparts, N, st, want_coef=True, batch_stats=True, sinks=(None, None), bound=None, minmax=None):
     """bound (optional) = (y_amax, g_amax, ginv, bound_out): the finalize launch also leaves, in the zeroed amax vector bound_out,
-    an upper bound of max |a*dy + b*y + c| for |y| <= amax(y_amax), |dy| <= amax(g_amax) * ginv (what sed_grad_bound computes)."""
+    an upper bound of max |a*dy + b*y + c| for |y| <= amax(y_amax), |dy| <= amax(g_amax) * ginv (what sed_grad_bound computes).
+    minmax (then y_amax = None): the per-part range of y [nparts][2][C] -- the bound uses each channel's own range."""
     C = st.mean.numel()
     dev = st.mean.device
     dgamma = _dst(sinks[0], (C,), dev)
@@ -683,7 +687,7 @@ def bn_bwd_finalize(partials, nparts, N, st, want_coef=True, batch_stats=True, s
     _call("sed_bn_bwd_finalize", _ptr(partials), nparts, N, C, _ptr(st.mean), _ptr(st.invstd), _ptr(st.scale),
           1 if batch_stats else 0, _ptr(dgamma), _ptr(dbeta), _ptr(coef), _ptr(_ws(C, dev)),
           _ptr(bound[0]) if bound else None, _ptr(bound[1]) if bound else None, float(bound[2]) if bound else 1.0,
-          _ptr(bound[3]) if bound else None, _stream())
+          _ptr(bound[3]) if bound else None, _ptr(minmax) if bound else None, _stream())
     return _ret(sinks[0], dgamma), _ret(sinks[1], dbeta), coef
 
 
@@ -1176,8 +1180,8 @@ class ConvBlockFn(torch.autograd.Function):
             part1 = torch.empty((np1, 2, Cout), dtype=torch.float32, device=dev)
             mm1 = torch.empty((np1, 2, Cout), dtype=torch.float32, device=dev)
             _call("sed_conv1_fwd", _ptr(x), _ptr(w1c), None, B, H, W, _ptr(part1), _ptr(mm1), _stream())   # statistics + range only
-            st1 = bn_finalize(part1, np1, rpp1, M, g1, b1, rm1, rv1)
-            a1 = act_amax(mm1, np1, Cout, st1)
+            a1 = _amax_buf(dev)
+            st1 = bn_finalize(part1, np1, rpp1, M, g1, b1, rm1, rv1, minmax=mm1, act_amax_out=a1)
             del mm1
             y1 = torch.empty((B, H, W, Cout), dtype=torch.int32, device=dev)       # split-f16 PAIRS of relu(bn1(conv1(x)))
             _call("sed_conv1_act_sf16", _ptr(x), _ptr(w1c), B, H, W, _ptr(st1.scale), _ptr(st1.shift), _ptr(a1), _ptr(y1),
@@ -1198,10 +1202,16 @@ class ConvBlockFn(torch.autograd.Function):
             y1 = _conv_fwd_like(x, w1c, B, H, W, Cin, Cout, epi=1 if training else 0, partials=part1, x_amax=x_amax, minmax=mm1,
                                 packs=pk1, presplit=bool(x_pairs))
         if not b1_pairs:
-            st1 = bn_finalize(part1, np1, rpp1, M, g1, b1, rm1, rv1) if training else bn_eval_affine(g1, b1, rm1, rv1)
             a1 = None
-            if need_a1:
-                a1 = act_amax(mm1, np1, Cout, st1) if mm1 is not None else act_amax_full(y1, st1)
+            if training and need_a1 and mm1 is not None:
+                # the operand amax of conv2 -- relu(bn1(y1)), never materialised -- from the range conv1's epilogue left, by the
+                # finalize launch itself (round 6: one launch fewer per block)
+                a1 = _amax_buf(dev)
+                st1 = bn_finalize(part1, np1, rpp1, M, g1, b1, rm1, rv1, minmax=mm1, act_amax_out=a1)
+            else:
+                st1 = bn_finalize(part1, np1, rpp1, M, g1, b1, rm1, rv1) if training else bn_eval_affine(g1, b1, rm1, rv1)
+                if need_a1:
+                    a1 = act_amax(mm1, np1, Cout, st1) if mm1 is not None else act_amax_full(y1, st1)
             del mm1
         if (EVAL_POOL_FUSION and no_backward and not training and pool_mode == 0 and pk2 is not None
                 and L.sed_conv3x3_sf16_eval_pool_supported(H, W, Cout, Cout, ph, pw)):
@@ -1343,13 +1353,21 @@ class ConvBlockFn(torch.autograd.Function):
             dw2 = _wgrad(y1, gy2, B, H, W, Cout, Cout, in_st=w_in_st, sink=sk[5], gy_amax=amax2, x_amax=ctx.a1, x_presplit=b1_pairs,
                          gy_presplit=pair2)
         del gy2
-        dg1, db1, coef1 = bn_bwd_finalize(partb, npb, M, st1, batch_stats=ctx.training, sinks=(sk[1], sk[2]))
+        amax1 = None
+        if Cin != 1 and pair1 and ctx.mm1[1] == npb:
+            # BOUND of max |a*gy1 + b*y1 + c| from the range of y1 and the amax of gy1, left by the finalize launch itself (round 6;
+            # the forward convolution and this dgrad cut the tensor into the same parts)
+            amax1 = _amax_buf(dev)
+            dg1, db1, coef1 = bn_bwd_finalize(partb, npb, M, st1, batch_stats=ctx.training, sinks=(sk[1], sk[2]),
+                                              bound=(None, d_amax, 1.0, amax1), minmax=ctx.mm1[0])
+        else:
+            dg1, db1, coef1 = bn_bwd_finalize(partb, npb, M, st1, batch_stats=ctx.training, sinks=(sk[1], sk[2]))
         # conv1
         gx = None
-        amax1 = None
         if Cin != 1 and pair1:
-            amax1 = _amax_buf(dev)                       # BOUND of max |a*gy1 + b*y1 + c| from the range of y1 and the amax of gy1
-            _call("sed_grad_bound", _ptr(ctx.mm1[0]), ctx.mm1[1], Cout, _ptr(coef1), _ptr(d_amax), 1.0, _ptr(amax1), None, _stream())
+            if amax1 is None:
+                amax1 = _amax_buf(dev)
+                _call("sed_grad_bound", _ptr(ctx.mm1[0]), ctx.mm1[1], Cout, _ptr(coef1), _ptr(d_amax), 1.0, _ptr(amax1), None, _stream())
             _call("sed_bn_bwd_apply_pairs", _ptr(gy1), _ptr(y1), M, Cout, _ptr(coef1), _ptr(amax1), _stream())
         elif Cin != 1:
             if (ctx.needs_input_grad[0] and _conv_algo(H, W, Cout, Cin) == 3) or _wgrad_algo(H, W, Cin, Cout) == 3:

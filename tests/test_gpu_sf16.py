@@ -811,3 +811,47 @@ def test_sf16_split_k_exchange_across_xcds():
     assert int(bad) == 0
     assert all(int(t.abs().sum()) == 0 for t in ops._TICKETS.values())
     ops.check_device_errors(synchronize=True)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 37, 32, 64, 128), (40, 125, 8, 64, 128), (9, 1001, 64, 64, 64)])
+def test_finalize_launches_carry_the_operand_amax_and_the_gradient_bound(B, H, W, Cin, Cout):
+    """Round 6 (launch diet): the amax of the never-materialised operand relu(bn1(y1)) and the bound of bn1's backward output
+    used to be launches of their own (sed_act_amax, sed_grad_bound) behind the BatchNorm finalize launches; now the finalize
+    launches leave them as by-products -- inside the launch while one wave per channel walks the parts in a few trips (<= 512
+    parts), by the chunked follow-up launch beyond (the third shape: 2259 parts).  Both must equal the stand-alone launches BIT
+    FOR BIT (max / min and the monotone affine are exact), and the statistics / coefficients must not move."""
+    from sound_event_detection_dcase2017_task4_amd import ops, _lib
+    g = torch.Generator().manual_seed(B + H)
+    x = torch.randn((B, H, W, Cin), generator=g).cuda()
+    w = (torch.randn((Cout, Cin, 3, 3), generator=g) * 0.05).cuda()
+    P = int(_lib.lib().sed_conv_sf16_num_parts(B, H, W, Cout))
+    parts = torch.zeros((P * 2 * Cout + P,), device="cuda")
+    mm = torch.full((P, 2, Cout), float("nan"), device="cuda")
+    y = ops.conv3x3_sf16(x, ops.pack_sf16(w), B, H, W, Cin, Cout, epi=1, partials=parts, minmax=mm)
+    gam = (torch.randn(Cout, generator=g)).cuda()                 # both signs
+    bet = (torch.randn(Cout, generator=g) * 0.5).cuda()
+    M = B * H * W
+    st0 = ops.bn_finalize(parts, P, -1, M, gam, bet, None, None)
+    a_sep = ops.act_amax(mm, P, Cout, st0)
+    a_fold = ops._amax_buf("cuda")
+    st1 = ops.bn_finalize(parts, P, -1, M, gam, bet, None, None, minmax=mm, act_amax_out=a_fold)
+    torch.cuda.synchronize()
+    for k in ("mean", "invstd", "scale", "shift"):
+        assert torch.equal(getattr(st0, k), getattr(st1, k)), k
+    assert ops.amax_value(a_fold) == ops.amax_value(a_sep) == ops.amax_value(ops.act_amax_full(y, st0)) > 0
+    # backward: (sum dy, sum dy * xhat) partials of a made-up gradient -> coefficients + the bound of |a*dy + b*y + c|
+    partb = (torch.randn((P, 2, Cout), generator=g) * 1e-3).cuda()
+    g_amax = ops.amax_of((torch.randn(1000, generator=g) * 1e-4).cuda())
+    dg0, db0, coef0 = ops.bn_bwd_finalize(partb, P, M, st0)
+    b_sep = ops._amax_buf("cuda")
+    ops._call("sed_grad_bound", ops._ptr(mm), P, Cout, ops._ptr(coef0), ops._ptr(g_amax), 1.0, ops._ptr(b_sep), None, ops._stream())
+    b_fold = ops._amax_buf("cuda")
+    dg1, db1, coef1 = ops.bn_bwd_finalize(partb, P, M, st0, bound=(None, g_amax, 1.0, b_fold), minmax=mm)
+    torch.cuda.synchronize()
+    assert torch.equal(coef0, coef1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    assert ops.amax_value(b_fold) == ops.amax_value(b_sep) > 0
+    # the bound really bounds: |a*dy + b*y + c| <= bound for |dy| <= G and y in the tensor
+    G = ops.amax_value(g_amax)
+    a, b, c = coef0[0].double(), coef0[1].double(), coef0[2].double()
+    worst = (a.abs() * G + (b * y.double().reshape(-1, Cout) + c).abs().max(dim=0).values).max()
+    assert float(worst) <= ops.amax_value(b_fold)
