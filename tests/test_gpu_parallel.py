@@ -182,6 +182,19 @@ def test_one_rank_over_rccl_runs_the_nccl_code_path():
     assert b["n_gpus"] == 1 and b["value"] > 0 and b["dist"]["allreduce_exposed_ms_per_step"] is not None
     assert "from inside backward" in b["config"]["grad_allreduce"] and len(b["config"]["grad_allreduce"]) > 0
     assert a["loss"] == b["loss"], (a["loss"], b["loss"])
+    # ... and the form the strong-scaling row of an N-GPU run takes: 4 clips per GPU replayed as ONE HIP graph per step while the
+    # nccl process group (its watchdog thread, its streams) is alive -- the capture, the rank-agreed 'capture refused' all-reduce
+    # (graph.GraphedTrainStep._capture_together) and the buckets issued behind the graph all go through ProcessGroupNCCL
+    gargs = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "5", "--batch_size", "4",
+             "--seconds", "2", "--hip_graph", "on", "--no_cpu_baseline", "--no_extra", "--no_kernel_events"]
+    gp = subprocess.run(gargs, capture_output=True, text=True, env=base, timeout=900)
+    gf = subprocess.run(gargs, capture_output=True, text=True, env=dict(env, MASTER_PORT=str(parallel.free_port())), timeout=900)
+    assert gp.returncode == 0 and gf.returncode == 0, (gp.stderr[-1500:], gf.stderr[-3000:])
+    c = json.loads([l for l in gp.stdout.splitlines() if l.startswith("{")][-1])
+    d = json.loads([l for l in gf.stdout.splitlines() if l.startswith("{")][-1])
+    assert c["hip_graph"] is True and d["hip_graph"] is True and d["hip_graph_replays"] >= 4, (c.get("hip_graph_error"), d.get("hip_graph_error"))
+    assert d["dist"]["backend"] == "nccl" and d["dist"]["allreduce_overlap"] is False
+    assert c["loss"] == d["loss"], (c["loss"], d["loss"])
 
 
 def test_bench_two_ranks_code_path_on_one_gpu():
