@@ -195,7 +195,7 @@ int sed_bn_relu_pool_bwd_apply(const float* y, const float* g_out, int B, int H,
  * sed_conv3x3_wgrad: dw (OIHW) = sum_p gy[p][co] * a[p + tap][ci]; partial: scratch of
  *   sed_wgrad_partial_floats(B*H*W, Cin, Cout, 9, ...) floats.
  * sed_conv1_*: conv_block1.conv1 (Cin = 1), HBM-bound direct kernels; partials [ceil(M/256)][2][64];
- *   scratch dw_partials ceil(M/1024)*576 floats, tbuf 9*M floats (only when gx0 != null).  sed_conv1_bwd with
+ *   scratch dw_partials sed_conv1_bwd_partial_floats(B, H, W) floats, tbuf 9*M floats (only when gx0 != null).  sed_conv1_bwd with
  *   bn_y / bn_coef non-null treats gy as the masked dgrad output dz and applies the BatchNorm backward
  *   g = a*dz + b*bn_y + c (coef [3][64] of sed_bn_bwd_finalize) on load, replacing a sed_bn_bwd_apply pass. */
 int sed_pack_conv_weights(const float* w_oihw, int Cout, int Cin, float* wf, float* wd, sed_stream_t stream);
@@ -321,6 +321,7 @@ int sed_conv1_fwd(const float* x0, const float* w_oihw, float* y, int B, int H, 
                   float* minmax /* nullable: [ceil(M/rows)][2][64] per-part (max, min) per channel, for sed_act_amax */,
                   sed_stream_t stream);
 int sed_conv1_rows_per_part(void);
+long sed_conv1_bwd_partial_floats(int B, int H, int W);
 int sed_conv1_bwd(const float* x0, const float* w_oihw, const float* gy, const float* bn_y, const float* bn_coef, int B,
                   int H, int W, float* dw, float* gx0, float* dw_partials, float* tbuf, sed_stream_t stream);
 

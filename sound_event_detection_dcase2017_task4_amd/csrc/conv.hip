@@ -680,15 +680,17 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 // backward of the Cin=1 conv: one pass over gy produces (i) per-block dW partials [nblk][9][64] and
 // (ii) t[p][tap] = <gy[p][:], w[:, tap]> (the scatter form of dgrad); conv1_dgrad_gather then sums 9 neighbours.
-constexpr int C1B_ROWS = 4096;      // rows per workgroup at most (scratch sized for 1024 by the callers: an upper bound)
+constexpr int C1B_ROWS = 4096;      // rows per workgroup at most
 // Rows per workgroup of a launch: 4096 while that gives at least three rounds of the 768 resident workgroups (three per CU), else
-// what gives ~two rounds, never fewer than 1024 (the callers' scratch).  At the metric's batch size 4096 rows meant 501
-// workgroups on 768 slots.
+// what gives ~two rounds, never fewer than 256 (one row per thread and trip).  At the metric's batch size 4096 rows meant 501
+// workgroups on 768 slots; at 4 clips per GPU the floor of 1024 rows (until round 6: the callers' fixed scratch) meant 250
+// workgroups on 256 CUs -- one latency-bound wave set per CU, 67 us for a pass that takes 31 us at the rate of bs=32.  The scratch
+// is sized by sed_conv1_bwd_partial_floats() now.
 static int c1b_rows_for(long M) {
     if (M / C1B_ROWS >= 3 * 768) return C1B_ROWS;
     long rows = (M + 2 * 768 - 1) / (2 * 768);
     rows = (rows + 15) / 16 * 16;
-    if (rows < 1024) rows = 1024;
+    if (rows < 256) rows = 256;
     if (rows > C1B_ROWS) rows = C1B_ROWS;
     return (int)rows;
 }
@@ -991,9 +993,15 @@ SED_API int sed_conv1_act_sf16(const float* x0, const float* w_oihw, int B, int 
 }
 
 // backward of conv_block1.conv1: dw [64][1][3][3]; gx0 [M] (nullable: skip the input gradient).
-// scratch: dw_partials ceil(M/1024)*576 floats; tbuf M*9 floats (only if gx0).
+// scratch: dw_partials sed_conv1_bwd_partial_floats(B, H, W) floats; tbuf M*9 floats (only if gx0).
 // bn_coef (nullable): gy is then the masked dgrad output dz and g = a*dz + b*y1 + c is formed on load (coef [3][64] from
 // sed_bn_bwd_finalize), replacing a sed_bn_bwd_apply pass; y1 = bn_y, or recomputed from x0 when bn_y is null.
+SED_API long sed_conv1_bwd_partial_floats(int B, int H, int W) {
+    const long M = (long)B * H * W;
+    if (M <= 0) return 0;
+    return (long)sed_cdiv(M, c1b_rows_for(M)) * 576;
+}
+
 SED_API int sed_conv1_bwd(const float* x0, const float* w_oihw, const float* gy, const float* bn_y, const float* bn_coef,
                           int B, int H, int W, float* dw, float* gx0, float* dw_partials, float* tbuf, hipStream_t stream) {
     long M = (long)B * H * W;

@@ -40,7 +40,10 @@ namespace {
 constexpr int NFFT = 1024;
 constexpr int HOP = 320;
 constexpr int MELW_MAX = 2048;
-constexpr int FPW = 32;                          // frames per wave (8 iterations x 2 FFT pairs), 128 frames per workgroup
+// frames per wave: 32 (8 iterations x 2 FFT pairs, 128 frames per workgroup: the ~150 table loads of a wave are amortised over 16 FFTs),
+// or 8 for launches that would otherwise leave most CUs empty (4 clips per GPU: 8 waveforms x 8 workgroups of 128 frames = 64
+// workgroups on 256 CUs, 41 us -- latency, not work)
+constexpr int FPW_FULL = 32, FPW_SMALL = 8;
 constexpr int TASK_TAPS = 12;
 constexpr int MAX_TASKS = 128;
 
@@ -199,7 +202,7 @@ __device__ __forceinline__ float dpp_swap1(float v) {      // value of lane ^ 1
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
 
-template <typename T>
+template <typename T, int FPW = FPW_FULL>
 __global__ __launch_bounds__(256, 2) void logmel32_kernel(const T* __restrict__ wave, int L, int T_frames,
                                                           const float* __restrict__ window,      // [32 n1][32 n2] = natural order
                                                           const float2* __restrict__ tw1024t,    // [32 k1][32 n2] W1024^(n2*k1)
@@ -336,10 +339,18 @@ int launch_logmel(const T* wave, int B2, int L, const float* window, const float
         max_band_tasks <= 0 || max_band_tasks > 4)
         return SED_EINVAL;
     int T_frames = L / HOP + 1;
-    dim3 grid(sed_cdiv(T_frames, 4 * FPW), B2);
-    hipLaunchKernelGGL(logmel32_kernel<T>, grid, dim3(256), 0, stream, wave, L, T_frames, window,
-                       reinterpret_cast<const float2*>(tw1024t), reinterpret_cast<const int4*>(tasks), ntasks,
-                       reinterpret_cast<const int4*>(bands), max_band_tasks, mel_w, amin, (float)(10.0 * log10((double)amin)), out);
+    const float floor_db = (float)(10.0 * log10((double)amin));
+    if ((long)sed_cdiv(T_frames, 4 * FPW_FULL) * B2 < 256) {        // fewer workgroups than CUs: quarter the frames per workgroup
+        dim3 grid(sed_cdiv(T_frames, 4 * FPW_SMALL), B2);
+        hipLaunchKernelGGL((logmel32_kernel<T, FPW_SMALL>), grid, dim3(256), 0, stream, wave, L, T_frames, window,
+                           reinterpret_cast<const float2*>(tw1024t), reinterpret_cast<const int4*>(tasks), ntasks,
+                           reinterpret_cast<const int4*>(bands), max_band_tasks, mel_w, amin, floor_db, out);
+    } else {
+        dim3 grid(sed_cdiv(T_frames, 4 * FPW_FULL), B2);
+        hipLaunchKernelGGL((logmel32_kernel<T, FPW_FULL>), grid, dim3(256), 0, stream, wave, L, T_frames, window,
+                           reinterpret_cast<const float2*>(tw1024t), reinterpret_cast<const int4*>(tasks), ntasks,
+                           reinterpret_cast<const int4*>(bands), max_band_tasks, mel_w, amin, floor_db, out);
+    }
     SED_LAUNCH_CHECK();
     return 0;
 }

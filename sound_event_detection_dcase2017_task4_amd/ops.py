@@ -1374,8 +1374,7 @@ class ConvBlockFn(torch.autograd.Function):
                 amax1 = _amax_buf(dev)
             _call("sed_bn_bwd_apply", _ptr(gy1), _ptr(y1), M, Cout, _ptr(coef1), _ptr(amax1), _stream())
         if Cin == 1:                                   # BN1 backward g = a*dz + b*y1 + c is applied on load by the kernel
-            nblk = (M + 1023) // 1024
-            dwp = torch.empty((nblk, 576), dtype=torch.float32, device=dev)
+            dwp = torch.empty((int(_lib.lib().sed_conv1_bwd_partial_floats(B, H, W)),), dtype=torch.float32, device=dev)
             dw1 = _dst(sk[0], (Cout, 1, 3, 3), dev)
             want_gx = ctx.needs_input_grad[0]
             tbuf = torch.empty((M, 9), dtype=torch.float32, device=dev) if want_gx else None

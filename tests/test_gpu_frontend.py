@@ -79,3 +79,26 @@ def test_logmel_large_batch_linearity_property(model):
     # and it matches the oracle on a few clips
     ref = ofe.logmel(x[:2].cpu())[:, 0]
     assert (a[:2].cpu() - ref).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("dtype", ["f32", "i16"])
+def test_logmel_small_and_full_launch_forms_agree_bit_for_bit(model, golden_dir, dtype):
+    """The kernel runs 32 frames per wave (128 per workgroup) -- or 8 (32 per workgroup) when the launch would otherwise be fewer
+    workgroups than the chip has CUs (round 6: 4 clips per GPU = 8 waveforms, the strong-scaling regime).  A frame pair goes through
+    the same instructions either way, so the two forms must agree BIT FOR BIT: the golden 10 s clip alone (small form) and as row 17
+    of a 40-waveform batch (320 workgroups: full form), float32 and int16 input, ragged last workgroup included."""
+    fx = np.load(os.path.join(golden_dir, "frontend.npz"))
+    w1 = waves(4321, 1, 320000)
+    batch = waves(99, 40, 320000)
+    batch[17] = w1[0]
+    if dtype == "i16":
+        w1, batch = (np.round(w1 * 32767.0)).astype(np.int16), (np.round(batch * 32767.0)).astype(np.int16)
+    alone = model.extract_logmel(torch.from_numpy(w1).cuda())[0]
+    full = model.extract_logmel(torch.from_numpy(batch).cuda())
+    torch.cuda.synchronize()
+    assert full.shape == (40, 1001, 64)
+    assert torch.equal(full[17], alone)
+    if dtype == "f32":
+        assert np.abs(alone.cpu().numpy() - fx["logmel_10s"]).max() < 1e-3
+    few = model.extract_logmel(torch.from_numpy(batch[16:19]).cuda())           # 3 waveforms: small form again, another batch row
+    assert torch.equal(few[1], alone) and torch.equal(few[0], full[16])

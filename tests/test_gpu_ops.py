@@ -102,7 +102,7 @@ def test_conv1_direct_fwd_bwd(ops):
     assert (st.mean.cpu() - y_ref.mean(dim=(0, 2, 3))).abs().max() < 1e-5
     assert rel(st.invstd.cpu(), 1 / torch.sqrt(y_ref.var(dim=(0, 2, 3), unbiased=False) + 1e-5)) < 1e-5
     dw = torch.empty((64, 1, 3, 3), device="cuda"); gx = torch.empty((B, H, W, 1), device="cuda")
-    dwp = torch.empty(((M + 1023) // 1024, 576), device="cuda"); tb = torch.empty((M, 9), device="cuda")
+    dwp = torch.empty((int(L.sed_conv1_bwd_partial_floats(B, H, W)),), device="cuda"); tb = torch.empty((M, 9), device="cuda")
     ops._call("sed_conv1_bwd", ops._ptr(xd), ops._ptr(wdev), ops._ptr(gyd), None, None, B, H, W, ops._ptr(dw), ops._ptr(gx),
               ops._ptr(dwp), ops._ptr(tb), ops._stream())
     assert rel(dw.cpu(), wr.grad) < 1e-5

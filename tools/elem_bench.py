@@ -61,8 +61,7 @@ def main():
                                                                    ops._ptr(part), None, s)))
         if C == 64:                                      # ... and its backward (BN1 backward applied on load, dW partials, dX taps)
             coef1 = torch.randn(3, 64, device="cuda")
-            nblk = (M + 1023) // 1024
-            dwp = torch.empty((nblk, 576), device="cuda")
+            dwp = torch.empty((int(ops._lib.lib().sed_conv1_bwd_partial_floats(B, H, W)),), device="cuda")
             dw1 = torch.empty((64, 1, 3, 3), device="cuda")
             tbuf = torch.empty((M, 9), device="cuda")
             gx = torch.empty((B, H, W, 1), device="cuda")
