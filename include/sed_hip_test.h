@@ -16,6 +16,10 @@ int sed_gru_set_spin_limit(long spins);
 int sed_gru_force_agent_scope(int on);
 /* holds `blocks` CUs (one workgroup with lds_bytes of LDS each) for `microseconds` */
 int sed_debug_occupy(int blocks, int lds_bytes, long microseconds, sed_stream_t stream);
+/* the slice reduce of sed_conv3x3_wgrad_sf16 alone (tools/wgrad_reduce_bench.py: which cut for which slice count), partial
+ * [nparts][9][Cout][Cin]; variant 0 = the library's choice, 1 = 64 elements x 4 part groups, 2 = x 16 part groups, 3 = rows form */
+int sed_test_wgrad_sf16_reduce(const float* partial, int nparts, int Cout, int Cin, const float* gy_amax, const float* x_amax,
+                               float* dw_oihw, int variant, sed_stream_t stream);
 #ifdef __cplusplus
 }
 #endif

@@ -125,15 +125,22 @@ __device__ __forceinline__ float fma_scalar(float a, float b, float c) {
     return d;
 }
 
+// SPLITK = the SMALL-LAUNCH form (round 6): launches of at most two workgroups per CU -- 4 to 8 clips per GPU, the strong-scaling
+// regime -- where nothing co-resident hides a workgroup's own latencies.  It (i) may split the K range of a tile over workgroups
+// (below) and (ii) streams the weights through FOUR stage buffers instead of two, requested three stages ahead: with one or two
+// waves per SIMD a stage computes for ~0.55 us and then sat ~0.7 us behind the LDS-DMA it had requested at its own start (L2 /
+// Infinity-Cache round trip); now only the last stage of a K-step waits, for the request it made itself.  74 KB of LDS and up to
+// 256 VGPRs: two workgroups per CU, which is all such a launch has.
 template <int MW, bool INT, int EPI, bool PRE = false, bool SPLITK = false>
-__global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p) {
+__global__ __launch_bounds__(256, (MW == 4 && !SPLITK) ? 3 : 2) void conv_sf16_kernel(Sf16P p) {
     constexpr int NW = 4 / MW, BN = 64 * NW, RB = BN / 32;
     constexpr int AROWS = MW == 2 ? 264 : 408;         // >= (TR+2) * WP over the supported W (W = 8: 34 * 12)
     constexpr int APLANE = AROWS * 32;
     constexpr int BPLANE = 3 * BN * 32, BSTAGE = 2 * BPLANE;
+    constexpr int NB = SPLITK ? 4 : 2;                 // weight stage buffers; stages are requested NB - 1 ahead
     constexpr int NI = MW == 2 ? 4 : 6;                // staging items per thread
     constexpr int NDMA = 6 * RB / 4;                   // LDS-DMA instructions per wave and stage
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * APLANE + 2 * BSTAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * APLANE + NB * BSTAGE];
     unsigned char* const As = smem;
     unsigned char* const Bs = smem + 2 * APLANE;
 
@@ -268,6 +275,10 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
     }
     sf_aload(k_begin);
     sf_bdma(k_begin * 3, 0);
+    if (NB == 4) {                                     // (every K range holds at least one K-step = three stages)
+        sf_bdma(k_begin * 3 + 1, 1);
+        sf_bdma(k_begin * 3 + 2, 2);
+    }
     sf_astore();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -304,53 +315,79 @@ __global__ __launch_bounds__(256, MW == 4 ? 3 : 2) void conv_sf16_kernel(Sf16P p
     const int nsteps = (KT - k_begin) * 3, step0 = k_begin * 3;
     int step = 0;
     for (int ks = k_begin; ks < KT; ++ks) {
+        half8 ah[2][2], al[2][2], bh[2][2], bl[2][2];          // [register set][block]; the small-launch form carries them across stages
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy, ++step) {
-            const int st = step & 1;
-            if (step + 1 < nsteps) {
-                if (st) { sf_bdma(step0 + step + 1, 0) } else { sf_bdma(step0 + step + 1, 1) }
+            const int st = step & (NB - 1);
+            if (NB == 2) {
+                if (step + 1 < nsteps) {
+                    if (st) { sf_bdma(step0 + step + 1, 0) } else { sf_bdma(step0 + step + 1, 1) }
+                }
+            } else if (step + 3 < nsteps) {
+                const int st3 = __builtin_amdgcn_readfirstlane((step + 3) & 3);      // the buffer the previous stage has just released
+                sf_bdma(step0 + step + 3, st3);
             }
             if (dy == 0 && ks + 1 < KT) sf_aload(ks + 1);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
             const unsigned char* const Bst = Bs + st * BSTAGE;
-            // (requesting the fragments of tap dx+1 before the MFMAs of tap dx -- two register sets -- measured +-1 %: the
-            // second wave of the SIMD already hides the LDS latency; one set keeps the kernel at 3 waves per SIMD for MW = 4)
+            // (requesting the fragments of tap dx+1 before the MFMAs of tap dx -- two register sets -- measured +-1 % at three waves
+            // per SIMD: the other waves already hide the LDS latency, and one set keeps the kernel at three waves.)
+            // Small-launch form: one or two waves per SIMD and 256 registers.  Left to itself the scheduler sinks every ds_read
+            // next to the MFMA that consumes it (~17 lgkmcnt waits per stage, each an exposed LDS round trip with nobody else on
+            // the SIMD): here the nine taps of a K-step form ONE software pipeline over two register sets -- the fragments of tap
+            // t + 1 are requested before the MFMAs of tap t, ACROSS the stage boundaries (the next stage's weights landed a K-step
+            // ago and the patch does not change inside a K-step), pinned in place by scheduling barriers.  The LDS round trip is
+            // exposed once per K-step.
+#define SF_FRAGS(SET, DYV, DX, BSTV)                                                                            \
+            {                                                                                                   \
+                _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) {                                              \
+                    ah[SET][mb] = *reinterpret_cast<const half8*>(As + aoffs[mb][(DYV) * 3 + (DX)]);            \
+                    al[SET][mb] = *reinterpret_cast<const half8*>(As + APLANE + aoffs[mb][(DYV) * 3 + (DX)]);   \
+                }                                                                                               \
+                _Pragma("unroll") for (int nk = 0; nk < 2; ++nk) {                                              \
+                    bh[SET][nk] = *reinterpret_cast<const half8*>((BSTV) + boffs[nk][DX]);                      \
+                    bl[SET][nk] = *reinterpret_cast<const half8*>((BSTV) + BPLANE + boffs[nk][DX]);             \
+                }                                                                                               \
+            }
+            const unsigned char* const Bnx = Bs + ((step + 1) & (NB - 1)) * BSTAGE;
+            if (SPLITK && dy == 0) SF_FRAGS(0, 0, 0, Bst)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                half8 ah[2], al[2], bh[2], bl[2];
-                {
-#pragma unroll
-                    for (int mb = 0; mb < 2; ++mb) {
-                        ah[mb] = *reinterpret_cast<const half8*>(As + aoffs[mb][dy * 3 + dx]);
-                        al[mb] = *reinterpret_cast<const half8*>(As + APLANE + aoffs[mb][dy * 3 + dx]);
-                    }
-#pragma unroll
-                    for (int nk = 0; nk < 2; ++nk) {
-                        bh[nk] = *reinterpret_cast<const half8*>(Bst + boffs[nk][dx]);
-                        bl[nk] = *reinterpret_cast<const half8*>(Bst + BPLANE + boffs[nk][dx]);
-                    }
+                const int cur = SPLITK ? ((3 * dy + dx) & 1) : 0;
+                if (SPLITK) {
+                    if (dx < 2) { if (cur) SF_FRAGS(0, dy, dx + 1, Bst) else SF_FRAGS(1, dy, dx + 1, Bst) }
+                    else if (dy < 2) { if (cur) SF_FRAGS(0, dy + 1, 0, Bnx) else SF_FRAGS(1, dy + 1, 0, Bnx) }
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    if (dx == 0) SF_FRAGS(0, dy, 0, Bst) else if (dx == 1) SF_FRAGS(0, dy, 1, Bst) else SF_FRAGS(0, dy, 2, Bst)
                 }
                 // the three products of a tile are spread over the four tiles: no MFMA waits for its predecessor's result
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                     for (int nk = 0; nk < 2; ++nk)
-                        acc[mb][nk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mb], bh[nk], acc[mb][nk], 0, 0, 0);
+                        acc[mb][nk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][mb], bh[cur][nk], acc[mb][nk], 0, 0, 0);
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                     for (int nk = 0; nk < 2; ++nk)
-                        acc[mb][nk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bl[nk], acc[mb][nk], 0, 0, 0);
+                        acc[mb][nk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][mb], bl[cur][nk], acc[mb][nk], 0, 0, 0);
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                     for (int nk = 0; nk < 2; ++nk)
-                        acc[mb][nk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bh[nk], acc[mb][nk], 0, 0, 0);
+                        acc[mb][nk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][mb], bh[cur][nk], acc[mb][nk], 0, 0, 0);
+                if (SPLITK) __builtin_amdgcn_sched_barrier(0);
             }
+#undef SF_FRAGS
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // NB = 2: the next stage's weights (requested at the start of this one) must have landed.  NB = 4: the three stages of
+            // the NEXT K-step were requested during this one, each into the buffer released a stage earlier; everything a stage
+            // reads was requested one K-step ago and is drained HERE, at the end of every K-step (with the patch loads the
+            // staging below needs anyway) -- the first two stages of a K-step wait for nothing
+            if (NB == 2 || dy == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (dy == 2 && ks + 1 < KT) {          // every wave is done with this k-step's patch: replace it
                 sf_astore();
@@ -969,7 +1006,9 @@ int conv_sf16_launch(const float* x, const void* wp, const float* wscale, float*
     if (nblk > 0x7fffffffL) return SED_EINVAL;
     const dim3 g((unsigned)nblk), blk(256);
     hipStream_t s = (hipStream_t)stream;
-    if (ksplit > 1) {
+    // the small-launch form (deep weight pipeline, two workgroups per CU) for every launch of at most two workgroups per CU,
+    // split or not
+    if (ksplit > 1 || nblk <= 2 * 256) {
         const bool itk = in_scale != nullptr;
 #define SF_LAUNCHK(INTV, EPIV, PREV) hipLaunchKernelGGL((conv_sf16_kernel<4, INTV, EPIV, PREV, true>), g, blk, 0, s, p)
         if (pre) { if (epi == 0) SF_LAUNCHK(false, 0, true); else if (epi == 1) SF_LAUNCHK(false, 1, true); else SF_LAUNCHK(false, 2, true); }
@@ -1402,11 +1441,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_sf16_kernel(WSf16P p) {
 
 // sum the slices in fp64, unscale, scatter to OIHW.  Two cuts of the same sum (fixed orders: deterministic), chosen by the slice
 // count -- the partials are always ~38 MB (512 workgroups x 74 KB), what changes is their shape:
-//   MANY slices x few elements (the <= 128-channel layers: 32 .. 256 slices of 37 K .. 295 K elements): 64 elements x G part
-//     groups per block, group g sums parts g, g + G, ... with four independent loads in flight, the groups meet in LDS.  G = 16
-//     (1024 threads) since round 6: with G = 4 a thread walked 64 parts in 16 dependent rounds of four loads -- latency, not
-//     bandwidth (14.5 us per launch for 38 MB = 2.7 TB/s, whatever the layer).  (One thread per element walking all parts in a
-//     dependent chain took 315 us for the 1000 partials of the 64 -> 64 layer at batch 32.)
+//   MANY slices x few elements (the <= 128-channel layers: 32 .. 256 slices of 37 K .. 295 K elements): 64 elements x G = 4 part
+//     groups per block, group g sums parts g, g + 4, ... with eight independent loads in flight, the groups meet in LDS: 7.7-8.5 us
+//     for 38 MB.  (G = 16 / 1024 threads was built in round 6 and is never faster; kept as a test-hook variant.  One thread per
+//     element walking all parts in a dependent chain took 315 us for the 1000 partials of the 64 -> 64 layer at batch 32.)
 //   FEW slices x many elements (>= 256 input channels: 4 .. 16 slices of 0.6 .. 2.4 M elements): a block owns one output channel
 //     x 64 input channels x all 9 taps, every thread sums the parts of two or three taps (all loads independent), the 576 sums
 //     meet in LDS and leave as ONE contiguous 2304-byte run of the OIHW tensor -- the element-per-thread form wrote 4 bytes every
@@ -1478,6 +1516,25 @@ __global__ __launch_bounds__(256) void wgrad_sf16_reduce_rows_kernel(const float
     __syncthreads();
     float* dst = dw + ((long)co * K + ci0) * 9;             // 64 input channels x 9 taps of this output channel: contiguous in OIHW
     for (int i = threadIdx.x; i < 576; i += 256) dst[i] = outs[i];
+}
+
+// variant 0: the library's choice by slice count; 1 .. 3: forced (sed_test_wgrad_sf16_reduce)
+static void wsf_reduce_launch(const float* partial, int ns, int Cout, int Cin, const float* gy_amax, const float* x_amax,
+                              float* dw_oihw, int variant, hipStream_t s) {
+    const long nk = 9L * Cin * Cout;
+    // measured per cut on the production shapes (tools/wgrad_reduce_bench.py, profiles/r06/wgrad_reduce_bench.txt; 38 MB of partials):
+    // rows 8-10 us where the 4-group form takes 11 / 19 / 31 us (256 -> 256, 256 -> 512, 512 -> 512), 4 groups 7.7-8.5 us on the
+    // <= 128-channel layers where rows takes 11-18 us; 16 groups never wins (8.7 ... 117 us)
+    if (variant == 0) variant = (nk >= 9L * 256 * 256 && ns <= 64 && Cin % 64 == 0) ? 3 : 1;
+    if (variant == 3)
+        hipLaunchKernelGGL(wgrad_sf16_reduce_rows_kernel, dim3((unsigned)((long)Cout * (Cin / 64))), dim3(256), 0, s, partial, ns,
+                           Cout, Cin, gy_amax, x_amax, dw_oihw);
+    else if (variant == 2)
+        hipLaunchKernelGGL(wgrad_sf16_reduce_kernel<16>, dim3((unsigned)(nk / 64)), dim3(1024), 0, s, partial, ns, Cout, Cin,
+                           gy_amax, x_amax, dw_oihw);
+    else
+        hipLaunchKernelGGL(wgrad_sf16_reduce_kernel<4>, dim3((unsigned)(nk / 64)), dim3(256), 0, s, partial, ns, Cout, Cin,
+                           gy_amax, x_amax, dw_oihw);
 }
 
 static void wsf_slicing(int B, int H, int W, int Cin, int Cout, int* spi, int* ips, int* spimg, long* nslices) {
@@ -1555,16 +1612,18 @@ SED_API int sed_conv3x3_wgrad_sf16(const float* x, const float* gy, float* dw_oi
     if (W == 64) { WSF_LAUNCH(6) } else if (W == 32) { WSF_LAUNCH(5) } else if (W == 16) { WSF_LAUNCH(4) } else { WSF_LAUNCH(3) }
 #undef WSF_LAUNCH
     SED_LAUNCH_CHECK();
-    const long nk = 9L * Cin * Cout;
-    if (ns <= 16 && Cin % 64 == 0)
-        hipLaunchKernelGGL(wgrad_sf16_reduce_rows_kernel, dim3((unsigned)((long)Cout * (Cin / 64))), dim3(256), 0, s, partial, (int)ns,
-                           Cout, Cin, gy_amax, x_amax, dw_oihw);
-    else if (ns >= 32)
-        hipLaunchKernelGGL(wgrad_sf16_reduce_kernel<16>, dim3((unsigned)(nk / 64)), dim3(1024), 0, s, partial, (int)ns, Cout, Cin,
-                           gy_amax, x_amax, dw_oihw);
-    else
-        hipLaunchKernelGGL(wgrad_sf16_reduce_kernel<4>, dim3((unsigned)(nk / 64)), dim3(256), 0, s, partial, (int)ns, Cout, Cin,
-                           gy_amax, x_amax, dw_oihw);
+    wsf_reduce_launch(partial, (int)ns, Cout, Cin, gy_amax, x_amax, dw_oihw, 0, s);
+    SED_LAUNCH_CHECK();
+    return 0;
+}
+
+#include "sed_hip_test.h"
+SED_API int sed_test_wgrad_sf16_reduce(const float* partial, int nparts, int Cout, int Cin, const float* gy_amax, const float* x_amax,
+                                       float* dw_oihw, int variant, sed_stream_t stream) {
+    if (!partial || !gy_amax || !x_amax || !dw_oihw || nparts <= 0 || Cin % 32 || Cout % 64 || variant < 0 || variant > 3 ||
+        (variant == 3 && Cin % 64))
+        return SED_EINVAL;
+    wsf_reduce_launch(partial, nparts, Cout, Cin, gy_amax, x_amax, dw_oihw, variant, (hipStream_t)stream);
     SED_LAUNCH_CHECK();
     return 0;
 }

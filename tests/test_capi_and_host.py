@@ -24,7 +24,8 @@ def test_header_symbols_all_exported():
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (sed_\w+)", out))
     hooks = set(_lib.parse_header(_lib.TEST_HEADER))        # test hooks live in their own header, outside the product ABI
-    assert hooks == {"sed_gru_set_spin_limit", "sed_gru_force_agent_scope", "sed_debug_occupy"} and not hooks & set(protos)
+    assert hooks == {"sed_gru_set_spin_limit", "sed_gru_force_agent_scope", "sed_debug_occupy",
+                     "sed_test_wgrad_sf16_reduce"} and not hooks & set(protos)
     assert exported == set(protos) | hooks, exported ^ (set(protos) | hooks)
     # ... and no product module calls a hook (tests / tools reach them through _lib.test_hooks())
     root = os.path.dirname(_lib.__file__)
