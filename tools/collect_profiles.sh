@@ -51,5 +51,12 @@ for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sqD MfmaUtil" "sqB SQ_VALU_MF
   set -- $pass; name=$1; shift
   SED_WGRAD_SIDE_STREAM=0 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_b32_$name -o p -- $B32 --steps 1 --warmup 1 > /dev/null 2> $OUT/pmc_b32_$name.err
 done
+# 4 clips per GPU (the strong-scaling regime: --batch_size 32 over 8 GPUs): serial kernel trace + digest, eager and graphed lines
+SED_WGRAD_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_b4 -o bench -- $B32 --batch_size 4 --steps 6 --warmup 3 > $OUT/bench_line_b4_under_rocprofv3_main_stream_only.json 2> $OUT/stats_b4.err
+python $R/tools/step_gaps.py $(find $OUT/stats_b4 -name "*kernel_trace.csv") 4 > $OUT/step_digest_b4_main_stream_only.txt 2>&1
+$B32 --batch_size 4 --steps 60 --warmup 8 --by_shape > $OUT/bench_line_b4_eager.json 2> $OUT/by_shape_b4.txt
+$B32 --batch_size 4 --steps 60 --warmup 8 --hip_graph on > $OUT/bench_line_b4_hip_graph.json 2> /dev/null
+# the driver's own command, complete (extra_configs, strict_fp32, cpu_baseline)
+python $R/bench.py > $OUT/bench_line_full_default_run.json 2> /dev/null
 find $OUT -name "*kernel_trace.csv" -size +30M -delete
 ls $OUT

@@ -22,6 +22,10 @@ for f in bench_line_under_rocprofv3.json bench_line_under_rocprofv3_main_stream_
 done
 cp $G/by_shape.txt $P/by_shape__b256_steps10_warmup3.txt
 cp $G/by_shape_b32.txt $P/by_shape__b32_steps40_warmup5.txt
+for f in step_digest_b4_main_stream_only.txt bench_line_b4_eager.json bench_line_b4_hip_graph.json bench_line_full_default_run.json; do
+  if [ -f $G/$f ]; then cp $G/$f $P/$f; fi
+done
+if [ -f $G/by_shape_b4.txt ]; then cp $G/by_shape_b4.txt $P/by_shape__b4_steps60_warmup8.txt; fi
 if [ -n "$EXTRA" ]; then
   cp $EXTRA/bench_full_default.json $P/bench_line_full_default_run.json
   tail -3 $EXTRA/pytest_gpu.log > $P/pytest_gpu_tail.txt
