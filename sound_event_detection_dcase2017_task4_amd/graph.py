@@ -90,6 +90,7 @@ class GraphedTrainStep(object):
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         prev, buckets.deferred = getattr(buckets, "deferred", False), True   # no collective inside the graph
+        bn_before = ops._BN_LAST               # BatchNorm groups tracked before the capture (normally none: a step has just ended)
         try:
             with torch.cuda.graph(g):
                 ops.reset_amax_pool()           # the zero fill of the amax rows used below becomes part of the graph
@@ -102,6 +103,11 @@ class GraphedTrainStep(object):
         finally:
             buckets.deferred = prev
             ops.reset_amax_pool()               # ... and eager code never gets rows of the graph's pool
+            # the forward pass that was only RECORDED tracked its BatchNorm entries (ops._BN_LAST) although nothing ran: their
+            # `cand` tensors hold no statistics yet.  They belong to the replays (below), never to the eager bookkeeping -- a
+            # step refused later must not 'restore' running statistics from them
+            captured_bn = (ops._BN_LAST or [])[len(bn_before or []):]
+            ops._BN_LAST = bn_before
         if ops.pending_sink_indices():
             ops.drop_pending_wgrads()
             raise GraphCaptureError("GraphedTrainStep: side-stream weight gradients were left un-joined by the captured backward pass")
@@ -112,7 +118,7 @@ class GraphedTrainStep(object):
         # nothing and ZERO the slice the graph has just filled
         self._written = set(buckets.written)
         # ... and likewise the BatchNorm entries of the captured forward pass (ops.restore_bn_if_refused() after every replay)
-        self._bn_last = ops._BN_LAST
+        self._bn_last = captured_bn or None
 
     def _capture_together(self):
         """Capture, and agree on the outcome with the other ranks: a rank that fell back to the eager loop alone would fire its

@@ -434,3 +434,58 @@ def test_train_cli_eight_ranks_global_batch_32(tmp_path):
     ck = os.path.join(ws, "checkpoints", "main", "holdout_fold=1", "model_type=Cnn_9layers_FrameAvg", "loss_type=clip_bce",
                       "augmentation=mixup", "batch_size=32", "0_iterations.pth")
     assert os.path.exists(ck)
+
+
+def test_train_cli_two_ranks_fall_back_together_when_one_capture_is_refused(tmp_path):
+    """`--hip_graph auto` with two ranks (4 clips each: the graphed regime), and the HIP-graph capture is refused on RANK 1 ONLY.
+    A rank that fell back alone would fire its gradient buckets from inside backward while its peer, still graphed, issues them
+    behind the graph -- the collective sequences would diverge (round-5 advisor).  graph.GraphedTrainStep._capture_together agrees
+    on the outcome with one MAX all-reduce at capture time: BOTH ranks drop the graph at the same step, log it, run that batch
+    eagerly and finish the run with identical, finite parameters."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SED_SHARE_GPU"] = "1"
+    env["PYTHONPATH"] = REPO + os.pathsep + env.get("PYTHONPATH", "")
+    ws = str(tmp_path)
+    probe = os.path.join(ws, "probe.py")
+    with open(probe, "w") as f:
+        f.write("import os, sys, logging, torch\n"
+                "from sound_event_detection_dcase2017_task4_amd import graph, optim\n"
+                "from sound_event_detection_dcase2017_task4_amd.pytorch import main as cli\n"
+                "rank = int(os.environ['RANK'])\n"
+                "real_body = graph.GraphedTrainStep._body\n"
+                "def body(self):\n"
+                "    if rank == 1 and torch.cuda.is_current_stream_capturing():\n"
+                "        raise RuntimeError('capture refused on rank 1 (test)')\n"
+                "    return real_body(self)\n"
+                "graph.GraphedTrainStep._body = body\n"
+                "keep, steppers = [], []\n"
+                "orig = optim.FusedAdamAmsgrad.__init__\n"
+                "def init(self, *a, **k):\n"
+                "    orig(self, *a, **k); keep.append(self)\n"
+                "optim.FusedAdamAmsgrad.__init__ = init\n"
+                "cli.FusedAdamAmsgrad = optim.FusedAdamAmsgrad\n"
+                "ginit = graph.GraphedTrainStep.__init__\n"
+                "def gi(self, *a, **k):\n"
+                "    ginit(self, *a, **k); steppers.append(self)\n"
+                "graph.GraphedTrainStep.__init__ = gi\n"
+                "ws = sys.argv[sys.argv.index('--workspace') + 1]\n"
+                "warns = []\n"
+                "def warn(msg, *a):\n"
+                "    warns.append(msg % a if a else msg)\n"
+                "logging.warning = warn\n"
+                "cli.main(sys.argv[1:])\n"
+                "torch.save({'flat': keep[0].flat.cpu(), 'steps': keep[0].step_count, 'replays': steppers[0].replays, 'warns': warns},\n"
+                "           os.path.join(ws, 'state_rank%d.pt' % rank))\n")
+    args = ["train", "--dataset_dir", ws, "--workspace", ws, "--holdout_fold", "1", "--model_type", "Cnn_9layers_FrameAvg",
+            "--loss_type", "clip_bce", "--augmentation", "mixup", "--learning_rate", "1e-3", "--batch_size", "8",
+            "--resume_iteration", "0", "--stop_iteration", "6", "--cuda", "--synthetic", "24", "--print_every", "1"]
+    r = _torchrun(2, [probe] + args, env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    a, b = (torch.load(os.path.join(ws, "state_rank%d.pt" % k)) for k in (0, 1))
+    assert torch.equal(a["flat"], b["flat"]) and torch.isfinite(a["flat"]).all()
+    for k, st in enumerate((a, b)):
+        assert st["steps"] == 7 and st["replays"] == 0, (k, st["steps"], st["replays"])        # every step ran, none as a replay
+        assert sum("HIP graph capture failed" in w for w in st["warns"]) == 1, (k, st["warns"])
+    assert any("another rank" in w for w in a["warns"]) and any("rank 1 (test)" in w for w in b["warns"])
+    losses = [float(l.split()[1]) for l in r.stdout.splitlines() if len(l.split()) == 2 and l.split()[0].isdigit()]
+    assert len(losses) == 7 and all(np.isfinite(losses))
