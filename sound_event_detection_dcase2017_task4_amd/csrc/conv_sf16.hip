@@ -1008,8 +1008,9 @@ int conv_sf16_launch(const float* x, const void* wp, const float* wscale, float*
     hipStream_t s = (hipStream_t)stream;
     // the small-launch form (deep weight pipeline, two workgroups per CU) for every launch of at most two workgroups per CU,
     // split or not
-    static const long small_max = getenv("SED_CONV_SMALL_MAX") ? atol(getenv("SED_CONV_SMALL_MAX")) : 2 * 256;     // (A/B runs)
-    if (ksplit > 1 || nblk <= small_max) {
+    // (measured with the form forced on every launch at bs=32: 4-8 % slower than three plain workgroups per CU on the large layers,
+    // level on the 1024-workgroup ones)
+    if (ksplit > 1 || nblk <= 2 * 256) {
         const bool itk = in_scale != nullptr;
 #define SF_LAUNCHK(INTV, EPIV, PREV) hipLaunchKernelGGL((conv_sf16_kernel<4, INTV, EPIV, PREV, true>), g, blk, 0, s, p)
         if (pre) { if (epi == 0) SF_LAUNCHK(false, 0, true); else if (epi == 1) SF_LAUNCHK(false, 1, true); else SF_LAUNCHK(false, 2, true); }
@@ -1073,15 +1074,12 @@ SED_API int sed_conv_sf16_split_plan(int B, int H, int W, int Cin, int Cout, int
     const int tr = 256 >> sf_log2w(W);
     const long wgs = (long)B * ((H + tr - 1) / tr) * (Cout / 64);
     const int kt = Cin >> 4;
-    static const long smallm_max = getenv("SED_CONV_SMALLM_MAX") ? atol(getenv("SED_CONV_SMALLM_MAX")) : 160;      // (A/B runs)
-    if (wgs <= smallm_max) {
+    if (wgs <= 160) {
         // small-M: only launches that leave most CUs EMPTY are split (<= 160 workgroups on 256 CUs; measured at 4 clips per GPU:
         // the 250 x 16 layers -- 252 workgroups -- lose 20-40 % when split, the 125 x 8 layers -- 64-128 workgroups -- gain
         // 15-50 %), up to the 768 resident slots, never below 6 K-steps per share (prologue + epilogue of a workgroup cost about 2)
         int s = 1;
         while (s < 8 && wgs * (s * 2) <= SF_SLOTS && kt / (s * 2) >= 6) s *= 2;
-        static const int force = getenv("SED_CONV_SMALLM_KS") ? atoi(getenv("SED_CONV_SMALLM_KS")) : 0;      // (A/B runs)
-        if (force >= 1 && force <= 8 && kt / force >= 2) s = force;
         return s;
     }
     if (tail_ks < 2 || tail_ks > 8 || wgs <= SF_SLOTS) return 1;
