@@ -151,3 +151,68 @@ def test_segment_based_metrics_known_answers():
         assert r["class_wise_average"]["f_measure"]["f_measure"] == pytest.approx(f_mean)
         acc = o["accuracy"]
         assert 0.0 <= acc["accuracy"] <= 1.0 and acc["balanced_accuracy"] == pytest.approx(0.5 * (acc["sensitivity"] + acc["specificity"]))
+
+
+def test_segment_based_metrics_against_an_independent_formulation():
+    """sed_eval is not installed, so `utilities.segment_based_metrics` (what reference utilities.py:142-185 gets from
+    sed_eval.sound_event.SegmentBasedMetrics) cannot be held to sed_eval's code.  Beside the hand-derived known answers it is held
+    here to a SECOND, independently written evaluation of the published definitions (Mesaros, Heittola, Virtanen 2016) on 300 random
+    event lists: segment activity by interval OVERLAP (a label is active in segment k iff an event has onset < k + 1 and offset > k)
+    instead of floor / ceil slicing; micro and class-wise precision / recall / F from scikit-learn on the flattened segment x label
+    matrices; substitutions / deletions / insertions per segment from the paper's FN / FP form (S = min(FN, FP), D = max(0, FN - FP),
+    I = max(0, FP - FN)) instead of the Nref / Nsys / Ntp form.  Onsets and offsets fall on quarter seconds, so segment boundaries
+    are hit exactly; files may be missing from the estimate, the estimate may name files and labels the reference does not have."""
+    from sklearn.metrics import precision_recall_fscore_support
+    from sound_event_detection_dcase2017_task4_amd.utils import utilities as U
+    rs = np.random.RandomState(2017)
+    labels_all = ["Car", "Bus", "Train horn", "Skateboard", "Bicycle"]
+    for case in range(300):
+        labels = labels_all[:rs.randint(2, 6)]
+        files = ["f%d.wav" % i for i in range(rs.randint(1, 4))]
+
+        def events(fnames, lab, p_file):
+            out = []
+            for f in fnames:
+                if rs.rand() > p_file:
+                    continue
+                for _ in range(rs.randint(0, 5)):
+                    on = rs.randint(0, 36) / 4.0
+                    out.append({"filename": f, "onset": on, "offset": on + rs.randint(0, 13) / 4.0, "event_label": lab[rs.randint(len(lab))]})
+            return out
+        ref = events(files, labels, 1.0)
+        for f in files:                                   # every reference file is LISTED (sed_eval evaluates the files of the reference)
+            if not any(e["filename"] == f for e in ref):
+                ref.append({"filename": f, "onset": 0.0, "offset": 0.0, "event_label": None})
+        est = events(files + ["stranger.wav"], labels + ["Unknown"], 0.8)
+        got = U.segment_based_metrics(ref, est, time_resolution=1.0, event_label_list=labels)
+        # ---- the independent evaluation
+        R_all, S_all, Ssub = [], [], [0.0, 0.0, 0.0]
+        for f in files:
+            r_ev = [e for e in ref if e["filename"] == f and e["event_label"] in labels]
+            s_ev = [e for e in est if e["filename"] == f and e["event_label"] in labels]
+            end = max([e["offset"] for e in r_ev + s_ev] + [0.0])
+            nseg = int(np.ceil(end))
+            for k in range(nseg):
+                r = np.array([any(e["event_label"] == l and e["onset"] < k + 1 and e["offset"] > k for e in r_ev) for l in labels])
+                s = np.array([any(e["event_label"] == l and e["onset"] < k + 1 and e["offset"] > k for e in s_ev) for l in labels])
+                fn, fp = int((r & ~s).sum()), int((s & ~r).sum())
+                Ssub[0] += min(fn, fp); Ssub[1] += max(0, fn - fp); Ssub[2] += max(0, fp - fn)
+                R_all.append(r); S_all.append(s)
+        R_all = np.array(R_all, dtype=int).reshape(-1, len(labels)); S_all = np.array(S_all, dtype=int).reshape(-1, len(labels))
+        nref, nsys = float(R_all.sum()), float(S_all.sum())
+        o = got["overall"]
+        assert o["count"] == {"Nref": nref, "Nsys": nsys}, case
+        d = nref if nref > 0 else 1.0
+        assert o["error_rate"]["substitution_rate"] == pytest.approx(Ssub[0] / d) and o["error_rate"]["deletion_rate"] == pytest.approx(Ssub[1] / d)
+        assert o["error_rate"]["insertion_rate"] == pytest.approx(Ssub[2] / d) and o["error_rate"]["error_rate"] == pytest.approx(sum(Ssub) / d)
+        if R_all.size:
+            p, r_, f1, _ = precision_recall_fscore_support(R_all.reshape(-1), S_all.reshape(-1), average="binary", zero_division=0)
+            assert o["f_measure"]["precision"] == pytest.approx(p) and o["f_measure"]["recall"] == pytest.approx(r_), case
+            assert o["f_measure"]["f_measure"] == pytest.approx(f1), case
+            pc, rc, fc, _ = precision_recall_fscore_support(R_all, S_all, average=None, zero_division=0)
+            for i, l in enumerate(labels):
+                cw = got["class_wise"][l]
+                assert cw["f_measure"]["f_measure"] == pytest.approx(fc[i]) and cw["f_measure"]["precision"] == pytest.approx(pc[i]), (case, l)
+                assert cw["count"] == {"Nref": float(R_all[:, i].sum()), "Nsys": float(S_all[:, i].sum())}
+                assert cw["error_rate"]["error_rate"] == pytest.approx(((R_all[:, i] & (1 - S_all[:, i])).sum() + (S_all[:, i] & (1 - R_all[:, i])).sum())
+                                                                       / (R_all[:, i].sum() if R_all[:, i].sum() > 0 else 1.0))
