@@ -92,7 +92,11 @@ class GraphedTrainStep(object):
         prev, buckets.deferred = getattr(buckets, "deferred", False), True   # no collective inside the graph
         bn_before = ops._BN_LAST               # BatchNorm groups tracked before the capture (normally none: a step has just ended)
         try:
-            with torch.cuda.graph(g):
+            # thread_local: only THIS thread's actions can invalidate the recording.  Other threads of the process make HIP calls
+            # of their own all the time -- the NCCL watchdog polls its events, the input pipeline's producer thread synchronises
+            # its copy events and allocates page-locked buffers -- and under the default "global" mode any such call during the
+            # few hundred ms of a capture refuses it (seen once in ~10 runs with a process group alive: round 6)
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 ops.reset_amax_pool()           # the zero fill of the amax rows used below becomes part of the graph
                 loss = self._body()
         except GraphCaptureError:

@@ -310,7 +310,8 @@ class FusedAdamAmsgrad(object):
     def load_state_dict(self, sd):
         """Accepts this class's own state_dict() AND a stock `torch.optim.Adam(amsgrad=True)` one (the 'optimizer' entry of a
         checkpoint written by the reference, main.py:222-230: {'state', 'param_groups'}); anything else is refused with the reason
-        (ValueError) -- never half-loaded."""
+        (ValueError) -- never half-loaded.  Moments and the step counter are taken over; lr / betas / eps stay those this
+        optimiser was constructed with (the train CLI's flags decide, as in the reference, which never reloads its optimiser)."""
         if "exp_avg" in sd and "step" in sd:
             step = int(sd["step"])
             moments = [torch.as_tensor(sd[k]) for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq")]
